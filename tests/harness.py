@@ -1,0 +1,238 @@
+"""ctypes harness over the two CPU checkers under oracle/ (test infrastructure only).
+
+`CpuWorld("orc")` drives oracle/liboracle.so (our CPU restatement),
+`CpuWorld("ref")` drives oracle/_ref/libavbd_ref.so (the unmodified reference sources,
+built by oracle/Makefile where /root/reference exists; prebuilt file elsewhere).
+Both export the same entry points (oracle/harness_api.h) with different prefixes.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+BODY_DT = np.dtype([
+    ("pos", "<f4", 3), ("quat", "<f4", 4), ("linVel", "<f4", 3), ("angVel", "<f4", 3),
+    ("prevLinVel", "<f4", 3), ("prevAngVel", "<f4", 3), ("initialPos", "<f4", 3), ("initialQuat", "<f4", 4),
+    ("inertialPos", "<f4", 3), ("inertialQuat", "<f4", 4), ("size", "<f4", 3),
+    ("mass", "<f4"), ("invMass", "<f4"), ("friction", "<f4"), ("radius", "<f4"),
+])
+assert BODY_DT.itemsize == 160
+
+CONTACT_DT = np.dtype([
+    ("feature", "<i4"), ("rA", "<f4", 3), ("rB", "<f4", 3), ("normal", "<f4", 3),
+    ("penetration", "<f4"), ("C0_n", "<f4"), ("C0_t", "<f4", 3), ("stick", "<i4"),
+])
+assert CONTACT_DT.itemsize == 64
+
+FORCE_DT = np.dtype([
+    ("kind", "<i4"), ("bodyA", "<i4"), ("bodyB", "<i4"), ("rows", "<i4"),
+    ("C", "<f4", 12), ("fmin", "<f4", 12), ("fmax", "<f4", 12), ("lambda", "<f4", 12),
+    ("penalty", "<f4", 12), ("motor", "<f4", 12), ("stiffness", "<f4", 12),
+    ("numContacts", "<i4"), ("combinedFriction", "<f4"), ("contacts", CONTACT_DT, 4),
+    ("rA", "<f4", 3), ("rB", "<f4", 3), ("q0", "<f4", 4), ("restLength", "<f4"),
+])
+assert FORCE_DT.itemsize == 16 + 7 * 48 + 8 + 256 + 44
+
+DIAG_DT = np.dtype([
+    ("maxPenetration", "<f4"), ("maxConstraintViolation", "<f4"), ("maxLinearSpeed", "<f4"),
+    ("maxAngularSpeed", "<f4"), ("maxNormalImpulse", "<f4"),
+    ("activeContacts", "<i4"), ("activeManifolds", "<i4"), ("dynamicBodies", "<i4"),
+])
+
+PARAMS_DT = np.dtype([
+    ("dt", "<f4"), ("gravity", "<f4", 3), ("iterations", "<i4"), ("alpha", "<f4"), ("beta", "<f4"),
+    ("gamma", "<f4"), ("postStabilize", "<i4"),
+])
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+_libs = {}
+
+
+def build_oracle():
+    """(Re)build oracle/liboracle.so (+ _ref when the reference sources are present)."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    if os.path.exists("/root/reference/source/solver.cpp"):
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
+
+
+def lib_path(prefix):
+    return os.path.join(ORACLE_DIR, "liboracle.so") if prefix == "orc" else os.path.join(ORACLE_DIR, "_ref", "libavbd_ref.so")
+
+
+def have(prefix):
+    return os.path.exists(lib_path(prefix))
+
+
+def _f(p):
+    return np.ascontiguousarray(p, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+
+
+def load(prefix):
+    if prefix in _libs:
+        return _libs[prefix]
+    path = lib_path(prefix)
+    if prefix == "orc" and not os.path.exists(path):
+        build_oracle()
+    lib = C.CDLL(path)
+    g = lambda n: getattr(lib, prefix + "_" + n)
+    g("create").restype = C.c_void_p
+    for n in ("destroy", "step", "get_bodies", "get_forces", "get_diag", "get_params", "set_params",
+              "set_diag_logging", "print_step", "solve3", "solve6", "world_inertia"):
+        g(n).restype = None
+    for n in ("scene", "add_body", "add_joint", "add_spring", "add_ignore", "num_bodies", "num_forces",
+              "step_index", "collide"):
+        g(n).restype = C.c_int
+    _libs[prefix] = lib
+    return lib
+
+
+class CpuWorld:
+    def __init__(self, prefix="orc"):
+        self.prefix = prefix
+        self.lib = load(prefix)
+        self._c = lambda n: getattr(self.lib, prefix + "_" + n)
+        self.h = C.c_void_p(self._c("create")())
+        self._c("set_diag_logging")(self.h, 0, 60)
+
+    def close(self):
+        if self.h:
+            self._c("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scene(self, name):
+        r = self._c("scene")(self.h, name.encode())
+        if r < 0:
+            raise ValueError("unknown scene " + name)
+        return r
+
+    def params(self):
+        p = np.zeros(1, PARAMS_DT)
+        self._c("get_params")(self.h, p.ctypes.data_as(C.c_void_p))
+        return p[0]
+
+    def set_params(self, **kw):
+        p = np.zeros(1, PARAMS_DT)
+        self._c("get_params")(self.h, p.ctypes.data_as(C.c_void_p))
+        for k, v in kw.items():
+            p[0][k] = v
+        self._c("set_params")(self.h, p.ctypes.data_as(C.c_void_p))
+
+    def add_body(self, size, density, friction, pos, quat=(0, 0, 0, 1), lin=(0, 0, 0), ang=(0, 0, 0)):
+        return self._c("add_body")(self.h, _f(size), C.c_float(density), C.c_float(friction), _f(pos), _f(quat), _f(lin), _f(ang))
+
+    def add_joint(self, a, b, rA, rB=(0, 0, 0), lin_stiff=FLT_MAX, ang_stiff=FLT_MAX):
+        return self._c("add_joint")(self.h, a, b, _f(rA), _f(rB), C.c_float(lin_stiff), C.c_float(ang_stiff))
+
+    def add_spring(self, a, b, rA, rB, stiffness, rest=-1.0):
+        return self._c("add_spring")(self.h, a, b, _f(rA), _f(rB), C.c_float(stiffness), C.c_float(rest))
+
+    def add_ignore(self, a, b):
+        return self._c("add_ignore")(self.h, a, b)
+
+    def step(self, n=1):
+        self._c("step")(self.h, n)
+
+    def step_index(self):
+        return self._c("step_index")(self.h)
+
+    def bodies(self):
+        n = self._c("num_bodies")(self.h)
+        out = np.zeros(n, BODY_DT)
+        if n:
+            self._c("get_bodies")(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def forces(self):
+        n = self._c("num_forces")(self.h)
+        out = np.zeros(n, FORCE_DT)
+        if n:
+            self._c("get_forces")(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def diag(self):
+        d = np.zeros(1, DIAG_DT)
+        self._c("get_diag")(self.h, d.ctypes.data_as(C.c_void_p))
+        return d[0]
+
+    # teacher forcing (restatement only)
+    def set_bodies(self, arr):
+        assert self.prefix == "orc"
+        arr = np.ascontiguousarray(arr, dtype=BODY_DT)
+        self.lib.orc_set_bodies(self.h, arr.ctypes.data_as(C.c_void_p))
+
+    def set_forces(self, arr):
+        assert self.prefix == "orc"
+        arr = np.ascontiguousarray(arr, dtype=FORCE_DT)
+        self.lib.orc_set_forces(self.h, arr.ctypes.data_as(C.c_void_p), len(arr))
+
+    def set_step_index(self, s):
+        assert self.prefix == "orc"
+        self.lib.orc_set_step_index(self.h, s)
+
+
+def collide(prefix, posA, qA, sizeA, posB, qB, sizeB):
+    lib = load(prefix)
+    out = np.zeros(4, CONTACT_DT)
+    n = getattr(lib, prefix + "_collide")(_f(posA), _f(qA), _f(sizeA), _f(posB), _f(qB), _f(sizeB), out.ctypes.data_as(C.c_void_p))
+    return out[:n]
+
+
+def solve3(prefix, A, b):
+    lib = load(prefix)
+    x = np.zeros(3, np.float32)
+    getattr(lib, prefix + "_solve3")(_f(A), _f(b), x.ctypes.data_as(C.POINTER(C.c_float)))
+    return x
+
+
+def solve6(prefix, A, b):
+    lib = load(prefix)
+    x = np.zeros(6, np.float32)
+    getattr(lib, prefix + "_solve6")(_f(A), _f(b), x.ctypes.data_as(C.POINTER(C.c_float)))
+    return x
+
+
+def world_inertia(prefix, size, density, q):
+    lib = load(prefix)
+    I = np.zeros(9, np.float32)
+    J = np.zeros(9, np.float32)
+    getattr(lib, prefix + "_world_inertia")(_f(size), C.c_float(density), _f(q), I.ctypes.data_as(C.POINTER(C.c_float)), J.ctypes.data_as(C.POINTER(C.c_float)))
+    return I, J
+
+
+def bits(a):
+    """View a float32 (structured or plain) array as raw bytes for bit-exact comparison."""
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and bool(np.array_equal(bits(a), bits(b)))
+
+
+def rand_quat(rng):
+    q = rng.normal(size=4).astype(np.float32)
+    q /= np.float32(np.linalg.norm(q))
+    return q
+
+
+def random_pile(world, rng, n, spread=2.0, height=6.0, ground=True, size_range=(0.4, 1.2)):
+    """Drop-in random scene: a ground slab plus n randomly oriented boxes; same calls for any backend."""
+    if ground:
+        world.add_body((40, 1, 40), 0.0, 0.6, (0, -0.5, 0))
+    for _ in range(n):
+        size = rng.uniform(size_range[0], size_range[1], size=3).astype(np.float32)
+        pos = np.array([rng.uniform(-spread, spread), rng.uniform(0.8, height), rng.uniform(-spread, spread)], np.float32)
+        world.add_body(size, float(np.float32(rng.uniform(0.5, 2.0))), float(np.float32(rng.uniform(0.2, 0.9))), pos,
+                       rand_quat(rng), rng.normal(scale=0.5, size=3).astype(np.float32), rng.normal(scale=0.5, size=3).astype(np.float32))
