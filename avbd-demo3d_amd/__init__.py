@@ -1,0 +1,303 @@
+"""avbd-demo3d_amd — MI355X (gfx950) implementation of the AVBD constraint-solve hot path.
+
+This Python module is plumbing only: a ctypes binding of the C ABI in include/avbd_hip.h
+(libavbd_hip.so, built in-tree by `make -C avbd-demo3d_amd/csrc`), used by tests/ and bench.py.
+The product is the HIP library plus the C++17 host mirror in avbd-demo3d_amd/host/.
+
+There is NO CPU fallback: importing works without a GPU (so symbols can be checked), but creating
+a `World` raises unless a gfx950 device and the compiled library are present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavbd_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "avbd_hip.h")
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+BODY_DT = np.dtype([
+    ("position", "<f4", 3), ("orientation", "<f4", 4), ("linearVelocity", "<f4", 3), ("angularVelocity", "<f4", 3),
+    ("prevLinearVelocity", "<f4", 3), ("prevAngularVelocity", "<f4", 3), ("initialPosition", "<f4", 3),
+    ("initialOrientation", "<f4", 4), ("inertialPosition", "<f4", 3), ("inertialOrientation", "<f4", 4),
+    ("size", "<f4", 3), ("mass", "<f4"), ("invMass", "<f4"), ("friction", "<f4"), ("radius", "<f4"),
+])
+CONTACT_DT = np.dtype([
+    ("feature", "<i4"), ("rA", "<f4", 3), ("rB", "<f4", 3), ("normal", "<f4", 3),
+    ("penetration", "<f4"), ("C0_n", "<f4"), ("C0_t", "<f4", 3), ("stick", "<i4"),
+])
+FORCE_DT = np.dtype([
+    ("kind", "<i4"), ("bodyA", "<i4"), ("bodyB", "<i4"), ("rows", "<i4"),
+    ("C", "<f4", 12), ("fmin", "<f4", 12), ("fmax", "<f4", 12), ("lambda", "<f4", 12),
+    ("penalty", "<f4", 12), ("motor", "<f4", 12), ("stiffness", "<f4", 12),
+    ("numContacts", "<i4"), ("combinedFriction", "<f4"), ("contacts", CONTACT_DT, 4),
+    ("rA", "<f4", 3), ("rB", "<f4", 3), ("q0", "<f4", 4), ("restLength", "<f4"),
+])
+DIAG_DT = np.dtype([
+    ("maxPenetration", "<f4"), ("maxConstraintViolation", "<f4"), ("maxLinearSpeed", "<f4"),
+    ("maxAngularSpeed", "<f4"), ("maxNormalImpulse", "<f4"),
+    ("activeContacts", "<i4"), ("activeManifolds", "<i4"), ("dynamicBodies", "<i4"),
+])
+PARAMS_DT = np.dtype([
+    ("dt", "<f4"), ("gravity", "<f4", 3), ("iterations", "<i4"), ("alpha", "<f4"), ("beta", "<f4"),
+    ("gamma", "<f4"), ("postStabilize", "<i4"),
+])
+STATS_DT = np.dtype([(n, "<i4") for n in (
+    "numBodies", "numDynamic", "numManifolds", "numContacts", "numIncidences", "numCandidates", "numLevels",
+    "numJoints", "numSprings", "numIgnores", "warnings", "reserved")])
+PROFILE_DT = np.dtype([
+    ("ms_broadphase", "<f8"), ("ms_narrowphase", "<f8"), ("ms_topology", "<f8"), ("ms_predict", "<f8"),
+    ("ms_primal", "<f8"), ("ms_dual", "<f8"), ("ms_velocity", "<f8"),
+    ("launches_primal", "<i8"), ("launches_dual", "<i8"), ("launches_total", "<i8"), ("steps", "<i8"),
+    ("algorithmic_bytes_primal", "<f8"), ("algorithmic_bytes_dual", "<f8"),
+])
+
+EXPORTS = [
+    "avbd_abi_version", "avbd_create", "avbd_destroy", "avbd_last_error", "avbd_default_params", "avbd_set_params",
+    "avbd_get_params", "avbd_clear", "avbd_add_bodies", "avbd_add_joint", "avbd_add_spring", "avbd_add_ignore", "avbd_add_force",
+    "avbd_step", "avbd_synchronize", "avbd_step_index", "avbd_get_diagnostics", "avbd_get_step_stats",
+    "avbd_num_bodies", "avbd_download_bodies", "avbd_download_state13", "avbd_upload_state13", "avbd_upload_bodies",
+    "avbd_num_forces", "avbd_download_forces", "avbd_upload_forces", "avbd_force_row_count",
+    "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
+    "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
+    "avbd_build_scene",
+]
+
+
+class AvbdError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libavbd_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise AvbdError("hipcc build of libavbd_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libavbd_hip.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AvbdError(f"{LIB_PATH} is missing: run `make -C avbd-demo3d_amd/csrc` (no CPU fallback exists)")
+    L = C.CDLL(LIB_PATH)
+    L.avbd_last_error.restype = C.c_char_p
+    L.avbd_last_error.argtypes = [C.c_void_p]
+    L.avbd_stream.restype = C.c_void_p
+    L.avbd_stream.argtypes = [C.c_void_p]
+    for name in EXPORTS:
+        if name in ("avbd_last_error", "avbd_stream"):
+            continue
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class World:
+    """One solver context on one MI355X: the `Solver` object of solver.h:146-181 behind the C ABI."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.avbd_create(int(device), C.byref(h))
+        if rc != 0:
+            raise AvbdError(f"avbd_create(device={device}) failed with code {rc}: no usable gfx950 device / HIP runtime "
+                            "(this framework has no CPU fallback)")
+        self.h = h
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.avbd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise AvbdError(f"avbd error {rc}: {self.L.avbd_last_error(self.h).decode()}")
+        return rc
+
+    # -- params
+    def params(self):
+        p = np.zeros(1, PARAMS_DT)
+        self._chk(self.L.avbd_get_params(self.h, p.ctypes.data_as(C.c_void_p)))
+        return p[0]
+
+    def set_params(self, **kw):
+        p = np.zeros(1, PARAMS_DT)
+        self._chk(self.L.avbd_get_params(self.h, p.ctypes.data_as(C.c_void_p)))
+        for k, v in kw.items():
+            p[0][k] = v
+        self._chk(self.L.avbd_set_params(self.h, p.ctypes.data_as(C.c_void_p)))
+
+    def clear(self):
+        self._chk(self.L.avbd_clear(self.h))
+
+    def scene(self, name):
+        """Build one of the reference scenes (scenes.h) or StressN:<n> / Packed:<n> through the host mirror."""
+        rc = self.L.avbd_build_scene(self.h, name.encode())
+        if rc < 0:
+            raise AvbdError(f"unknown scene {name!r}")
+        return rc
+
+    # -- construction
+    def add_bodies(self, size, density, friction, position, orientation=None, linear_velocity=None, angular_velocity=None):
+        size = _f32(size, (-1, 3))
+        n = size.shape[0]
+        density = _f32(np.broadcast_to(np.asarray(density, np.float32), (n,)))
+        friction = _f32(np.broadcast_to(np.asarray(friction, np.float32), (n,)))
+        position = _f32(position, (n, 3))
+        orientation = _f32(orientation, (n, 4))
+        lv = _f32(linear_velocity, (n, 3))
+        av = _f32(angular_velocity, (n, 3))
+        first = C.c_int(-1)
+        self._chk(self.L.avbd_add_bodies(self.h, n, _fp(size), _fp(density), _fp(friction), _fp(position), _fp(orientation),
+                                         _fp(lv), _fp(av), C.byref(first)))
+        return first.value
+
+    def add_body(self, size, density, friction, pos, quat=(0, 0, 0, 1), lin=(0, 0, 0), ang=(0, 0, 0)):
+        return self.add_bodies([size], [density], [friction], [pos], [quat], [lin], [ang])
+
+    def add_joint(self, a, b, rA, rB=(0, 0, 0), lin_stiff=FLT_MAX, ang_stiff=FLT_MAX):
+        self._chk(self.L.avbd_add_joint(self.h, int(a), int(b), _fp(_f32(rA)), _fp(_f32(rB)), C.c_float(lin_stiff), C.c_float(ang_stiff)))
+
+    def add_spring(self, a, b, rA, rB, stiffness, rest=-1.0):
+        self._chk(self.L.avbd_add_spring(self.h, int(a), int(b), _fp(_f32(rA)), _fp(_f32(rB)), C.c_float(stiffness), C.c_float(rest)))
+
+    def add_ignore(self, a, b):
+        self._chk(self.L.avbd_add_ignore(self.h, int(a), int(b)))
+
+    # -- stepping
+    def step(self, n=1):
+        self._chk(self.L.avbd_step(self.h, int(n)))
+
+    def synchronize(self):
+        self._chk(self.L.avbd_synchronize(self.h))
+
+    def step_index(self):
+        return self.L.avbd_step_index(self.h)
+
+    def diag(self):
+        d = np.zeros(1, DIAG_DT)
+        self._chk(self.L.avbd_get_diagnostics(self.h, d.ctypes.data_as(C.c_void_p)))
+        return d[0]
+
+    def stats(self):
+        s = np.zeros(1, STATS_DT)
+        self._chk(self.L.avbd_get_step_stats(self.h, s.ctypes.data_as(C.c_void_p)))
+        return s[0]
+
+    # -- state
+    def num_bodies(self):
+        return self.L.avbd_num_bodies(self.h)
+
+    def bodies(self):
+        n = self.num_bodies()
+        out = np.zeros(n, BODY_DT)
+        self._chk(self.L.avbd_download_bodies(self.h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def state13(self):
+        n = self.num_bodies()
+        out = np.zeros((n, 13), np.float32)
+        self._chk(self.L.avbd_download_state13(self.h, _fp(out), n))
+        return out
+
+    def set_state13(self, s):
+        s = _f32(s, (-1, 13))
+        self._chk(self.L.avbd_upload_state13(self.h, _fp(s), s.shape[0]))
+
+    def set_bodies(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=BODY_DT)
+        self._chk(self.L.avbd_upload_bodies(self.h, arr.ctypes.data_as(C.c_void_p), len(arr)))
+
+    def forces(self):
+        n = self._chk(self.L.avbd_num_forces(self.h))
+        out = np.zeros(n, FORCE_DT)
+        if n:
+            self._chk(self.L.avbd_download_forces(self.h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def set_forces(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=FORCE_DT)
+        self._chk(self.L.avbd_upload_forces(self.h, arr.ctypes.data_as(C.c_void_p), len(arr)))
+
+    # -- row API (solver.h:102-108) evaluated on the device
+    def force_row_count(self, i):
+        r = C.c_int(0)
+        self._chk(self.L.avbd_force_row_count(self.h, int(i), C.byref(r)))
+        return r.value
+
+    def force_compute_constraint(self, i, alpha):
+        Cc, lo, hi, lam = (np.zeros(12, np.float32) for _ in range(4))
+        self._chk(self.L.avbd_force_compute_constraint(self.h, int(i), C.c_float(alpha), _fp(Cc), _fp(lo), _fp(hi), _fp(lam)))
+        return Cc, lo, hi, lam
+
+    def force_compute_derivatives(self, i, body, row):
+        Jl, Ja = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._chk(self.L.avbd_force_compute_derivatives(self.h, int(i), int(body), int(row), _fp(Jl), _fp(Ja)))
+        return Jl, Ja
+
+    # -- KATs
+    def kat_collide(self, pA, qA, sA, pB, qB, sB):
+        pA, qA, sA, pB, qB, sB = _f32(pA, (-1, 3)), _f32(qA, (-1, 4)), _f32(sA, (-1, 3)), _f32(pB, (-1, 3)), _f32(qB, (-1, 4)), _f32(sB, (-1, 3))
+        n = pA.shape[0]
+        out = np.zeros((n, 4), CONTACT_DT)
+        cnt = np.zeros(n, np.int32)
+        self._chk(self.L.avbd_kat_collide(self.h, n, _fp(pA), _fp(qA), _fp(sA), _fp(pB), _fp(qB), _fp(sB), out.ctypes.data_as(C.c_void_p),
+                                          cnt.ctypes.data_as(C.POINTER(C.c_int))))
+        return out, cnt
+
+    def kat_solve6(self, A, b):
+        A, b = _f32(A, (-1, 36)), _f32(b, (-1, 6))
+        x = np.zeros_like(b)
+        self._chk(self.L.avbd_kat_solve6(self.h, A.shape[0], _fp(A), _fp(b), _fp(x)))
+        return x
+
+    def kat_arith(self, a, b):
+        a, b = _f32(a), _f32(b)
+        outs = [np.zeros_like(a) for _ in range(4)]
+        self._chk(self.L.avbd_kat_arith(self.h, a.size, _fp(a), _fp(b), *[_fp(o) for o in outs]))
+        return outs
+
+    # -- measurement
+    def profile_enable(self, on=True):
+        self._chk(self.L.avbd_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.avbd_profile_reset(self.h))
+
+    def profile(self):
+        p = np.zeros(1, PROFILE_DT)
+        self._chk(self.L.avbd_profile_get(self.h, p.ctypes.data_as(C.c_void_p)))
+        return p[0]
+
+    def stream(self):
+        return self.L.avbd_stream(self.h)

@@ -1,0 +1,1271 @@
+/*
+ * avbd_capi.hip — implementation of the C ABI in include/avbd_hip.h (libavbd_hip.so).
+ *
+ * Host orchestration of one Solver::step() (solver.cpp:255-514) on one gfx950 device / one stream:
+ *
+ *   begin → K1 broadphase → K2 narrowphase(+decay) → topology (scan, fill, sort/expand, levels)
+ *         → K4 predict → [readback: counters + level offsets]
+ *         → iterations × ( K5 primal per level, K6 dual ) → K7 velocity → K8 diagnostics
+ *
+ * The only host<->device synchronisation inside a step is the small readback of the level
+ * schedule.  No CPU fallback exists: every entry point fails with AVBD_E_HIP / AVBD_E_NODEVICE
+ * when the device or the kernels are unavailable.
+ */
+#include "../../include/avbd_hip.h"
+#include "avbd_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace avbd;
+
+namespace {
+
+constexpr int kReadbackLevels = 8192;
+
+struct Readback {
+    Counters cnt;
+    int lvlStart[kReadbackLevels + 1];
+};
+
+template <class T>
+struct DevArr {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+};
+
+struct ManifoldBuf {
+    DevArr<int2> pair; DevArr<uint64_t> key; DevArr<int> nc; DevArr<float> fric;
+    DevArr<float4> cRA, cRB, cN, cLam, cPen, cC, cFmin, cFmax; DevArr<int2> cFS;
+    int cap = 0;
+    hipError_t alloc(int c)
+    {
+        cap = c;
+        hipError_t e;
+        if ((e = pair.alloc(c)) != hipSuccess) return e;
+        if ((e = key.alloc(c)) != hipSuccess) return e;
+        if ((e = nc.alloc(c)) != hipSuccess) return e;
+        if ((e = fric.alloc(c)) != hipSuccess) return e;
+        size_t k = (size_t)c * 4;
+        if ((e = cRA.alloc(k)) != hipSuccess) return e;
+        if ((e = cRB.alloc(k)) != hipSuccess) return e;
+        if ((e = cN.alloc(k)) != hipSuccess) return e;
+        if ((e = cLam.alloc(k)) != hipSuccess) return e;
+        if ((e = cPen.alloc(k)) != hipSuccess) return e;
+        if ((e = cC.alloc(k)) != hipSuccess) return e;
+        if ((e = cFmin.alloc(k)) != hipSuccess) return e;
+        if ((e = cFmax.alloc(k)) != hipSuccess) return e;
+        if ((e = cFS.alloc(k)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    void release()
+    {
+        pair.release(); key.release(); nc.release(); fric.release(); cRA.release(); cRB.release(); cN.release();
+        cLam.release(); cPen.release(); cC.release(); cFmin.release(); cFmax.release(); cFS.release(); cap = 0;
+    }
+    ManifoldTable view() const
+    {
+        ManifoldTable t;
+        t.pair = pair.p; t.key = key.p; t.nc = nc.p; t.fric = fric.p; t.cRA = cRA.p; t.cRB = cRB.p; t.cN = cN.p;
+        t.cLam = cLam.p; t.cPen = cPen.p; t.cFS = cFS.p; t.cC = cC.p; t.cFmin = cFmin.p; t.cFmax = cFmax.p; t.cap = cap;
+        return t;
+    }
+};
+
+} // namespace
+
+struct AvbdContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    AvbdParams params;
+    int stepIndex = 0;
+
+    /* host mirror of bodies (authoritative only while !deviceAhead) */
+    std::vector<AvbdBody> hBodies;
+    std::vector<float> hI, hJ; /* 9 floats per body: inertiaTensor / invInertiaTensor, column-major */
+    bool bodiesStale = true;   /* host mirror must be (re)uploaded */
+    bool deviceAhead = false;  /* device holds newer dynamic state than hBodies */
+
+    /* device body table */
+    DevArr<float4> dPlanes;
+    int bodyCap = 0;
+
+    /* manifolds */
+    ManifoldBuf mbuf[2];
+    int cur = 0;
+    int mCap = 0;
+
+    /* generic forces */
+    std::vector<GForce> hG;
+    DevArr<GForce> dG;
+    int gCap = 0;
+    bool gStale = false;       /* host list changed → upload */
+    bool gDeviceAhead = false; /* device rows newer than hG */
+    uint64_t hostKeyCounter = 1;
+
+    /* topology */
+    DevArr<int> adjStart, incStart, degForce, degInc, level, order, lvlStart, lvlCount, adjRef, adjOther, inc;
+    DevArr<uint64_t> adjKey;
+    DevArr<int2> cand;
+    int candCap = 0, adjCap = 0, incCap = 0, lvlCap = 0;
+    bool adjDirty = true;
+
+    DevArr<Counters> dCnt;
+    DevArr<DiagAccum> dDiag;
+    DevArr<int> dNext;
+    Readback* hRb = nullptr; /* pinned */
+    AvbdStepStats stats{};
+    int lastLevels = 0;
+
+    /* profiling */
+    bool profiling = false;
+    AvbdProfile prof{};
+    std::vector<hipEvent_t> evPool;
+    size_t evUsed = 0;
+    struct Span { int family; size_t e0, e1; };
+    std::vector<Span> spans;
+
+    int fail(int code, const char* what, hipError_t e = hipSuccess)
+    {
+        char buf[512];
+        if (e != hipSuccess) std::snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        else std::snprintf(buf, sizeof(buf), "%s", what);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(ctx, call)                                                           \
+    do {                                                                            \
+        hipError_t _e = (call);                                                     \
+        if (_e != hipSuccess) return (ctx)->fail(AVBD_E_HIP, #call, _e);            \
+    } while (0)
+
+namespace {
+
+BodyTable body_table(AvbdContext* c)
+{
+    BodyTable t; t.planes = c->dPlanes.p; t.cap = c->bodyCap; t.n = (int)c->hBodies.size();
+    return t;
+}
+
+SolverParams solver_params(const AvbdContext* c)
+{
+    SolverParams p;
+    p.dt = c->params.dt; p.gx = c->params.gravity[0]; p.gy = c->params.gravity[1]; p.gz = c->params.gravity[2];
+    p.iterations = c->params.iterations; p.alpha = c->params.alpha; p.beta = c->params.beta; p.gamma = c->params.gamma;
+    p.postStabilize = c->params.postStabilize;
+    return p;
+}
+
+int grid_for(long long items, int block, int maxBlocks = 4096)
+{
+    long long g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > maxBlocks) g = maxBlocks;
+    return (int)g;
+}
+
+/* (re)allocate everything that scales with the body count; preserves manifolds */
+int ensure_capacity(AvbdContext* c, int nBodies)
+{
+    if (nBodies <= c->bodyCap && c->mCap > 0) return AVBD_OK;
+    int newCap = std::max(1024, c->bodyCap);
+    while (newCap < nBodies) newCap *= 2;
+    const int newMCap = std::max(8192, newCap * 16);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    HIPCHK(c, c->dPlanes.alloc((size_t)BP_COUNT * newCap));
+    c->bodyCap = newCap;
+
+    if (newMCap > c->mCap) {
+        /* keep live manifolds: copy the current buffer into the new allocation */
+        ManifoldBuf nb0, nb1;
+        HIPCHK(c, nb0.alloc(newMCap));
+        HIPCHK(c, nb1.alloc(newMCap));
+        if (c->mCap > 0) {
+            ManifoldBuf& o = c->mbuf[c->cur];
+            size_t m = (size_t)c->mCap;
+            HIPCHK(c, hipMemcpy(nb0.pair.p, o.pair.p, m * sizeof(int2), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.key.p, o.key.p, m * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.nc.p, o.nc.p, m * sizeof(int), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.fric.p, o.fric.p, m * sizeof(float), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cRA.p, o.cRA.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cRB.p, o.cRB.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cN.p, o.cN.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cLam.p, o.cLam.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cPen.p, o.cPen.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cC.p, o.cC.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cFmin.p, o.cFmin.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cFmax.p, o.cFmax.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cFS.p, o.cFS.p, 4 * m * sizeof(int2), hipMemcpyDeviceToDevice));
+        }
+        c->mbuf[0].release(); c->mbuf[1].release();
+        c->mbuf[0] = nb0; c->mbuf[1] = nb1; c->cur = 0;
+        c->mCap = newMCap;
+        c->candCap = newMCap;
+        HIPCHK(c, c->cand.alloc(c->candCap));
+    }
+    c->lvlCap = newCap + 2;
+    HIPCHK(c, c->adjStart.alloc(newCap + 1));
+    HIPCHK(c, c->incStart.alloc(newCap + 1));
+    HIPCHK(c, c->degForce.alloc(newCap));
+    HIPCHK(c, c->degInc.alloc(newCap));
+    HIPCHK(c, c->level.alloc(newCap));
+    HIPCHK(c, c->order.alloc(newCap));
+    HIPCHK(c, c->lvlStart.alloc(c->lvlCap + 1));
+    HIPCHK(c, c->lvlCount.alloc(c->lvlCap + 1));
+    HIPCHK(c, hipMemset(c->adjStart.p, 0, (newCap + 1) * sizeof(int)));
+    HIPCHK(c, hipMemset(c->incStart.p, 0, (newCap + 1) * sizeof(int)));
+    HIPCHK(c, hipMemset(c->degForce.p, 0, newCap * sizeof(int)));
+    HIPCHK(c, hipMemset(c->degInc.p, 0, newCap * sizeof(int)));
+    c->adjDirty = true;
+    c->bodiesStale = true;
+    return AVBD_OK;
+}
+
+int ensure_topology_capacity(AvbdContext* c)
+{
+    const int g = std::max(64, (int)c->hG.size());
+    if (g > c->gCap) {
+        int ng = std::max(64, c->gCap);
+        while (ng < g) ng *= 2;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        DevArr<GForce> nd;
+        HIPCHK(c, nd.alloc(ng));
+        if (c->dG.p && c->gCap) HIPCHK(c, hipMemcpy(nd.p, c->dG.p, (size_t)c->gCap * sizeof(GForce), hipMemcpyDeviceToDevice));
+        c->dG.release();
+        c->dG = nd;
+        c->gCap = ng;
+    }
+    const int needAdj = 2 * (c->mCap + c->gCap);
+    const int needInc = 8 * c->mCap + 4 * c->gCap;
+    if (needAdj > c->adjCap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->adjRef.alloc(needAdj));
+        HIPCHK(c, c->adjOther.alloc(needAdj));
+        HIPCHK(c, c->adjKey.alloc(needAdj));
+        c->adjCap = needAdj;
+        c->adjDirty = true;
+    }
+    if (needInc > c->incCap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->inc.alloc(needInc));
+        c->incCap = needInc;
+        c->adjDirty = true;
+    }
+    return AVBD_OK;
+}
+
+void pack_planes(const AvbdContext* c, std::vector<float4>& h)
+{
+    const int n = (int)c->hBodies.size(), cap = c->bodyCap;
+    h.assign((size_t)BP_COUNT * cap, make_float4(0.f, 0.f, 0.f, 0.f));
+    auto P = [&](int plane, int i) -> float4& { return h[(size_t)plane * cap + i]; };
+    for (int i = 0; i < n; ++i) {
+        const AvbdBody& b = c->hBodies[i];
+        P(BP_POSR, i) = make_float4(b.position[0], b.position[1], b.position[2], b.radius);
+        P(BP_QUAT, i) = make_float4(b.orientation[0], b.orientation[1], b.orientation[2], b.orientation[3]);
+        P(BP_LINV, i) = make_float4(b.linearVelocity[0], b.linearVelocity[1], b.linearVelocity[2], 0.f);
+        P(BP_ANGV, i) = make_float4(b.angularVelocity[0], b.angularVelocity[1], b.angularVelocity[2], 0.f);
+        P(BP_PLIN, i) = make_float4(b.prevLinearVelocity[0], b.prevLinearVelocity[1], b.prevLinearVelocity[2], 0.f);
+        P(BP_PANG, i) = make_float4(b.prevAngularVelocity[0], b.prevAngularVelocity[1], b.prevAngularVelocity[2], 0.f);
+        P(BP_IPOS, i) = make_float4(b.initialPosition[0], b.initialPosition[1], b.initialPosition[2], 0.f);
+        P(BP_IQUAT, i) = make_float4(b.initialOrientation[0], b.initialOrientation[1], b.initialOrientation[2], b.initialOrientation[3]);
+        P(BP_NPOS, i) = make_float4(b.inertialPosition[0], b.inertialPosition[1], b.inertialPosition[2], 0.f);
+        P(BP_NQUAT, i) = make_float4(b.inertialOrientation[0], b.inertialOrientation[1], b.inertialOrientation[2], b.inertialOrientation[3]);
+        P(BP_SIZE, i) = make_float4(b.size[0], b.size[1], b.size[2], b.friction);
+        P(BP_MASS, i) = make_float4(b.mass, b.invMass, b.friction, b.radius);
+        const float* I = &c->hI[9 * (size_t)i];
+        const float* J = &c->hJ[9 * (size_t)i];
+        for (int k = 0; k < 3; ++k) {
+            P(BP_I0 + k, i) = make_float4(I[3 * k], I[3 * k + 1], I[3 * k + 2], 0.f);
+            P(BP_J0 + k, i) = make_float4(J[3 * k], J[3 * k + 1], J[3 * k + 2], 0.f);
+        }
+    }
+}
+
+int upload_bodies_if_stale(AvbdContext* c)
+{
+    const int n = (int)c->hBodies.size();
+    int rc = ensure_capacity(c, n);
+    if (rc) return rc;
+    if (!c->bodiesStale) return AVBD_OK;
+    std::vector<float4> h;
+    pack_planes(c, h);
+    HIPCHK(c, hipMemcpyAsync(c->dPlanes.p, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bodiesStale = false;
+    c->deviceAhead = false;
+    return AVBD_OK;
+}
+
+int download_bodies_to_host(AvbdContext* c)
+{
+    if (!c->deviceAhead || c->bodiesStale) return AVBD_OK;
+    const int n = (int)c->hBodies.size(), cap = c->bodyCap;
+    if (!n) { c->deviceAhead = false; return AVBD_OK; }
+    std::vector<float4> h((size_t)BP_NQUAT * cap + cap); /* planes 0..BP_NQUAT are the dynamic ones */
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->dPlanes.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto P = [&](int plane, int i) -> const float4& { return h[(size_t)plane * cap + i]; };
+    auto put3 = [](float* d, const float4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+    auto put4 = [](float* d, const float4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
+    for (int i = 0; i < n; ++i) {
+        AvbdBody& b = c->hBodies[i];
+        put3(b.position, P(BP_POSR, i)); put4(b.orientation, P(BP_QUAT, i));
+        put3(b.linearVelocity, P(BP_LINV, i)); put3(b.angularVelocity, P(BP_ANGV, i));
+        put3(b.prevLinearVelocity, P(BP_PLIN, i)); put3(b.prevAngularVelocity, P(BP_PANG, i));
+        put3(b.initialPosition, P(BP_IPOS, i)); put4(b.initialOrientation, P(BP_IQUAT, i));
+        put3(b.inertialPosition, P(BP_NPOS, i)); put4(b.inertialOrientation, P(BP_NQUAT, i));
+    }
+    c->deviceAhead = false;
+    return AVBD_OK;
+}
+
+int gforces_to_host(AvbdContext* c)
+{
+    if (!c->gDeviceAhead || c->hG.empty()) { c->gDeviceAhead = false; return AVBD_OK; }
+    HIPCHK(c, hipMemcpyAsync(c->hG.data(), c->dG.p, c->hG.size() * sizeof(GForce), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gDeviceAhead = false;
+    return AVBD_OK;
+}
+
+int upload_gforces_if_stale(AvbdContext* c)
+{
+    int rc = ensure_topology_capacity(c);
+    if (rc) return rc;
+    if (!c->gStale) return AVBD_OK;
+    if (!c->hG.empty()) {
+        HIPCHK(c, hipMemcpyAsync(c->dG.p, c->hG.data(), c->hG.size() * sizeof(GForce), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->gStale = false;
+    c->gDeviceAhead = false;
+    c->adjDirty = true;
+    return AVBD_OK;
+}
+
+/* profiling spans */
+enum Family { F_BROAD = 0, F_NARROW, F_TOPO, F_PREDICT, F_PRIMAL, F_DUAL, F_VELOCITY };
+
+hipEvent_t next_event(AvbdContext* c)
+{
+    if (c->evUsed == c->evPool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->evPool.push_back(e);
+    }
+    return c->evPool[c->evUsed++];
+}
+
+struct SpanGuard {
+    AvbdContext* c; int fam; size_t e0 = 0;
+    SpanGuard(AvbdContext* ctx, int family) : c(ctx), fam(family)
+    {
+        if (c->profiling) { e0 = c->evUsed; (void)hipEventRecord(next_event(c), c->stream); }
+    }
+    ~SpanGuard()
+    {
+        if (c->profiling) { size_t e1 = c->evUsed; (void)hipEventRecord(next_event(c), c->stream); c->spans.push_back({fam, e0, e1}); }
+    }
+};
+
+void collect_spans(AvbdContext* c)
+{
+    if (!c->profiling) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (const auto& s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->evPool[s.e0], c->evPool[s.e1]) != hipSuccess) continue;
+        switch (s.family) {
+        case F_BROAD: c->prof.ms_broadphase += ms; break;
+        case F_NARROW: c->prof.ms_narrowphase += ms; break;
+        case F_TOPO: c->prof.ms_topology += ms; break;
+        case F_PREDICT: c->prof.ms_predict += ms; break;
+        case F_PRIMAL: c->prof.ms_primal += ms; break;
+        case F_DUAL: c->prof.ms_dual += ms; break;
+        case F_VELOCITY: c->prof.ms_velocity += ms; break;
+        }
+    }
+    c->spans.clear();
+    c->evUsed = 0;
+}
+
+/* k_count_deg: adjacency degrees of the manifolds already in the current buffer (used when the
+ * adjacency must be rebuilt outside a step: after host-side force creation or snapshot upload). */
+__global__ void k_count_deg(BodyTable B, ManifoldTable M, const Counters* cnt, int* degForce, int* degInc)
+{
+    const int nm = cnt->numManifolds;
+    const float4* mass = B.plane(BP_MASS);
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < nm; m += gridDim.x * blockDim.x) {
+        int2 p = M.pair[m]; int nc = M.nc[m];
+        atomicAdd(&degForce[p.x], 1); atomicAdd(&degForce[p.y], 1);
+        if (mass[p.x].y > 0.0f) atomicAdd(&degInc[p.x], nc);
+        if (mass[p.y].y > 0.0f) atomicAdd(&degInc[p.y], nc);
+    }
+}
+
+__global__ void k_copy_count(Counters* cnt, int* nextCount) { *nextCount = cnt->numManifolds; }
+
+int launch_topology(AvbdContext* c, bool fromStep)
+{
+    BodyTable B = body_table(c);
+    const int n = B.n;
+    ManifoldTable M = c->mbuf[c->cur].view();
+    const int ng = (int)c->hG.size();
+    SolverParams P = solver_params(c);
+    if (!fromStep) {
+        hipLaunchKernelGGL(k_copy_count, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dNext.p);
+        hipLaunchKernelGGL(k_count_deg, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, B, M, c->dCnt.p, c->degForce.p, c->degInc.p);
+    }
+    if (ng) hipLaunchKernelGGL(k_gforce_prepare, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, c->degForce.p, c->degInc.p, P, fromStep ? 1 : 0);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, n, c->degForce.p, c->degInc.p, c->adjStart.p, c->incStart.p, c->dCnt.p, c->dNext.p);
+    hipLaunchKernelGGL(k_fill_adj, dim3(grid_for((long long)c->stats.numManifolds + c->stats.numCandidates + ng + 4096, 256, 2048)), dim3(256), 0, c->stream,
+                       M, c->dCnt.p, c->dG.p, ng, c->adjStart.p, c->degForce.p, c->adjRef.p, c->adjOther.p, c->adjKey.p);
+    hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->adjStart.p, c->adjRef.p, c->adjOther.p,
+                       c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p);
+    if (fromStep)
+        hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), 0, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
+                           c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap);
+    HIPCHK(c, hipGetLastError());
+    c->adjDirty = false;
+    return AVBD_OK;
+}
+
+int step_once(AvbdContext* c)
+{
+    int rc;
+    if ((rc = upload_bodies_if_stale(c))) return rc;
+    if ((rc = upload_gforces_if_stale(c))) return rc;
+    BodyTable B = body_table(c);
+    const int n = B.n;
+    const int ng = (int)c->hG.size();
+    SolverParams P = solver_params(c);
+    if (c->adjDirty && (rc = launch_topology(c, false))) return rc;
+
+    ++c->stepIndex;
+    hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p);
+    {
+        SpanGuard g(c, F_BROAD);
+        if (n > 1) {
+            const int T = (n + 255) / 256;
+            hipLaunchKernelGGL(k_broadphase, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p);
+        }
+    }
+    {
+        SpanGuard g(c, F_NARROW);
+        ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
+        long long est = (long long)c->stats.numManifolds + std::max(c->stats.numCandidates, n) + 4096;
+        hipLaunchKernelGGL(k_narrowphase, dim3(grid_for(est * 2, 128, 8192)), dim3(128), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
+                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex);
+        c->cur ^= 1;
+    }
+    {
+        SpanGuard g(c, F_TOPO);
+        if ((rc = launch_topology(c, true))) return rc;
+    }
+    {
+        SpanGuard g(c, F_PREDICT);
+        hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
+    }
+    /* readback of the level schedule (the one host sync of the step) */
+    HIPCHK(c, hipMemcpyAsync(&c->hRb->cnt, c->dCnt.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->hRb->lvlStart, c->lvlStart.p, sizeof(int) * (std::min(kReadbackLevels, c->lvlCap) + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const Counters& cnt = c->hRb->cnt;
+    if (cnt.overflow) {
+        char buf[128];
+        std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
+        return c->fail(AVBD_E_CAPACITY, buf);
+    }
+    const int L = cnt.numLevels;
+    std::vector<int> lvl;
+    const int* lvlStart = c->hRb->lvlStart;
+    if (L > kReadbackLevels) {
+        lvl.resize(L + 1);
+        HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost));
+        lvlStart = lvl.data();
+    }
+    c->stats.numBodies = n; c->stats.numManifolds = cnt.numManifolds; c->stats.numContacts = cnt.numContacts;
+    c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = L;
+    c->stats.numDynamic = cnt.dynamicBodies;
+    int nj = 0, ns = 0, ni = 0;
+    for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
+    c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
+
+    ManifoldTable M = c->mbuf[c->cur].view();
+    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+    const long long contactSlots = (long long)cnt.numManifolds * 4;
+    for (int it = 0; it < totalIt; ++it) {
+        const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const int writeRows = it >= P.iterations ? 1 : 0;
+        {
+            SpanGuard g(c, F_PRIMAL);
+            for (int l = 0; l < L; ++l) {
+                const int count = lvlStart[l + 1] - lvlStart[l];
+                if (count <= 0) continue;
+                hipLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, B, M, c->dG.p,
+                                   c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
+                ++c->prof.launches_primal; ++c->prof.launches_total;
+            }
+        }
+        if (it < P.iterations) {
+            SpanGuard g(c, F_DUAL);
+            if (contactSlots > 0) {
+                hipLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dCnt.p, P, alphaCur);
+                ++c->prof.launches_dual; ++c->prof.launches_total;
+            }
+            if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
+        }
+    }
+    {
+        SpanGuard g(c, F_VELOCITY);
+        hipLaunchKernelGGL(k_velocity, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p, c->dDiag.p);
+        if (contactSlots > 0)
+            hipLaunchKernelGGL(k_diag_contacts, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dDiag.p);
+        hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->deviceAhead = true;
+    if (ng) c->gDeviceAhead = true;
+    /* algorithmic bytes of this step's iteration loop */
+    const double nbDyn = cnt.dynamicBodies, ninc = cnt.numIncidences, ncon = cnt.numContacts;
+    c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc);
+    c->prof.algorithmic_bytes_dual += (double)P.iterations * (160.0 * ncon);
+    ++c->prof.steps;
+    collect_spans(c);
+    return AVBD_OK;
+}
+
+void box_mass_properties(AvbdBody& b, float density, float* I9, float* J9)
+{
+    /* rigid.cpp:24-40 */
+    b.mass = b.size[0] * b.size[1] * b.size[2] * density;
+    b.invMass = (b.mass > 0.0f) ? 1.0f / b.mass : 0.0f;
+    b.radius = sqrtf(b.size[0] * b.size[0] + b.size[1] * b.size[1] + b.size[2] * b.size[2]) * 0.5f;
+    for (int k = 0; k < 9; ++k) { I9[k] = 0.0f; J9[k] = 0.0f; }
+    if (b.invMass > 0.0f) {
+        float Ixx = (1.0f / 12.0f) * b.mass * (b.size[1] * b.size[1] + b.size[2] * b.size[2]);
+        float Iyy = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[2] * b.size[2]);
+        float Izz = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[1] * b.size[1]);
+        I9[0] = Ixx; I9[4] = Iyy; I9[8] = Izz;
+        J9[0] = 1.0f / Ixx; J9[4] = 1.0f / Iyy; J9[8] = 1.0f / Izz;
+    }
+}
+
+/* host-side quaternion helpers for Joint construction (joint.cpp:17-20, 46-52) — same
+ * expression trees as avbd_math.h (that header is host/device) */
+f3 H3(const float* p) { return mk3(p[0], p[1], p[2]); }
+q4 HQ(const float* p) { return mkq(p[0], p[1], p[2], p[3]); }
+
+} // namespace
+
+/* ========================================================================================== */
+extern "C" {
+
+int avbd_abi_version(void) { return AVBD_ABI_VERSION; }
+
+int avbd_default_params(AvbdParams* p)
+{
+    if (!p) return AVBD_E_INVALID;
+    p->dt = 1.0f / 60.0f; p->gravity[0] = 0.0f; p->gravity[1] = -10.0f; p->gravity[2] = 0.0f;
+    p->iterations = 10; p->alpha = 0.95f; p->beta = 100000.0f; p->gamma = 0.99f; p->postStabilize = 0;
+    return AVBD_OK;
+}
+
+int avbd_create(int device, AvbdContext** out)
+{
+    if (!out) return AVBD_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return AVBD_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return AVBD_E_NODEVICE;
+    AvbdContext* c = new AvbdContext();
+    c->device = device;
+    avbd_default_params(&c->params);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    if (hipHostMalloc((void**)&c->hRb, sizeof(Readback), hipHostMallocDefault) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    std::memset(c->hRb, 0, sizeof(Readback));
+    if (c->dCnt.alloc(1) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    (void)hipMemset(c->dCnt.p, 0, sizeof(Counters));
+    (void)hipMemset(c->dDiag.p, 0, sizeof(DiagAccum));
+    (void)hipMemset(c->dNext.p, 0, sizeof(int));
+    if (ensure_capacity(c, 0) != AVBD_OK || ensure_topology_capacity(c) != AVBD_OK) { delete c; return AVBD_E_HIP; }
+    *out = c;
+    return AVBD_OK;
+}
+
+int avbd_destroy(AvbdContext* c)
+{
+    if (!c) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->evPool) (void)hipEventDestroy(e);
+    c->dPlanes.release(); c->mbuf[0].release(); c->mbuf[1].release(); c->dG.release();
+    c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
+    c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
+    c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release();
+    if (c->hRb) (void)hipHostFree(c->hRb);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return AVBD_OK;
+}
+
+const char* avbd_last_error(const AvbdContext* c) { return c ? c->err.c_str() : "null context"; }
+
+int avbd_set_params(AvbdContext* c, const AvbdParams* p)
+{
+    if (!c || !p) return AVBD_E_INVALID;
+    c->params = *p;
+    return AVBD_OK;
+}
+
+int avbd_get_params(const AvbdContext* c, AvbdParams* p)
+{
+    if (!c || !p) return AVBD_E_INVALID;
+    *p = c->params;
+    return AVBD_OK;
+}
+
+int avbd_clear(AvbdContext* c)
+{
+    if (!c) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hBodies.clear(); c->hI.clear(); c->hJ.clear(); c->hG.clear();
+    c->bodiesStale = true; c->deviceAhead = false; c->gStale = true; c->gDeviceAhead = false; c->adjDirty = true;
+    c->stepIndex = 0; c->hostKeyCounter = 1;
+    c->stats = AvbdStepStats{};
+    HIPCHK(c, hipMemset(c->dCnt.p, 0, sizeof(Counters)));
+    HIPCHK(c, hipMemset(c->dDiag.p, 0, sizeof(DiagAccum)));
+    return AVBD_OK;
+}
+
+int avbd_add_bodies(AvbdContext* c, int n, const float* size, const float* density, const float* friction, const float* position,
+                    const float* orientation, const float* linearVelocity, const float* angularVelocity, int* first_index)
+{
+    if (!c || n < 0 || (n && (!size || !density || !friction || !position))) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    const int first = (int)c->hBodies.size();
+    if (first + n > (1 << 20) - 2) return c->fail(AVBD_E_INVALID, "more than 2^20-2 bodies");
+    for (int i = 0; i < n; ++i) {
+        AvbdBody b;
+        std::memset(&b, 0, sizeof(b));
+        for (int k = 0; k < 3; ++k) {
+            b.size[k] = size[3 * i + k]; b.position[k] = position[3 * i + k];
+            b.linearVelocity[k] = linearVelocity ? linearVelocity[3 * i + k] : 0.0f;
+            b.angularVelocity[k] = angularVelocity ? angularVelocity[3 * i + k] : 0.0f;
+            b.prevLinearVelocity[k] = b.linearVelocity[k]; b.prevAngularVelocity[k] = b.angularVelocity[k];
+        }
+        for (int k = 0; k < 4; ++k) b.orientation[k] = orientation ? orientation[4 * i + k] : (k == 3 ? 1.0f : 0.0f);
+        b.initialOrientation[3] = 1.0f; b.inertialOrientation[3] = 1.0f;
+        b.friction = friction[i];
+        float I9[9], J9[9];
+        box_mass_properties(b, density[i], I9, J9);
+        c->hBodies.push_back(b);
+        c->hI.insert(c->hI.end(), I9, I9 + 9);
+        c->hJ.insert(c->hJ.end(), J9, J9 + 9);
+    }
+    if (first_index) *first_index = first;
+    c->bodiesStale = true;
+    c->adjDirty = true;
+    return AVBD_OK;
+}
+
+static int add_gforce(AvbdContext* c, const GForce& g)
+{
+    int rc = gforces_to_host(c);
+    if (rc) return rc;
+    c->hG.push_back(g);
+    c->hG.back().key = make_host_key(c->stepIndex, c->hostKeyCounter++);
+    c->gStale = true;
+    c->adjDirty = true;
+    return AVBD_OK;
+}
+
+static void init_gforce(GForce& g, int kind, int a, int b)
+{
+    std::memset(&g, 0, sizeof(g));
+    g.kind = kind; g.bodyA = a; g.bodyB = b;
+    g.q0[3] = 1.0f;
+    for (int i = 0; i < 6; ++i) { g.fmin[i] = -FLT_MAX; g.fmax[i] = FLT_MAX; } /* force.cpp:32-40 */
+}
+
+int avbd_add_joint(AvbdContext* c, int bodyA, int bodyB, const float rA[3], const float rB[3], float linearStiffness, float angularStiffness)
+{
+    if (!c || !rA) return AVBD_E_INVALID;
+    const int n = (int)c->hBodies.size();
+    if (bodyB < 0 || bodyB >= n || bodyA >= n || bodyA < -1) return c->fail(AVBD_E_INVALID, "joint body index out of range");
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    GForce g; init_gforce(g, FK_JOINT, bodyA, bodyB);
+    const AvbdBody& B = c->hBodies[bodyB];
+    if (bodyA >= 0) {               /* joint.cpp:11-39 */
+        if (!rB) return AVBD_E_INVALID;
+        for (int k = 0; k < 3; ++k) { g.rA[k] = rA[k]; g.rB[k] = rB[k]; }
+        q4 q = qconj(HQ(c->hBodies[bodyA].orientation)) * HQ(B.orientation);
+        g.q0[0] = q.x; g.q0[1] = q.y; g.q0[2] = q.z; g.q0[3] = q.w;
+    } else {                        /* joint.cpp:42-61 */
+        for (int k = 0; k < 3; ++k) g.rA[k] = rA[k];
+        f3 r = mtranspose(quat_to_mat(HQ(B.orientation))) * (H3(rA) - H3(B.position));
+        g.rB[0] = r.x; g.rB[1] = r.y; g.rB[2] = r.z;
+        for (int k = 0; k < 4; ++k) g.q0[k] = B.orientation[k];
+    }
+    for (int i = 0; i < 3; ++i) { g.stiffness[i] = linearStiffness; g.lambda[i] = 0; g.penalty[i] = kPenaltyMin; }
+    for (int i = 3; i < 6; ++i) { g.stiffness[i] = angularStiffness; g.lambda[i] = 0; g.penalty[i] = kPenaltyMin; }
+    return add_gforce(c, g);
+}
+
+int avbd_add_spring(AvbdContext* c, int bodyA, int bodyB, const float rA[3], const float rB[3], float stiffness, float rest)
+{
+    if (!c || !rA || !rB) return AVBD_E_INVALID;
+    const int n = (int)c->hBodies.size();
+    if (bodyA < 0 || bodyA >= n || bodyB < 0 || bodyB >= n) return c->fail(AVBD_E_INVALID, "spring body index out of range");
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    GForce g; init_gforce(g, FK_SPRING, bodyA, bodyB);
+    for (int k = 0; k < 3; ++k) { g.rA[k] = rA[k]; g.rB[k] = rB[k]; }
+    g.restLength = rest;
+    g.stiffness[0] = stiffness;     /* spring.cpp:16 */
+    if (g.restLength < 0) {         /* spring.cpp:19-23 */
+        const AvbdBody& A = c->hBodies[bodyA]; const AvbdBody& B = c->hBodies[bodyB];
+        f3 pA = H3(A.position) + qrotate(HQ(A.orientation), H3(rA));
+        f3 pB = H3(B.position) + qrotate(HQ(B.orientation), H3(rB));
+        g.restLength = len3(pA - pB);
+    }
+    g.lambda[0] = 0.0f; g.penalty[0] = kPenaltyMin;
+    return add_gforce(c, g);
+}
+
+int avbd_add_ignore(AvbdContext* c, int bodyA, int bodyB)
+{
+    if (!c) return AVBD_E_INVALID;
+    const int n = (int)c->hBodies.size();
+    if (bodyA < 0 || bodyA >= n || bodyB < 0 || bodyB >= n) return c->fail(AVBD_E_INVALID, "ignore body index out of range");
+    GForce g; init_gforce(g, FK_IGNORE, bodyA, bodyB);
+    return add_gforce(c, g);
+}
+
+int avbd_add_force(AvbdContext* c, const AvbdForce* r)
+{
+    if (!c || !r) return AVBD_E_INVALID;
+    const int n = (int)c->hBodies.size();
+    if (r->kind != AVBD_FORCE_JOINT && r->kind != AVBD_FORCE_SPRING && r->kind != AVBD_FORCE_IGNORE)
+        return c->fail(AVBD_E_INVALID, "avbd_add_force: only Joint / Spring / IgnoreCollision can be host-created");
+    if (r->bodyB < 0 || r->bodyB >= n || r->bodyA >= n || r->bodyA < -1) return c->fail(AVBD_E_INVALID, "force body index out of range");
+    (void)hipSetDevice(c->device);
+    GForce g; init_gforce(g, r->kind, r->bodyA, r->bodyB);
+    for (int i = 0; i < 6; ++i) {
+        g.C[i] = r->C[i]; g.fmin[i] = r->fmin[i]; g.fmax[i] = r->fmax[i]; g.lambda[i] = r->lambda[i];
+        g.penalty[i] = r->penalty[i]; g.stiffness[i] = r->stiffness[i]; g.motor[i] = r->motor[i];
+    }
+    for (int k = 0; k < 3; ++k) { g.rA[k] = r->rA[k]; g.rB[k] = r->rB[k]; }
+    for (int k = 0; k < 4; ++k) g.q0[k] = r->q0[k];
+    g.restLength = r->restLength;
+    return add_gforce(c, g);
+}
+
+int avbd_step(AvbdContext* c, int nsteps)
+{
+    if (!c || nsteps < 0) return AVBD_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(AVBD_E_NODEVICE, "hipSetDevice failed");
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = step_once(c);
+        if (rc) return rc;
+    }
+    return AVBD_OK;
+}
+
+int avbd_synchronize(AvbdContext* c)
+{
+    if (!c) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AVBD_OK;
+}
+
+int avbd_step_index(const AvbdContext* c) { return c ? c->stepIndex : AVBD_E_INVALID; }
+
+int avbd_get_diagnostics(AvbdContext* c, AvbdDiagnostics* out)
+{
+    if (!c || !out) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    DiagAccum d;
+    HIPCHK(c, hipMemcpyAsync(&d, c->dDiag.p, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto f = [](unsigned u) { float v; std::memcpy(&v, &u, 4); return v; };
+    out->maxPenetration = f(d.maxPenetration); out->maxConstraintViolation = f(d.maxViolation);
+    out->maxLinearSpeed = f(d.maxLinearSpeed); out->maxAngularSpeed = f(d.maxAngularSpeed); out->maxNormalImpulse = f(d.maxNormalImpulse);
+    out->activeContacts = d.activeContacts; out->activeManifolds = d.activeManifolds; out->dynamicBodies = d.dynamicBodies;
+    return AVBD_OK;
+}
+
+int avbd_get_step_stats(AvbdContext* c, AvbdStepStats* out)
+{
+    if (!c || !out) return AVBD_E_INVALID;
+    *out = c->stats;
+    out->warnings = c->hRb ? c->hRb->cnt.warnings : 0;
+    return AVBD_OK;
+}
+
+int avbd_num_bodies(const AvbdContext* c) { return c ? (int)c->hBodies.size() : AVBD_E_INVALID; }
+
+int avbd_download_bodies(AvbdContext* c, AvbdBody* out, int capacity)
+{
+    if (!c || (!out && capacity > 0)) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    const int n = std::min(capacity, (int)c->hBodies.size());
+    if (n > 0) std::memcpy(out, c->hBodies.data(), (size_t)n * sizeof(AvbdBody));
+    return n;
+}
+
+int avbd_download_state13(AvbdContext* c, float* out, int capacity)
+{
+    if (!c || (!out && capacity > 0)) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    const int n = std::min(capacity, (int)c->hBodies.size());
+    for (int i = 0; i < n; ++i) {
+        const AvbdBody& b = c->hBodies[i];
+        float* o = out + 13 * (size_t)i;
+        std::memcpy(o, b.position, 12); std::memcpy(o + 3, b.orientation, 16);
+        std::memcpy(o + 7, b.linearVelocity, 12); std::memcpy(o + 10, b.angularVelocity, 12);
+    }
+    return n;
+}
+
+int avbd_upload_state13(AvbdContext* c, const float* in, int n)
+{
+    if (!c || !in || n < 0 || n > (int)c->hBodies.size()) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        AvbdBody& b = c->hBodies[i];
+        const float* o = in + 13 * (size_t)i;
+        std::memcpy(b.position, o, 12); std::memcpy(b.orientation, o + 3, 16);
+        std::memcpy(b.linearVelocity, o + 7, 12); std::memcpy(b.angularVelocity, o + 10, 12);
+    }
+    c->bodiesStale = true;
+    return AVBD_OK;
+}
+
+int avbd_upload_bodies(AvbdContext* c, const AvbdBody* in, int n)
+{
+    if (!c || !in || n < 0 || n > (int)c->hBodies.size()) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        AvbdBody& b = c->hBodies[i];
+        const AvbdBody& s = in[i];
+        std::memcpy(b.position, s.position, sizeof(float) * 33); /* all dynamic members; static ones keep the ctor values */
+    }
+    c->bodiesStale = true;
+    return AVBD_OK;
+}
+
+/* ---- forces --------------------------------------------------------------------------- */
+namespace {
+struct HostManifolds {
+    int n = 0;
+    std::vector<int2> pair; std::vector<uint64_t> key; std::vector<int> nc; std::vector<float> fric;
+    std::vector<float4> cRA, cRB, cN, cLam, cPen, cC, cFmin, cFmax; std::vector<int2> cFS;
+};
+
+int fetch_manifolds(AvbdContext* c, HostManifolds& h)
+{
+    Counters cnt;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->dCnt.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = cnt.numManifolds;
+    h.n = n;
+    if (!n) return AVBD_OK;
+    ManifoldBuf& b = c->mbuf[c->cur];
+    h.pair.resize(n); h.key.resize(n); h.nc.resize(n); h.fric.resize(n);
+    size_t k = (size_t)n * 4;
+    h.cRA.resize(k); h.cRB.resize(k); h.cN.resize(k); h.cLam.resize(k); h.cPen.resize(k); h.cC.resize(k); h.cFmin.resize(k); h.cFmax.resize(k); h.cFS.resize(k);
+    HIPCHK(c, hipMemcpy(h.pair.data(), b.pair.p, n * sizeof(int2), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.key.data(), b.key.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.nc.data(), b.nc.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.fric.data(), b.fric.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cRA.data(), b.cRA.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cRB.data(), b.cRB.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cN.data(), b.cN.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cLam.data(), b.cLam.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cPen.data(), b.cPen.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cC.data(), b.cC.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cFmin.data(), b.cFmin.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cFmax.data(), b.cFmax.p, k * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.cFS.data(), b.cFS.p, k * sizeof(int2), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
+struct ForceRef { uint64_t key; int kind; int index; };
+
+int sorted_force_refs(AvbdContext* c, HostManifolds& hm, std::vector<ForceRef>& refs)
+{
+    int rc = fetch_manifolds(c, hm);
+    if (rc) return rc;
+    if ((rc = gforces_to_host(c))) return rc;
+    refs.clear();
+    for (int m = 0; m < hm.n; ++m) refs.push_back({hm.key[m], FK_MANIFOLD, m});
+    for (size_t g = 0; g < c->hG.size(); ++g) refs.push_back({c->hG[g].key, c->hG[g].kind, (int)g});
+    std::sort(refs.begin(), refs.end(), [](const ForceRef& a, const ForceRef& b) { return a.key > b.key; });
+    return AVBD_OK;
+}
+} // namespace
+
+int avbd_num_forces(AvbdContext* c)
+{
+    if (!c) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    Counters cnt;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->dCnt.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return cnt.numManifolds + (int)c->hG.size();
+}
+
+int avbd_download_forces(AvbdContext* c, AvbdForce* out, int capacity)
+{
+    if (!c || (!out && capacity > 0)) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HostManifolds hm; std::vector<ForceRef> refs;
+    int rc = sorted_force_refs(c, hm, refs);
+    if (rc) return rc;
+    const int n = std::min(capacity, (int)refs.size());
+    for (int i = 0; i < n; ++i) {
+        AvbdForce& o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        for (int r = 0; r < 12; ++r) { o.fmin[r] = -FLT_MAX; o.fmax[r] = FLT_MAX; }
+        o.kind = refs[i].kind;
+        if (refs[i].kind == FK_MANIFOLD) {
+            const int m = refs[i].index;
+            o.bodyA = hm.pair[m].x; o.bodyB = hm.pair[m].y; o.numContacts = hm.nc[m]; o.rows = 3 * hm.nc[m];
+            o.combinedFriction = hm.fric[m];
+            for (int ci = 0; ci < hm.nc[m]; ++ci) {
+                const size_t s = (size_t)m * 4 + ci;
+                AvbdContact& d = o.contacts[ci];
+                d.feature = hm.cFS[s].x; d.stick = hm.cFS[s].y;
+                d.rA[0] = hm.cRA[s].x; d.rA[1] = hm.cRA[s].y; d.rA[2] = hm.cRA[s].z; d.C0_n = hm.cRA[s].w;
+                d.rB[0] = hm.cRB[s].x; d.rB[1] = hm.cRB[s].y; d.rB[2] = hm.cRB[s].z; d.C0_t[0] = hm.cRB[s].w;
+                d.normal[0] = hm.cN[s].x; d.normal[1] = hm.cN[s].y; d.normal[2] = hm.cN[s].z; d.C0_t[1] = hm.cN[s].w; d.C0_t[2] = 0.0f;
+                d.penetration = hm.cLam[s].w;
+                const float lam[3] = {hm.cLam[s].x, hm.cLam[s].y, hm.cLam[s].z}, pen[3] = {hm.cPen[s].x, hm.cPen[s].y, hm.cPen[s].z};
+                const float C[3] = {hm.cC[s].x, hm.cC[s].y, hm.cC[s].z}, lo[3] = {hm.cFmin[s].x, hm.cFmin[s].y, hm.cFmin[s].z};
+                const float hi[3] = {hm.cFmax[s].x, hm.cFmax[s].y, hm.cFmax[s].z};
+                for (int k = 0; k < 3; ++k) {
+                    const int r = ci * 3 + k;
+                    o.lambda[r] = lam[k]; o.penalty[r] = pen[k]; o.C[r] = C[k]; o.fmin[r] = lo[k]; o.fmax[r] = hi[k];
+                    o.stiffness[r] = FLT_MAX; o.motor[r] = 0.0f;
+                }
+            }
+        } else {
+            const GForce& g = c->hG[refs[i].index];
+            o.bodyA = g.bodyA; o.bodyB = g.bodyB; o.rows = force_row_count(g.kind, 0);
+            for (int r = 0; r < 6; ++r) {
+                o.C[r] = g.C[r]; o.fmin[r] = g.fmin[r]; o.fmax[r] = g.fmax[r]; o.lambda[r] = g.lambda[r];
+                o.penalty[r] = g.penalty[r]; o.stiffness[r] = g.stiffness[r]; o.motor[r] = g.motor[r];
+            }
+            for (int k = 0; k < 3; ++k) { o.rA[k] = g.rA[k]; o.rB[k] = g.rB[k]; }
+            for (int k = 0; k < 4; ++k) o.q0[k] = g.q0[k];
+            o.restLength = g.restLength;
+        }
+    }
+    return n;
+}
+
+int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
+{
+    if (!c || (!in && n > 0) || n < 0) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload_bodies_if_stale(c))) return rc;
+    int nm = 0;
+    for (int i = 0; i < n; ++i) nm += in[i].kind == AVBD_FORCE_MANIFOLD;
+    if (nm > c->mCap) return c->fail(AVBD_E_CAPACITY, "manifold pool too small for upload");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HostManifolds h;
+    h.n = nm;
+    h.pair.resize(nm); h.key.resize(nm); h.nc.resize(nm); h.fric.resize(nm);
+    size_t k4 = (size_t)nm * 4;
+    h.cRA.assign(k4, make_float4(0, 0, 0, 0)); h.cRB = h.cRA; h.cN = h.cRA; h.cLam = h.cRA; h.cPen = h.cRA; h.cC = h.cRA; h.cFmin = h.cRA; h.cFmax = h.cRA;
+    h.cFS.assign(k4, make_int2(0, 0));
+    c->hG.clear();
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const AvbdForce& f = in[i];
+        const uint64_t key = make_host_key(0, (uint64_t)(n - i)); /* newest first → descending keys */
+        if (f.kind == AVBD_FORCE_MANIFOLD) {
+            h.pair[m] = make_int2(f.bodyA, f.bodyB); h.key[m] = key; h.nc[m] = f.numContacts; h.fric[m] = f.combinedFriction;
+            for (int ci = 0; ci < f.numContacts; ++ci) {
+                const size_t s = (size_t)m * 4 + ci;
+                const AvbdContact& d = f.contacts[ci];
+                h.cRA[s] = make_float4(d.rA[0], d.rA[1], d.rA[2], d.C0_n);
+                h.cRB[s] = make_float4(d.rB[0], d.rB[1], d.rB[2], d.C0_t[0]);
+                h.cN[s] = make_float4(d.normal[0], d.normal[1], d.normal[2], d.C0_t[1]);
+                h.cLam[s] = make_float4(f.lambda[ci * 3], f.lambda[ci * 3 + 1], f.lambda[ci * 3 + 2], d.penetration);
+                h.cPen[s] = make_float4(f.penalty[ci * 3], f.penalty[ci * 3 + 1], f.penalty[ci * 3 + 2], 0.f);
+                h.cC[s] = make_float4(f.C[ci * 3], f.C[ci * 3 + 1], f.C[ci * 3 + 2], 0.f);
+                h.cFmin[s] = make_float4(f.fmin[ci * 3], f.fmin[ci * 3 + 1], f.fmin[ci * 3 + 2], 0.f);
+                h.cFmax[s] = make_float4(f.fmax[ci * 3], f.fmax[ci * 3 + 1], f.fmax[ci * 3 + 2], 0.f);
+                h.cFS[s] = make_int2(d.feature, d.stick);
+            }
+            ++m;
+        } else {
+            GForce g; init_gforce(g, f.kind, f.bodyA, f.bodyB);
+            g.key = key;
+            for (int r = 0; r < 6; ++r) {
+                g.C[r] = f.C[r]; g.fmin[r] = f.fmin[r]; g.fmax[r] = f.fmax[r]; g.lambda[r] = f.lambda[r];
+                g.penalty[r] = f.penalty[r]; g.stiffness[r] = f.stiffness[r]; g.motor[r] = f.motor[r];
+            }
+            for (int k = 0; k < 3; ++k) { g.rA[k] = f.rA[k]; g.rB[k] = f.rB[k]; }
+            for (int k = 0; k < 4; ++k) g.q0[k] = f.q0[k];
+            g.restLength = f.restLength;
+            c->hG.push_back(g);
+        }
+    }
+    c->hostKeyCounter = (uint64_t)n + 1;
+    ManifoldBuf& b = c->mbuf[c->cur];
+    if (nm) {
+        HIPCHK(c, hipMemcpy(b.pair.p, h.pair.data(), nm * sizeof(int2), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.key.p, h.key.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.nc.p, h.nc.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.fric.p, h.fric.data(), nm * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cRA.p, h.cRA.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cRB.p, h.cRB.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cN.p, h.cN.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cLam.p, h.cLam.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cPen.p, h.cPen.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cC.p, h.cC.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cFmin.p, h.cFmin.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cFmax.p, h.cFmax.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cFS.p, h.cFS.data(), k4 * sizeof(int2), hipMemcpyHostToDevice));
+    }
+    Counters cnt;
+    std::memset(&cnt, 0, sizeof(cnt));
+    cnt.numManifolds = nm;
+    HIPCHK(c, hipMemcpy(c->dCnt.p, &cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    c->stats.numManifolds = nm;
+    c->gStale = true; c->gDeviceAhead = false; c->adjDirty = true;
+    return AVBD_OK;
+}
+
+/* ---- row API on the device ------------------------------------------------------------- */
+namespace {
+__global__ void k_row_api(BodyTable B, ManifoldTable M, GForce* gf, int kind, int index, float alpha, int mode, int body, int row, float* out)
+{
+    /* out: mode 0 → C[12] fmin[12] fmax[12] lambda[12]; mode 1 → Jl[3] Ja[3] */
+    if (threadIdx.x != 0) return;
+    if (kind == FK_MANIFOLD) {
+        const int2 pr = M.pair[index];
+        const f3 posA = ld3(B.plane(BP_POSR), pr.x), posB = ld3(B.plane(BP_POSR), pr.y);
+        const q4 rotA = ldq(B.plane(BP_QUAT), pr.x), rotB = ldq(B.plane(BP_QUAT), pr.y);
+        const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
+        const int nc = M.nc[index];
+        for (int ci = 0; ci < nc; ++ci) {
+            if (mode == 1 && ci != row / 3) continue;
+            const int s = index * 4 + ci;
+            ContactRows c;
+            float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s], lam = M.cLam[s], pen = M.cPen[s];
+            c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w; c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
+            c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
+            c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
+            c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z; c.stick = M.cFS[s].y != 0;
+            if (mode == 0) {
+                contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[index]);
+                M.cN[s] = pack3(c.normal, c.C0t2);
+                M.cLam[s] = make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration);
+                M.cFS[s].y = c.stick ? 1 : 0;
+                M.cC[s] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
+                M.cFmin[s] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
+                M.cFmax[s] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
+                for (int k = 0; k < 3; ++k) { out[ci * 3 + k] = c.C[k]; out[12 + ci * 3 + k] = c.fmin[k]; out[24 + ci * 3 + k] = c.fmax[k]; out[36 + ci * 3 + k] = c.lambda[k]; }
+            } else {
+                const bool isA = body == pr.x;
+                f3 Jl[3], Ja[3];
+                contact_compute_derivatives(c, isA, isA ? rotA : rotB, Jl, Ja);
+                const int k = row % 3;
+                out[0] = Jl[k].x; out[1] = Jl[k].y; out[2] = Jl[k].z; out[3] = Ja[k].x; out[4] = Ja[k].y; out[5] = Ja[k].z;
+            }
+        }
+    } else if (kind == FK_JOINT || kind == FK_SPRING) {
+        GForce& f = gf[index];
+        const bool hasA = f.bodyA >= 0;
+        f3 posA = zero3(); q4 rotA = identq();
+        if (hasA) { posA = ld3(B.plane(BP_POSR), f.bodyA); rotA = ldq(B.plane(BP_QUAT), f.bodyA); }
+        f3 posB = ld3(B.plane(BP_POSR), f.bodyB); q4 rotB = ldq(B.plane(BP_QUAT), f.bodyB);
+        const bool isA = body == f.bodyA;
+        if (kind == FK_JOINT) {
+            JointRows j;
+            j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+            if (mode == 0) {
+                joint_compute_constraint(j, hasA, posA, rotA, posB, rotB);
+                for (int r = 0; r < 6; ++r) { f.C[r] = j.C[r]; f.fmin[r] = -FLT_MAX; f.fmax[r] = FLT_MAX; out[r] = j.C[r]; out[12 + r] = -FLT_MAX; out[24 + r] = FLT_MAX; out[36 + r] = f.lambda[r]; }
+            } else {
+                f3 Jl, Ja;
+                joint_compute_derivatives(j, isA, isA && !hasA, isA ? rotA : rotB, row, Jl, Ja);
+                out[0] = Jl.x; out[1] = Jl.y; out[2] = Jl.z; out[3] = Ja.x; out[4] = Ja.y; out[5] = Ja.z;
+            }
+        } else {
+            SpringRows s;
+            s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
+            if (mode == 0) {
+                spring_compute_constraint(s, hasA, posA, rotA, posB, rotB);
+                f.C[0] = s.C; out[0] = s.C; out[12] = f.fmin[0]; out[24] = f.fmax[0]; out[36] = f.lambda[0];
+            } else {
+                f3 Jl, Ja;
+                spring_compute_derivatives(s, isA, hasA, posA, rotA, posB, rotB, Jl, Ja);
+                out[0] = Jl.x; out[1] = Jl.y; out[2] = Jl.z; out[3] = Ja.x; out[4] = Ja.y; out[5] = Ja.z;
+            }
+        }
+    }
+}
+
+int resolve_force(AvbdContext* c, int force_index, ForceRef& ref, HostManifolds& hm)
+{
+    std::vector<ForceRef> refs;
+    int rc = sorted_force_refs(c, hm, refs);
+    if (rc) return rc;
+    if (force_index < 0 || force_index >= (int)refs.size()) return c->fail(AVBD_E_INVALID, "force index out of range");
+    ref = refs[force_index];
+    return AVBD_OK;
+}
+} // namespace
+
+int avbd_force_row_count(AvbdContext* c, int force_index, int* rows)
+{
+    if (!c || !rows) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    ForceRef ref; HostManifolds hm;
+    int rc = resolve_force(c, force_index, ref, hm);
+    if (rc) return rc;
+    *rows = force_row_count(ref.kind, ref.kind == FK_MANIFOLD ? hm.nc[ref.index] : 0);
+    return AVBD_OK;
+}
+
+static int run_row_api(AvbdContext* c, int force_index, float alpha, int mode, int body, int row, float* host_out, int nfloats)
+{
+    int rc;
+    if ((rc = upload_bodies_if_stale(c))) return rc;
+    ForceRef ref; HostManifolds hm;
+    if ((rc = resolve_force(c, force_index, ref, hm))) return rc;
+    if ((rc = upload_gforces_if_stale(c))) return rc;
+    DevArr<float> d;
+    HIPCHK(c, d.alloc(48));
+    HIPCHK(c, hipMemset(d.p, 0, 48 * sizeof(float)));
+    hipLaunchKernelGGL(k_row_api, dim3(1), dim3(64), 0, c->stream, body_table(c), c->mbuf[c->cur].view(), c->dG.p, ref.kind, ref.index, alpha, mode, body, row, d.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(host_out, d.p, nfloats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    d.release();
+    if (ref.kind != FK_MANIFOLD) c->gDeviceAhead = true;
+    return AVBD_OK;
+}
+
+int avbd_force_compute_constraint(AvbdContext* c, int force_index, float alpha, float* C, float* fmin, float* fmax, float* lambda)
+{
+    if (!c) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    float buf[48];
+    int rc = run_row_api(c, force_index, alpha, 0, -1, 0, buf, 48);
+    if (rc) return rc;
+    if (C) std::memcpy(C, buf, 48); if (fmin) std::memcpy(fmin, buf + 12, 48);
+    if (fmax) std::memcpy(fmax, buf + 24, 48); if (lambda) std::memcpy(lambda, buf + 36, 48);
+    return AVBD_OK;
+}
+
+int avbd_force_compute_derivatives(AvbdContext* c, int force_index, int body, int row, float J_linear[3], float J_angular[3])
+{
+    if (!c || !J_linear || !J_angular) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    float buf[48];
+    int rc = run_row_api(c, force_index, 0.0f, 1, body, row, buf, 6);
+    if (rc) return rc;
+    std::memcpy(J_linear, buf, 12); std::memcpy(J_angular, buf + 3, 12);
+    return AVBD_OK;
+}
+
+/* ---- known-answer entry points ---------------------------------------------------------- */
+int avbd_kat_collide(AvbdContext* c, int n, const float* posA, const float* quatA, const float* sizeA, const float* posB, const float* quatB,
+                     const float* sizeB, AvbdContact* out, int* counts)
+{
+    if (!c || n < 0) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    DevArr<float> dpA, dqA, dsA, dpB, dqB, dsB; DevArr<KatContact> dout; DevArr<int> dcnt;
+    HIPCHK(c, dpA.alloc(3 * n)); HIPCHK(c, dqA.alloc(4 * n)); HIPCHK(c, dsA.alloc(3 * n));
+    HIPCHK(c, dpB.alloc(3 * n)); HIPCHK(c, dqB.alloc(4 * n)); HIPCHK(c, dsB.alloc(3 * n));
+    HIPCHK(c, dout.alloc(4 * n)); HIPCHK(c, dcnt.alloc(n));
+    HIPCHK(c, hipMemcpy(dpA.p, posA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dqA.p, quatA, 16 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dsA.p, sizeA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dpB.p, posB, 12 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dqB.p, quatB, 16 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dsB.p, sizeB, 12 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(dout.p, 0, sizeof(KatContact) * 4 * n));
+    hipLaunchKernelGGL(k_kat_collide, dim3(grid_for(n, 64, 1 << 20)), dim3(64), 0, c->stream, n, dpA.p, dqA.p, dsA.p, dpB.p, dqB.p, dsB.p, dout.p, dcnt.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    static_assert(sizeof(KatContact) == sizeof(AvbdContact), "contact record layout");
+    HIPCHK(c, hipMemcpy(out, dout.p, sizeof(AvbdContact) * 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(counts, dcnt.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    dpA.release(); dqA.release(); dsA.release(); dpB.release(); dqB.release(); dsB.release(); dout.release(); dcnt.release();
+    return AVBD_OK;
+}
+
+int avbd_kat_solve6(AvbdContext* c, int n, const float* A, const float* b, float* x)
+{
+    if (!c || n < 0) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    DevArr<float> dA, db, dx;
+    HIPCHK(c, dA.alloc(36 * n)); HIPCHK(c, db.alloc(6 * n)); HIPCHK(c, dx.alloc(6 * n));
+    HIPCHK(c, hipMemcpy(dA.p, A, 144 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(db.p, b, 24 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_solve6, dim3(grid_for(n, 64, 1 << 20)), dim3(64), 0, c->stream, n, dA.p, db.p, dx.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(x, dx.p, 24 * n, hipMemcpyDeviceToHost));
+    dA.release(); db.release(); dx.release();
+    return AVBD_OK;
+}
+
+int avbd_kat_arith(AvbdContext* c, int n, const float* a, const float* b, float* od, float* os, float* om, float* oa)
+{
+    if (!c || n < 0) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    DevArr<float> da, db, d0, d1, d2, d3;
+    HIPCHK(c, da.alloc(n)); HIPCHK(c, db.alloc(n)); HIPCHK(c, d0.alloc(n)); HIPCHK(c, d1.alloc(n)); HIPCHK(c, d2.alloc(n)); HIPCHK(c, d3.alloc(n));
+    HIPCHK(c, hipMemcpy(da.p, a, 4 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(db.p, b, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_arith, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0, c->stream, n, da.p, db.p, d0.p, d1.p, d2.p, d3.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(od, d0.p, 4 * n, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(os, d1.p, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(om, d2.p, 4 * n, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(oa, d3.p, 4 * n, hipMemcpyDeviceToHost));
+    da.release(); db.release(); d0.release(); d1.release(); d2.release(); d3.release();
+    return AVBD_OK;
+}
+
+/* ---- measurement ------------------------------------------------------------------------ */
+int avbd_profile_enable(AvbdContext* c, int enable) { if (!c) return AVBD_E_INVALID; c->profiling = enable != 0; return AVBD_OK; }
+int avbd_profile_reset(AvbdContext* c) { if (!c) return AVBD_E_INVALID; c->prof = AvbdProfile{}; return AVBD_OK; }
+int avbd_profile_get(AvbdContext* c, AvbdProfile* out) { if (!c || !out) return AVBD_E_INVALID; *out = c->prof; return AVBD_OK; }
+void* avbd_stream(AvbdContext* c) { return c ? (void*)c->stream : nullptr; }
+
+} // extern "C"

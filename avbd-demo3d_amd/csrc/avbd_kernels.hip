@@ -1,0 +1,870 @@
+/*
+ * avbd_kernels.hip — gfx950 kernels for the phases of Solver::step() (solver.cpp:255-514).
+ *
+ *   K1  k_broadphase        solver.cpp:262-270   O(n^2) sphere test, LDS-tiled, + isConstrainedTo (rigid.cpp:61-69)
+ *   K2  k_narrowphase       manifold.cpp:71-175 + collision.cpp:420-489 + warm-start decay solver.cpp:281-293
+ *       k_gforce_prepare    same decay for Joint/Spring rows
+ *       k_scan / k_fill_adj / k_sort_expand / k_levels   — replace the intrusive lists of force.cpp
+ *   K4  k_predict           solver.cpp:299-337
+ *   K5  k_primal            solver.cpp:344-409   one wavefront per body, one Gauss-Seidel level per launch
+ *   K6  k_dual / k_dual_gforce   solver.cpp:411-430
+ *   K7  k_velocity          solver.cpp:434-469
+ *   K8  k_diag_contacts     solver.cpp:472-497
+ *
+ * Exactness: the primal sweep of the reference is sequential over bodies (newest first) and each
+ * body accumulates its rows force by force, row by row.  Here bodies are grouped into dependency
+ * levels (a body's level is 1 + the max level of its later-created dynamic neighbours), launched
+ * level by level, and inside a body the per-row contributions are computed by parallel lanes but
+ * ADDED in the reference's order by one lane per accumulator entry.  Results are bit-identical
+ * to the serial sweep.  No MFMA: there is no dense contraction on this path.
+ */
+#include "avbd_types.h"
+#include "avbd_rows.h"
+
+#pragma clang fp contract(off)
+
+namespace avbd {
+
+__device__ __forceinline__ f3 ld3(const float4* p, int i) { float4 v = p[i]; return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ q4 ldq(const float4* p, int i) { float4 v = p[i]; return mkq(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 pack3(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ float4 packq(q4 q) { return make_float4(q.x, q.y, q.z, q.w); }
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* max over non-negative floats through their uint bit patterns; NaNs are skipped */
+__device__ __forceinline__ void atomic_max_nonneg(unsigned* dst, float v)
+{
+    if (v == v) atomicMax(dst, __float_as_uint(v));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K1 broadphase.  Grid = T(T+1)/2 tiles of 256x256 (T = ceil(n/256)); tile (ti,tj), tj<=ti, tests
+ * bodies A in tile ti against bodies B in tile tj with B < A (A is the later-created body: it
+ * precedes B in the reference's list).  16 B per body staged in LDS.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_broadphase(BodyTable B, const int* __restrict__ adjStart, const int* __restrict__ adjOther,
+                                                     int2* cand, int candCap, Counters* cnt)
+{
+    __shared__ float4 sB[256];
+    const float4* posr = B.plane(BP_POSR);
+    const int n = B.n;
+    const int bid = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    while (ti * (ti + 1) / 2 > bid) --ti;
+    const int tj = bid - ti * (ti + 1) / 2;
+    const int i = ti * 256 + threadIdx.x;
+    const int j0 = tj * 256;
+    {
+        int j = j0 + threadIdx.x;
+        sB[threadIdx.x] = (j < n) ? posr[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (i >= n) return;
+    const float4 a = posr[i];
+    const f3 pa = mk3(a.x, a.y, a.z);
+    int jEnd = n - j0; if (jEnd > 256) jEnd = 256;
+    if (i - j0 < jEnd) jEnd = i - j0; /* only j < i */
+    for (int jj = 0; jj < jEnd; ++jj) {
+        const float4 b = sB[jj];
+        f3 dp = pa - mk3(b.x, b.y, b.z);
+        float r = a.w + b.w;
+        if (dot3(dp, dp) <= r * r) {
+            const int j = j0 + jj;
+            /* Rigid::isConstrainedTo: does any live force connect i and j?  scan the shorter list */
+            int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
+            int s, e, other;
+            if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
+            bool constrained = false;
+            for (int k = s; k < e; ++k) if (adjOther[k] == other) { constrained = true; break; }
+            if (!constrained) {
+                int slot = atomicAdd(&cnt->numCandidates, 1);
+                if (slot < candCap) cand[slot] = make_int2(i, j);
+                else atomicOr(&cnt->overflow, 1);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K2 narrow phase + Manifold::initialize + warm-start decay.  One lane per pair: last step's
+ * manifolds (src) followed by this step's candidates.  Survivors are appended to dst.
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ BoxPose load_box(const BodyTable& B, int i, float& friction, float& invMass)
+{
+    BoxPose p;
+    p.pos = ld3(B.plane(BP_POSR), i);
+    p.rot = ldq(B.plane(BP_QUAT), i);
+    float4 s = B.plane(BP_SIZE)[i];
+    p.size = mk3(s.x, s.y, s.z);
+    friction = s.w;
+    invMass = B.plane(BP_MASS)[i].y;
+    return p;
+}
+
+__global__ __launch_bounds__(128) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
+                                                      int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
+{
+    const int nOld = cnt->numManifolds;
+    int nCand = cnt->numCandidates; if (nCand > candCap) nCand = candCap;
+    const int total = nOld + nCand;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        ManifoldInit mi;
+        int a, b; uint64_t key;
+        if (item < nOld) {
+            int2 pr = src.pair[item]; a = pr.x; b = pr.y; key = src.key[item];
+            mi.numContacts = src.nc[item];
+            for (int c = 0; c < 4; ++c) {
+                if (c < mi.numContacts) {
+                    int s = item * 4 + c;
+                    float4 ra = src.cRA[s], rb = src.cRB[s], nn = src.cN[s], lam = src.cLam[s], pen = src.cPen[s];
+                    int2 fs = src.cFS[s];
+                    mi.feature[c] = fs.x; mi.stick[c] = fs.y != 0;
+                    mi.rA[c] = mk3(ra.x, ra.y, ra.z); mi.rB[c] = mk3(rb.x, rb.y, rb.z); mi.normal[c] = mk3(nn.x, nn.y, nn.z);
+                    mi.lambda[c * 3 + 0] = lam.x; mi.lambda[c * 3 + 1] = lam.y; mi.lambda[c * 3 + 2] = lam.z;
+                    mi.penalty[c * 3 + 0] = pen.x; mi.penalty[c * 3 + 1] = pen.y; mi.penalty[c * 3 + 2] = pen.z;
+                }
+            }
+        } else {
+            int2 pr = cand[item - nOld]; a = pr.x; b = pr.y;
+            key = make_manifold_key(step, a, b);
+            mi.numContacts = 0;
+        }
+        float fa, fb, ima, imb;
+        BoxPose A = load_box(B, a, fa, ima);
+        BoxPose Bp = load_box(B, b, fb, imb);
+        if (!manifold_initialize(mi, A, fa, Bp, fb)) continue;
+
+        /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
+        const int rows = mi.numContacts * 3;
+        for (int r = 0; r < 12; ++r) {
+            if (r < rows) {
+                if (!P.postStabilize) mi.lambda[r] *= P.alpha * P.gamma;
+                mi.penalty[r] = rclamp(mi.penalty[r] * P.gamma, kPenaltyMin, kPenaltyMax);
+            }
+        }
+
+        int slot = atomicAdd(nextCount, 1);
+        if (slot >= dst.cap) { atomicOr(&cnt->overflow, 2); continue; }
+        dst.pair[slot] = make_int2(a, b);
+        dst.key[slot] = key;
+        dst.nc[slot] = mi.numContacts;
+        dst.fric[slot] = mi.combinedFriction;
+        for (int c = 0; c < 4; ++c) {
+            if (c < mi.numContacts) {
+                int s = slot * 4 + c;
+                dst.cRA[s] = pack3(mi.rA[c], mi.C0n[c]);
+                dst.cRB[s] = pack3(mi.rB[c], mi.C0t1[c]);
+                dst.cN[s] = pack3(mi.normal[c], mi.C0t2[c]);
+                dst.cLam[s] = make_float4(mi.lambda[c * 3], mi.lambda[c * 3 + 1], mi.lambda[c * 3 + 2], mi.penetration[c]);
+                dst.cPen[s] = make_float4(mi.penalty[c * 3], mi.penalty[c * 3 + 1], mi.penalty[c * 3 + 2], 0.0f);
+                dst.cFS[s] = make_int2(mi.feature[c], mi.stick[c] ? 1 : 0);
+                dst.cC[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst.cFmin[s] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+                dst.cFmax[s] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+            }
+        }
+        atomicAdd(&degForce[a], 1);
+        atomicAdd(&degForce[b], 1);
+        int inc = 0;
+        if (ima > 0.0f) { atomicAdd(&degInc[a], mi.numContacts); inc += mi.numContacts; }
+        if (imb > 0.0f) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
+        atomicAdd(&cnt->numContacts, mi.numContacts);
+        atomicAdd(&cnt->numIncidences, inc);
+    }
+}
+
+/* Joint / Spring / IgnoreCollision: initialize() is a no-op returning true; apply the row decay
+ * (solver.cpp:281-293 incl. the finite-stiffness cap) and count adjacency degrees. */
+__global__ void k_gforce_prepare(BodyTable B, GForce* gf, int ng, int* degForce, int* degInc, SolverParams P, int decay)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    GForce& f = gf[g];
+    int rows = force_row_count(f.kind, 0);
+    if (decay) {
+        for (int r = 0; r < rows; ++r) {
+            if (!P.postStabilize) f.lambda[r] *= P.alpha * P.gamma;
+            f.penalty[r] = rclamp(f.penalty[r] * P.gamma, kPenaltyMin, kPenaltyMax);
+            if (f.stiffness[r] > 0.0f && f.stiffness[r] < FLT_MAX) f.penalty[r] = rmin(f.penalty[r], f.stiffness[r]);
+        }
+    }
+    int entries = f.kind == FK_JOINT ? 2 : (f.kind == FK_SPRING ? 1 : 0);
+    const float4* mass = B.plane(BP_MASS);
+    if (f.bodyA >= 0) { atomicAdd(&degForce[f.bodyA], 1); if (mass[f.bodyA].y > 0.0f) atomicAdd(&degInc[f.bodyA], entries); }
+    if (f.bodyB >= 0) { atomicAdd(&degForce[f.bodyB], 1); if (mass[f.bodyB].y > 0.0f) atomicAdd(&degInc[f.bodyB], entries); }
+}
+
+/* Exclusive scans of the two degree arrays (single workgroup; n+1 outputs each), and cursor reset. */
+__global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc, int* adjStart, int* incStart, Counters* cnt, const int* nextCount)
+{
+    __shared__ int sA[1024], sB[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = min(n, lo + chunk);
+    int a = 0, b = 0;
+    for (int i = lo; i < hi; ++i) { a += degForce[i]; b += degInc[i]; }
+    sA[t] = a; sB[t] = b;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int va = 0, vb = 0;
+        if (t >= off) { va = sA[t - off]; vb = sB[t - off]; }
+        __syncthreads();
+        sA[t] += va; sB[t] += vb;
+        __syncthreads();
+    }
+    int baseA = sA[t] - a, baseB = sB[t] - b;
+    for (int i = lo; i < hi; ++i) {
+        int da = degForce[i], db = degInc[i];
+        adjStart[i] = baseA; incStart[i] = baseB;
+        baseA += da; baseB += db;
+        degForce[i] = 0; degInc[i] = 0; /* become fill cursors */
+    }
+    if (t == 1023) { adjStart[n] = sA[1023]; incStart[n] = sB[1023]; }
+    if (t == 0) cnt->numManifolds = *nextCount;
+}
+
+__global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* gf, int ng, const int* adjStart, int* cursor,
+                           int* adjRef, int* adjOther, uint64_t* adjKey)
+{
+    const int nm = cnt->numManifolds;
+    const int total = nm + ng;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        int a, b, kind, index; uint64_t key;
+        if (item < nm) { int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; }
+        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = f.kind; index = item - nm; key = f.key; }
+        if (a >= 0) {
+            int pos = adjStart[a] + atomicAdd(&cursor[a], 1);
+            adjRef[pos] = make_inc(1, kind, index); adjOther[pos] = b; adjKey[pos] = key;
+        }
+        if (b >= 0) {
+            int pos = adjStart[b] + atomicAdd(&cursor[b], 1);
+            adjRef[pos] = make_inc(0, kind, index); adjOther[pos] = a; adjKey[pos] = key;
+        }
+    }
+}
+
+/* Per dynamic body: order its adjacency newest-first (= the reference's body->forces walk,
+ * force.cpp:21-29) and expand it into the row-incidence list consumed by k_primal. */
+__global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart, int* adjRef, int* adjOther, uint64_t* adjKey,
+                              const int* incStart, int* inc, int* level, int* cursor)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B.n) return;
+    cursor[b] = 0;
+    level[b] = 0;
+    if (!(B.plane(BP_MASS)[b].y > 0.0f)) return;
+    const int s = adjStart[b], e = adjStart[b + 1];
+    for (int i = s + 1; i < e; ++i) {
+        uint64_t k = adjKey[i]; int r = adjRef[i], o = adjOther[i];
+        int j = i - 1;
+        while (j >= s && adjKey[j] < k) { adjKey[j + 1] = adjKey[j]; adjRef[j + 1] = adjRef[j]; adjOther[j + 1] = adjOther[j]; --j; }
+        adjKey[j + 1] = k; adjRef[j + 1] = r; adjOther[j + 1] = o;
+    }
+    int o = incStart[b];
+    for (int i = s; i < e; ++i) {
+        int r = adjRef[i];
+        int kind = inc_kind(r), idx = inc_index(r), isA = inc_isA(r);
+        if (kind == FK_MANIFOLD) {
+            int nc = M.nc[idx];
+            for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c);
+        } else if (kind == FK_JOINT) {
+            inc[o++] = make_inc(isA, FK_JOINT, idx * 2);
+            inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1);
+        } else if (kind == FK_SPRING) {
+            inc[o++] = make_inc(isA, FK_SPRING, idx);
+        }
+    }
+}
+
+/* Dependency levels of the Gauss-Seidel sweep: level(b) = 1 + max level of dynamic neighbours
+ * created later than b (they precede b in the reference's body list).  Single workgroup. */
+__global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStart, const int* adjRef, const int* adjOther, int* level,
+                                                  int* lvlCount, int* lvlStart, int* order, Counters* cnt, int lvlCap)
+{
+    __shared__ int sChanged, sMax;
+    __shared__ int sScan[1024];
+    const int n = B.n, t = threadIdx.x;
+    const float4* mass = B.plane(BP_MASS);
+    for (int sweep = 0; sweep <= n; ++sweep) {
+        if (t == 0) sChanged = 0;
+        __syncthreads();
+        int changed = 0;
+        for (int b = t; b < n; b += 1024) {
+            if (!(mass[b].y > 0.0f)) continue;
+            int lv = 1;
+            for (int k = adjStart[b]; k < adjStart[b + 1]; ++k) {
+                int o = adjOther[k];
+                if (o > b && inc_kind(adjRef[k]) != FK_IGNORE && mass[o].y > 0.0f) {
+                    int lo = ((volatile int*)level)[o] + 1;
+                    if (lo > lv) lv = lo;
+                }
+            }
+            if (lv != level[b]) { level[b] = lv; changed = 1; }
+        }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        int c = sChanged;
+        __syncthreads();
+        if (!c) break;
+    }
+    /* histogram */
+    if (t == 0) sMax = 0;
+    for (int l = t; l < lvlCap; l += 1024) lvlCount[l] = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int b = t; b < n; b += 1024) {
+        int lv = level[b];
+        if (lv > 0) { if (lv < lvlCap) atomicAdd(&lvlCount[lv], 1); if (lv > mx) mx = lv; }
+    }
+    atomicMax(&sMax, mx);
+    __syncthreads();
+    const int L = sMax; /* levels are 1..L */
+    /* exclusive scan of lvlCount[1..L] into lvlStart[0..L] (lvlStart[l-1] = start of level l) */
+    const int chunk = (L + 1023) / 1024;
+    const int lo = t * chunk, hi = min(L, lo + chunk);
+    int a = 0;
+    for (int i = lo; i < hi; ++i) a += lvlCount[i + 1];
+    sScan[t] = a;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (t >= off) ? sScan[t - off] : 0;
+        __syncthreads();
+        sScan[t] += v;
+        __syncthreads();
+    }
+    int base = sScan[t] - a;
+    for (int i = lo; i < hi; ++i) { lvlStart[i] = base; base += lvlCount[i + 1]; lvlCount[i + 1] = 0; }
+    if (t == 1023) lvlStart[L] = sScan[1023];
+    __syncthreads();
+    for (int b = t; b < n; b += 1024) {
+        int lv = level[b];
+        if (lv > 0 && lv < lvlCap) order[lvlStart[lv - 1] + atomicAdd(&lvlCount[lv], 1)] = b;
+    }
+    if (t == 0) { cnt->numLevels = L; if (L >= lvlCap) atomicOr(&cnt->overflow, 8); }
+}
+
+/* Sort the bodies of each level by index (placement only: results do not depend on it). */
+__global__ void k_sort_levels(const int* lvlStart, int* order, const Counters* cnt)
+{
+    const int L = cnt->numLevels;
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+        int s = lvlStart[l], e = lvlStart[l + 1];
+        if (e - s > 4096) continue;
+        for (int i = s + 1; i < e; ++i) {
+            int v = order[i], j = i - 1;
+            while (j >= s && order[j] > v) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K4 predict — solver.cpp:299-337
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ void sanitize3(f3& v, Counters* cnt) { if (!finite3(v)) { atomicAdd(&cnt->warnings, 1); v = zero3(); } }
+__device__ __forceinline__ void sanitizeq(q4& q, Counters* cnt) { if (!finiteq(q)) { atomicAdd(&cnt->warnings, 1); q = identq(); } }
+
+__global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    float4 pr = B.plane(BP_POSR)[i];
+    f3 pos = mk3(pr.x, pr.y, pr.z);
+    q4 rot = ldq(B.plane(BP_QUAT), i);
+    f3 w = ld3(B.plane(BP_ANGV), i);
+    {   /* clampAngularVelocity, solver.cpp:85-92 */
+        const float maxSpeed = 80.0f;
+        float len = len3(w);
+        if (len > maxSpeed && len > kVecEps) w = w * (maxSpeed / len);
+    }
+    B.plane(BP_IPOS)[i] = pack3(pos, 0.f);
+    B.plane(BP_IQUAT)[i] = packq(rot);
+    f3 npos = pos; q4 nrot = rot;
+    const float invMass = B.plane(BP_MASS)[i].y;
+    if (invMass > 0.0f) {
+        atomicAdd(&cnt->dynamicBodies, 1);
+        f3 v = ld3(B.plane(BP_LINV), i);
+        f3 vprev = ld3(B.plane(BP_PLIN), i);
+        sanitize3(v, cnt);
+        sanitize3(w, cnt);
+        const float dt = P.dt;
+        const f3 g = mk3(P.gx, P.gy, P.gz);
+        npos = pos + v * dt + g * (dt * dt);
+        q4 omega = mkq(w.x, w.y, w.z, 0.0f);
+        nrot = qnormalize(rot + (omega * rot) * (0.5f * dt));
+        float gLen = len3(g);
+        float aw = 0.0f;
+        if (gLen > 1e-5f) {
+            f3 accel = (v - vprev) / dt;
+            float proj = dot3(accel, g / gLen);
+            aw = rclamp(proj / gLen, 0.0f, 1.0f);
+            if (!isfinite(aw)) aw = 0.0f;
+        }
+        pos = pos + (v * dt + g * (aw * dt * dt));
+        rot = nrot;
+        sanitize3(pos, cnt);
+        sanitizeq(rot, cnt);
+        B.plane(BP_LINV)[i] = pack3(v, 0.f);
+    }
+    B.plane(BP_ANGV)[i] = pack3(w, 0.f);
+    B.plane(BP_NPOS)[i] = pack3(npos, 0.f);
+    B.plane(BP_NQUAT)[i] = packq(nrot);
+    B.plane(BP_POSR)[i] = pack3(pos, pr.w);
+    B.plane(BP_QUAT)[i] = packq(rot);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K5 primal — solver.cpp:344-409.  One wavefront per body of the current level.
+ *   phase 1: lane e evaluates incidence entry e (<= 3 rows): computeConstraint + computeDerivatives,
+ *            writes the entry's row records to LDS and the reference's in-place mutations to HBM
+ *   phase 2: lanes 0..26 each own one entry of (lhs lower triangles, la, rhs) and add the row terms
+ *            in list order (newest force first, row 0..n) — the reference's summation order
+ *   phase 3: lane 0 runs solve6x6 and the pose update
+ * ------------------------------------------------------------------------------------------ */
+constexpr int kRowRec = 12;                 /* Jl[3] Ja[3] f pen gyro[3] flags */
+constexpr int kEntryRec = 3 * kRowRec;
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
+                                                                 const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
+                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt)
+{
+    __shared__ float sRows[kWavesPerBlock][64 * kEntryRec];
+    __shared__ float sAcc[kWavesPerBlock][32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int first = lvlStart[level], last = lvlStart[level + 1];
+    const int slot = first + blockIdx.x * kWavesPerBlock + wv;
+    if (slot >= last) return; /* wave-uniform */
+    const int body = order[slot];
+    float* rows = sRows[wv];
+    float* accs = sAcc[wv];
+
+    /* body state (every lane holds a copy) */
+    const f3 pos = ld3(B.plane(BP_POSR), body);
+    const q4 rot = ldq(B.plane(BP_QUAT), body);
+    const f3 npos = ld3(B.plane(BP_NPOS), body);
+    const q4 nrot = ldq(B.plane(BP_NQUAT), body);
+    const float4 mp = B.plane(BP_MASS)[body];
+    const float mass = mp.x;
+    const m33 Ib = mkm(ld3(B.plane(BP_I0), body), ld3(B.plane(BP_I1), body), ld3(B.plane(BP_I2), body));
+    const m33 Jb = mkm(ld3(B.plane(BP_J0), body), ld3(B.plane(BP_J1), body), ld3(B.plane(BP_J2), body));
+    const m33 R = quat_to_mat(rot);
+    const m33 Rt = mtranspose(R);
+    const m33 Iw = R * Ib * Rt;       /* rigid.cpp:56-59 */
+    const m33 invIw = R * Jb * Rt;    /* rigid.cpp:51-54 */
+    const float invDt2 = 1.0f / (P.dt * P.dt);
+
+    /* accumulator owned by this lane: 0-5 ll lower, 6-14 la, 15-20 aa lower, 21-23 rhs.l, 24-26 rhs.a */
+    int opA = 0, opB = 0, mode = 3, gy = -1; /* mode 0: lhs, 1: lhs aa (+gyro/+0), 2: rhs, 3: idle */
+    float acc = 0.0f;
+    {
+        const m33 massMat = diagm(mk3(mass, mass, mass));
+        const m33 ll0 = zerom() + massMat * invDt2;
+        const m33 aa0 = zerom() + Iw * invDt2;
+        const f3 rl0 = massMat * ((pos - npos) * invDt2);
+        q4 qErr = rot * qconj(nrot);
+        f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
+        rotErr = rotErr * 2.0f;
+        if (qErr.w < 0.0f) rotErr = -rotErr;
+        const f3 ra0 = Iw * (rotErr * invDt2);
+        const int li[6] = {0, 1, 2, 1, 2, 2}, lj[6] = {0, 0, 0, 1, 1, 2}; /* (row i, col j) of a lower triangle */
+        if (lane < 6) {
+            int i = li[lane], j = lj[lane];
+            mode = 0; opA = i; opB = j;
+            f3 col = j == 0 ? ll0.c0 : (j == 1 ? ll0.c1 : ll0.c2);
+            acc = comp3(col, i);
+        } else if (lane < 15) {
+            int k = lane - 6, i = k % 3, j = k / 3; /* la(row i, col j) = Jl_i * Ja_j */
+            mode = 0; opA = i; opB = 3 + j; acc = 0.0f;
+        } else if (lane < 21) {
+            int k = lane - 15, i = li[k], j = lj[k];
+            mode = 1; opA = 3 + i; opB = 3 + j; gy = (i == j) ? (8 + i) : -1;
+            f3 col = j == 0 ? aa0.c0 : (j == 1 ? aa0.c1 : aa0.c2);
+            acc = comp3(col, i);
+        } else if (lane < 24) {
+            int i = lane - 21; mode = 2; opA = i; opB = 6; acc = comp3(rl0, i);
+        } else if (lane < 27) {
+            int i = lane - 24; mode = 2; opA = 3 + i; opB = 6; acc = comp3(ra0, i);
+        }
+    }
+
+    const int eBeg = incStart[body], eEnd = incStart[body + 1];
+    for (int base = eBeg; base < eEnd; base += 64) {
+        const int nHere = min(64, eEnd - base);
+        /* ---- phase 1: one entry per lane ---- */
+        if (lane < nHere) {
+            const int ent = inc[base + lane];
+            const int kind = inc_kind(ent), idx = inc_index(ent);
+            const bool isA = inc_isA(ent) != 0;
+            float* rec = rows + lane * kEntryRec;
+            if (kind == FK_MANIFOLD) {
+                const int m = idx >> 2;
+                const int2 pr = M.pair[m];
+                const int other = isA ? pr.y : pr.x;
+                const f3 opos = ld3(B.plane(BP_POSR), other);
+                const q4 orot = ldq(B.plane(BP_QUAT), other);
+                const float oinv = B.plane(BP_MASS)[other].y;
+                ContactRows c;
+                {
+                    float4 ra = M.cRA[idx], rb = M.cRB[idx], nn = M.cN[idx], lam = M.cLam[idx], pen = M.cPen[idx];
+                    c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w;
+                    c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
+                    c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
+                    c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
+                    c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
+                    c.stick = M.cFS[idx].y != 0;
+                }
+                const float fric = M.fric[m];
+                if (isA) contact_compute_constraint(c, alpha, pos, rot, mp.y, opos, orot, oinv, fric);
+                else     contact_compute_constraint(c, alpha, opos, orot, oinv, pos, rot, mp.y, fric);
+                /* the reference's in-place mutations (manifold.cpp:185-186, 224-231, 241, 243) */
+                M.cN[idx] = pack3(c.normal, c.C0t2);
+                M.cLam[idx] = make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration);
+                M.cFS[idx].y = c.stick ? 1 : 0;
+                if (writeRows) {
+                    M.cC[idx] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
+                    M.cFmin[idx] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
+                    M.cFmax[idx] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
+                }
+                f3 Jl[3], Ja[3];
+                contact_compute_derivatives(c, isA, rot, Jl, Ja);
+                for (int k = 0; k < 3; ++k) {
+                    /* stiffness == FLT_MAX for manifold rows, motor == 0 (manifold.cpp:102-106) */
+                    float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
+                    float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+                    f3 gyro = abs3(cross3(Ja[k], invIw * Ja[k])) * fabsf(f);
+                    float* r = rec + k * kRowRec;
+                    r[0] = Jl[k].x; r[1] = Jl[k].y; r[2] = Jl[k].z; r[3] = Ja[k].x; r[4] = Ja[k].y; r[5] = Ja[k].z;
+                    r[6] = f; r[7] = c.penalty[k]; r[8] = gyro.x; r[9] = gyro.y; r[10] = gyro.z;
+                    r[11] = __int_as_float(3); /* valid | manifold */
+                }
+            } else if (kind == FK_JOINT) {
+                const int g = idx >> 1, part = idx & 1;
+                GForce& f = gf[g];
+                const bool hasA = f.bodyA >= 0;
+                const int other = isA ? f.bodyB : f.bodyA;
+                f3 opos = zero3(); q4 orot = identq();
+                if (other >= 0) { opos = ld3(B.plane(BP_POSR), other); orot = ldq(B.plane(BP_QUAT), other); }
+                JointRows j;
+                j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
+                j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+                if (isA) joint_compute_constraint(j, hasA, pos, rot, opos, orot);
+                else     joint_compute_constraint(j, hasA, opos, orot, pos, rot);
+                for (int k = 0; k < 3; ++k) {
+                    const int row = part * 3 + k;
+                    f3 Jl, Ja;
+                    joint_compute_derivatives(j, isA, false, rot, row, Jl, Ja);
+                    float lw = (f.stiffness[row] == FLT_MAX) ? f.lambda[row] : 0.0f;
+                    float desired = f.penalty[row] * j.C[row] + lw + f.motor[row];
+                    float fr = rclamp(desired, -FLT_MAX, FLT_MAX);
+                    float* r = rec + k * kRowRec;
+                    r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
+                    r[6] = fr; r[7] = f.penalty[row]; r[8] = 0.f; r[9] = 0.f; r[10] = 0.f;
+                    r[11] = __int_as_float(1);
+                }
+            } else { /* FK_SPRING */
+                GForce& f = gf[idx];
+                const bool hasA = f.bodyA >= 0;
+                const int other = isA ? f.bodyB : f.bodyA;
+                f3 opos = zero3(); q4 orot = identq();
+                if (other >= 0) { opos = ld3(B.plane(BP_POSR), other); orot = ldq(B.plane(BP_QUAT), other); }
+                SpringRows s;
+                s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
+                f3 pA = isA ? pos : opos, pB = isA ? opos : pos; q4 qA = isA ? rot : orot, qB = isA ? orot : rot;
+                spring_compute_constraint(s, hasA, pA, qA, pB, qB);
+                f3 Jl, Ja;
+                spring_compute_derivatives(s, isA, hasA, pA, qA, pB, qB, Jl, Ja);
+                float lw = (f.stiffness[0] == FLT_MAX) ? f.lambda[0] : 0.0f;
+                float desired = f.penalty[0] * s.C + lw + f.motor[0];
+                float fr = rclamp(desired, f.fmin[0], f.fmax[0]);
+                float* r = rec;
+                r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
+                r[6] = fr; r[7] = f.penalty[0]; r[8] = 0.f; r[9] = 0.f; r[10] = 0.f; r[11] = __int_as_float(1);
+                rec[kRowRec + 11] = __int_as_float(0);
+                rec[2 * kRowRec + 11] = __int_as_float(0);
+            }
+        }
+        wave_sync();
+        /* ---- phase 2: ordered accumulation ---- */
+        if (mode != 3) {
+            for (int e = 0; e < nHere; ++e) {
+                const float* rec = rows + e * kEntryRec;
+                for (int k = 0; k < 3; ++k) {
+                    const float* r = rec + k * kRowRec;
+                    const int flags = __float_as_int(r[11]);
+                    if (!(flags & 1)) continue;
+                    if (mode == 2) {
+                        acc = acc + r[opA] * r[opB];          /* rhs += J * f, solver.cpp:383-384 */
+                    } else {
+                        const float pen = r[7];
+                        if (pen > 0.0f && isfinite(pen)) {    /* solver.cpp:387 */
+                            acc = acc + (r[opA] * r[opB]) * pen;
+                            if (mode == 1 && (flags & 2)) acc = acc + (gy >= 0 ? r[gy] : 0.0f); /* solver.cpp:393-397 */
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+
+    /* ---- phase 3: gather the 27 entries, solve, update the pose ---- */
+    if (lane < 27) accs[lane] = acc;
+    wave_sync();
+    if (lane == 0) {
+        m33 ll, la, al, aa;
+        /* lower triangles; the strictly-upper entries are never read by solve (maths.h:104) */
+        ll.c0 = mk3(accs[0], accs[1], accs[2]); ll.c1 = mk3(accs[1], accs[3], accs[4]); ll.c2 = mk3(accs[2], accs[4], accs[5]);
+        la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
+        al = mtranspose(la); /* al accumulates (Ja_i*Jl_j)*pen = la(j,i) bit for bit (solver.cpp:389-390) */
+        aa.c0 = mk3(accs[15], accs[16], accs[17]); aa.c1 = mk3(accs[16], accs[18], accs[19]); aa.c2 = mk3(accs[17], accs[19], accs[20]);
+        f3 bl = mk3(accs[21], accs[22], accs[23]), ba = mk3(accs[24], accs[25], accs[26]);
+        f3 dl, da;
+        solve_block6(ll, la, al, aa, bl, ba, dl, da);
+        f3 p = pos - dl;
+        q4 dq = mkq(da.x, da.y, da.z, 0.0f);
+        q4 q = qnormalize(rot - (dq * rot) * 0.5f);
+        sanitize3(p, cnt);
+        sanitizeq(q, cnt);
+        float4 pr = B.plane(BP_POSR)[body];
+        B.plane(BP_POSR)[body] = pack3(p, pr.w);
+        B.plane(BP_QUAT)[body] = packq(q);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K6 dual — solver.cpp:411-430, one lane per contact (3 rows)
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_dual(BodyTable B, ManifoldTable M, const Counters* cnt, SolverParams P, float alpha)
+{
+    const int total = cnt->numManifolds * 4;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        const int m = s >> 2, ci = s & 3;
+        if (ci >= M.nc[m]) continue;
+        const int2 pr = M.pair[m];
+        const f3 posA = ld3(B.plane(BP_POSR), pr.x), posB = ld3(B.plane(BP_POSR), pr.y);
+        const q4 rotA = ldq(B.plane(BP_QUAT), pr.x), rotB = ldq(B.plane(BP_QUAT), pr.y);
+        const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
+        ContactRows c;
+        {
+            float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s], lam = M.cLam[s], pen = M.cPen[s];
+            c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w;
+            c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
+            c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
+            c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
+            c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
+            c.stick = M.cFS[s].y != 0;
+        }
+        contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[m]);
+        bool needJ = false;
+        bool active[3];
+        for (int k = 0; k < 3; ++k) {
+            float lu = rclamp(c.penalty[k] * c.C[k] + c.lambda[k], c.fmin[k], c.fmax[k]);
+            active[k] = lu > c.fmin[k] && lu < c.fmax[k];
+            c.lambda[k] = lu;
+            needJ |= active[k];
+        }
+        if (needJ) {
+            f3 JlA[3], JaA[3], JlB[3], JaB[3];
+            contact_compute_derivatives(c, true, rotA, JlA, JaA);
+            contact_compute_derivatives(c, false, rotB, JlB, JaB);
+            for (int k = 0; k < 3; ++k) {
+                if (!active[k]) continue;
+                float lw = 0.0f, aw = 0.0f;                 /* rowPenaltyGain, solver.cpp:94-125 */
+                lw += lensq3(JlA[k]); aw += lensq3(JaA[k]);
+                lw += lensq3(JlB[k]); aw += lensq3(JaB[k]);
+                float betaRow = row_penalty_gain(lw, aw, P.beta);
+                c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kManifoldPenaltyCap);
+            }
+        }
+        M.cN[s] = pack3(c.normal, c.C0t2);
+        M.cLam[s] = make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration);
+        M.cPen[s] = make_float4(c.penalty[0], c.penalty[1], c.penalty[2], 0.f);
+        M.cFS[s].y = c.stick ? 1 : 0;
+        M.cC[s] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
+        M.cFmin[s] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
+        M.cFmax[s] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
+    }
+}
+
+__global__ void k_dual_gforce(BodyTable B, GForce* gf, int ng, SolverParams P)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    GForce& f = gf[g];
+    if (f.kind == FK_IGNORE) return;
+    const bool hasA = f.bodyA >= 0;
+    f3 posA = zero3(), posB; q4 rotA = identq(), rotB;
+    if (hasA) { posA = ld3(B.plane(BP_POSR), f.bodyA); rotA = ldq(B.plane(BP_QUAT), f.bodyA); }
+    posB = ld3(B.plane(BP_POSR), f.bodyB); rotB = ldq(B.plane(BP_QUAT), f.bodyB);
+    if (f.kind == FK_JOINT) {
+        JointRows j;
+        j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+        joint_compute_constraint(j, hasA, posA, rotA, posB, rotB);
+        for (int r = 0; r < 6; ++r) {
+            f.C[r] = j.C[r]; f.fmin[r] = -FLT_MAX; f.fmax[r] = FLT_MAX;
+            if (f.stiffness[r] != FLT_MAX) continue;
+            float lu = rclamp(f.penalty[r] * f.C[r] + f.lambda[r], f.fmin[r], f.fmax[r]);
+            bool active = lu > f.fmin[r] && lu < f.fmax[r];
+            f.lambda[r] = lu;
+            if (active) {
+                float lw = 0.0f, aw = 0.0f;
+                f3 Jl, Ja;
+                if (hasA) { joint_compute_derivatives(j, true, false, rotA, r, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+                joint_compute_derivatives(j, false, false, rotB, r, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+                float betaRow = row_penalty_gain(lw, aw, P.beta);
+                f.penalty[r] = rmin(f.penalty[r] + betaRow * fabsf(f.C[r]), kPenaltyMax);
+            }
+        }
+    } else { /* spring: finite stiffness rows are skipped by the dual (solver.cpp:416-418) unless FLT_MAX */
+        SpringRows s;
+        s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
+        spring_compute_constraint(s, hasA, posA, rotA, posB, rotB);
+        f.C[0] = s.C;
+        if (f.stiffness[0] == FLT_MAX) {
+            float lu = rclamp(f.penalty[0] * f.C[0] + f.lambda[0], f.fmin[0], f.fmax[0]);
+            bool active = lu > f.fmin[0] && lu < f.fmax[0];
+            f.lambda[0] = lu;
+            if (active) {
+                float lw = 0.0f, aw = 0.0f;
+                f3 Jl, Ja;
+                if (hasA) { spring_compute_derivatives(s, true, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+                spring_compute_derivatives(s, false, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+                float betaRow = row_penalty_gain(lw, aw, P.beta);
+                f.penalty[0] = rmin(f.penalty[0] + betaRow * fabsf(f.C[0]), kPenaltyMax);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K7 velocities — solver.cpp:434-469
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_velocity(BodyTable B, SolverParams P, Counters* cnt, DiagAccum* diag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    if (!(B.plane(BP_MASS)[i].y > 0.0f)) return;
+    const float linearDamping = 0.995f, angularDamping = 0.97f;
+    f3 v = ld3(B.plane(BP_LINV), i), w = ld3(B.plane(BP_ANGV), i);
+    B.plane(BP_PLIN)[i] = pack3(v, 0.f);
+    B.plane(BP_PANG)[i] = pack3(w, 0.f);
+    f3 pos = ld3(B.plane(BP_POSR), i), ipos = ld3(B.plane(BP_IPOS), i);
+    q4 rot = ldq(B.plane(BP_QUAT), i), irot = ldq(B.plane(BP_IQUAT), i);
+    v = (pos - ipos) / P.dt;
+    q4 dq = rot * qconj(irot);
+    f3 av = mk3(dq.x, dq.y, dq.z);
+    av = av * (2.0f / P.dt);
+    if (dq.w < 0.0f) av = -av;
+    w = av;
+    v = v * linearDamping;
+    w = w * angularDamping;
+    sanitize3(v, cnt);
+    sanitize3(w, cnt);
+    B.plane(BP_LINV)[i] = pack3(v, 0.f);
+    B.plane(BP_ANGV)[i] = pack3(w, 0.f);
+    atomic_max_nonneg(&diag->maxLinearSpeed, len3(v));
+    atomic_max_nonneg(&diag->maxAngularSpeed, len3(w));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K8 diagnostics — solver.cpp:472-497 (max and integer sums only: order-independent)
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_diag_contacts(BodyTable B, ManifoldTable M, const Counters* cnt, DiagAccum* diag)
+{
+    const int nm = cnt->numManifolds;
+    const int total = nm * 4;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        const int m = s >> 2, ci = s & 3;
+        const int nc = M.nc[m];
+        if (ci == 0) { atomicAdd(&diag->activeManifolds, 1); atomicAdd(&diag->activeContacts, nc); }
+        if (ci >= nc) continue;
+        const int2 pr = M.pair[m];
+        float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s];
+        f3 wrA = qrotate(ldq(B.plane(BP_QUAT), pr.x), mk3(ra.x, ra.y, ra.z));
+        f3 wrB = qrotate(ldq(B.plane(BP_QUAT), pr.y), mk3(rb.x, rb.y, rb.z));
+        f3 pA = ld3(B.plane(BP_POSR), pr.x) + wrA;
+        f3 pB = ld3(B.plane(BP_POSR), pr.y) + wrB;
+        float separation = dot3(pA - pB, mk3(nn.x, nn.y, nn.z));
+        float pen = rmax(0.0f, -separation);
+        float viol = rmax(0.0f, kPenetrationSlop - separation);
+        atomic_max_nonneg(&diag->maxPenetration, pen);
+        atomic_max_nonneg(&diag->maxViolation, viol);
+        atomic_max_nonneg(&diag->maxNormalImpulse, fabsf(M.cLam[s].x));
+    }
+}
+
+__global__ void k_finish_step(Counters* cnt, DiagAccum* diag)
+{
+    diag->dynamicBodies = cnt->dynamicBodies;
+}
+
+/* start-of-step reset of the per-step counters */
+__global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount)
+{
+    cnt->numCandidates = 0; cnt->numContacts = 0; cnt->numIncidences = 0; cnt->warnings = 0; cnt->dynamicBodies = 0;
+    cnt->numLevels = 0;
+    *nextCount = 0;
+    diag->maxPenetration = 0; diag->maxViolation = 0; diag->maxLinearSpeed = 0; diag->maxAngularSpeed = 0; diag->maxNormalImpulse = 0;
+    diag->activeContacts = 0; diag->activeManifolds = 0; diag->dynamicBodies = 0;
+}
+
+/* ---- known-answer kernels --------------------------------------------------------------- */
+struct KatContact { int feature; float rA[3], rB[3], normal[3]; float penetration, C0_n, C0_t[3]; int stick; };
+
+__global__ void k_kat_collide(int n, const float* pA, const float* qA, const float* sA, const float* pB, const float* qB, const float* sB,
+                              KatContact* out, int* counts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BoxPose A, Bx;
+    A.pos = mk3(pA[3 * i], pA[3 * i + 1], pA[3 * i + 2]); A.rot = mkq(qA[4 * i], qA[4 * i + 1], qA[4 * i + 2], qA[4 * i + 3]);
+    A.size = mk3(sA[3 * i], sA[3 * i + 1], sA[3 * i + 2]);
+    Bx.pos = mk3(pB[3 * i], pB[3 * i + 1], pB[3 * i + 2]); Bx.rot = mkq(qB[4 * i], qB[4 * i + 1], qB[4 * i + 2], qB[4 * i + 3]);
+    Bx.size = mk3(sB[3 * i], sB[3 * i + 1], sB[3 * i + 2]);
+    RawContact raw[4];
+    int nc = collide_boxes(A, Bx, raw);
+    counts[i] = nc;
+    for (int c = 0; c < 4; ++c) {
+        KatContact& o = out[4 * i + c];
+        if (c < nc) {
+            o.feature = raw[c].feature;
+            o.rA[0] = raw[c].rA.x; o.rA[1] = raw[c].rA.y; o.rA[2] = raw[c].rA.z;
+            o.rB[0] = raw[c].rB.x; o.rB[1] = raw[c].rB.y; o.rB[2] = raw[c].rB.z;
+            o.normal[0] = raw[c].normal.x; o.normal[1] = raw[c].normal.y; o.normal[2] = raw[c].normal.z;
+            o.penetration = raw[c].penetration; o.C0_n = 0.f; o.C0_t[0] = o.C0_t[1] = o.C0_t[2] = 0.f; o.stick = 0;
+        }
+    }
+}
+
+__global__ void k_kat_solve6(int n, const float* A, const float* b, float* x)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = A + 36 * i;
+    m33 m[4];
+    for (int k = 0; k < 4; ++k)
+        m[k] = mkm(mk3(a[9 * k], a[9 * k + 1], a[9 * k + 2]), mk3(a[9 * k + 3], a[9 * k + 4], a[9 * k + 5]), mk3(a[9 * k + 6], a[9 * k + 7], a[9 * k + 8]));
+    f3 xl, xa;
+    solve_block6(m[0], m[1], m[2], m[3], mk3(b[6 * i], b[6 * i + 1], b[6 * i + 2]), mk3(b[6 * i + 3], b[6 * i + 4], b[6 * i + 5]), xl, xa);
+    x[6 * i] = xl.x; x[6 * i + 1] = xl.y; x[6 * i + 2] = xl.z; x[6 * i + 3] = xa.x; x[6 * i + 4] = xa.y; x[6 * i + 5] = xa.z;
+}
+
+__global__ void k_kat_arith(int n, const float* a, const float* b, float* od, float* os, float* om, float* oa)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    od[i] = a[i] / b[i];
+    os[i] = sqrtf(fabsf(a[i]));
+    om[i] = a[i] * b[i] + a[i]; /* must round twice (no FMA contraction) */
+    oa[i] = 1.0f / sqrtf(fabsf(b[i]));
+}
+
+} // namespace avbd

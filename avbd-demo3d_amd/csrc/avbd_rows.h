@@ -1,0 +1,297 @@
+/*
+ * avbd_rows.h — the row-based Force API (solver.h:85-109) as device functions.
+ *
+ * The reference exposes every constraint kind through four virtuals:
+ *   getRowCount() / initialize() / computeConstraint(alpha) / computeDerivatives(Jl, Ja, body, row)
+ * The solver kernels (avbd_kernels.hip) are written against exactly that interface; what is
+ * virtual dispatch in the reference is a switch over `ForceKind` here, and what is a 704-byte
+ * heap object there is a register-resident view (`ContactRows`, `JointRows`, `SpringRows`) loaded
+ * from / stored to the SoA arrays of avbd_types.h by the calling kernel.
+ *
+ * A Manifold is evaluated contact by contact (3 rows each): the reference's per-contact loop
+ * bodies in manifold.cpp:177-245 / 247-271 are independent of each other, so one lane per contact
+ * reproduces the whole-manifold call exactly, including its in-place mutations (normal
+ * re-normalisation, friction-cone rescale of lambda, stick flag).
+ */
+#pragma once
+#include "avbd_math.h"
+#include "avbd_collide.h"
+
+#pragma clang fp contract(off)
+
+namespace avbd {
+
+constexpr int   kMaxRows            = 12;           /* solver.h:25 */
+constexpr float kPenaltyMin         = 20000.0f;     /* solver.h:26 */
+constexpr float kPenaltyMax         = 1000000000.0f;/* solver.h:27 */
+constexpr float kStickThresh        = 0.02f;        /* solver.h:29 */
+constexpr float kPenetrationSlop    = 0.005f;       /* solver.h:36 */
+constexpr float kManifoldPenaltyCap = 2000000.0f;   /* solver.cpp:29, manifold.cpp:23 */
+constexpr float kNormalMargin       = 0.01f;        /* manifold.cpp:17 */
+constexpr float kStickMaxDrift      = 0.015f;       /* manifold.cpp:18 */
+constexpr float kStickMinDot        = 0.995f;       /* manifold.cpp:19 */
+constexpr float kWarmMaxDrift       = 0.08f;        /* manifold.cpp:20 */
+constexpr float kWarmMinDot         = 0.9f;         /* manifold.cpp:21 */
+constexpr float kNormalForceCap     = 5000.0f;      /* manifold.cpp:22 */
+
+enum ForceKind : int { FK_MANIFOLD = 0, FK_JOINT = 1, FK_SPRING = 2, FK_IGNORE = 3 };
+
+/* getRowCount(): manifold.cpp:66-69, joint.h:42, spring.h:33, ignorecollision.h:19 */
+AVBD_HD int force_row_count(int kind, int numContacts)
+{
+    return kind == FK_MANIFOLD ? numContacts * 3 : (kind == FK_JOINT ? 6 : (kind == FK_SPRING ? 1 : 0));
+}
+
+AVBD_HD f3 world_point(f3 pos, q4 rot, f3 local) { return pos + qrotate(rot, local); }   /* manifold.cpp:25-28 */
+
+AVBD_HD f3 normalize_safe(f3 v, f3 fallback)                                             /* manifold.cpp:30-37 */
+{
+    float lenSq = lensq3(v);
+    if (lenSq < kVecEps) return fallback;
+    return v / sqrtf(lenSq);
+}
+
+AVBD_HD void contact_basis(f3 nIn, f3& n, f3& t1, f3& t2)                                /* manifold.cpp:39-50 */
+{
+    n = normalize_safe(nIn, mk3(0.0f, 1.0f, 0.0f));
+    if (fabsf(n.x) >= fabsf(n.z)) t1 = mk3(-n.y, n.x, 0.0f);
+    else t1 = mk3(0.0f, -n.z, n.y);
+    t1 = normalize_safe(t1, mk3(1.0f, 0.0f, 0.0f));
+    t2 = normalize_safe(cross3(n, t1), mk3(0.0f, 0.0f, 1.0f));
+}
+
+/* ---- one contact of a Manifold = 3 rows (normal, tangent1, tangent2) ------------------- */
+struct ContactRows {
+    f3    rA, rB, normal;        /* Manifold::Contact, solver.h:120-130 */
+    float C0n, C0t1, C0t2;
+    float penetration;
+    bool  stick;
+    float lambda[3], penalty[3]; /* Force::lambda/penalty rows base..base+2 */
+    float C[3], fmin[3], fmax[3];/* outputs of computeConstraint */
+};
+
+/* Manifold::computeConstraint for one contact (manifold.cpp:183-243).  Mutates normal, lambda[1..2],
+ * stick, penetration exactly like the reference. */
+AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4 rotA, float invMassA, f3 posB, q4 rotB,
+                                        float invMassB, float combinedFriction)
+{
+    float biasScale = rclamp(1.0f - alpha, 0.0f, 1.0f);
+    f3 n, t1, t2;
+    contact_basis(c.normal, n, t1, t2);
+    c.normal = n;
+    f3 pA = world_point(posA, rotA, c.rA);
+    f3 pB = world_point(posB, rotB, c.rB);
+    f3 d = pA - pB;
+    float separation = dot3(d, n) - kNormalMargin;
+    float slip1 = dot3(d, t1);
+    float slip2 = dot3(d, t2);
+
+    c.C[0] = separation + biasScale * c.C0n;
+    float invMassSum = invMassA + invMassB;
+    float massScale = (invMassSum > 1.0e-6f) ? (1.0f / invMassSum) : 1.0f;
+    float cap = kNormalForceCap * massScale;
+    c.fmin[0] = -cap;
+    c.fmax[0] = 0.0f;
+
+    c.C[1] = slip1 + biasScale * c.C0t1;
+    c.C[2] = slip2 + biasScale * c.C0t2;
+
+    float warmMag = fabsf(rmin(c.lambda[0], 0.0f));
+    float trial = c.penalty[0] * c.C[0] + c.lambda[0];
+    float trialMag = fabsf(rmin(trial, 0.0f));
+    float nMag = rmax(warmMag, trialMag);
+    nMag = rmin(nMag, cap);
+
+    float mu = combinedFriction;
+    if (!c.stick) mu *= 0.9f;
+    float limit = mu * nMag;
+
+    float lt1 = c.lambda[1], lt2 = c.lambda[2];
+    float tanMag = sqrtf(lt1 * lt1 + lt2 * lt2);
+    if (tanMag > limit && tanMag > 1.0e-8f) {
+        float s = limit / tanMag;
+        c.lambda[1] *= s;
+        c.lambda[2] *= s;
+    }
+    c.fmin[1] = -limit; c.fmax[1] = limit;
+    c.fmin[2] = -limit; c.fmax[2] = limit;
+
+    float slipSq = c.C[1] * c.C[1] + c.C[2] * c.C[2];
+    float tanSq = c.lambda[1] * c.lambda[1] + c.lambda[2] * c.lambda[2];
+    float stickSq = kStickThresh * kStickThresh;
+    c.stick = (slipSq <= stickSq) && (tanSq <= limit * limit + 1.0e-8f);
+    c.penetration = rmax(0.0f, -dot3(d, n));
+}
+
+/* Manifold::computeDerivatives for the three rows of one contact (manifold.cpp:247-271).  The
+ * reference rebuilds the basis from the STORED normal on every call; the stored normal is the
+ * one computeConstraint just wrote, so the basis below is normalised once more, as there. */
+AVBD_HD void contact_compute_derivatives(const ContactRows& c, bool isBodyA, q4 rotBody, f3 Jl[3], f3 Ja[3])
+{
+    f3 n, t1, t2;
+    contact_basis(c.normal, n, t1, t2);
+    float sign = isBodyA ? 1.0f : -1.0f;
+    f3 wr = qrotate(rotBody, isBodyA ? c.rA : c.rB);
+    Jl[0] = n * sign;  Ja[0] = cross3(wr, n) * sign;
+    Jl[1] = t1 * sign; Ja[1] = cross3(wr, t1) * sign;
+    Jl[2] = t2 * sign; Ja[2] = cross3(wr, t2) * sign;
+}
+
+/* ---- Manifold::initialize (manifold.cpp:71-175) ----------------------------------------- */
+struct ManifoldInit {
+    int   numContacts;
+    float combinedFriction;
+    int   feature[4];
+    f3    rA[4], rB[4], normal[4];
+    float penetration[4], C0n[4], C0t1[4], C0t2[4];
+    bool  stick[4];
+    float lambda[12], penalty[12];
+};
+
+/* `m` holds the previous step's contacts on entry (numContacts = 0 for a fresh manifold) and the
+ * new manifold on exit.  Returns false when the pair no longer touches (the reference deletes it). */
+AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float frictionA, const BoxPose& B, float frictionB)
+{
+    m.combinedFriction = sqrtf(frictionA * frictionB);
+
+    int   oldN = m.numContacts;
+    int   oldFeature[4]; f3 oldRA[4], oldRB[4], oldNormal[4]; bool oldStick[4];
+    float oldLambda[12], oldPenalty[12];
+    bool  oldUsed[4] = {false, false, false, false};
+    for (int i = 0; i < 4; ++i) {
+        if (i < oldN) {
+            oldFeature[i] = m.feature[i]; oldRA[i] = m.rA[i]; oldRB[i] = m.rB[i]; oldNormal[i] = m.normal[i]; oldStick[i] = m.stick[i];
+            for (int k = 0; k < 3; ++k) { oldLambda[i * 3 + k] = m.lambda[i * 3 + k]; oldPenalty[i * 3 + k] = m.penalty[i * 3 + k]; }
+        }
+    }
+
+    RawContact raw[4];
+    m.numContacts = collide_boxes(A, B, raw);
+    if (m.numContacts == 0) return false;
+
+    for (int i = 0; i < 4; ++i) {
+        if (i >= m.numContacts) break;
+        int base = i * 3;
+        m.feature[i] = raw[i].feature; m.rA[i] = raw[i].rA; m.rB[i] = raw[i].rB; m.normal[i] = raw[i].normal;
+        for (int k = 0; k < 3; ++k) { m.lambda[base + k] = 0.0f; m.penalty[base + k] = kPenaltyMin; }
+        m.stick[i] = false;
+
+        int best = -1;
+        for (int j = 0; j < 4; ++j) {
+            if (j >= oldN) break;
+            if (oldUsed[j]) continue;
+            if (m.feature[i] == oldFeature[j]) { best = j; break; }
+        }
+        if (best >= 0) {
+            oldUsed[best] = true;
+            f3 newN = normalize_safe(m.normal[i], mk3(0.0f, 1.0f, 0.0f));
+            f3 oldNn = normalize_safe(oldNormal[best], newN);
+            float nd = dot3(newN, oldNn);
+            f3 oldMid = (world_point(A.pos, A.rot, oldRA[best]) + world_point(B.pos, B.rot, oldRB[best])) * 0.5f;
+            f3 newMid = (world_point(A.pos, A.rot, m.rA[i]) + world_point(B.pos, B.rot, m.rB[i])) * 0.5f;
+            float driftSq = lensq3(newMid - oldMid);
+            bool valid = (nd >= kWarmMinDot) && (driftSq <= kWarmMaxDrift * kWarmMaxDrift);
+            if (valid) {
+                for (int k = 0; k < 3; ++k) {
+                    m.lambda[base + k] = oldLambda[best * 3 + k];
+                    m.penalty[base + k] = rclamp(oldPenalty[best * 3 + k], kPenaltyMin, kManifoldPenaltyCap);
+                }
+            }
+            bool reuse = false;
+            if (oldStick[best] && valid)
+                reuse = (nd >= kStickMinDot) && (driftSq <= kStickMaxDrift * kStickMaxDrift);
+            m.stick[i] = oldStick[best] && reuse;
+            if (reuse) { m.rA[i] = oldRA[best]; m.rB[i] = oldRB[best]; }
+        }
+
+        f3 n, t1, t2;
+        contact_basis(m.normal[i], n, t1, t2);
+        m.normal[i] = n;
+        f3 pA = world_point(A.pos, A.rot, m.rA[i]);
+        f3 pB = world_point(B.pos, B.rot, m.rB[i]);
+        f3 d = pA - pB;
+        m.C0n[i] = dot3(d, n) - kNormalMargin;
+        m.C0t1[i] = dot3(d, t1);
+        m.C0t2[i] = dot3(d, t2);
+        m.penetration[i] = rmax(0.0f, -dot3(d, n));
+    }
+    return true;
+}
+
+/* ---- Joint (6 rows) — joint.cpp:68-139, bug-compatible angular Jacobian sign --- */
+struct JointRows {
+    f3 rA, rB; q4 q0;
+    float C[6];
+};
+
+AVBD_HD void joint_compute_constraint(JointRows& j, bool hasA, f3 posA, q4 rotA, f3 posB, q4 rotB)  /* joint.cpp:68-106 */
+{
+    f3 pA; q4 qA;
+    if (hasA) { qA = rotA; pA = posA + qrotate(qA, j.rA); }
+    else { qA = identq(); pA = j.rA; }
+    f3 pB = posB + qrotate(rotB, j.rB);
+    f3 lc = pA - pB;
+    j.C[0] = lc.x; j.C[1] = lc.y; j.C[2] = lc.z;
+    q4 cur = qconj(qA) * rotB;
+    q4 dq = cur * qconj(j.q0);
+    f3 ac = mk3(dq.x, dq.y, dq.z) * 2.0f;
+    j.C[3] = ac.x; j.C[4] = ac.y; j.C[5] = ac.z;
+    /* fmin/fmax = -/+FLT_MAX for all six rows (joint.cpp:101-105) */
+}
+
+AVBD_HD void joint_compute_derivatives(const JointRows& j, bool isBodyA, bool bodyIsWorld, q4 rotBody, int row, f3& Jl, f3& Ja) /* joint.cpp:108-139 */
+{
+    Jl = zero3(); Ja = zero3();
+    float sign = isBodyA ? 1.0f : -1.0f;
+    if (isBodyA && bodyIsWorld) return;
+    if (row < 3) {
+        f3 ax = mk3(row == 0 ? 1.0f : 0.0f, row == 1 ? 1.0f : 0.0f, row == 2 ? 1.0f : 0.0f);
+        f3 r = qrotate(rotBody, isBodyA ? j.rA : j.rB);
+        Jl = ax * sign;
+        Ja = cross3(r, ax) * sign;
+    } else {
+        int k = row - 3;
+        f3 ax = mk3(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
+        Ja = ax * sign;
+    }
+}
+
+/* ---- Spring (1 row) — spring.cpp:33-90 -------------------------------------------------- */
+struct SpringRows { f3 rA, rB; float restLength; float C; };
+
+AVBD_HD void spring_compute_constraint(SpringRows& s, bool hasA, f3 posA, q4 rotA, f3 posB, q4 rotB)  /* spring.cpp:33-58 */
+{
+    q4 qA = hasA ? rotA : identq();
+    f3 pA = hasA ? posA + qrotate(qA, s.rA) : s.rA;
+    f3 pB = posB + qrotate(rotB, s.rB);
+    s.C = len3(pA - pB) - s.restLength;
+}
+
+AVBD_HD void spring_compute_derivatives(const SpringRows& s, bool isBodyA, bool hasA, f3 posA, q4 rotA, f3 posB, q4 rotB, f3& Jl, f3& Ja) /* spring.cpp:61-90 */
+{
+    q4 qA = hasA ? rotA : identq();
+    f3 pA = hasA ? posA + qrotate(qA, s.rA) : s.rA;
+    f3 pB = posB + qrotate(rotB, s.rB);
+    f3 d = pA - pB;
+    float len = len3(d);
+    if (len < kVecEps) { Jl = zero3(); Ja = zero3(); return; }
+    f3 n = d / len;
+    float sign = isBodyA ? 1.0f : -1.0f;
+    Jl = n * sign;
+    f3 rw = isBodyA ? qrotate(rotA, s.rA) : qrotate(rotB, s.rB);
+    Ja = cross3(rw, n) * sign;
+}
+
+/* rowPenaltyGain (solver.cpp:94-125) from the per-endpoint squared Jacobian norms. */
+AVBD_HD float row_penalty_gain(float linearWeight, float angularWeight, float beta)
+{
+    const float angularBetaScale = 0.01f;
+    const float epsilon = 1.0e-8f;
+    float total = linearWeight + angularWeight;
+    if (total < epsilon) return beta;
+    float betaLinear = beta;
+    float betaAngular = beta * angularBetaScale;
+    return (betaLinear * linearWeight + betaAngular * angularWeight) / total;
+}
+
+} // namespace avbd

@@ -1,0 +1,116 @@
+/*
+ * avbd_types.h — device-resident state of one solver context (SoA, sized for HBM3E).
+ *
+ * Replaces the reference's heap objects and intrusive lists (solver.h:47-109, force.cpp:12-69):
+ *   Rigid   (264 B object, pointer-chased)  → 18 float4 planes indexed by creation index
+ *   Manifold(704 B object)                  → per-manifold header arrays + per-contact float4 planes
+ *   body->forces list (nextA/nextB walk)    → CSR adjacency + per-dynamic-body row incidence list,
+ *                                              ordered newest-first by a 64-bit creation key
+ * All orders that influence results in the reference (broadphase creation order, Gauss-Seidel body
+ * order, per-body force order) are functions of creation order, which the key encodes, so the
+ * physical placement of a manifold in these arrays is free.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace avbd {
+
+/* float4 planes of the body table */
+enum BodyPlane : int {
+    BP_POSR = 0,   /* position.xyz, radius            (solver.h:56,69) */
+    BP_QUAT,       /* orientation x,y,z,w             (solver.h:57) */
+    BP_LINV,       /* linearVelocity.xyz              (solver.h:58) */
+    BP_ANGV,       /* angularVelocity.xyz */
+    BP_PLIN,       /* prevLinearVelocity.xyz          (solver.h:59) */
+    BP_PANG,       /* prevAngularVelocity.xyz */
+    BP_IPOS,       /* initialPosition.xyz             (solver.h:61) */
+    BP_IQUAT,      /* initialOrientation */
+    BP_NPOS,       /* inertialPosition.xyz            (solver.h:63) */
+    BP_NQUAT,      /* inertialOrientation */
+    BP_SIZE,       /* size.xyz, friction              (solver.h:66,69) */
+    BP_MASS,       /* mass, invMass, friction, radius (solver.h:67-70) */
+    BP_I0, BP_I1, BP_I2,    /* inertiaTensor columns    (solver.h:68) */
+    BP_J0, BP_J1, BP_J2,    /* invInertiaTensor columns */
+    BP_COUNT
+};
+
+struct BodyTable {
+    float4* planes; /* BP_COUNT * cap */
+    int cap;
+    int n;
+    __host__ __device__ float4* plane(int p) const { return planes + (size_t)p * cap; }
+};
+
+/* One buffer of manifolds; the context owns two and ping-pongs them every step (narrow phase
+ * reads last step's manifold, writes the surviving one compacted into the other buffer). */
+struct ManifoldTable {
+    int2*     pair;    /* bodyA (newer body, larger index), bodyB */
+    uint64_t* key;     /* creation key, larger = newer (see make_manifold_key) */
+    int*      nc;      /* numContacts 1..4 */
+    float*    fric;    /* combinedFriction */
+    /* per contact, index 4*m + c */
+    float4*   cRA;     /* rA.xyz, C0_n */
+    float4*   cRB;     /* rB.xyz, C0_t.x */
+    float4*   cN;      /* normal.xyz, C0_t.y */
+    float4*   cLam;    /* lambda n,t1,t2, penetration */
+    float4*   cPen;    /* penalty n,t1,t2, (unused) */
+    int2*     cFS;     /* feature key, stick */
+    float4*   cC;      /* last computeConstraint outputs: C n,t1,t2 */
+    float4*   cFmin;
+    float4*   cFmax;
+    int cap;
+};
+
+/* Joint / Spring / IgnoreCollision: few, host-created, kept AoS. */
+struct GForce {
+    int kind, bodyA, bodyB, pad;
+    uint64_t key;
+    float rA[3], rB[3], q0[4], restLength;
+    float C[6], fmin[6], fmax[6], lambda[6], penalty[6], stiffness[6], motor[6];
+};
+
+struct Counters {
+    int numManifolds;   /* manifolds alive in the current buffer */
+    int numCandidates;  /* broadphase output this step */
+    int overflow;       /* bit0: candidate pool, bit1: manifold pool, bit2: incidence pool */
+    int numLevels;
+    int numContacts;
+    int numIncidences;
+    int warnings;
+    int dynamicBodies;
+    int levelsConverged;
+    int pad[7];
+};
+
+struct DiagAccum { /* uint views of non-negative floats so atomicMax orders them */
+    unsigned maxPenetration, maxViolation, maxLinearSpeed, maxAngularSpeed, maxNormalImpulse;
+    int activeContacts, activeManifolds, dynamicBodies;
+};
+
+struct SolverParams {
+    float dt; float gx, gy, gz; int iterations; float alpha, beta, gamma; int postStabilize;
+};
+
+/* 64-bit creation key: [63:41] stepIndex at creation, [40] host-created flag, [39:0] payload.
+ * Broadphase (solver.cpp:262-270) creates manifolds for A descending, B descending (< A); a later
+ * creation is "newer" and sits earlier in every intrusive list, so larger key = earlier in lists. */
+__host__ __device__ inline uint64_t make_manifold_key(int step, int bodyA, int bodyB)
+{
+    const uint64_t M = (1u << 20) - 1;
+    return ((uint64_t)(unsigned)step << 41) | ((M - (uint64_t)bodyA) << 20) | (M - (uint64_t)bodyB);
+}
+__host__ __device__ inline uint64_t make_host_key(int step, uint64_t counter)
+{
+    return ((uint64_t)(unsigned)step << 41) | (1ull << 40) | (counter & ((1ull << 40) - 1));
+}
+
+/* incidence entry: bit31 = body is endpoint A, bits30:29 = kind, bits28:0 = index
+ * (manifold: contact slot 4*m+c; joint: 2*g+part (part 0 = linear rows 0-2, 1 = angular rows 3-5);
+ * spring: g) */
+__host__ __device__ inline int make_inc(int isA, int kind, int index) { return (isA << 31) | (kind << 29) | index; }
+__host__ __device__ inline int inc_isA(int e) { return (e >> 31) & 1; }
+__host__ __device__ inline int inc_kind(int e) { return (e >> 29) & 3; }
+__host__ __device__ inline int inc_index(int e) { return e & ((1 << 29) - 1); }
+
+} // namespace avbd

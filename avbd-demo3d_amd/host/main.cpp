@@ -1,0 +1,86 @@
+/*
+ * main.cpp — headless driver of the MI355X build: same flags and stdout wire format as the headless
+ * branch of the reference's main.cpp:189-248 (the SDL/OpenGL/ImGui front-end is out of scope).
+ *
+ *   avbd_demo3d --nogfx --scene Stack --steps 300        # trace identical to the reference CPU run
+ *
+ * Build-only flags (do not exist in the reference): --quiet (no per-step trace; one timing JSON line),
+ * --dump <file> (raw AvbdBody array after the last step), --device <n>, --batch (run all steps on the
+ * device without per-step downloads; implies --quiet).
+ */
+#include "solver.h"
+#include "joint.h"
+#include "spring.h"
+#include "ignorecollision.h"
+#include "scenes.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+int main(int argc, char** argv)
+{
+    const char* requested = nullptr;
+    const char* dumpPath = nullptr;
+    int steps = 300; /* main.cpp:192 */
+    bool quiet = false, batch = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--nogfx") || !strcmp(argv[i], "--headless")) { /* this build is always headless */ }
+        else if ((!strcmp(argv[i], "--scene") || !strcmp(argv[i], "-s")) && i + 1 < argc) requested = argv[++i];
+        else if ((!strcmp(argv[i], "--steps") || !strcmp(argv[i], "-n")) && i + 1 < argc) steps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!strcmp(argv[i], "--batch")) { batch = true; quiet = true; }
+        else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dumpPath = argv[++i];
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) setenv("AVBD_DEVICE", argv[++i], 1);
+    }
+
+    Solver* solver = new Solver();
+    if (!quiet) { solver->enableDiagnostics = true; solver->logFrequency = 1; } /* main.cpp:206-209 */
+
+    /* unknown names silently select scene 0 "Empty" (main.cpp:211-219) */
+    const char* shown = sceneNames[0];
+    int idx = requested ? buildSceneByName(solver, requested) : -1;
+    if (idx < 0) scenes[0](solver);
+    else if (idx < sceneCount) shown = sceneNames[idx];
+    else shown = requested;
+
+    if (!quiet) printf("Running in headless mode: scene '%s', steps=%d\n", shown, steps);
+    auto t0 = std::chrono::steady_clock::now();
+    if (batch) {
+        solver->hostSync = false;
+        solver->stepMany(steps);
+        solver->pull();
+    } else {
+        for (int step = 0; step < steps; ++step) {
+            solver->step();
+            if (quiet) continue;
+            printf("Step %d:\n", step);
+            for (Rigid* body = solver->bodies; body != nullptr; body = body->next) {
+                printf("  Body %d: Pos(%.4f, %.4f, %.4f)  ", body->id, body->position.x, body->position.y, body->position.z);
+                printf("Rot(%.4f, %.4f, %.4f, %.4f)  ", body->orientation.x, body->orientation.y, body->orientation.z, body->orientation.w);
+                printf("LinVel(%.4f, %.4f, %.4f)  ", body->linearVelocity.x, body->linearVelocity.y, body->linearVelocity.z);
+                printf("AngVel(%.4f, %.4f, %.4f)\n", body->angularVelocity.x, body->angularVelocity.y, body->angularVelocity.z);
+            }
+            const Solver::Diagnostics& d = solver->lastDiagnostics;
+            printf("  Diagnostics: manifolds=%d contacts=%d dynBodies=%d maxPen=%.6f maxDrift=%.6f maxLin=%.3f maxAng=%.3f maxLambda=%.3f\n",
+                   d.activeManifolds, d.activeContacts, d.dynamicBodies, d.maxPenetration, d.maxConstraintViolation, d.maxLinearSpeed,
+                   d.maxAngularSpeed, d.maxNormalImpulse);
+        }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (quiet) {
+        double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\"}\n", shown, steps, ms,
+               steps ? ms / steps : 0.0);
+    }
+    if (dumpPath) {
+        int n = solver->bodyCount();
+        std::vector<AvbdBody> hb((size_t)n);
+        if (n) avbd_download_bodies(solver->context(), hb.data(), n);
+        if (FILE* f = fopen(dumpPath, "wb")) { fwrite(hb.data(), sizeof(AvbdBody), (size_t)n, f); fclose(f); }
+    }
+    delete solver;
+    return 0;
+}

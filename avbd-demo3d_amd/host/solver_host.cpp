@@ -1,0 +1,502 @@
+/*
+ * solver_host.cpp — implementation of the drop-in host API (host/solver.h, joint.h, spring.h,
+ * ignorecollision.h) on top of the C ABI of include/avbd_hip.h.  No physics is computed here:
+ * construction-time set-up values (box mass properties rigid.cpp:24-40, joint frames
+ * joint.cpp:17-20/46-52, spring rest length spring.cpp:19-23) are evaluated with the shared
+ * expression trees of csrc/avbd_math.h; everything else is a call into the device library.
+ */
+#include "solver.h"
+#include "joint.h"
+#include "spring.h"
+#include "ignorecollision.h"
+#include "scenes.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+int Rigid::next_id = 1; /* never reset, like rigid.cpp:10 */
+
+struct Solver::Impl {
+    std::vector<Rigid*> byIndex;        /* creation order */
+    std::vector<Force*> userForces;     /* Joint/Spring/IgnoreCollision in creation order */
+    size_t flushedForces = 0;
+    std::vector<AvbdBody> shadow;       /* body state as last seen by the device */
+    std::vector<Manifold*> manifolds;   /* mirrors created by syncForces() */
+    bool clearing = false;
+};
+
+/* ------------------------------------------------------------------ Rigid ----------------- */
+Rigid::Rigid(Solver* s, const vec3& size_, float density_, float friction_, const vec3& pos, const quat& orient,
+             const vec3& linVel, const vec3& angVel)
+    : solver(s), forces(nullptr), next(nullptr), id(next_id++), position(pos), orientation(orient), linearVelocity(linVel),
+      angularVelocity(angVel), prevLinearVelocity(linVel), prevAngularVelocity(angVel), size(size_), friction(friction_),
+      density(density_)
+{
+    next = s->bodies;
+    s->bodies = this;
+    /* rigid.cpp:24-40 */
+    mass = size.x * size.y * size.z * density;
+    invMass = (mass > 0.0f) ? 1.0f / mass : 0.0f;
+    radius = length(size) * 0.5f;
+    if (invMass > 0.0f) {
+        float Ixx = (1.0f / 12.0f) * mass * (size.y * size.y + size.z * size.z);
+        float Iyy = (1.0f / 12.0f) * mass * (size.x * size.x + size.z * size.z);
+        float Izz = (1.0f / 12.0f) * mass * (size.x * size.x + size.y * size.y);
+        inertiaTensor = mat3(vec3(Ixx, 0, 0), vec3(0, Iyy, 0), vec3(0, 0, Izz));
+        invInertiaTensor = mat3(vec3(1.0f / Ixx, 0, 0), vec3(0, 1.0f / Iyy, 0), vec3(0, 0, 1.0f / Izz));
+    } else {
+        inertiaTensor = mat3(vec3(), vec3(), vec3());
+        invInertiaTensor = mat3(vec3(), vec3(), vec3());
+    }
+    index = s->numBodies++;
+    s->impl->byIndex.push_back(this);
+}
+
+Rigid::~Rigid()
+{
+    if (!solver->impl->clearing && index < solver->flushedBodies)
+        solver->fail("deleting a single body that already lives on the device is not supported; use Solver::clear()", AVBD_E_INVALID);
+    Rigid** p = &solver->bodies;
+    while (*p && *p != this) p = &(*p)->next;
+    if (*p) *p = next;
+    if (!solver->impl->clearing) { /* an unflushed body: drop it from the creation list */
+        auto& v = solver->impl->byIndex;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == this) { v.erase(v.begin() + (long)i); break; }
+        for (size_t i = 0; i < v.size(); ++i) v[i]->index = (int)i;
+        solver->numBodies = (int)v.size();
+    }
+}
+
+mat3 Rigid::getInvInertiaTensorWorld() const
+{
+    mat3 R = mat3_from_quat(orientation);
+    return R * invInertiaTensor * transpose(R);
+}
+
+mat3 Rigid::getInertiaTensorWorld() const
+{
+    mat3 R = mat3_from_quat(orientation);
+    return R * inertiaTensor * transpose(R);
+}
+
+bool Rigid::isConstrainedTo(Rigid* other) const
+{
+    for (Force* f = forces; f != nullptr; f = (f->bodyA == this) ? f->nextA : f->nextB)
+        if (f->bodyB == other || f->bodyA == other) return true;
+    return false;
+}
+
+/* ------------------------------------------------------------------ Force ----------------- */
+Force::Force(Solver* s, Rigid* a, Rigid* b) : solver(s), bodyA(a), bodyB(b), nextA(nullptr), nextB(nullptr), next(nullptr), deviceKind(-1), listIndex(-1)
+{
+    next = s->forces; s->forces = this;
+    if (a) { nextA = a->forces; a->forces = this; }
+    if (b) { nextB = b->forces; b->forces = this; }
+    for (int i = 0; i < MAX_CONSTRAINT_ROWS; ++i) { /* force.cpp:32-40 */
+        stiffness[i] = 0.0f; lambda[i] = 0.0f; penalty[i] = 0.0f; motor[i] = 0.0f;
+        fmin[i] = -FLT_MAX; fmax[i] = FLT_MAX; C[i] = 0.0f; fracture[i] = 0.0f;
+    }
+}
+
+static void unlinkForce(Force* f)
+{
+    Solver* s = f->solver;
+    Force** p = &s->forces;
+    while (*p && *p != f) p = &(*p)->next;
+    if (*p) *p = f->next;
+    Rigid* ends[2] = {f->bodyA, f->bodyB};
+    for (int e = 0; e < 2; ++e) {
+        Rigid* b = ends[e];
+        if (!b) continue;
+        p = &b->forces;
+        while (*p && *p != f) p = ((*p)->bodyA == b) ? &(*p)->nextA : &(*p)->nextB;
+        if (*p) *p = (f->bodyA == b) ? f->nextA : f->nextB;
+    }
+}
+
+Force::~Force()
+{
+    unlinkForce(this);
+    if (!isManifold() && !solver->impl->clearing) {
+        auto& v = solver->impl->userForces;
+        for (size_t i = 0; i < v.size(); ++i) {
+            if (v[i] != this) continue;
+            if (i < solver->impl->flushedForces)
+                solver->fail("deleting a single force that already lives on the device is not supported; use Solver::clear()", AVBD_E_INVALID);
+            v.erase(v.begin() + (long)i);
+            break;
+        }
+    }
+}
+
+void Force::deviceComputeConstraint(float alpha)
+{
+    solver->flush();
+    if (listIndex < 0) solver->syncForces();
+    int rc = avbd_force_compute_constraint(solver->ctx, listIndex, alpha, C, fmin, fmax, lambda);
+    if (rc) solver->fail("avbd_force_compute_constraint", rc);
+    solver->syncForces(); /* pick up the reference's in-place mutations (normal, stick, cone-clamped lambda) */
+}
+
+void Force::deviceComputeDerivatives(vec3& Jl, vec3& Ja, const Rigid* body, int row) const
+{
+    Solver* s = solver;
+    s->flush();
+    if (listIndex < 0) s->syncForces();
+    float jl[3], ja[3];
+    int rc = avbd_force_compute_derivatives(s->ctx, listIndex, body ? body->index : -1, row, jl, ja);
+    if (rc) s->fail("avbd_force_compute_derivatives", rc);
+    Jl = vec3(jl[0], jl[1], jl[2]);
+    Ja = vec3(ja[0], ja[1], ja[2]);
+}
+
+Manifold::Manifold(Solver* s, Rigid* a, Rigid* b) : Force(s, a, b), numContacts(0), combinedFriction(0.0f)
+{
+    deviceKind = AVBD_FORCE_MANIFOLD;
+    for (int i = 0; i < 4; ++i) { contacts[i].C0_n = 0.0f; contacts[i].C0_t = vec3(); contacts[i].stick = false; contacts[i].feature.value = 0; contacts[i].penetration = 0.0f; }
+}
+
+int Manifold::collide(Rigid* a, Rigid* b, Contact* out, bool flip)
+{
+    Solver* s = a->solver;
+    AvbdContact c[4];
+    int count = 0;
+    int rc = avbd_kat_collide(s->ctx, 1, &a->position.x, &a->orientation.x, &a->size.x, &b->position.x, &b->orientation.x, &b->size.x, c, &count);
+    if (rc) s->fail("avbd_kat_collide", rc);
+    for (int i = 0; i < count; ++i) {
+        out[i].feature.value = c[i].feature;
+        out[i].rA = vec3(c[i].rA[0], c[i].rA[1], c[i].rA[2]); out[i].rB = vec3(c[i].rB[0], c[i].rB[1], c[i].rB[2]);
+        out[i].normal = vec3(c[i].normal[0], c[i].normal[1], c[i].normal[2]);
+        out[i].penetration = c[i].penetration; out[i].C0_n = 0.0f; out[i].C0_t = vec3(); out[i].stick = false;
+        if (flip) { vec3 t = out[i].rA; out[i].rA = out[i].rB; out[i].rB = t; out[i].normal = -out[i].normal; } /* collision.cpp:479-486 */
+    }
+    return count;
+}
+
+/* ------------------------------------------------------------------ Joint / Spring / Ignore */
+Joint::Joint(Solver* s, Rigid* a, Rigid* b, const vec3& localAnchorA, const vec3& localAnchorB, float linearStiffness,
+             float angularStiffness_, float motor_, float fracture_)
+    : Force(s, a, b), rA(localAnchorA), rB(localAnchorB)
+{
+    deviceKind = AVBD_FORCE_JOINT;
+    quat qa = a ? a->orientation : quat();
+    initialRelativeOrientation = conjugate(qa) * b->orientation;          /* joint.cpp:17-20 */
+    for (int i = 0; i < 3; ++i) { stiffness[i] = linearStiffness; lambda[i] = 0; penalty[i] = PENALTY_MIN; }
+    for (int i = 3; i < 6; ++i) { stiffness[i] = angularStiffness_; lambda[i] = 0; penalty[i] = PENALTY_MIN; }
+    angularStiffness = angularStiffness_; angularMotor = motor_; angularFracture = fracture_;
+    s->impl->userForces.push_back(this);
+}
+
+Joint::Joint(Solver* s, Rigid* b, const vec3& worldAnchor, float linearStiffness, float angularStiffness_, float motor_, float fracture_)
+    : Force(s, nullptr, b)
+{
+    deviceKind = AVBD_FORCE_JOINT;
+    rA = worldAnchor;                                                     /* joint.cpp:46-52 */
+    rB = transpose(mat3_from_quat(b->orientation)) * (worldAnchor - b->position);
+    initialRelativeOrientation = b->orientation;
+    for (int i = 0; i < 3; ++i) { stiffness[i] = linearStiffness; lambda[i] = 0; penalty[i] = PENALTY_MIN; }
+    for (int i = 3; i < 6; ++i) { stiffness[i] = angularStiffness_; lambda[i] = 0; penalty[i] = PENALTY_MIN; }
+    angularStiffness = angularStiffness_; angularMotor = motor_; angularFracture = fracture_;
+    s->impl->userForces.push_back(this);
+}
+
+Spring::Spring(Solver* s, Rigid* a, Rigid* b, const vec3& localAnchorA, const vec3& localAnchorB, float k, float rest)
+    : Force(s, a, b), rA(localAnchorA), rB(localAnchorB), restLength(rest), springStiffness(k)
+{
+    deviceKind = AVBD_FORCE_SPRING;
+    stiffness[0] = springStiffness;                                       /* spring.cpp:16-30 */
+    if (restLength < 0) {
+        vec3 pA = a->position + rotate(a->orientation, rA);
+        vec3 pB = b->position + rotate(b->orientation, rB);
+        restLength = length(pA - pB);
+    }
+    lambda[0] = 0.0f; penalty[0] = PENALTY_MIN; fmin[0] = -FLT_MAX; fmax[0] = FLT_MAX;
+    s->impl->userForces.push_back(this);
+}
+
+IgnoreCollision::IgnoreCollision(Solver* s, Rigid* a, Rigid* b) : Force(s, a, b)
+{
+    deviceKind = AVBD_FORCE_IGNORE;
+    s->impl->userForces.push_back(this);
+}
+
+/* ------------------------------------------------------------------ Solver ---------------- */
+void Solver::fail(const char* what, int rc) const
+{
+    std::fprintf(stderr, "[avbd] fatal: %s (code %d): %s\n", what, rc, ctx ? avbd_last_error(ctx) : "no device context");
+    std::fflush(stderr);
+    std::abort();
+}
+
+void Solver::init(AvbdContext* borrowed)
+{
+    bodies = nullptr; forces = nullptr; enableDiagnostics = false; logFrequency = 60; stepIndex = 0;
+    std::memset(&lastDiagnostics, 0, sizeof(lastDiagnostics));
+    hostSync = true; mirrorManifolds = false; numBodies = 0; flushedBodies = 0;
+    impl = new Impl();
+    ctx = borrowed; ownsCtx = false;
+    if (!ctx) {
+        int device = 0;
+        if (const char* d = std::getenv("AVBD_DEVICE")) device = std::atoi(d);
+        int rc = avbd_create(device, &ctx);
+        if (rc) { ctx = nullptr; fail("avbd_create: no MI355X device / HIP runtime available (this build has no CPU solve path)", rc); }
+        ownsCtx = true;
+    }
+    defaultParams();
+}
+
+Solver::Solver() { init(nullptr); }
+Solver::Solver(AvbdContext* borrowed) { init(borrowed); }
+
+void Solver::releaseMirrors()
+{
+    impl->clearing = true;
+    while (forces) delete forces;
+    while (bodies) delete bodies;
+    impl->clearing = false;
+    impl->byIndex.clear(); impl->userForces.clear(); impl->flushedForces = 0; impl->shadow.clear(); impl->manifolds.clear();
+    bodies = nullptr; forces = nullptr; numBodies = 0; flushedBodies = 0;
+}
+
+Solver::~Solver()
+{
+    /* the reference's destructor calls clear() (solver.cpp:140-143); the device scene of a borrowed
+     * context outlives its mirror, an owned context is destroyed with everything in it */
+    releaseMirrors();
+    if (ownsCtx && ctx) avbd_destroy(ctx);
+    delete impl;
+}
+
+Rigid* Solver::pick(const vec3&, const vec3&, vec3&) { return nullptr; }
+
+void Solver::clear()                                                       /* solver.cpp:230-238 */
+{
+    releaseMirrors();
+    stepIndex = 0;
+    std::memset(&lastDiagnostics, 0, sizeof(lastDiagnostics));
+    int rc = avbd_clear(ctx);
+    if (rc) fail("avbd_clear", rc);
+}
+
+void Solver::defaultParams()                                               /* solver.cpp:240-253 */
+{
+    AvbdParams p;
+    avbd_default_params(&p);
+    dt = p.dt; gravity = vec3(p.gravity[0], p.gravity[1], p.gravity[2]); iterations = p.iterations;
+    alpha = p.alpha; beta = p.beta; gamma = p.gamma; postStabilize = p.postStabilize != 0;
+    if (logFrequency <= 0) logFrequency = 60;
+    std::memset(&lastDiagnostics, 0, sizeof(lastDiagnostics));
+}
+
+Rigid* Solver::bodyByIndex(int i) const { return (i >= 0 && i < (int)impl->byIndex.size()) ? impl->byIndex[(size_t)i] : nullptr; }
+
+static void packBody(const Rigid* b, AvbdBody& o)
+{
+    std::memcpy(o.position, &b->position.x, 12); std::memcpy(o.orientation, &b->orientation.x, 16);
+    std::memcpy(o.linearVelocity, &b->linearVelocity.x, 12); std::memcpy(o.angularVelocity, &b->angularVelocity.x, 12);
+    std::memcpy(o.prevLinearVelocity, &b->prevLinearVelocity.x, 12); std::memcpy(o.prevAngularVelocity, &b->prevAngularVelocity.x, 12);
+    std::memcpy(o.initialPosition, &b->initialPosition.x, 12); std::memcpy(o.initialOrientation, &b->initialOrientation.x, 16);
+    std::memcpy(o.inertialPosition, &b->inertialPosition.x, 12); std::memcpy(o.inertialOrientation, &b->inertialOrientation.x, 16);
+    std::memcpy(o.size, &b->size.x, 12);
+    o.mass = b->mass; o.invMass = b->invMass; o.friction = b->friction; o.radius = b->radius;
+}
+
+static void unpackBody(Rigid* b, const AvbdBody& o)
+{
+    std::memcpy(&b->position.x, o.position, 12); std::memcpy(&b->orientation.x, o.orientation, 16);
+    std::memcpy(&b->linearVelocity.x, o.linearVelocity, 12); std::memcpy(&b->angularVelocity.x, o.angularVelocity, 12);
+    std::memcpy(&b->prevLinearVelocity.x, o.prevLinearVelocity, 12); std::memcpy(&b->prevAngularVelocity.x, o.prevAngularVelocity, 12);
+    std::memcpy(&b->initialPosition.x, o.initialPosition, 12); std::memcpy(&b->initialOrientation.x, o.initialOrientation, 16);
+    std::memcpy(&b->inertialPosition.x, o.inertialPosition, 12); std::memcpy(&b->inertialOrientation.x, o.inertialOrientation, 16);
+}
+
+void Solver::flush()
+{
+    const int n = numBodies;
+    if (n > flushedBodies) {
+        const int k = n - flushedBodies;
+        std::vector<float> size(3 * k), dens(k), fric(k), pos(3 * k), rot(4 * k), lv(3 * k), av(3 * k);
+        for (int i = 0; i < k; ++i) {
+            const Rigid* b = impl->byIndex[(size_t)(flushedBodies + i)];
+            std::memcpy(&size[3 * i], &b->size.x, 12); dens[i] = b->density; fric[i] = b->friction;
+            std::memcpy(&pos[3 * i], &b->position.x, 12); std::memcpy(&rot[4 * i], &b->orientation.x, 16);
+            std::memcpy(&lv[3 * i], &b->linearVelocity.x, 12); std::memcpy(&av[3 * i], &b->angularVelocity.x, 12);
+        }
+        int first = -1;
+        int rc = avbd_add_bodies(ctx, k, size.data(), dens.data(), fric.data(), pos.data(), rot.data(), lv.data(), av.data(), &first);
+        if (rc) fail("avbd_add_bodies", rc);
+        impl->shadow.resize((size_t)n);
+        for (int i = flushedBodies; i < n; ++i) packBody(impl->byIndex[(size_t)i], impl->shadow[(size_t)i]);
+        flushedBodies = n;
+    }
+    for (; impl->flushedForces < impl->userForces.size(); ++impl->flushedForces) {
+        Force* f = impl->userForces[impl->flushedForces];
+        if (f->deviceKind < 0) fail("user-defined Force subclasses cannot run on the device (no CPU solve path exists)", AVBD_E_INVALID);
+        AvbdForce r;
+        std::memset(&r, 0, sizeof(r));
+        r.kind = f->deviceKind; r.bodyA = f->bodyA ? f->bodyA->index : -1; r.bodyB = f->bodyB ? f->bodyB->index : -1;
+        r.rows = f->getRowCount();
+        for (int i = 0; i < MAX_CONSTRAINT_ROWS; ++i) {
+            r.C[i] = f->C[i]; r.fmin[i] = f->fmin[i]; r.fmax[i] = f->fmax[i]; r.lambda[i] = f->lambda[i];
+            r.penalty[i] = f->penalty[i]; r.motor[i] = f->motor[i]; r.stiffness[i] = f->stiffness[i];
+        }
+        r.q0[3] = 1.0f;
+        if (f->deviceKind == AVBD_FORCE_JOINT) {
+            const Joint* j = static_cast<const Joint*>(f);
+            std::memcpy(r.rA, &j->rA.x, 12); std::memcpy(r.rB, &j->rB.x, 12); std::memcpy(r.q0, &j->initialRelativeOrientation.x, 16);
+        } else if (f->deviceKind == AVBD_FORCE_SPRING) {
+            const Spring* sp = static_cast<const Spring*>(f);
+            std::memcpy(r.rA, &sp->rA.x, 12); std::memcpy(r.rB, &sp->rB.x, 12); r.restLength = sp->restLength;
+        }
+        int rc = avbd_add_force(ctx, &r);
+        if (rc) fail("avbd_add_force", rc);
+    }
+    /* a Force that registered only with the base constructor is a user subclass */
+    for (Force* f = forces; f; f = f->next)
+        if (f->deviceKind < 0) fail("user-defined Force subclasses cannot run on the device (no CPU solve path exists)", AVBD_E_INVALID);
+}
+
+void Solver::pushParams()
+{
+    AvbdParams p;
+    p.dt = dt; p.gravity[0] = gravity.x; p.gravity[1] = gravity.y; p.gravity[2] = gravity.z; p.iterations = iterations;
+    p.alpha = alpha; p.beta = beta; p.gamma = gamma; p.postStabilize = postStabilize ? 1 : 0;
+    int rc = avbd_set_params(ctx, &p);
+    if (rc) fail("avbd_set_params", rc);
+}
+
+void Solver::pushEditedBodies()
+{
+    const size_t n = impl->byIndex.size();
+    bool edited = false;
+    std::vector<AvbdBody> now(n);
+    for (size_t i = 0; i < n; ++i) {
+        packBody(impl->byIndex[i], now[i]);
+        if (!edited && std::memcmp(&now[i], &impl->shadow[i], sizeof(float) * 33) != 0) edited = true;
+    }
+    if (!edited) return;
+    int rc = avbd_upload_bodies(ctx, now.data(), (int)n);
+    if (rc) fail("avbd_upload_bodies", rc);
+    impl->shadow = now;
+}
+
+void Solver::pull()
+{
+    const size_t n = impl->byIndex.size();
+    impl->shadow.resize(n);
+    if (n) {
+        int rc = avbd_download_bodies(ctx, impl->shadow.data(), (int)n);
+        if (rc < 0) fail("avbd_download_bodies", rc);
+        for (size_t i = 0; i < n; ++i) unpackBody(impl->byIndex[i], impl->shadow[i]);
+    }
+    AvbdDiagnostics d;
+    int rc = avbd_get_diagnostics(ctx, &d);
+    if (rc) fail("avbd_get_diagnostics", rc);
+    lastDiagnostics.maxPenetration = d.maxPenetration; lastDiagnostics.maxConstraintViolation = d.maxConstraintViolation;
+    lastDiagnostics.maxLinearSpeed = d.maxLinearSpeed; lastDiagnostics.maxAngularSpeed = d.maxAngularSpeed;
+    lastDiagnostics.maxNormalImpulse = d.maxNormalImpulse; lastDiagnostics.activeContacts = d.activeContacts;
+    lastDiagnostics.activeManifolds = d.activeManifolds; lastDiagnostics.dynamicBodies = d.dynamicBodies;
+    stepIndex = avbd_step_index(ctx);
+}
+
+void Solver::stepMany(int n)
+{
+    flush();
+    pushParams();
+    if (hostSync) pushEditedBodies();
+    for (Manifold* m : impl->manifolds) m->listIndex = -1;
+    for (Force* f : impl->userForces) f->listIndex = -1;
+    int rc = avbd_step(ctx, n);
+    if (rc) fail("avbd_step", rc);
+    stepIndex += n;
+    if (hostSync) pull();
+    if (mirrorManifolds) syncForces();
+}
+
+void Solver::step()                                                        /* solver.cpp:255-514 */
+{
+    stepMany(1);
+    if (enableDiagnostics) {                                               /* solver.cpp:499-513 */
+        if (!hostSync) pull();
+        int frequency = logFrequency > 0 ? logFrequency : 1;
+        if (stepIndex % frequency == 0) {
+            const Diagnostics& s = lastDiagnostics;
+            std::printf("[Physics] step %d | manifolds: %d | contacts: %d | dyn bodies: %d | maxPen: %.6f | maxDrift: %.6f | maxLin: %.3f | maxAng: %.3f | maxLambda: %.3f\n",
+                        stepIndex, s.activeManifolds, s.activeContacts, s.dynamicBodies, s.maxPenetration, s.maxConstraintViolation,
+                        s.maxLinearSpeed, s.maxAngularSpeed, s.maxNormalImpulse);
+        }
+    }
+}
+
+void Solver::syncForces()
+{
+    flush();
+    int n = avbd_num_forces(ctx);
+    if (n < 0) fail("avbd_num_forces", n);
+    std::vector<AvbdForce> rec((size_t)n);
+    if (n) {
+        int rc = avbd_download_forces(ctx, rec.data(), n);
+        if (rc < 0) fail("avbd_download_forces", rc);
+    }
+    /* drop the old manifold mirrors and every list link, then rebuild oldest → newest with head insertion */
+    impl->clearing = true;
+    for (Manifold* m : impl->manifolds) delete m;
+    impl->clearing = false;
+    impl->manifolds.clear();
+    forces = nullptr;
+    for (Rigid* b : impl->byIndex) b->forces = nullptr;
+    size_t userLeft = impl->userForces.size();
+    for (int i = n - 1; i >= 0; --i) {
+        const AvbdForce& r = rec[(size_t)i];
+        Force* f = nullptr;
+        if (r.kind == AVBD_FORCE_MANIFOLD) {
+            Manifold* m = new Manifold(this, bodyByIndex(r.bodyA), bodyByIndex(r.bodyB));
+            m->numContacts = r.numContacts; m->combinedFriction = r.combinedFriction;
+            for (int c = 0; c < r.numContacts; ++c) {
+                const AvbdContact& s = r.contacts[c];
+                Manifold::Contact& d = m->contacts[c];
+                d.feature.value = s.feature; d.rA = vec3(s.rA[0], s.rA[1], s.rA[2]); d.rB = vec3(s.rB[0], s.rB[1], s.rB[2]);
+                d.normal = vec3(s.normal[0], s.normal[1], s.normal[2]); d.penetration = s.penetration; d.C0_n = s.C0_n;
+                d.C0_t = vec3(s.C0_t[0], s.C0_t[1], s.C0_t[2]); d.stick = s.stick != 0;
+            }
+            impl->manifolds.push_back(m);
+            f = m;
+        } else {
+            /* device generic forces are in creation order: the oldest unmatched user force is next */
+            size_t k = impl->userForces.size() - userLeft;
+            if (userLeft == 0) fail("device reports more user forces than the host created", AVBD_E_INVALID);
+            f = impl->userForces[k];
+            --userLeft;
+            f->next = forces; forces = f;
+            if (f->bodyA) { f->nextA = f->bodyA->forces; f->bodyA->forces = f; }
+            if (f->bodyB) { f->nextB = f->bodyB->forces; f->bodyB->forces = f; }
+        }
+        f->listIndex = i;
+        for (int k = 0; k < MAX_CONSTRAINT_ROWS; ++k) {
+            f->C[k] = r.C[k]; f->fmin[k] = r.fmin[k]; f->fmax[k] = r.fmax[k]; f->lambda[k] = r.lambda[k];
+            f->penalty[k] = r.penalty[k]; f->motor[k] = r.motor[k]; f->stiffness[k] = r.stiffness[k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ C ABI glue ------------ */
+extern "C" int avbd_build_scene(AvbdContext* ctx, const char* name)
+{
+    if (!ctx || !name) return AVBD_E_INVALID;
+    Solver s(ctx);
+    AvbdParams before;
+    avbd_get_params(ctx, &before);
+    s.dt = before.dt; s.gravity = vec3(before.gravity[0], before.gravity[1], before.gravity[2]); s.iterations = before.iterations;
+    s.alpha = before.alpha; s.beta = before.beta; s.gamma = before.gamma; s.postStabilize = before.postStabilize != 0;
+    int idx = buildSceneByName(&s, name);
+    if (idx < 0) return AVBD_E_INVALID;
+    s.flush();
+    AvbdParams p;
+    p.dt = s.dt; p.gravity[0] = s.gravity.x; p.gravity[1] = s.gravity.y; p.gravity[2] = s.gravity.z; p.iterations = s.iterations;
+    p.alpha = s.alpha; p.beta = s.beta; p.gamma = s.gamma; p.postStabilize = s.postStabilize ? 1 : 0;
+    avbd_set_params(ctx, &p);
+    return idx; /* ~Solver drops the mirror objects; the device scene stays in the borrowed context */
+}

@@ -1,0 +1,210 @@
+/*
+ * avbd_hip.h — C ABI of libavbd_hip.so: the MI355X (gfx950) implementation of the AVBD
+ * constraint-solve hot path of alxspiker/avbd-demo3d.
+ *
+ * The reference has no FFI: its boundary is the C++ object API of source/solver.h.  Each entry
+ * point below names the reference interface it replaces (file:line under /root/reference/source);
+ * the C++17 host mirror in avbd-demo3d_amd/host/ (Solver / Rigid / Force / Joint / Spring /
+ * IgnoreCollision, scenes, headless CLI) is a thin veneer over exactly these calls, and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; every call returns 0 on success or a negative
+ * AVBD_E_* code and never throws; `avbd_last_error` gives the message.  A context owns one device,
+ * one HIP stream and all device memory; calls on one context are not thread-safe.  Host buffers
+ * are caller-owned and only touched during the call.  Bodies are addressed by creation index
+ * (0 = first body added) — the reference's intrusive list order is the reverse (rigid.cpp:20-21).
+ * Quaternions are (x, y, z, w) like maths.h:55.  All floating point is IEEE binary32 and results
+ * are bit-identical to the reference CPU solver.
+ */
+#ifndef AVBD_HIP_H
+#define AVBD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVBD_ABI_VERSION 1
+
+enum {
+    AVBD_OK = 0,
+    AVBD_E_INVALID = -1,   /* bad argument */
+    AVBD_E_HIP = -2,       /* HIP runtime error (message in avbd_last_error) */
+    AVBD_E_CAPACITY = -3,  /* a device-side pool overflowed (candidate pairs / manifolds) */
+    AVBD_E_NODEVICE = -4,  /* no usable gfx950 device */
+    AVBD_E_COMM = -5       /* RCCL error */
+};
+
+typedef struct AvbdContext AvbdContext;
+
+/* Solver public parameters — solver.h:147-151, defaults solver.cpp:240-248. */
+typedef struct AvbdParams {
+    float dt;
+    float gravity[3];
+    int   iterations;
+    float alpha, beta, gamma;
+    int   postStabilize;
+} AvbdParams;
+
+/* Solver::Diagnostics — solver.h:155-164 (same field order). */
+typedef struct AvbdDiagnostics {
+    float maxPenetration;
+    float maxConstraintViolation;
+    float maxLinearSpeed;
+    float maxAngularSpeed;
+    float maxNormalImpulse;
+    int   activeContacts;
+    int   activeManifolds;
+    int   dynamicBodies;
+} AvbdDiagnostics;
+
+/* Full per-body record — the data members of struct Rigid, solver.h:56-70 (40 floats). */
+typedef struct AvbdBody {
+    float position[3];
+    float orientation[4];
+    float linearVelocity[3];
+    float angularVelocity[3];
+    float prevLinearVelocity[3];
+    float prevAngularVelocity[3];
+    float initialPosition[3];
+    float initialOrientation[4];
+    float inertialPosition[3];
+    float inertialOrientation[4];
+    float size[3];
+    float mass, invMass, friction, radius;
+} AvbdBody;
+
+/* Manifold::Contact — solver.h:120-130. */
+typedef struct AvbdContact {
+    int   feature;
+    float rA[3], rB[3], normal[3];
+    float penetration, C0_n, C0_t[3];
+    int   stick;
+} AvbdContact;
+
+enum { AVBD_FORCE_MANIFOLD = 0, AVBD_FORCE_JOINT = 1, AVBD_FORCE_SPRING = 2, AVBD_FORCE_IGNORE = 3 };
+
+/* One Force with its row arrays — struct Force solver.h:85-97 plus the Manifold / Joint / Spring
+ * payloads (solver.h:112-143, joint.h:16-24, spring.h:15-25).  bodyA = -1 means the world. */
+typedef struct AvbdForce {
+    int   kind;
+    int   bodyA, bodyB;
+    int   rows;
+    float C[12], fmin[12], fmax[12], lambda[12], penalty[12], motor[12], stiffness[12];
+    int   numContacts;
+    float combinedFriction;
+    AvbdContact contacts[4];
+    float rA[3], rB[3], q0[4], restLength;
+} AvbdForce;
+
+/* Live scene statistics of the last completed step; feeds the algorithmic-byte model of
+ * SURVEY.md §8d (B_iter = 100*Nb + 124*Ninc + 160*Nc) and the level schedule. */
+typedef struct AvbdStepStats {
+    int numBodies;          /* all bodies, static included */
+    int numDynamic;         /* Nb */
+    int numManifolds;       /* Nm */
+    int numContacts;        /* Nc */
+    int numIncidences;      /* Ninc = sum over contacts of dynamic endpoints */
+    int numCandidates;      /* sphere-overlap pairs tested by SAT this step that were not persistent */
+    int numLevels;          /* Gauss-Seidel dependency levels of the primal sweep */
+    int numJoints, numSprings, numIgnores;
+    int warnings;           /* non-finite sanitizer hits this step (solver.cpp:51-66) */
+    int reserved;
+} AvbdStepStats;
+
+/* Accumulated device time per kernel family since the last avbd_profile_reset, measured with HIP
+ * events on the context's stream (only while profiling is enabled: it serialises the stream). */
+typedef struct AvbdProfile {
+    double ms_broadphase, ms_narrowphase, ms_topology, ms_predict, ms_primal, ms_dual, ms_velocity;
+    long long launches_primal, launches_dual, launches_total;
+    long long steps;
+    double algorithmic_bytes_primal, algorithmic_bytes_dual; /* summed per launch, SURVEY §8d model */
+} AvbdProfile;
+
+/* ---- lifetime: `new Solver` / `delete solver` (solver.cpp:127-143) ---------------------- */
+int  avbd_create(int device, AvbdContext** out);
+int  avbd_destroy(AvbdContext* ctx);
+const char* avbd_last_error(const AvbdContext* ctx);
+int  avbd_abi_version(void);
+
+/* ---- Solver fields and Solver::defaultParams / clear (solver.cpp:230-253) ---------------- */
+int  avbd_default_params(AvbdParams* out);
+int  avbd_set_params(AvbdContext* ctx, const AvbdParams* p);
+int  avbd_get_params(const AvbdContext* ctx, AvbdParams* out);
+int  avbd_clear(AvbdContext* ctx);
+
+/* ---- `new Rigid(solver, size, density, friction, pos, orient, linVel, angVel)` (rigid.cpp:12-41).
+ * Adds n bodies in order; arrays are packed (size: 3n, density: n, friction: n, position: 3n,
+ * orientation: 4n or NULL for identity, linearVelocity / angularVelocity: 3n or NULL for zero).
+ * Returns the creation index of the first added body in *first_index (may be NULL). */
+int  avbd_add_bodies(AvbdContext* ctx, int n, const float* size, const float* density, const float* friction,
+                     const float* position, const float* orientation, const float* linearVelocity,
+                     const float* angularVelocity, int* first_index);
+
+/* ---- `new Joint(...)` both constructors (joint.cpp:11-61): bodyA = -1 selects the world-anchor
+ * form where rA is the world-space anchor and rB is ignored. ---- */
+int  avbd_add_joint(AvbdContext* ctx, int bodyA, int bodyB, const float rA[3], const float rB[3],
+                    float linearStiffness, float angularStiffness);
+/* ---- `new Spring(...)` (spring.cpp:10-31); rest < 0 means "use the current distance". ---- */
+int  avbd_add_spring(AvbdContext* ctx, int bodyA, int bodyB, const float rA[3], const float rB[3],
+                     float stiffness, float rest);
+/* ---- `new IgnoreCollision(...)` (ignorecollision.h:15-16). ---- */
+int  avbd_add_ignore(AvbdContext* ctx, int bodyA, int bodyB);
+
+/* ---- generic form of the three constructors above: append one host-created Joint / Spring /
+ * IgnoreCollision from an explicit record (kind, bodyA/bodyB, rA, rB, q0, restLength and the row
+ * arrays lambda / penalty / stiffness / motor / fmin / fmax as the reference constructors leave them:
+ * force.cpp:32-40, joint.cpp:22-38, spring.cpp:16-30).  Used by the C++ host mirror, which evaluates
+ * the constructor arithmetic itself at construction time like the reference does. ---- */
+int  avbd_add_force(AvbdContext* ctx, const AvbdForce* record);
+
+/* ---- scene builders of scenes.h:23-212 by exact name ("Stack", "Stress1000", ...), plus the build's
+ * "StressN:<n>" / "Packed:<n>"; clears the context first like every reference scene does.  Returns
+ * the scene index (>= 0) or AVBD_E_INVALID for an unknown name. ---- */
+int  avbd_build_scene(AvbdContext* ctx, const char* name);
+
+/* ---- Solver::step() (solver.cpp:255-514), nsteps times back to back on the device. ---- */
+int  avbd_step(AvbdContext* ctx, int nsteps);
+int  avbd_synchronize(AvbdContext* ctx);
+int  avbd_step_index(const AvbdContext* ctx);                       /* Solver::stepIndex */
+int  avbd_get_diagnostics(AvbdContext* ctx, AvbdDiagnostics* out);  /* Solver::lastDiagnostics */
+int  avbd_get_step_stats(AvbdContext* ctx, AvbdStepStats* out);
+
+/* ---- state access (what main.cpp:228-234 reads from Rigid every step) ---- */
+int  avbd_num_bodies(const AvbdContext* ctx);
+int  avbd_download_bodies(AvbdContext* ctx, AvbdBody* out, int capacity);
+/* 13-float rows: position[3], orientation[4], linearVelocity[3], angularVelocity[3] */
+int  avbd_download_state13(AvbdContext* ctx, float* out, int capacity_bodies);
+int  avbd_upload_state13(AvbdContext* ctx, const float* in, int n_bodies);
+/* full dynamic state incl. prev velocities (teacher forcing / snapshots) */
+int  avbd_upload_bodies(AvbdContext* ctx, const AvbdBody* in, int n_bodies);
+
+/* ---- force list in the reference's solver-list order: newest first (force.cpp:16-18) ---- */
+int  avbd_num_forces(AvbdContext* ctx);
+int  avbd_download_forces(AvbdContext* ctx, AvbdForce* out, int capacity);
+/* replace every force by `n` records given newest first (snapshot restore / teacher forcing) */
+int  avbd_upload_forces(AvbdContext* ctx, const AvbdForce* in, int n);
+
+/* ---- row API on the device for one force of the downloaded list (index into newest-first order):
+ * Force::computeConstraint / computeDerivatives (solver.h:104-106).  compute_constraint applies the
+ * reference's in-place mutations to the device-resident force and returns its rows. ---- */
+int  avbd_force_row_count(AvbdContext* ctx, int force_index, int* rows);
+int  avbd_force_compute_constraint(AvbdContext* ctx, int force_index, float alpha, float* C, float* fmin, float* fmax, float* lambda);
+int  avbd_force_compute_derivatives(AvbdContext* ctx, int force_index, int body, int row, float J_linear[3], float J_angular[3]);
+
+/* ---- known-answer entry points evaluated on the device (one lane) ---- */
+int  avbd_kat_collide(AvbdContext* ctx, int npairs, const float* posA, const float* quatA, const float* sizeA,
+                      const float* posB, const float* quatB, const float* sizeB, AvbdContact* out /* 4*npairs */, int* counts);
+int  avbd_kat_solve6(AvbdContext* ctx, int n, const float* A /* 36n: ll,la,al,aa column-major */, const float* b /* 6n */, float* x /* 6n */);
+int  avbd_kat_arith(AvbdContext* ctx, int n, const float* a, const float* b, float* out_div, float* out_sqrt, float* out_mul, float* out_add);
+
+/* ---- measurement ---- */
+int  avbd_profile_enable(AvbdContext* ctx, int enable);
+int  avbd_profile_reset(AvbdContext* ctx);
+int  avbd_profile_get(AvbdContext* ctx, AvbdProfile* out);
+/* the raw hipStream_t of the context (as void*), so a caller can record its own events on it */
+void* avbd_stream(AvbdContext* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVBD_HIP_H */

@@ -236,3 +236,112 @@ def random_pile(world, rng, n, spread=2.0, height=6.0, ground=True, size_range=(
         pos = np.array([rng.uniform(-spread, spread), rng.uniform(0.8, height), rng.uniform(-spread, spread)], np.float32)
         world.add_body(size, float(np.float32(rng.uniform(0.5, 2.0))), float(np.float32(rng.uniform(0.2, 0.9))), pos,
                        rand_quat(rng), rng.normal(scale=0.5, size=3).astype(np.float32), rng.normal(scale=0.5, size=3).astype(np.float32))
+
+
+# --------------------------------------------------------------------------------------------
+# product side: the HIP library through its C ABI (avbd-demo3d_amd/__init__.py is the ctypes binding)
+# --------------------------------------------------------------------------------------------
+def load_product():
+    import importlib.util
+    import sys
+    name = "avbd_demo3d_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    pkg_dir = os.path.join(ROOT, "avbd-demo3d_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class HipWorld:
+    """Same surface as CpuWorld, backed by libavbd_hip.so on cuda:0 (no CPU fallback)."""
+
+    prefix = "hip"
+
+    def __init__(self, device=0):
+        self.pkg = load_product()
+        self.w = self.pkg.World(device)
+
+    def close(self):
+        self.w.close()
+
+    def scene(self, name):
+        return self.w.scene(name)
+
+    def params(self):
+        return self.w.params()
+
+    def set_params(self, **kw):
+        self.w.set_params(**kw)
+
+    def add_body(self, size, density, friction, pos, quat=(0, 0, 0, 1), lin=(0, 0, 0), ang=(0, 0, 0)):
+        return self.w.add_body(size, density, friction, pos, quat, lin, ang)
+
+    def add_joint(self, a, b, rA, rB=(0, 0, 0), lin_stiff=FLT_MAX, ang_stiff=FLT_MAX):
+        self.w.add_joint(a, b, rA, rB, lin_stiff, ang_stiff)
+
+    def add_spring(self, a, b, rA, rB, stiffness, rest=-1.0):
+        self.w.add_spring(a, b, rA, rB, stiffness, rest)
+
+    def add_ignore(self, a, b):
+        self.w.add_ignore(a, b)
+
+    def step(self, n=1):
+        self.w.step(n)
+
+    def step_index(self):
+        return self.w.step_index()
+
+    def bodies(self):
+        return self.w.bodies().view(BODY_DT)
+
+    def forces(self):
+        return self.w.forces().view(FORCE_DT)
+
+    def diag(self):
+        return self.w.diag()
+
+    def set_bodies(self, arr):
+        self.w.set_bodies(np.ascontiguousarray(arr).view(self.pkg.BODY_DT))
+
+    def set_forces(self, arr):
+        self.w.set_forces(np.ascontiguousarray(arr).view(self.pkg.FORCE_DT))
+
+    def copy_scene_from(self, cpu, density=1.0):
+        """Recreate `cpu`'s bodies (bit-exact initial state) in this world; dynamic bodies get `density`."""
+        b = cpu.bodies()
+        n = len(b)
+        dens = np.where(b["mass"] > 0, np.float32(density), np.float32(0.0)).astype(np.float32)
+        self.w.add_bodies(b["size"], dens, b["friction"], b["pos"], b["quat"], b["linVel"], b["angVel"])
+        p = cpu.params()
+        self.w.set_params(dt=p["dt"], gravity=p["gravity"], iterations=p["iterations"], alpha=p["alpha"], beta=p["beta"],
+                          gamma=p["gamma"], postStabilize=p["postStabilize"])
+        return n
+
+
+def assert_same_world(a, b, what, check_rows=True):
+    """Bit-exact comparison of two worlds: bodies, force list (order, rows, contacts) and diagnostics."""
+    ba, bb = a.bodies(), b.bodies()
+    if not same_bits(ba, bb):
+        for name in ba.dtype.names:
+            if not same_bits(ba[name], bb[name]):
+                bad = np.nonzero(np.any(np.atleast_2d(ba[name].reshape(len(ba), -1).view(np.uint32) != bb[name].reshape(len(bb), -1).view(np.uint32)), axis=1))[0]
+                raise AssertionError(f"{what}: body field {name} differs for {len(bad)} bodies, first {bad[:5]}: "
+                                     f"{ba[name][bad[0]]} vs {bb[name][bad[0]]}")
+    fa, fb = a.forces(), b.forces()
+    assert len(fa) == len(fb), f"{what}: force count {len(fa)} vs {len(fb)}"
+    for name in ("kind", "bodyA", "bodyB", "rows", "numContacts", "combinedFriction", "rA", "rB", "q0", "restLength"):
+        assert same_bits(fa[name], fb[name]), f"{what}: force field {name} differs"
+    for i in range(len(fa)):
+        r = int(fa["rows"][i])
+        names = ("lambda", "penalty", "stiffness", "motor") + (("C", "fmin", "fmax") if check_rows else ())
+        for name in names:
+            assert same_bits(fa[name][i][:r], fb[name][i][:r]), f"{what}: force {i} (kind {fa['kind'][i]}, bodies {fa['bodyA'][i]},{fa['bodyB'][i]}) {name}: {fa[name][i][:r]} vs {fb[name][i][:r]}"
+        n = int(fa["numContacts"][i])
+        for cn in CONTACT_DT.names:
+            assert same_bits(fa["contacts"][i][:n][cn], fb["contacts"][i][:n][cn]), f"{what}: force {i} contact field {cn}: {fa['contacts'][i][:n][cn]} vs {fb['contacts'][i][:n][cn]}"
+    da, db = np.array([a.diag()]), np.array([b.diag()])
+    for name in DIAG_DT.names:
+        assert same_bits(da[name], db[name]), f"{what}: diagnostics {name}: {da[name]} vs {db[name]}"

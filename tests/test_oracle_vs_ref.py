@@ -12,22 +12,7 @@ import harness as H
 pytestmark = pytest.mark.skipif(not H.have("ref"), reason="oracle/_ref not built (reference sources absent)")
 
 
-def assert_same_world(a, b, what):
-    ba, bb = a.bodies(), b.bodies()
-    assert H.same_bits(ba, bb), f"{what}: body state differs"
-    fa, fb = a.forces(), b.forces()
-    assert len(fa) == len(fb), f"{what}: force count {len(fa)} vs {len(fb)}"
-    for name in ("kind", "bodyA", "bodyB", "rows", "numContacts", "lambda", "penalty", "stiffness", "motor",
-                 "combinedFriction", "rA", "rB", "q0", "restLength"):
-        assert H.same_bits(fa[name], fb[name]), f"{what}: force field {name} differs"
-    # per-row C/fmin/fmax and contacts are only defined up to rows / numContacts
-    for i in range(len(fa)):
-        r = int(fa["rows"][i])
-        for name in ("C", "fmin", "fmax"):
-            assert H.same_bits(fa[name][i][:r], fb[name][i][:r]), f"{what}: force {i} {name}"
-        n = int(fa["numContacts"][i])
-        assert H.same_bits(fa["contacts"][i][:n], fb["contacts"][i][:n]), f"{what}: force {i} contacts"
-    assert H.same_bits(np.array([a.diag()]), np.array([b.diag()])), f"{what}: diagnostics differ"
+assert_same_world = H.assert_same_world
 
 
 @pytest.mark.parametrize("scene,steps", [("Stack", 120), ("Pyramid", 60), ("Wall", 60), ("TwoBlockDrop", 200),
