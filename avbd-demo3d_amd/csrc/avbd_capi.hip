@@ -13,6 +13,7 @@
  */
 #include "../../include/avbd_hip.h"
 #include "avbd_kernels.hip"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -513,20 +514,21 @@ int step_once(AvbdContext* c)
     for (int it = 0; it < totalIt; ++it) {
         const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const int writeRows = it >= P.iterations ? 1 : 0;
-        {
-            SpanGuard g(c, F_PRIMAL);
-            for (int l = 0; l < L; ++l) {
-                const int count = lvlStart[l + 1] - lvlStart[l];
-                if (count <= 0) continue;
-                hipLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, B, M, c->dG.p,
-                                   c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
-                ++c->prof.launches_primal; ++c->prof.launches_total;
-            }
+        for (int l = 0; l < L; ++l) {
+            const int count = lvlStart[l + 1] - lvlStart[l];
+            if (count <= 0) continue;
+            /* profiling: per-launch start/stop events (kernel begin → end, like a kernel trace) */
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+            hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
+                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
+            ++c->prof.launches_primal; ++c->prof.launches_total;
         }
         if (it < P.iterations) {
-            SpanGuard g(c, F_DUAL);
             if (contactSlots > 0) {
-                hipLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dCnt.p, P, alphaCur);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_DUAL, i0, i0 + 1}); }
+                hipExtLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, e0, e1, 0, B, M, c->dCnt.p, P, alphaCur);
                 ++c->prof.launches_dual; ++c->prof.launches_total;
             }
             if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
@@ -988,9 +990,9 @@ int avbd_download_forces(AvbdContext* c, AvbdForce* out, int capacity)
                 o.C[r] = g.C[r]; o.fmin[r] = g.fmin[r]; o.fmax[r] = g.fmax[r]; o.lambda[r] = g.lambda[r];
                 o.penalty[r] = g.penalty[r]; o.stiffness[r] = g.stiffness[r]; o.motor[r] = g.motor[r];
             }
-            for (int k = 0; k < 3; ++k) { o.rA[k] = g.rA[k]; o.rB[k] = g.rB[k]; }
-            for (int k = 0; k < 4; ++k) o.q0[k] = g.q0[k];
-            o.restLength = g.restLength;
+            if (g.kind != FK_IGNORE) for (int k = 0; k < 3; ++k) { o.rA[k] = g.rA[k]; o.rB[k] = g.rB[k]; }
+            if (g.kind == FK_JOINT) for (int k = 0; k < 4; ++k) o.q0[k] = g.q0[k];
+            if (g.kind == FK_SPRING) o.restLength = g.restLength;
         }
     }
     return n;

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — solver steps/s of the AVBD hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one Solver::step() (solver.cpp:255-514) on the device.  Workload at N=1 is
+BASELINE.json configs[1]: Stress1000 (1000 unit cubes, iterations=20, beta=3e4, gamma=0.995),
+measured in its contact-rich steady window: the scene is first simulated `--presim` steps untimed
+(default 400, the window SURVEY.md §8d names), then W warm-up steps, then exactly K timed steps with
+all state resident in HBM, bracketed by barrier + device synchronize; value = steps / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (k_primal): algorithmic bytes per launch (SURVEY.md §8d model, recomputed
+                from the live scene every step) / mean launch duration from HIP events recorded around every
+                launch on the solver's own stream, against 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (port of the reference, bit-identical to it) timed on this box's host, one
+                thread, started from the SAME state as the timed GPU window; when it covers the whole window the
+                final states are compared bit for bit ("parity": "bit-exact").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def load_pkg():
+    import importlib.util
+    name = "avbd_demo3d_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    d = os.path.join(ROOT, "avbd-demo3d_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, "__init__.py"), submodule_search_locations=[d])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def algorithmic_bytes(stats, iterations):
+    """B_iter = 100*Nb + 124*Ninc + 160*Nc ; B_step = iters*B_iter + 264*Nb + 704*Nm."""
+    nb, ninc, nc, nm = int(stats["numDynamic"]), int(stats["numIncidences"]), int(stats["numContacts"]), int(stats["numManifolds"])
+    b_iter = 100 * nb + 124 * ninc + 160 * nc
+    return {"B_iter": b_iter, "B_step": iterations * b_iter + 264 * nb + 704 * nm,
+            "B_primal_iter": 100 * nb + 124 * ninc, "B_dual_iter": 160 * nc}
+
+
+def cpu_baseline(pkg, world, scene, snapshot_bodies, snapshot_forces, step_index, cpu_steps):
+    """Time the CPU oracle (kind 'port') from the given snapshot on one host thread."""
+    import harness as H
+    o = H.CpuWorld("orc")
+    o.scene(scene)
+    o.set_bodies(snapshot_bodies.view(H.BODY_DT))
+    o.set_forces(snapshot_forces.view(H.FORCE_DT))
+    o.set_step_index(step_index)
+    t0 = time.perf_counter()
+    o.step(cpu_steps)
+    dt = time.perf_counter() - t0
+    return o, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default=None, help="override the workload (e.g. StressN:20, Packed:10)")
+    ap.add_argument("--presim", type=int, default=None, help="untimed steps before warm-up (default 400 for falling scenes)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=None)
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world_size > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = load_pkg()
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build()
+    w = pkg.World(local_rank)
+
+    scene = args.scene or "Stress1000"
+    presim = args.presim if args.presim is not None else (0 if scene.startswith("Packed") else 400)
+    w.scene(scene)
+    iterations = int(w.params()["iterations"])
+    if presim:
+        w.step(presim)
+    w.step(args.warmup)
+    w.synchronize()
+
+    # snapshot for the CPU leg / parity (rank 0, N=1 only)
+    want_cpu = (rank == 0 and world_size == 1 and not args.no_cpu)
+    snap_b = snap_f = None
+    snap_step = w.step_index()
+    if want_cpu:
+        snap_b, snap_f = w.bodies(), w.forces()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        w.synchronize()
+
+    # ---- timed region: exactly K steps -----------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    w.step(args.steps)
+    w.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+    end_b = w.bodies() if want_cpu else None
+    stats = w.stats()
+    ab = algorithmic_bytes(stats, iterations)
+
+    # ---- roofline of the dominant kernel: HIP events around every launch on the solver's stream ----
+    roof = None
+    prof_steps = min(args.steps, 50)
+    w.profile_enable(True)
+    w.profile_reset()
+    w.step(prof_steps)
+    w.synchronize()
+    p = w.profile()
+    w.profile_enable(False)
+    if p["launches_primal"] > 0 and p["ms_primal"] > 0:
+        per_launch_s = p["ms_primal"] * 1e-3 / p["launches_primal"]
+        bytes_per_launch = p["algorithmic_bytes_primal"] / p["launches_primal"]
+        achieved = bytes_per_launch / per_launch_s / 1e9
+        roof = {"bound": "hbm", "kernel": "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "bytes_per_launch": round(bytes_per_launch, 1), "us_per_launch": round(per_launch_s * 1e6, 3),
+                "launches_per_step": round(p["launches_primal"] / max(1, p["steps"]), 2),
+                "step_algorithmic_GBps": round(ab["B_step"] * args.steps / elapsed / 1e9, 3),
+                "kernel_ms_per_step": {k[3:]: round(float(p[k]) / max(1, p["steps"]), 4) for k in
+                                       ("ms_broadphase", "ms_narrowphase", "ms_topology", "ms_predict", "ms_primal", "ms_dual", "ms_velocity")}}
+
+    # ---- CPU baseline on the same window ----------------------------------------------------
+    cpu = None
+    if want_cpu:
+        try:
+            ms_guess = 50.0 * max(1, int(stats["numDynamic"])) / 1000.0  # ~45 ms/step at Stress1000 steady state
+            cpu_steps = args.cpu_steps or max(1, min(args.steps, int(20000.0 / ms_guess)))
+            o, dt = cpu_baseline(pkg, w, scene, snap_b, snap_f, snap_step, cpu_steps)
+            parity = "not-compared"
+            if cpu_steps == args.steps:
+                import harness as H
+                parity = "bit-exact" if H.same_bits(o.bodies(), end_b.view(H.BODY_DT)) else "MISMATCH"
+            cpu = {"value": round(cpu_steps / dt, 3), "unit": "steps/s", "cores": 1, "kind": "port",
+                   "sample": f"{cpu_steps} steps of {scene} from the GPU run's own state at step {snap_step} (oracle/liboracle.so, "
+                             f"-O2 -ffp-contract=off, 1 thread of {os.cpu_count()} host cores)",
+                   "ms_per_step": round(dt / cpu_steps * 1e3, 3), "parity": parity}
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
+            cpu = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        total_steps = args.steps * world_size
+        line = {
+            "metric": "solver steps/sec + ms/step, Stress1000 @ iters=20, 1/2/4/8 MI355X",
+            "value": round(total_steps / elapsed, 3), "unit": "steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{scene} (iterations={iterations}) steady window: steps {snap_step}..{snap_step + args.steps}",
+                       "mode": "exact (bit-identical to the reference CPU solver)",
+                       "parallelism": "1 GPU" if world_size == 1 else f"{world_size} independent replicas (sharded exchange not implemented yet)",
+                       "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
+                       "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"]},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,7 +161,7 @@ def test_teacher_forced_single_step_from_snapshot():
     bodies, forces = o.bodies(), o.forces()
     g = H.HipWorld(); g.scene("Packed:4")
     g.set_bodies(bodies); g.set_forces(forces)
-    H.assert_same_world(o, g, "snapshot upload round trip", check_rows=True)
+    H.assert_same_world(o, g, "snapshot upload round trip", check_rows=True, check_diag=False)
     o.step(); g.step()
     H.assert_same_world(o, g, "one teacher-forced step")
     o.step(5); g.step(5)
