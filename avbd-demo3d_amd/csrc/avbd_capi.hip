@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -126,6 +127,11 @@ struct AvbdContext {
     DevArr<Counters> dCnt;
     DevArr<DiagAccum> dDiag;
     DevArr<int> dNext;
+    DevArr<int> dFlags;        /* primalDone[bodyCap] | dualDone[bodyCap] | error word (data-flow kernel) */
+    int mode = 1;              /* 1: persistent data-flow iteration kernel (default), 0: one launch per level */
+    int iterBlocks = 512;      /* resident workgroups of k_iterate */
+    int numStatic = 0;
+    bool statsFresh = true;
     Readback* hRb = nullptr; /* pinned */
     AvbdStepStats stats{};
     int lastLevels = 0;
@@ -232,6 +238,8 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, hipMemset(c->incStart.p, 0, (newCap + 1) * sizeof(int)));
     HIPCHK(c, hipMemset(c->degForce.p, 0, newCap * sizeof(int)));
     HIPCHK(c, hipMemset(c->degInc.p, 0, newCap * sizeof(int)));
+    HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 16));
+    HIPCHK(c, hipMemset(c->dFlags.p, 0, ((size_t)2 * newCap + 16) * sizeof(int)));
     c->adjDirty = true;
     c->bodiesStale = true;
     return AVBD_OK;
@@ -313,8 +321,11 @@ int upload_bodies_if_stale(AvbdContext* c)
     return AVBD_OK;
 }
 
+int refresh_stats(AvbdContext* c, bool withLevels);
+
 int download_bodies_to_host(AvbdContext* c)
 {
+    if (!c->statsFresh) { int rc = refresh_stats(c, false); if (rc) return rc; }
     if (!c->deviceAhead || c->bodiesStale) return AVBD_OK;
     const int n = (int)c->hBodies.size(), cap = c->bodyCap;
     if (!n) { c->deviceAhead = false; return AVBD_OK; }
@@ -447,6 +458,34 @@ int launch_topology(AvbdContext* c, bool fromStep)
     return AVBD_OK;
 }
 
+/* Copy the device counters (and, for the level mode, the level offsets) to the host and turn device-side
+ * failure words into error codes.  Synchronises the stream. */
+int refresh_stats(AvbdContext* c, bool withLevels)
+{
+    HIPCHK(c, hipMemcpyAsync(&c->hRb->cnt, c->dCnt.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    if (withLevels)
+        HIPCHK(c, hipMemcpyAsync(c->hRb->lvlStart, c->lvlStart.p, sizeof(int) * (std::min(kReadbackLevels, c->lvlCap) + 1), hipMemcpyDeviceToHost, c->stream));
+    int iterError = 0;
+    if (c->dFlags.p)
+        HIPCHK(c, hipMemcpyAsync(&iterError, c->dFlags.p + 2 * (size_t)c->bodyCap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const Counters& cnt = c->hRb->cnt;
+    c->stats.numBodies = (int)c->hBodies.size(); c->stats.numManifolds = cnt.numManifolds; c->stats.numContacts = cnt.numContacts;
+    c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = cnt.numLevels;
+    c->stats.numDynamic = cnt.dynamicBodies;
+    int nj = 0, ns = 0, ni = 0;
+    for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
+    c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
+    c->statsFresh = true;
+    if (cnt.overflow) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
+        return c->fail(AVBD_E_CAPACITY, buf);
+    }
+    if (iterError) return c->fail(AVBD_E_HIP, "k_iterate: dependency wait timed out (grid not resident?)");
+    return AVBD_OK;
+}
+
 int step_once(AvbdContext* c)
 {
     int rc;
@@ -483,56 +522,67 @@ int step_once(AvbdContext* c)
         SpanGuard g(c, F_PREDICT);
         hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
     }
-    /* readback of the level schedule (the one host sync of the step) */
-    HIPCHK(c, hipMemcpyAsync(&c->hRb->cnt, c->dCnt.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->hRb->lvlStart, c->lvlStart.p, sizeof(int) * (std::min(kReadbackLevels, c->lvlCap) + 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const Counters& cnt = c->hRb->cnt;
-    if (cnt.overflow) {
-        char buf[128];
-        std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
-        return c->fail(AVBD_E_CAPACITY, buf);
-    }
-    const int L = cnt.numLevels;
-    std::vector<int> lvl;
-    const int* lvlStart = c->hRb->lvlStart;
-    if (L > kReadbackLevels) {
-        lvl.resize(L + 1);
-        HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost));
-        lvlStart = lvl.data();
-    }
-    c->stats.numBodies = n; c->stats.numManifolds = cnt.numManifolds; c->stats.numContacts = cnt.numContacts;
-    c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = L;
-    c->stats.numDynamic = cnt.dynamicBodies;
-    int nj = 0, ns = 0, ni = 0;
-    for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
-    c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
-
     ManifoldTable M = c->mbuf[c->cur].view();
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
-    const long long contactSlots = (long long)cnt.numManifolds * 4;
-    for (int it = 0; it < totalIt; ++it) {
-        const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
-        const int writeRows = it >= P.iterations ? 1 : 0;
-        for (int l = 0; l < L; ++l) {
-            const int count = lvlStart[l + 1] - lvlStart[l];
-            if (count <= 0) continue;
-            /* profiling: per-launch start/stop events (kernel begin → end, like a kernel trace) */
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-            hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
-                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
-            ++c->prof.launches_primal; ++c->prof.launches_total;
+    const bool needReadback = (c->mode == 0) || c->profiling;
+    if (needReadback) {
+        /* level mode: the host launches one kernel per level, so it needs the schedule (one sync per step) */
+        int rc2 = refresh_stats(c, true);
+        if (rc2) return rc2;
+    } else {
+        c->statsFresh = false;
+    }
+    const Counters& cnt = c->hRb->cnt;
+    /* without a readback the grid sizes come from the last known counts (all kernels grid-stride) */
+    const long long contactSlots = needReadback ? (long long)cnt.numManifolds * 4 : (long long)std::max(c->stats.numManifolds + c->stats.numCandidates, n) * 4 + 4096;
+
+    if (c->mode == 0) {
+        const int L = cnt.numLevels;
+        std::vector<int> lvl;
+        const int* lvlStart = c->hRb->lvlStart;
+        if (L > kReadbackLevels) {
+            lvl.resize(L + 1);
+            HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost));
+            lvlStart = lvl.data();
         }
-        if (it < P.iterations) {
-            if (contactSlots > 0) {
+        for (int it = 0; it < totalIt; ++it) {
+            const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+            const int writeRows = it >= P.iterations ? 1 : 0;
+            for (int l = 0; l < L; ++l) {
+                const int count = lvlStart[l + 1] - lvlStart[l];
+                if (count <= 0) continue;
+                /* profiling: per-launch start/stop events (kernel begin → end, like a kernel trace) */
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_DUAL, i0, i0 + 1}); }
-                hipExtLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, e0, e1, 0, B, M, c->dCnt.p, P, alphaCur);
-                ++c->prof.launches_dual; ++c->prof.launches_total;
+                if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+                hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
+                                      c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
+                ++c->prof.launches_primal; ++c->prof.launches_total;
             }
-            if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
+            if (it < P.iterations) {
+                if (contactSlots > 0) {
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_DUAL, i0, i0 + 1}); }
+                    hipExtLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, e0, e1, 0, B, M, c->dCnt.p, P, alphaCur);
+                    ++c->prof.launches_dual; ++c->prof.launches_total;
+                }
+                if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
+            }
         }
+    } else {
+        /* data-flow mode: the whole iteration loop is one persistent launch (avbd_iterate.h) */
+        IterateState S;
+        S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
+        HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * c->bodyCap + 16) * sizeof(int), c->stream));
+        long long tasks = (long long)n * totalIt;
+        int blocks = (int)std::min<long long>(c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
+        if (blocks < 1) blocks = 1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+        hipExtLaunchKernelGGL(k_iterate, dim3(blocks), dim3(64 * kIterWaves), 0, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p);
+        ++c->prof.launches_primal; ++c->prof.launches_total;
+        if (c->numStatic > 1 || ng > 0)
+            hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
     }
     {
         SpanGuard g(c, F_VELOCITY);
@@ -544,10 +594,16 @@ int step_once(AvbdContext* c)
     HIPCHK(c, hipGetLastError());
     c->deviceAhead = true;
     if (ng) c->gDeviceAhead = true;
-    /* algorithmic bytes of this step's iteration loop */
-    const double nbDyn = cnt.dynamicBodies, ninc = cnt.numIncidences, ncon = cnt.numContacts;
-    c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc);
-    c->prof.algorithmic_bytes_dual += (double)P.iterations * (160.0 * ncon);
+    if (needReadback) {
+        /* algorithmic bytes of this step's iteration loop */
+        const double nbDyn = cnt.dynamicBodies, ninc = cnt.numIncidences, ncon = cnt.numContacts;
+        if (c->mode == 0) {
+            c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc);
+            c->prof.algorithmic_bytes_dual += (double)P.iterations * (160.0 * ncon);
+        } else {
+            c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc) + (double)P.iterations * (160.0 * ncon);
+        }
+    }
     ++c->prof.steps;
     collect_spans(c);
     return AVBD_OK;
@@ -599,6 +655,7 @@ int avbd_create(int device, AvbdContext** out)
     AvbdContext* c = new AvbdContext();
     c->device = device;
     avbd_default_params(&c->params);
+    if (const char* m = std::getenv("AVBD_MODE")) c->mode = (std::strcmp(m, "levels") == 0) ? 0 : 1;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVBD_E_HIP; }
     if (hipHostMalloc((void**)&c->hRb, sizeof(Readback), hipHostMallocDefault) != hipSuccess) { delete c; return AVBD_E_HIP; }
     std::memset(c->hRb, 0, sizeof(Readback));
@@ -607,6 +664,18 @@ int avbd_create(int device, AvbdContext** out)
     (void)hipMemset(c->dDiag.p, 0, sizeof(DiagAccum));
     (void)hipMemset(c->dNext.p, 0, sizeof(int));
     if (ensure_capacity(c, 0) != AVBD_OK || ensure_topology_capacity(c) != AVBD_OK) { delete c; return AVBD_E_HIP; }
+    {   /* k_iterate needs every workgroup resident: size its grid from the occupancy query, with margin
+         * (MI355X_MICROARCH.md "Residency and cooperative launch": the API can over-report by one block/CU) */
+        hipDeviceProp_t prop;
+        int perCU = 0;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_iterate, 64 * kIterWaves, 0) != hipSuccess || perCU < 1) { delete c; return AVBD_E_HIP; }
+        int use = perCU >= 3 ? 2 : 1;
+        if (perCU < 2) use = 1;
+        c->iterBlocks = std::max(1, prop.multiProcessorCount * use);
+        if (perCU == 1) c->iterBlocks = std::max(1, prop.multiProcessorCount / 2);
+        if (const char* e = std::getenv("AVBD_ITER_BLOCKS")) c->iterBlocks = std::max(1, std::atoi(e));
+    }
     *out = c;
     return AVBD_OK;
 }
@@ -620,7 +689,7 @@ int avbd_destroy(AvbdContext* c)
     c->dPlanes.release(); c->mbuf[0].release(); c->mbuf[1].release(); c->dG.release();
     c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
-    c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release();
+    c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
     if (c->hRb) (void)hipHostFree(c->hRb);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -650,7 +719,7 @@ int avbd_clear(AvbdContext* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->hBodies.clear(); c->hI.clear(); c->hJ.clear(); c->hG.clear();
     c->bodiesStale = true; c->deviceAhead = false; c->gStale = true; c->gDeviceAhead = false; c->adjDirty = true;
-    c->stepIndex = 0; c->hostKeyCounter = 1;
+    c->stepIndex = 0; c->hostKeyCounter = 1; c->numStatic = 0;
     c->stats = AvbdStepStats{};
     HIPCHK(c, hipMemset(c->dCnt.p, 0, sizeof(Counters)));
     HIPCHK(c, hipMemset(c->dDiag.p, 0, sizeof(DiagAccum)));
@@ -680,6 +749,7 @@ int avbd_add_bodies(AvbdContext* c, int n, const float* size, const float* densi
         b.friction = friction[i];
         float I9[9], J9[9];
         box_mass_properties(b, density[i], I9, J9);
+        if (!(b.invMass > 0.0f)) ++c->numStatic;
         c->hBodies.push_back(b);
         c->hI.insert(c->hI.end(), I9, I9 + 9);
         c->hJ.insert(c->hJ.end(), J9, J9 + 9);
@@ -800,6 +870,7 @@ int avbd_synchronize(AvbdContext* c)
 {
     if (!c) return AVBD_E_INVALID;
     (void)hipSetDevice(c->device);
+    if (!c->statsFresh) return refresh_stats(c, false);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AVBD_OK;
 }
@@ -823,6 +894,8 @@ int avbd_get_diagnostics(AvbdContext* c, AvbdDiagnostics* out)
 int avbd_get_step_stats(AvbdContext* c, AvbdStepStats* out)
 {
     if (!c || !out) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (!c->statsFresh) { int rc = refresh_stats(c, false); if (rc) return rc; }
     *out = c->stats;
     out->warnings = c->hRb ? c->hRb->cnt.warnings : 0;
     return AVBD_OK;

@@ -420,329 +420,11 @@ __global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
     B.plane(BP_QUAT)[i] = packq(rot);
 }
 
-/* ------------------------------------------------------------------------------------------
- * K5 primal — solver.cpp:344-409.  One wavefront per body of the current level.
- *   phase 1: lane e evaluates incidence entry e (<= 3 rows): computeConstraint + computeDerivatives,
- *            writes the entry's row records to LDS and the reference's in-place mutations to HBM
- *   phase 2: lanes 0..26 each own one entry of (lhs lower triangles, la, rhs) and add the row terms
- *            in list order (newest force first, row 0..n) — the reference's summation order
- *   phase 3: lane 0 runs solve6x6 and the pose update
- * ------------------------------------------------------------------------------------------ */
-constexpr int kRowRec = 12;                 /* Jl[3] Ja[3] f pen gyro[3] flags */
-constexpr int kEntryRec = 3 * kRowRec;
-constexpr int kWavesPerBlock = 4;
-
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
-                                                                 const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
-                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt)
-{
-    __shared__ float sRows[kWavesPerBlock][64 * kEntryRec];
-    __shared__ float sAcc[kWavesPerBlock][32];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int first = lvlStart[level], last = lvlStart[level + 1];
-    const int slot = first + blockIdx.x * kWavesPerBlock + wv;
-    if (slot >= last) return; /* wave-uniform */
-    const int body = order[slot];
-    float* rows = sRows[wv];
-    float* accs = sAcc[wv];
-
-    /* body state (every lane holds a copy) */
-    const f3 pos = ld3(B.plane(BP_POSR), body);
-    const q4 rot = ldq(B.plane(BP_QUAT), body);
-    const f3 npos = ld3(B.plane(BP_NPOS), body);
-    const q4 nrot = ldq(B.plane(BP_NQUAT), body);
-    const float4 mp = B.plane(BP_MASS)[body];
-    const float mass = mp.x;
-    const m33 Ib = mkm(ld3(B.plane(BP_I0), body), ld3(B.plane(BP_I1), body), ld3(B.plane(BP_I2), body));
-    const m33 Jb = mkm(ld3(B.plane(BP_J0), body), ld3(B.plane(BP_J1), body), ld3(B.plane(BP_J2), body));
-    const m33 R = quat_to_mat(rot);
-    const m33 Rt = mtranspose(R);
-    const m33 Iw = R * Ib * Rt;       /* rigid.cpp:56-59 */
-    const m33 invIw = R * Jb * Rt;    /* rigid.cpp:51-54 */
-    const float invDt2 = 1.0f / (P.dt * P.dt);
-
-    /* accumulator owned by this lane: 0-5 ll lower, 6-14 la, 15-20 aa lower, 21-23 rhs.l, 24-26 rhs.a */
-    int opA = 0, opB = 0, mode = 3, gy = -1; /* mode 0: lhs, 1: lhs aa (+gyro/+0), 2: rhs, 3: idle */
-    float acc = 0.0f;
-    {
-        const m33 massMat = diagm(mk3(mass, mass, mass));
-        const m33 ll0 = zerom() + massMat * invDt2;
-        const m33 aa0 = zerom() + Iw * invDt2;
-        const f3 rl0 = massMat * ((pos - npos) * invDt2);
-        q4 qErr = rot * qconj(nrot);
-        f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
-        rotErr = rotErr * 2.0f;
-        if (qErr.w < 0.0f) rotErr = -rotErr;
-        const f3 ra0 = Iw * (rotErr * invDt2);
-        const int li[6] = {0, 1, 2, 1, 2, 2}, lj[6] = {0, 0, 0, 1, 1, 2}; /* (row i, col j) of a lower triangle */
-        if (lane < 6) {
-            int i = li[lane], j = lj[lane];
-            mode = 0; opA = i; opB = j;
-            f3 col = j == 0 ? ll0.c0 : (j == 1 ? ll0.c1 : ll0.c2);
-            acc = comp3(col, i);
-        } else if (lane < 15) {
-            int k = lane - 6, i = k % 3, j = k / 3; /* la(row i, col j) = Jl_i * Ja_j */
-            mode = 0; opA = i; opB = 3 + j; acc = 0.0f;
-        } else if (lane < 21) {
-            int k = lane - 15, i = li[k], j = lj[k];
-            mode = 1; opA = 3 + i; opB = 3 + j; gy = (i == j) ? (8 + i) : -1;
-            f3 col = j == 0 ? aa0.c0 : (j == 1 ? aa0.c1 : aa0.c2);
-            acc = comp3(col, i);
-        } else if (lane < 24) {
-            int i = lane - 21; mode = 2; opA = i; opB = 6; acc = comp3(rl0, i);
-        } else if (lane < 27) {
-            int i = lane - 24; mode = 2; opA = 3 + i; opB = 6; acc = comp3(ra0, i);
-        }
-    }
-
-    const int eBeg = incStart[body], eEnd = incStart[body + 1];
-    for (int base = eBeg; base < eEnd; base += 64) {
-        const int nHere = min(64, eEnd - base);
-        /* ---- phase 1: one entry per lane ---- */
-        if (lane < nHere) {
-            const int ent = inc[base + lane];
-            const int kind = inc_kind(ent), idx = inc_index(ent);
-            const bool isA = inc_isA(ent) != 0;
-            float* rec = rows + lane * kEntryRec;
-            if (kind == FK_MANIFOLD) {
-                const int m = idx >> 2;
-                const int2 pr = M.pair[m];
-                const int other = isA ? pr.y : pr.x;
-                const f3 opos = ld3(B.plane(BP_POSR), other);
-                const q4 orot = ldq(B.plane(BP_QUAT), other);
-                const float oinv = B.plane(BP_MASS)[other].y;
-                ContactRows c;
-                {
-                    float4 ra = M.cRA[idx], rb = M.cRB[idx], nn = M.cN[idx], lam = M.cLam[idx], pen = M.cPen[idx];
-                    c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w;
-                    c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
-                    c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
-                    c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
-                    c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
-                    c.stick = M.cFS[idx].y != 0;
-                }
-                const float fric = M.fric[m];
-                if (isA) contact_compute_constraint(c, alpha, pos, rot, mp.y, opos, orot, oinv, fric);
-                else     contact_compute_constraint(c, alpha, opos, orot, oinv, pos, rot, mp.y, fric);
-                /* the reference's in-place mutations (manifold.cpp:185-186, 224-231, 241, 243) */
-                M.cN[idx] = pack3(c.normal, c.C0t2);
-                M.cLam[idx] = make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration);
-                M.cFS[idx].y = c.stick ? 1 : 0;
-                if (writeRows) {
-                    M.cC[idx] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
-                    M.cFmin[idx] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
-                    M.cFmax[idx] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
-                }
-                f3 Jl[3], Ja[3];
-                contact_compute_derivatives(c, isA, rot, Jl, Ja);
-                for (int k = 0; k < 3; ++k) {
-                    /* stiffness == FLT_MAX for manifold rows, motor == 0 (manifold.cpp:102-106) */
-                    float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
-                    float f = rclamp(desired, c.fmin[k], c.fmax[k]);
-                    f3 gyro = abs3(cross3(Ja[k], invIw * Ja[k])) * fabsf(f);
-                    float* r = rec + k * kRowRec;
-                    r[0] = Jl[k].x; r[1] = Jl[k].y; r[2] = Jl[k].z; r[3] = Ja[k].x; r[4] = Ja[k].y; r[5] = Ja[k].z;
-                    r[6] = f; r[7] = c.penalty[k]; r[8] = gyro.x; r[9] = gyro.y; r[10] = gyro.z;
-                    r[11] = __int_as_float(3); /* valid | manifold */
-                }
-            } else if (kind == FK_JOINT) {
-                const int g = idx >> 1, part = idx & 1;
-                GForce& f = gf[g];
-                const bool hasA = f.bodyA >= 0;
-                const int other = isA ? f.bodyB : f.bodyA;
-                f3 opos = zero3(); q4 orot = identq();
-                if (other >= 0) { opos = ld3(B.plane(BP_POSR), other); orot = ldq(B.plane(BP_QUAT), other); }
-                JointRows j;
-                j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
-                j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
-                if (isA) joint_compute_constraint(j, hasA, pos, rot, opos, orot);
-                else     joint_compute_constraint(j, hasA, opos, orot, pos, rot);
-                for (int k = 0; k < 3; ++k) {
-                    const int row = part * 3 + k;
-                    f3 Jl, Ja;
-                    joint_compute_derivatives(j, isA, false, rot, row, Jl, Ja);
-                    float lw = (f.stiffness[row] == FLT_MAX) ? f.lambda[row] : 0.0f;
-                    float desired = f.penalty[row] * j.C[row] + lw + f.motor[row];
-                    float fr = rclamp(desired, -FLT_MAX, FLT_MAX);
-                    float* r = rec + k * kRowRec;
-                    r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
-                    r[6] = fr; r[7] = f.penalty[row]; r[8] = 0.f; r[9] = 0.f; r[10] = 0.f;
-                    r[11] = __int_as_float(1);
-                }
-            } else { /* FK_SPRING */
-                GForce& f = gf[idx];
-                const bool hasA = f.bodyA >= 0;
-                const int other = isA ? f.bodyB : f.bodyA;
-                f3 opos = zero3(); q4 orot = identq();
-                if (other >= 0) { opos = ld3(B.plane(BP_POSR), other); orot = ldq(B.plane(BP_QUAT), other); }
-                SpringRows s;
-                s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
-                f3 pA = isA ? pos : opos, pB = isA ? opos : pos; q4 qA = isA ? rot : orot, qB = isA ? orot : rot;
-                spring_compute_constraint(s, hasA, pA, qA, pB, qB);
-                f3 Jl, Ja;
-                spring_compute_derivatives(s, isA, hasA, pA, qA, pB, qB, Jl, Ja);
-                float lw = (f.stiffness[0] == FLT_MAX) ? f.lambda[0] : 0.0f;
-                float desired = f.penalty[0] * s.C + lw + f.motor[0];
-                float fr = rclamp(desired, f.fmin[0], f.fmax[0]);
-                float* r = rec;
-                r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
-                r[6] = fr; r[7] = f.penalty[0]; r[8] = 0.f; r[9] = 0.f; r[10] = 0.f; r[11] = __int_as_float(1);
-                rec[kRowRec + 11] = __int_as_float(0);
-                rec[2 * kRowRec + 11] = __int_as_float(0);
-            }
-        }
-        wave_sync();
-        /* ---- phase 2: ordered accumulation ---- */
-        if (mode != 3) {
-            for (int e = 0; e < nHere; ++e) {
-                const float* rec = rows + e * kEntryRec;
-                for (int k = 0; k < 3; ++k) {
-                    const float* r = rec + k * kRowRec;
-                    const int flags = __float_as_int(r[11]);
-                    if (!(flags & 1)) continue;
-                    if (mode == 2) {
-                        acc = acc + r[opA] * r[opB];          /* rhs += J * f, solver.cpp:383-384 */
-                    } else {
-                        const float pen = r[7];
-                        if (pen > 0.0f && isfinite(pen)) {    /* solver.cpp:387 */
-                            acc = acc + (r[opA] * r[opB]) * pen;
-                            if (mode == 1 && (flags & 2)) acc = acc + (gy >= 0 ? r[gy] : 0.0f); /* solver.cpp:393-397 */
-                        }
-                    }
-                }
-            }
-        }
-        wave_sync();
-    }
-
-    /* ---- phase 3: gather the 27 entries, solve, update the pose ---- */
-    if (lane < 27) accs[lane] = acc;
-    wave_sync();
-    if (lane == 0) {
-        m33 ll, la, al, aa;
-        /* lower triangles; the strictly-upper entries are never read by solve (maths.h:104) */
-        ll.c0 = mk3(accs[0], accs[1], accs[2]); ll.c1 = mk3(accs[1], accs[3], accs[4]); ll.c2 = mk3(accs[2], accs[4], accs[5]);
-        la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
-        al = mtranspose(la); /* al accumulates (Ja_i*Jl_j)*pen = la(j,i) bit for bit (solver.cpp:389-390) */
-        aa.c0 = mk3(accs[15], accs[16], accs[17]); aa.c1 = mk3(accs[16], accs[18], accs[19]); aa.c2 = mk3(accs[17], accs[19], accs[20]);
-        f3 bl = mk3(accs[21], accs[22], accs[23]), ba = mk3(accs[24], accs[25], accs[26]);
-        f3 dl, da;
-        solve_block6(ll, la, al, aa, bl, ba, dl, da);
-        f3 p = pos - dl;
-        q4 dq = mkq(da.x, da.y, da.z, 0.0f);
-        q4 q = qnormalize(rot - (dq * rot) * 0.5f);
-        sanitize3(p, cnt);
-        sanitizeq(q, cnt);
-        float4 pr = B.plane(BP_POSR)[body];
-        B.plane(BP_POSR)[body] = pack3(p, pr.w);
-        B.plane(BP_QUAT)[body] = packq(q);
-    }
-}
-
-/* ------------------------------------------------------------------------------------------
- * K6 dual — solver.cpp:411-430, one lane per contact (3 rows)
- * ------------------------------------------------------------------------------------------ */
-__global__ void k_dual(BodyTable B, ManifoldTable M, const Counters* cnt, SolverParams P, float alpha)
-{
-    const int total = cnt->numManifolds * 4;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
-        const int m = s >> 2, ci = s & 3;
-        if (ci >= M.nc[m]) continue;
-        const int2 pr = M.pair[m];
-        const f3 posA = ld3(B.plane(BP_POSR), pr.x), posB = ld3(B.plane(BP_POSR), pr.y);
-        const q4 rotA = ldq(B.plane(BP_QUAT), pr.x), rotB = ldq(B.plane(BP_QUAT), pr.y);
-        const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
-        ContactRows c;
-        {
-            float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s], lam = M.cLam[s], pen = M.cPen[s];
-            c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w;
-            c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
-            c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
-            c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
-            c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
-            c.stick = M.cFS[s].y != 0;
-        }
-        contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[m]);
-        bool needJ = false;
-        bool active[3];
-        for (int k = 0; k < 3; ++k) {
-            float lu = rclamp(c.penalty[k] * c.C[k] + c.lambda[k], c.fmin[k], c.fmax[k]);
-            active[k] = lu > c.fmin[k] && lu < c.fmax[k];
-            c.lambda[k] = lu;
-            needJ |= active[k];
-        }
-        if (needJ) {
-            f3 JlA[3], JaA[3], JlB[3], JaB[3];
-            contact_compute_derivatives(c, true, rotA, JlA, JaA);
-            contact_compute_derivatives(c, false, rotB, JlB, JaB);
-            for (int k = 0; k < 3; ++k) {
-                if (!active[k]) continue;
-                float lw = 0.0f, aw = 0.0f;                 /* rowPenaltyGain, solver.cpp:94-125 */
-                lw += lensq3(JlA[k]); aw += lensq3(JaA[k]);
-                lw += lensq3(JlB[k]); aw += lensq3(JaB[k]);
-                float betaRow = row_penalty_gain(lw, aw, P.beta);
-                c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kManifoldPenaltyCap);
-            }
-        }
-        M.cN[s] = pack3(c.normal, c.C0t2);
-        M.cLam[s] = make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration);
-        M.cPen[s] = make_float4(c.penalty[0], c.penalty[1], c.penalty[2], 0.f);
-        M.cFS[s].y = c.stick ? 1 : 0;
-        M.cC[s] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
-        M.cFmin[s] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
-        M.cFmax[s] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
-    }
-}
-
-__global__ void k_dual_gforce(BodyTable B, GForce* gf, int ng, SolverParams P)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ng) return;
-    GForce& f = gf[g];
-    if (f.kind == FK_IGNORE) return;
-    const bool hasA = f.bodyA >= 0;
-    f3 posA = zero3(), posB; q4 rotA = identq(), rotB;
-    if (hasA) { posA = ld3(B.plane(BP_POSR), f.bodyA); rotA = ldq(B.plane(BP_QUAT), f.bodyA); }
-    posB = ld3(B.plane(BP_POSR), f.bodyB); rotB = ldq(B.plane(BP_QUAT), f.bodyB);
-    if (f.kind == FK_JOINT) {
-        JointRows j;
-        j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
-        joint_compute_constraint(j, hasA, posA, rotA, posB, rotB);
-        for (int r = 0; r < 6; ++r) {
-            f.C[r] = j.C[r]; f.fmin[r] = -FLT_MAX; f.fmax[r] = FLT_MAX;
-            if (f.stiffness[r] != FLT_MAX) continue;
-            float lu = rclamp(f.penalty[r] * f.C[r] + f.lambda[r], f.fmin[r], f.fmax[r]);
-            bool active = lu > f.fmin[r] && lu < f.fmax[r];
-            f.lambda[r] = lu;
-            if (active) {
-                float lw = 0.0f, aw = 0.0f;
-                f3 Jl, Ja;
-                if (hasA) { joint_compute_derivatives(j, true, false, rotA, r, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
-                joint_compute_derivatives(j, false, false, rotB, r, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
-                float betaRow = row_penalty_gain(lw, aw, P.beta);
-                f.penalty[r] = rmin(f.penalty[r] + betaRow * fabsf(f.C[r]), kPenaltyMax);
-            }
-        }
-    } else { /* spring: finite stiffness rows are skipped by the dual (solver.cpp:416-418) unless FLT_MAX */
-        SpringRows s;
-        s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
-        spring_compute_constraint(s, hasA, posA, rotA, posB, rotB);
-        f.C[0] = s.C;
-        if (f.stiffness[0] == FLT_MAX) {
-            float lu = rclamp(f.penalty[0] * f.C[0] + f.lambda[0], f.fmin[0], f.fmax[0]);
-            bool active = lu > f.fmin[0] && lu < f.fmax[0];
-            f.lambda[0] = lu;
-            if (active) {
-                float lw = 0.0f, aw = 0.0f;
-                f3 Jl, Ja;
-                if (hasA) { spring_compute_derivatives(s, true, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
-                spring_compute_derivatives(s, false, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
-                float betaRow = row_penalty_gain(lw, aw, P.beta);
-                f.penalty[0] = rmin(f.penalty[0] + betaRow * fabsf(f.C[0]), kPenaltyMax);
-            }
-        }
-    }
-}
+/* K5 primal, K6 dual and the fused data-flow iteration kernel live in avbd_primal.h / avbd_iterate.h */
+} // namespace avbd
+#include "avbd_primal.h"
+#include "avbd_iterate.h"
+namespace avbd {
 
 /* ------------------------------------------------------------------------------------------
  * K7 velocities — solver.cpp:434-469

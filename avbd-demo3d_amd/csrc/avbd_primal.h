@@ -1,0 +1,459 @@
+/*
+ * avbd_primal.h — building blocks of the per-body primal solve (solver.cpp:344-409) and the per-force
+ * dual update (solver.cpp:411-430), shared by
+ *   - the level-launch kernels k_primal / k_dual (one launch per Gauss-Seidel level; plain loads), and
+ *   - the persistent data-flow kernel k_iterate (avbd_iterate.h; every byte that another workgroup may
+ *     have written in the same launch is moved with agent-scope `sc1` accesses — template COH=true).
+ *
+ * One wavefront works on one body:
+ *   phase 1  lane e evaluates incidence entry e (<= 3 rows): computeConstraint + computeDerivatives,
+ *            stages the row records in LDS, writes the reference's in-place mutations back
+ *   phase 2  lanes 0..26 each own one entry of (ll lower, la, aa lower, rhs) and add the row terms
+ *            IN LIST ORDER (newest force first, row 0..n) — the reference's summation order
+ *   phase 3  lane 0 runs solve6x6 and the pose update
+ */
+#pragma once
+#include "avbd_types.h"
+#include "avbd_rows.h"
+
+#pragma clang fp contract(off)
+
+namespace avbd {
+
+/* ---- memory access flavours ---------------------------------------------------------------
+ * COH=false: plain global loads/stores (data produced by an earlier launch).
+ * COH=true : relaxed agent-scope atomics = global_load/store ... sc1 — bypass this CU's L1 and the
+ *            (non-coherent) per-XCD L2 copy; used for hand-offs inside one launch
+ *            (cdna_hip_programming.md Guideline 16; MI355X_MICROARCH.md "Valid forms"). */
+template <bool COH>
+__device__ __forceinline__ float4 ld4(const float4* p)
+{
+    if constexpr (COH) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                           __uint_as_float((unsigned)(b >> 32)));
+    } else {
+        return *p;
+    }
+}
+
+template <bool COH>
+__device__ __forceinline__ void st4(float4* p, float4 v)
+{
+    if constexpr (COH) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+        unsigned long long a = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+        unsigned long long b = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
+        __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
+}
+
+template <bool COH>
+__device__ __forceinline__ int ldi(const int* p)
+{
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+template <bool COH>
+__device__ __forceinline__ void sti(int* p, int v)
+{
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool COH>
+__device__ __forceinline__ float ldf(const float* p)
+{
+    if constexpr (COH) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+
+template <bool COH>
+__device__ __forceinline__ void stf(float* p, float v)
+{
+    if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool COH>
+__device__ __forceinline__ void load_pose(const BodyTable& B, int i, f3& pos, q4& rot)
+{
+    float4 p = ld4<COH>(B.plane(BP_POSR) + i), q = ld4<COH>(B.plane(BP_QUAT) + i);
+    pos = mk3(p.x, p.y, p.z); rot = mkq(q.x, q.y, q.z, q.w);
+}
+
+/* ---- one Manifold contact in registers ---------------------------------------------------- */
+template <bool COH>
+__device__ __forceinline__ void load_contact(const ManifoldTable& M, int s, ContactRows& c)
+{
+    const float4 ra = M.cRA[s], rb = M.cRB[s];                       /* constant during the iteration loop */
+    const float4 nn = ld4<COH>(M.cN + s), lam = ld4<COH>(M.cLam + s), pen = ld4<COH>(M.cPen + s);
+    c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w;
+    c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
+    c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
+    c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
+    c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
+    c.stick = ldi<COH>(&M.cFS[s].y) != 0;
+}
+
+/* the reference's in-place mutations of computeConstraint (manifold.cpp:185-186, 224-231, 241, 243) */
+template <bool COH>
+__device__ __forceinline__ void store_contact_mutations(const ManifoldTable& M, int s, const ContactRows& c, bool writeRows)
+{
+    st4<COH>(M.cN + s, make_float4(c.normal.x, c.normal.y, c.normal.z, c.C0t2));
+    st4<COH>(M.cLam + s, make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration));
+    sti<COH>(&M.cFS[s].y, c.stick ? 1 : 0);
+    if (writeRows) { /* API visibility of Force::C/fmin/fmax only; never read back by the solver */
+        st4<COH>(M.cC + s, make_float4(c.C[0], c.C[1], c.C[2], 0.f));
+        st4<COH>(M.cFmin + s, make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f));
+        st4<COH>(M.cFmax + s, make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f));
+    }
+}
+
+/* ---- per-body constants of one primal visit ------------------------------------------------ */
+struct BodyLocal {
+    f3 pos; q4 rot; f3 npos; q4 nrot;
+    float mass, invMass, invDt2;
+    m33 Iw, invIw;
+};
+
+template <bool COH>
+__device__ __forceinline__ BodyLocal load_body_local(const BodyTable& B, int body, const SolverParams& P)
+{
+    BodyLocal L;
+    load_pose<COH>(B, body, L.pos, L.rot);
+    float4 np = B.plane(BP_NPOS)[body], nq = B.plane(BP_NQUAT)[body], mp = B.plane(BP_MASS)[body];
+    L.npos = mk3(np.x, np.y, np.z); L.nrot = mkq(nq.x, nq.y, nq.z, nq.w);
+    L.mass = mp.x; L.invMass = mp.y;
+    float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
+    float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
+    const m33 Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
+    const m33 Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
+    const m33 R = quat_to_mat(L.rot);
+    const m33 Rt = mtranspose(R);
+    L.Iw = R * Ib * Rt;       /* rigid.cpp:56-59 */
+    L.invIw = R * Jb * Rt;    /* rigid.cpp:51-54 */
+    L.invDt2 = 1.0f / (P.dt * P.dt);
+    return L;
+}
+
+/* ---- ordered accumulation ------------------------------------------------------------------ */
+constexpr int kRowRec = 12;                 /* Jl[3] Ja[3] f pen gyro[3] flags */
+constexpr int kEntryRec = 3 * kRowRec;
+
+/* accumulator owned by a lane: 0-5 ll lower, 6-14 la, 15-20 aa lower, 21-23 rhs.l, 24-26 rhs.a */
+struct AccLane { int opA, opB, mode, gy; float acc; }; /* mode 0: lhs, 1: lhs aa (+gyro/+0), 2: rhs, 3: idle */
+
+__device__ __forceinline__ AccLane init_acc_lane(int lane, const BodyLocal& L)
+{
+    AccLane a; a.opA = 0; a.opB = 0; a.mode = 3; a.gy = -1; a.acc = 0.0f;
+    const m33 massMat = diagm(mk3(L.mass, L.mass, L.mass));
+    const m33 ll0 = zerom() + massMat * L.invDt2;                     /* solver.cpp:350-361 */
+    const m33 aa0 = zerom() + L.Iw * L.invDt2;
+    const f3 rl0 = massMat * ((L.pos - L.npos) * L.invDt2);           /* solver.cpp:363 */
+    q4 qErr = L.rot * qconj(L.nrot);                                  /* solver.cpp:365-369 */
+    f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
+    rotErr = rotErr * 2.0f;
+    if (qErr.w < 0.0f) rotErr = -rotErr;
+    const f3 ra0 = L.Iw * (rotErr * L.invDt2);
+    /* (row i, col j) of a lower triangle, lane order (0,0) (1,0) (2,0) (1,1) (2,1) (2,2) */
+    const int k6 = lane < 6 ? lane : (lane >= 15 && lane < 21 ? lane - 15 : 0);
+    const int ti = k6 < 3 ? k6 : (k6 < 5 ? k6 - 2 : 2);
+    const int tj = k6 < 3 ? 0 : (k6 < 5 ? 1 : 2);
+    if (lane < 6) {
+        a.mode = 0; a.opA = ti; a.opB = tj;
+        a.acc = comp3(tj == 0 ? ll0.c0 : (tj == 1 ? ll0.c1 : ll0.c2), ti);
+    } else if (lane < 15) {
+        const int k = lane - 6, i = k % 3, j = k / 3;                 /* la(row i, col j) = Jl_i * Ja_j */
+        a.mode = 0; a.opA = i; a.opB = 3 + j; a.acc = 0.0f;
+    } else if (lane < 21) {
+        a.mode = 1; a.opA = 3 + ti; a.opB = 3 + tj; a.gy = (ti == tj) ? (8 + ti) : -1;
+        a.acc = comp3(tj == 0 ? aa0.c0 : (tj == 1 ? aa0.c1 : aa0.c2), ti);
+    } else if (lane < 24) {
+        const int i = lane - 21; a.mode = 2; a.opA = i; a.opB = 6; a.acc = comp3(rl0, i);
+    } else if (lane < 27) {
+        const int i = lane - 24; a.mode = 2; a.opA = 3 + i; a.opB = 6; a.acc = comp3(ra0, i);
+    }
+    return a;
+}
+
+__device__ __forceinline__ void accumulate_rows(AccLane& a, const float* rows, int nEntries)
+{
+    if (a.mode == 3) return;
+    for (int e = 0; e < nEntries; ++e) {
+        const float* rec = rows + e * kEntryRec;
+        for (int k = 0; k < 3; ++k) {
+            const float* r = rec + k * kRowRec;
+            const int flags = __float_as_int(r[11]);
+            if (!(flags & 1)) continue;
+            if (a.mode == 2) {
+                a.acc = a.acc + r[a.opA] * r[a.opB];                  /* rhs += J * f, solver.cpp:383-384 */
+            } else {
+                const float pen = r[7];
+                if (pen > 0.0f && isfinite(pen)) {                    /* solver.cpp:387 */
+                    a.acc = a.acc + (r[a.opA] * r[a.opB]) * pen;      /* solver.cpp:388-391 */
+                    if (a.mode == 1 && (flags & 2)) a.acc = a.acc + (a.gy >= 0 ? r[a.gy] : 0.0f); /* solver.cpp:393-397 */
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void put_row(float* r, f3 Jl, f3 Ja, float f, float pen, f3 gyro, int flags)
+{
+    r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
+    r[6] = f; r[7] = pen; r[8] = gyro.x; r[9] = gyro.y; r[10] = gyro.z; r[11] = __int_as_float(flags);
+}
+
+/* ---- phase 1: evaluate one incidence entry (<= 3 rows) for `body` ---------------------------- */
+template <bool COH>
+__device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const ManifoldTable& M, GForce* gf, const BodyLocal& L, float alpha,
+                                           bool writeRows, float* rec)
+{
+    const int kind = inc_kind(ent), idx = inc_index(ent);
+    const bool isA = inc_isA(ent) != 0;
+    if (kind == FK_MANIFOLD) {
+        const int m = idx >> 2;
+        const int2 pr = M.pair[m];
+        const int other = isA ? pr.y : pr.x;
+        f3 opos; q4 orot;
+        load_pose<COH>(B, other, opos, orot);
+        const float oinv = B.plane(BP_MASS)[other].y;
+        ContactRows c;
+        load_contact<COH>(M, idx, c);
+        const float fric = M.fric[m];
+        if (isA) contact_compute_constraint(c, alpha, L.pos, L.rot, L.invMass, opos, orot, oinv, fric);
+        else     contact_compute_constraint(c, alpha, opos, orot, oinv, L.pos, L.rot, L.invMass, fric);
+        store_contact_mutations<COH>(M, idx, c, writeRows);
+        f3 Jl[3], Ja[3];
+        contact_compute_derivatives(c, isA, L.rot, Jl, Ja);
+        for (int k = 0; k < 3; ++k) {
+            /* stiffness == FLT_MAX for manifold rows, motor == 0 (manifold.cpp:102-106): solver.cpp:379-381 */
+            float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
+            float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+            f3 gyro = abs3(cross3(Ja[k], L.invIw * Ja[k])) * fabsf(f);
+            put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, 3 /* valid | manifold */);
+        }
+    } else if (kind == FK_JOINT) {
+        const int g = idx >> 1, part = idx & 1;
+        GForce& f = gf[g];
+        const bool hasA = f.bodyA >= 0;
+        const int other = isA ? f.bodyB : f.bodyA;
+        f3 opos = zero3(); q4 orot = identq();
+        if (other >= 0) load_pose<COH>(B, other, opos, orot);
+        JointRows j;
+        j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
+        j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+        if (isA) joint_compute_constraint(j, hasA, L.pos, L.rot, opos, orot);
+        else     joint_compute_constraint(j, hasA, opos, orot, L.pos, L.rot);
+        for (int k = 0; k < 3; ++k) {
+            const int row = part * 3 + k;
+            f3 Jl, Ja;
+            joint_compute_derivatives(j, isA, false, L.rot, row, Jl, Ja);
+            const float stiff = f.stiffness[row];
+            const float pen = ldf<COH>(&f.penalty[row]);
+            float lw = (stiff == FLT_MAX) ? ldf<COH>(&f.lambda[row]) : 0.0f;
+            float desired = pen * j.C[row] + lw + f.motor[row];
+            float fr = rclamp(desired, -FLT_MAX, FLT_MAX);
+            put_row(rec + k * kRowRec, Jl, Ja, fr, pen, zero3(), 1);
+        }
+    } else { /* FK_SPRING */
+        GForce& f = gf[idx];
+        const bool hasA = f.bodyA >= 0;
+        const int other = isA ? f.bodyB : f.bodyA;
+        f3 opos = zero3(); q4 orot = identq();
+        if (other >= 0) load_pose<COH>(B, other, opos, orot);
+        SpringRows s;
+        s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
+        f3 pA = isA ? L.pos : opos, pB = isA ? opos : L.pos; q4 qA = isA ? L.rot : orot, qB = isA ? orot : L.rot;
+        spring_compute_constraint(s, hasA, pA, qA, pB, qB);
+        f3 Jl, Ja;
+        spring_compute_derivatives(s, isA, hasA, pA, qA, pB, qB, Jl, Ja);
+        const float pen = ldf<COH>(&f.penalty[0]);
+        float lw = (f.stiffness[0] == FLT_MAX) ? ldf<COH>(&f.lambda[0]) : 0.0f;
+        float desired = pen * s.C + lw + f.motor[0];
+        float fr = rclamp(desired, f.fmin[0], f.fmax[0]);
+        put_row(rec, Jl, Ja, fr, pen, zero3(), 1);
+        rec[kRowRec + 11] = __int_as_float(0);
+        rec[2 * kRowRec + 11] = __int_as_float(0);
+    }
+}
+
+/* ---- phase 3: solve6x6 + pose update (lane 0) ---------------------------------------------------- */
+__device__ __forceinline__ void solve_pose(const float* accs, const BodyLocal& L, f3& p, q4& q)
+{
+    m33 ll, la, al, aa;
+    /* lower triangles; the strictly-upper entries are never read by solve (maths.h:104) */
+    ll.c0 = mk3(accs[0], accs[1], accs[2]); ll.c1 = mk3(accs[1], accs[3], accs[4]); ll.c2 = mk3(accs[2], accs[4], accs[5]);
+    la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
+    al = mtranspose(la); /* al accumulates (Ja_i*Jl_j)*pen = la(j,i) bit for bit (solver.cpp:389-390) */
+    aa.c0 = mk3(accs[15], accs[16], accs[17]); aa.c1 = mk3(accs[16], accs[18], accs[19]); aa.c2 = mk3(accs[17], accs[19], accs[20]);
+    f3 bl = mk3(accs[21], accs[22], accs[23]), ba = mk3(accs[24], accs[25], accs[26]);
+    f3 dl, da;
+    solve_block6(ll, la, al, aa, bl, ba, dl, da);                     /* solver.cpp:402 */
+    p = L.pos - dl;                                                   /* solver.cpp:403-405 */
+    q4 dq = mkq(da.x, da.y, da.z, 0.0f);
+    q = qnormalize(L.rot - (dq * L.rot) * 0.5f);
+}
+
+/* ---- dual update of one Manifold contact (solver.cpp:411-430 for rows 3c..3c+2) ------------------- */
+template <bool COH>
+__device__ __forceinline__ void dual_contact(const BodyTable& B, const ManifoldTable& M, int s, const SolverParams& P, float alpha, bool writeRows)
+{
+    const int m = s >> 2;
+    const int2 pr = M.pair[m];
+    f3 posA, posB; q4 rotA, rotB;
+    load_pose<COH>(B, pr.x, posA, rotA);
+    load_pose<COH>(B, pr.y, posB, rotB);
+    const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
+    ContactRows c;
+    load_contact<COH>(M, s, c);
+    contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[m]);
+    bool needJ = false;
+    bool active[3];
+    for (int k = 0; k < 3; ++k) {
+        float lu = rclamp(c.penalty[k] * c.C[k] + c.lambda[k], c.fmin[k], c.fmax[k]);
+        active[k] = lu > c.fmin[k] && lu < c.fmax[k];
+        c.lambda[k] = lu;
+        needJ |= active[k];
+    }
+    if (needJ) {
+        f3 JlA[3], JaA[3], JlB[3], JaB[3];
+        contact_compute_derivatives(c, true, rotA, JlA, JaA);
+        contact_compute_derivatives(c, false, rotB, JlB, JaB);
+        for (int k = 0; k < 3; ++k) {
+            if (!active[k]) continue;
+            float lw = 0.0f, aw = 0.0f;                               /* rowPenaltyGain, solver.cpp:94-125 */
+            lw += lensq3(JlA[k]); aw += lensq3(JaA[k]);
+            lw += lensq3(JlB[k]); aw += lensq3(JaB[k]);
+            float betaRow = row_penalty_gain(lw, aw, P.beta);
+            c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kManifoldPenaltyCap);
+        }
+    }
+    st4<COH>(M.cN + s, make_float4(c.normal.x, c.normal.y, c.normal.z, c.C0t2));
+    st4<COH>(M.cLam + s, make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration));
+    st4<COH>(M.cPen + s, make_float4(c.penalty[0], c.penalty[1], c.penalty[2], 0.f));
+    sti<COH>(&M.cFS[s].y, c.stick ? 1 : 0);
+    if (writeRows) { /* Force::C/fmin/fmax as the last computeConstraint of the step leaves them (API visibility only) */
+        st4<COH>(M.cC + s, make_float4(c.C[0], c.C[1], c.C[2], 0.f));
+        st4<COH>(M.cFmin + s, make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f));
+        st4<COH>(M.cFmax + s, make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f));
+    }
+}
+
+/* ---- dual update of one Joint / Spring -------------------------------------------------------------- */
+template <bool COH>
+__device__ __forceinline__ void dual_gforce(const BodyTable& B, GForce& f, const SolverParams& P, bool writeRows)
+{
+    if (f.kind == FK_IGNORE) return;
+    const bool hasA = f.bodyA >= 0;
+    f3 posA = zero3(), posB; q4 rotA = identq(), rotB;
+    if (hasA) load_pose<COH>(B, f.bodyA, posA, rotA);
+    load_pose<COH>(B, f.bodyB, posB, rotB);
+    if (f.kind == FK_JOINT) {
+        JointRows j;
+        j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+        joint_compute_constraint(j, hasA, posA, rotA, posB, rotB);
+        for (int r = 0; r < 6; ++r) {
+            if (writeRows) { stf<COH>(&f.C[r], j.C[r]); stf<COH>(&f.fmin[r], -FLT_MAX); stf<COH>(&f.fmax[r], FLT_MAX); }
+            if (f.stiffness[r] != FLT_MAX) continue;
+            const float pen = ldf<COH>(&f.penalty[r]);
+            float lu = rclamp(pen * j.C[r] + ldf<COH>(&f.lambda[r]), -FLT_MAX, FLT_MAX);
+            bool active = lu > -FLT_MAX && lu < FLT_MAX;
+            stf<COH>(&f.lambda[r], lu);
+            if (active) {
+                float lw = 0.0f, aw = 0.0f;
+                f3 Jl, Ja;
+                if (hasA) { joint_compute_derivatives(j, true, false, rotA, r, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+                joint_compute_derivatives(j, false, false, rotB, r, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+                float betaRow = row_penalty_gain(lw, aw, P.beta);
+                stf<COH>(&f.penalty[r], rmin(pen + betaRow * fabsf(j.C[r]), kPenaltyMax));
+            }
+        }
+    } else { /* spring: rows with finite stiffness are skipped by the dual (solver.cpp:416-418) */
+        SpringRows s;
+        s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
+        spring_compute_constraint(s, hasA, posA, rotA, posB, rotB);
+        if (writeRows) stf<COH>(&f.C[0], s.C);
+        if (f.stiffness[0] == FLT_MAX) {
+            const float pen = ldf<COH>(&f.penalty[0]);
+            float lu = rclamp(pen * s.C + ldf<COH>(&f.lambda[0]), f.fmin[0], f.fmax[0]);
+            bool active = lu > f.fmin[0] && lu < f.fmax[0];
+            stf<COH>(&f.lambda[0], lu);
+            if (active) {
+                float lw = 0.0f, aw = 0.0f;
+                f3 Jl, Ja;
+                if (hasA) { spring_compute_derivatives(s, true, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+                spring_compute_derivatives(s, false, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+                float betaRow = row_penalty_gain(lw, aw, P.beta);
+                stf<COH>(&f.penalty[0], rmin(pen + betaRow * fabsf(s.C), kPenaltyMax));
+            }
+        }
+    }
+}
+
+/* ==========================================================================================
+ * Level-launch kernels (one launch per Gauss-Seidel level, plain memory accesses)
+ * ========================================================================================== */
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
+                                                                 const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
+                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt)
+{
+    __shared__ float sRows[kWavesPerBlock][64 * kEntryRec];
+    __shared__ float sAcc[kWavesPerBlock][32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int first = lvlStart[level], last = lvlStart[level + 1];
+    const int slot = first + blockIdx.x * kWavesPerBlock + wv;
+    if (slot >= last) return; /* wave-uniform */
+    const int body = order[slot];
+    float* rows = sRows[wv];
+    float* accs = sAcc[wv];
+
+    const BodyLocal L = load_body_local<false>(B, body, P);
+    AccLane a = init_acc_lane(lane, L);
+    const int eBeg = incStart[body], eEnd = incStart[body + 1];
+    for (int base = eBeg; base < eEnd; base += 64) {
+        const int nHere = min(64, eEnd - base);
+        if (lane < nHere) eval_entry<false>(inc[base + lane], B, M, gf, L, alpha, writeRows != 0, rows + lane * kEntryRec);
+        wave_sync();
+        accumulate_rows(a, rows, nHere);
+        wave_sync();
+    }
+    if (lane < 27) accs[lane] = a.acc;
+    wave_sync();
+    if (lane == 0) {
+        f3 p; q4 q;
+        solve_pose(accs, L, p, q);
+        sanitize3(p, cnt);                                            /* solver.cpp:407-408 */
+        sanitizeq(q, cnt);
+        float4 pr = B.plane(BP_POSR)[body];
+        B.plane(BP_POSR)[body] = pack3(p, pr.w);
+        B.plane(BP_QUAT)[body] = packq(q);
+    }
+}
+
+__global__ void k_dual(BodyTable B, ManifoldTable M, const Counters* cnt, SolverParams P, float alpha)
+{
+    const int total = cnt->numManifolds * 4;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        if ((s & 3) >= M.nc[s >> 2]) continue;
+        dual_contact<false>(B, M, s, P, alpha, true);
+    }
+}
+
+__global__ void k_dual_gforce(BodyTable B, GForce* gf, int ng, SolverParams P)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    dual_gforce<false>(B, gf[g], P, true);
+}
+
+} // namespace avbd
