@@ -49,7 +49,7 @@ struct DevArr {
 
 struct ManifoldBuf {
     DevArr<int2> pair; DevArr<uint64_t> key; DevArr<int> nc; DevArr<float> fric;
-    DevArr<float4> cRA, cRB, cN, cLam, cPen, cC, cFmin, cFmax; DevArr<int2> cFS;
+    DevArr<float4> cRA, cRB, cN, cU1, cU2, cLam, cPen, cC, cFmin, cFmax; DevArr<int2> cFS;
     int cap = 0;
     hipError_t alloc(int c)
     {
@@ -63,6 +63,8 @@ struct ManifoldBuf {
         if ((e = cRA.alloc(k)) != hipSuccess) return e;
         if ((e = cRB.alloc(k)) != hipSuccess) return e;
         if ((e = cN.alloc(k)) != hipSuccess) return e;
+        if ((e = cU1.alloc(k)) != hipSuccess) return e;
+        if ((e = cU2.alloc(k)) != hipSuccess) return e;
         if ((e = cLam.alloc(k)) != hipSuccess) return e;
         if ((e = cPen.alloc(k)) != hipSuccess) return e;
         if ((e = cC.alloc(k)) != hipSuccess) return e;
@@ -73,13 +75,13 @@ struct ManifoldBuf {
     }
     void release()
     {
-        pair.release(); key.release(); nc.release(); fric.release(); cRA.release(); cRB.release(); cN.release();
+        pair.release(); key.release(); nc.release(); fric.release(); cRA.release(); cRB.release(); cN.release(); cU1.release(); cU2.release();
         cLam.release(); cPen.release(); cC.release(); cFmin.release(); cFmax.release(); cFS.release(); cap = 0;
     }
     ManifoldTable view() const
     {
         ManifoldTable t;
-        t.pair = pair.p; t.key = key.p; t.nc = nc.p; t.fric = fric.p; t.cRA = cRA.p; t.cRB = cRB.p; t.cN = cN.p;
+        t.pair = pair.p; t.key = key.p; t.nc = nc.p; t.fric = fric.p; t.cRA = cRA.p; t.cRB = cRB.p; t.cN = cN.p; t.cU1 = cU1.p; t.cU2 = cU2.p;
         t.cLam = cLam.p; t.cPen = cPen.p; t.cFS = cFS.p; t.cC = cC.p; t.cFmin = cFmin.p; t.cFmax = cFmax.p; t.cap = cap;
         return t;
     }
@@ -212,6 +214,8 @@ int ensure_capacity(AvbdContext* c, int nBodies)
             HIPCHK(c, hipMemcpy(nb0.cRA.p, o.cRA.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
             HIPCHK(c, hipMemcpy(nb0.cRB.p, o.cRB.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
             HIPCHK(c, hipMemcpy(nb0.cN.p, o.cN.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cU1.p, o.cU1.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nb0.cU2.p, o.cU2.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
             HIPCHK(c, hipMemcpy(nb0.cLam.p, o.cLam.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
             HIPCHK(c, hipMemcpy(nb0.cPen.p, o.cPen.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
             HIPCHK(c, hipMemcpy(nb0.cC.p, o.cC.p, 4 * m * sizeof(float4), hipMemcpyDeviceToDevice));
@@ -238,8 +242,8 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, hipMemset(c->incStart.p, 0, (newCap + 1) * sizeof(int)));
     HIPCHK(c, hipMemset(c->degForce.p, 0, newCap * sizeof(int)));
     HIPCHK(c, hipMemset(c->degInc.p, 0, newCap * sizeof(int)));
-    HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 16));
-    HIPCHK(c, hipMemset(c->dFlags.p, 0, ((size_t)2 * newCap + 16) * sizeof(int)));
+    HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 32 + 8192 * 16));
+    HIPCHK(c, hipMemset(c->dFlags.p, 0, ((size_t)2 * newCap + 32 + 8192 * 16) * sizeof(int)));
     c->adjDirty = true;
     c->bodiesStale = true;
     return AVBD_OK;
@@ -1085,6 +1089,7 @@ int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
     h.n = nm;
     h.pair.resize(nm); h.key.resize(nm); h.nc.resize(nm); h.fric.resize(nm);
     size_t k4 = (size_t)nm * 4;
+    std::vector<float4> hU1(k4, make_float4(0, 0, 0, 0)), hU2(k4, make_float4(0, 0, 0, 0));
     h.cRA.assign(k4, make_float4(0, 0, 0, 0)); h.cRB = h.cRA; h.cN = h.cRA; h.cLam = h.cRA; h.cPen = h.cRA; h.cC = h.cRA; h.cFmin = h.cRA; h.cFmax = h.cRA;
     h.cFS.assign(k4, make_int2(0, 0));
     c->hG.clear();
@@ -1100,6 +1105,11 @@ int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
                 h.cRA[s] = make_float4(d.rA[0], d.rA[1], d.rA[2], d.C0_n);
                 h.cRB[s] = make_float4(d.rB[0], d.rB[1], d.rB[2], d.C0_t[0]);
                 h.cN[s] = make_float4(d.normal[0], d.normal[1], d.normal[2], d.C0_t[1]);
+                {   /* tangent memo of the stored normal (contact_basis_memo invariant) */
+                    f3 t1, t2;
+                    contact_tangents(mk3(d.normal[0], d.normal[1], d.normal[2]), t1, t2);
+                    hU1[s] = make_float4(t1.x, t1.y, t1.z, 0.f); hU2[s] = make_float4(t2.x, t2.y, t2.z, 0.f);
+                }
                 h.cLam[s] = make_float4(f.lambda[ci * 3], f.lambda[ci * 3 + 1], f.lambda[ci * 3 + 2], d.penetration);
                 h.cPen[s] = make_float4(f.penalty[ci * 3], f.penalty[ci * 3 + 1], f.penalty[ci * 3 + 2], 0.f);
                 h.cC[s] = make_float4(f.C[ci * 3], f.C[ci * 3 + 1], f.C[ci * 3 + 2], 0.f);
@@ -1131,6 +1141,8 @@ int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
         HIPCHK(c, hipMemcpy(b.cRA.p, h.cRA.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(b.cRB.p, h.cRB.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(b.cN.p, h.cN.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cU1.p, hU1.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b.cU2.p, hU2.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(b.cLam.p, h.cLam.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(b.cPen.p, h.cPen.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(b.cC.p, h.cC.data(), k4 * sizeof(float4), hipMemcpyHostToDevice));
@@ -1163,19 +1175,10 @@ __global__ void k_row_api(BodyTable B, ManifoldTable M, GForce* gf, int kind, in
             if (mode == 1 && ci != row / 3) continue;
             const int s = index * 4 + ci;
             ContactRows c;
-            float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s], lam = M.cLam[s], pen = M.cPen[s];
-            c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w; c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
-            c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
-            c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
-            c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z; c.stick = M.cFS[s].y != 0;
+            load_contact<false>(M, s, c);
             if (mode == 0) {
                 contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[index]);
-                M.cN[s] = pack3(c.normal, c.C0t2);
-                M.cLam[s] = make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration);
-                M.cFS[s].y = c.stick ? 1 : 0;
-                M.cC[s] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
-                M.cFmin[s] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
-                M.cFmax[s] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
+                store_contact_mutations<false>(M, s, c, true);
                 for (int k = 0; k < 3; ++k) { out[ci * 3 + k] = c.C[k]; out[12 + ci * 3 + k] = c.fmin[k]; out[24 + ci * 3 + k] = c.fmax[k]; out[36 + ci * 3 + k] = c.lambda[k]; }
             } else {
                 const bool isA = body == pr.x;
@@ -1338,6 +1341,16 @@ int avbd_kat_arith(AvbdContext* c, int n, const float* a, const float* b, float*
 }
 
 /* ---- measurement ------------------------------------------------------------------------ */
+/* debug: per-wave time breakdown of the last k_iterate launch (only in -DAVBD_DF_STATS builds) */
+int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)
+{
+    if (!c || !out) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dFlags.p + 2 * (size_t)c->bodyCap + 16, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
 int avbd_profile_enable(AvbdContext* c, int enable) { if (!c) return AVBD_E_INVALID; c->profiling = enable != 0; return AVBD_OK; }
 int avbd_profile_reset(AvbdContext* c) { if (!c) return AVBD_E_INVALID; c->prof = AvbdProfile{}; return AVBD_OK; }
 int avbd_profile_get(AvbdContext* c, AvbdProfile* out) { if (!c || !out) return AVBD_E_INVALID; *out = c->prof; return AVBD_OK; }

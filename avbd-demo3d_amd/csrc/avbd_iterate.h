@@ -42,13 +42,7 @@ struct IterateState {
 constexpr int kIterWaves = 4;                      /* waves per workgroup */
 constexpr unsigned long long kSpinTimeoutTicks = 400000000ull; /* 4 s of s_memrealtime (100 MHz) */
 
-__device__ __forceinline__ void drain_stores()
-{
-#ifdef AVBD_DF_FENCES
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 /* is this incidence entry's force owned by `body` (= body is its earliest-created dynamic endpoint)? */
 __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& B, const ManifoldTable& M, const GForce* gf, int& other)
@@ -63,6 +57,48 @@ __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& 
     return other > body;                                           /* partner is visited earlier in the sweep */
 }
 
+#ifdef AVBD_DF_STATS
+#define DF_STAMP(i) do { unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)
+#else
+#define DF_STAMP(i) do { } while (0)
+#endif
+
+/* dependency wait of task (body, it); returns false when the launch must be abandoned */
+__device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, const int* adjStart, const int* adjRef, const int* adjOther,
+                                                  const float4* massPlane, const IterateState& S)
+{
+    const int aBeg = adjStart[body], aEnd = adjStart[body + 1];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    /* lane 63 of the first round also waits for this body's own previous task (pose + owned duals) */
+    for (int base = aBeg; base < aEnd || base == aBeg; base += 63) {
+        const int k = base + lane;
+        int need = 0; const int* word = nullptr;
+        if (lane == 63) {
+            if (base == aBeg && it > 0) { word = S.dualDone + body; need = it; }
+        } else if (k < aEnd) {
+            const int o = adjOther[k];
+            if (o >= 0 && inc_kind(adjRef[k]) != FK_IGNORE && massPlane[o].y > 0.0f) {
+                if (o > body) { word = S.primalDone + o; need = it + 1; }
+                else if (it > 0) { word = S.dualDone + o; need = it; }
+            }
+        }
+        bool ok = (word == nullptr);
+        unsigned spins = 0;
+        while (true) {
+            if (!ok) ok = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0) {
+                bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+                            __hip_atomic_load(S.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__any(dead)) { if (lane == 0) __hip_atomic_store(S.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* keep the payload loads below the polls */
+    return true;
+}
+
 __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
@@ -70,7 +106,7 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
                                                               const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW)
 {
     __shared__ float sRows[kIterWaves][64 * kEntryRec];
-    __shared__ float sAcc[kIterWaves][32];
+    __shared__ float sAcc[kIterWaves][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* rows = sRows[wv];
     float* accs = sAcc[wv];
@@ -81,99 +117,172 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
     const long long nTasks = (long long)nd * totalIt;
     const float4* massPlane = B.plane(BP_MASS);
 
+#ifdef AVBD_DF_STATS
+    unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tstart = tprev;
+#endif
     for (long long t = w; t < nTasks; t += W) {
+        DF_STAMP(7);
         const int it = (int)(t / nd);
         const int slot = (int)(t - (long long)it * nd);
         const int body = order[slot];
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool writeRows = it >= P.iterations;
-
-        /* ---- wait for the dependencies of task (body, it) ---- */
-        {
-            const int aBeg = adjStart[body], aEnd = adjStart[body + 1];
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            /* lane 63 of the first round also waits for this body's own previous task (pose + owned duals) */
-            for (int base = aBeg; base < aEnd || base == aBeg; base += 63) {
-                const int k = base + lane;
-                int need = 0; const int* word = nullptr;
-                if (lane == 63) {
-                    if (base == aBeg && it > 0) { word = S.dualDone + body; need = it; }
-                } else if (k < aEnd) {
-                    const int o = adjOther[k];
-                    if (o >= 0 && inc_kind(adjRef[k]) != FK_IGNORE && massPlane[o].y > 0.0f) {
-                        if (o > body) { word = S.primalDone + o; need = it + 1; }
-                        else if (it > 0) { word = S.dualDone + o; need = it; }
-                    }
-                }
-                bool ok = (word == nullptr);
-                unsigned spins = 0;
-                while (true) {
-                    if (!ok) ok = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 1023u) == 0) {
-                        bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
-                                    __hip_atomic_load(S.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                        if (__any(dead)) { if (lane == 0) __hip_atomic_store(S.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-                    }
-                }
-            }
-#ifdef AVBD_DF_FENCES
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* keep the payload loads below the polls */
-#endif
-        }
-
-        /* ---- primal visit ---- */
-        const BodyLocal L = load_body_local<true>(B, body, P);
-#ifdef AVBD_DF_DEBUG
-        if (body == 1 && lane == 63) printf("task t=%lld it=%d body=%d wave=%d W=%d nd=%d dualDone=%d primalDone=%d posy=%.7f\n", t, it, body, w, W, nd,
-            __hip_atomic_load(S.dualDone + body, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(S.primalDone + body, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), L.pos.y);
-#endif
-        AccLane a = init_acc_lane(lane, L);
+        const bool doDual = it < P.iterations;
+        const bool lastDual = it == P.iterations - 1;              /* rows are API-visible only after the step */
         const int eBeg = incStart[body], eEnd = incStart[body + 1];
-        for (int base = eBeg; base < eEnd; base += 64) {
-            const int nHere = min(64, eEnd - base);
-            if (lane < nHere) eval_entry<true>(inc[base + lane], B, M, gf, L, alpha, writeRows, rows + lane * kEntryRec);
-            wave_sync();
-            accumulate_rows(a, rows, nHere);
-            wave_sync();
-        }
-        if (lane < 27) accs[lane] = a.acc;
-        wave_sync();
-        if (lane == 0) {
-            f3 p; q4 q;
-            solve_pose(accs, L, p, q);
-            sanitize3(p, cntW);
-            sanitizeq(q, cntW);
-            const float radius = B.plane(BP_MASS)[body].w;
-            st4<true>(B.plane(BP_POSR) + body, pack3(p, radius));
-            st4<true>(B.plane(BP_QUAT) + body, packq(q));
-        }
-        drain_stores();                                            /* every lane's sc1 stores have left the wave */
-        if (lane == 0) __hip_atomic_store(S.primalDone + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nEnt = eEnd - eBeg;
 
-        /* ---- dual update of the forces this body owns (solver.cpp:411-430) ---- */
-        if (it < P.iterations) {
+        /* ---- everything that is constant during the launch is fetched BEFORE the wait ---- */
+        const bool has = lane < nEnt;
+        const int ent = has ? inc[eBeg + lane] : 0;
+        const bool fast = nEnt <= 64 && __all(!has || inc_kind(ent) == FK_MANIFOLD);
+        int idx = 0, other = 0; bool isA = false, owned = false;
+        float oinv = 0.0f, fric = 0.0f;
+        float4 sra = make_float4(0.f, 0.f, 0.f, 0.f), srb = sra;
+        if (fast && has) {
+            idx = inc_index(ent); isA = inc_isA(ent) != 0;
+            const int m = idx >> 2;
+            const int2 pr = M.pair[m];
+            other = isA ? pr.y : pr.x;
+            oinv = massPlane[other].y;
+            fric = M.fric[m];
+            sra = M.cRA[idx]; srb = M.cRB[idx];
+            owned = !(oinv > 0.0f) || other > body;
+        }
+        const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
+        const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
+        const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
+
+        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, massPlane, S)) return;
+        DF_STAMP(0);
+
+        if (fast) {
+            /* ---- one stage of sc1 loads: own pose, partner pose, the mutable contact fields ---- */
+            const float4 pp = ld4<true>(B.plane(BP_POSR) + body), pq = ld4<true>(B.plane(BP_QUAT) + body);
+            float4 op = pp, oq = pq, nn = sra, lam = sra, pen = sra, mu1 = sra, mu2 = sra; int stick = 0;
+            if (has) {
+                op = ld4<true>(B.plane(BP_POSR) + other); oq = ld4<true>(B.plane(BP_QUAT) + other);
+                nn = ld4<true>(M.cN + idx); lam = ld4<true>(M.cLam + idx); pen = ld4<true>(M.cPen + idx);
+                mu1 = ld4<true>(M.cU1 + idx); mu2 = ld4<true>(M.cU2 + idx);
+                stick = ldi<true>(&M.cFS[idx].y);
+            }
+            BodyLocal L;
+            L.pos = mk3(pp.x, pp.y, pp.z); L.rot = mkq(pq.x, pq.y, pq.z, pq.w);
+            L.npos = mk3(snp.x, snp.y, snp.z); L.nrot = mkq(snq.x, snq.y, snq.z, snq.w);
+            L.mass = smp.x; L.invMass = smp.y;
+            {
+                const m33 Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
+                const m33 Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
+                const m33 R = quat_to_mat(L.rot);
+                const m33 Rt = mtranspose(R);
+                L.Iw = R * Ib * Rt;       /* rigid.cpp:56-59 */
+                L.invIw = R * Jb * Rt;    /* rigid.cpp:51-54 */
+                L.invDt2 = 1.0f / (P.dt * P.dt);
+            }
+            AccLane a = init_acc_lane(lane, L);
+            ContactRows c;
+            const f3 opos = mk3(op.x, op.y, op.z); const q4 orot = mkq(oq.x, oq.y, oq.z, oq.w);
+            if (has) {
+                c.rA = mk3(sra.x, sra.y, sra.z); c.C0n = sra.w;
+                c.rB = mk3(srb.x, srb.y, srb.z); c.C0t1 = srb.w;
+                c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
+                c.u1 = mk3(mu1.x, mu1.y, mu1.z); c.u2 = mk3(mu2.x, mu2.y, mu2.z);
+                c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
+                c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
+                c.stick = stick != 0;
+                eval_contact_core(c, isA, L, opos, orot, oinv, fric, alpha, rows + lane * kEntryRec);
+                /* a contact this wave is about to update again in its dual pass needs no intermediate store unless the
+                 * partner reads it first: the partner of an owned contact has already finished this iteration */
+                if (!(owned && doDual)) store_contact_mutations<true>(M, idx, c, writeRows);
+            }
+            wave_sync();
+            accumulate_rows(a, rows, nEnt);
+            if (lane < 27) accs[lane] = a.acc;
+            wave_sync();
+            DF_STAMP(1);
+            f3 p; q4 q;
+            solve_pose(accs, accs + 32, lane, L, p, q);
+            if (lane == 0) {
+                sanitize3(p, cntW);
+                sanitizeq(q, cntW);
+                st4<true>(B.plane(BP_POSR) + body, pack3(p, smp.w));
+                st4<true>(B.plane(BP_QUAT) + body, packq(q));
+                accs[56] = p.x; accs[57] = p.y; accs[58] = p.z; accs[59] = q.x; accs[60] = q.y; accs[61] = q.z; accs[62] = q.w;
+            }
+            DF_STAMP(2);
+            drain_stores();                                            /* every lane's sc1 stores have left the wave */
+            if (lane == 0) __hip_atomic_store(S.primalDone + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DF_STAMP(3);
+            if (doDual) {
+                wave_sync();
+                if (has && owned) {
+                    const f3 np = mk3(accs[56], accs[57], accs[58]); const q4 nq = mkq(accs[59], accs[60], accs[61], accs[62]);
+                    if (isA) dual_contact_core(c, np, nq, L.invMass, opos, orot, oinv, fric, P, alpha);
+                    else     dual_contact_core(c, opos, orot, oinv, np, nq, L.invMass, fric, P, alpha);
+                    store_contact_dual<true>(M, idx, c, lastDual);
+                }
+                drain_stores();
+            }
+            if (lane == 0) __hip_atomic_store(S.dualDone + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DF_STAMP(4);
+        } else {
+            /* ---- generic path: any entry kinds, any count (chunks of 64), state re-read per phase ---- */
+            const BodyLocal L = load_body_local<true>(B, body, P);
+            AccLane a = init_acc_lane(lane, L);
             for (int base = eBeg; base < eEnd; base += 64) {
-                const int e = base + lane;
-                if (e < eEnd) {
-                    const int ent = inc[e];
-                    int other;
-                    if (entry_owned(ent, body, B, M, gf, other)) {
-                        const int kind = inc_kind(ent), idx = inc_index(ent);
-                        const bool lastDual = it == P.iterations - 1; /* rows are API-visible only after the step */
-                        if (kind == FK_MANIFOLD) dual_contact<true>(B, M, idx, P, alpha, lastDual);
-                        else if (kind == FK_JOINT) { if ((idx & 1) == 0) dual_gforce<true>(B, gf[idx >> 1], P, lastDual); }
-                        else dual_gforce<true>(B, gf[idx], P, lastDual);
+                const int nHere = min(64, eEnd - base);
+                if (lane < nHere) eval_entry<true>(inc[base + lane], B, M, gf, L, alpha, writeRows, rows + lane * kEntryRec);
+                wave_sync();
+                accumulate_rows(a, rows, nHere);
+                wave_sync();
+            }
+            if (lane < 27) accs[lane] = a.acc;
+            wave_sync();
+            DF_STAMP(1);
+            f3 p; q4 q;
+            solve_pose(accs, accs + 32, lane, L, p, q);
+            if (lane == 0) {
+                sanitize3(p, cntW);
+                sanitizeq(q, cntW);
+                st4<true>(B.plane(BP_POSR) + body, pack3(p, smp.w));
+                st4<true>(B.plane(BP_QUAT) + body, packq(q));
+            }
+            DF_STAMP(2);
+            drain_stores();
+            if (lane == 0) __hip_atomic_store(S.primalDone + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DF_STAMP(3);
+            if (doDual) {
+                for (int base = eBeg; base < eEnd; base += 64) {
+                    const int e = base + lane;
+                    if (e < eEnd) {
+                        const int en = inc[e];
+                        int oth;
+                        if (entry_owned(en, body, B, M, gf, oth)) {
+                            const int kind = inc_kind(en), ix = inc_index(en);
+                            if (kind == FK_MANIFOLD) dual_contact<true>(B, M, ix, P, alpha, lastDual);
+                            else if (kind == FK_JOINT) { if ((ix & 1) == 0) dual_gforce<true>(B, gf[ix >> 1], P, lastDual); }
+                            else dual_gforce<true>(B, gf[ix], P, lastDual);
+                        }
                     }
                 }
+                drain_stores();
             }
-            drain_stores();
+            if (lane == 0) __hip_atomic_store(S.dualDone + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DF_STAMP(4);
         }
-        if (lane == 0) __hip_atomic_store(S.dualDone + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef AVBD_DF_STATS
+        stat[5] += 1;
+#endif
     }
+#ifdef AVBD_DF_STATS
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(S.error + 16) + (size_t)w * 8;
+        stat[6] = __builtin_amdgcn_s_memrealtime() - tstart;
+        for (int i = 0; i < 8; ++i) o[i] = stat[i];
+    }
+#endif
 }
 
 /* Forces with no dynamic endpoint (static-static manifolds, joints between statics) take no part in any

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(128) void k_narrowphase(BodyTable B, ManifoldTable 
                 dst.cRA[s] = pack3(mi.rA[c], mi.C0n[c]);
                 dst.cRB[s] = pack3(mi.rB[c], mi.C0t1[c]);
                 dst.cN[s] = pack3(mi.normal[c], mi.C0t2[c]);
+                dst.cU1[s] = pack3(mi.u1[c], 0.f);
+                dst.cU2[s] = pack3(mi.u2[c], 0.f);
                 dst.cLam[s] = make_float4(mi.lambda[c * 3], mi.lambda[c * 3 + 1], mi.lambda[c * 3 + 2], mi.penetration[c]);
                 dst.cPen[s] = make_float4(mi.penalty[c * 3], mi.penalty[c * 3 + 1], mi.penalty[c * 3 + 2], 0.0f);
                 dst.cFS[s] = make_int2(mi.feature[c], mi.stick[c] ? 1 : 0);

@@ -94,6 +94,8 @@ __device__ __forceinline__ void load_contact(const ManifoldTable& M, int s, Cont
 {
     const float4 ra = M.cRA[s], rb = M.cRB[s];                       /* constant during the iteration loop */
     const float4 nn = ld4<COH>(M.cN + s), lam = ld4<COH>(M.cLam + s), pen = ld4<COH>(M.cPen + s);
+    const float4 u1 = ld4<COH>(M.cU1 + s), u2 = ld4<COH>(M.cU2 + s);
+    c.u1 = mk3(u1.x, u1.y, u1.z); c.u2 = mk3(u2.x, u2.y, u2.z);
     c.rA = mk3(ra.x, ra.y, ra.z); c.C0n = ra.w;
     c.rB = mk3(rb.x, rb.y, rb.z); c.C0t1 = rb.w;
     c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
@@ -107,6 +109,8 @@ template <bool COH>
 __device__ __forceinline__ void store_contact_mutations(const ManifoldTable& M, int s, const ContactRows& c, bool writeRows)
 {
     st4<COH>(M.cN + s, make_float4(c.normal.x, c.normal.y, c.normal.z, c.C0t2));
+    st4<COH>(M.cU1 + s, make_float4(c.u1.x, c.u1.y, c.u1.z, 0.f));
+    st4<COH>(M.cU2 + s, make_float4(c.u2.x, c.u2.y, c.u2.z, 0.f));
     st4<COH>(M.cLam + s, make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration));
     sti<COH>(&M.cFS[s].y, c.stick ? 1 : 0);
     if (writeRows) { /* API visibility of Force::C/fmin/fmax only; never read back by the solver */
@@ -186,20 +190,32 @@ __device__ __forceinline__ AccLane init_acc_lane(int lane, const BodyLocal& L)
 __device__ __forceinline__ void accumulate_rows(AccLane& a, const float* rows, int nEntries)
 {
     if (a.mode == 3) return;
-    for (int e = 0; e < nEntries; ++e) {
-        const float* rec = rows + e * kEntryRec;
-        for (int k = 0; k < 3; ++k) {
-            const float* r = rec + k * kRowRec;
-            const int flags = __float_as_int(r[11]);
-            if (!(flags & 1)) continue;
+    /* The additions must happen in row order, but the LDS reads of different rows are independent: fetch a
+     * block of rows into registers first, then run the dependent chain of adds (selects instead of branches). */
+    constexpr int kBlock = 6;
+    const int nRows = nEntries * 3;
+    const int gy = a.gy >= 0 ? a.gy : 0;
+    for (int r0 = 0; r0 < nRows; r0 += kBlock) {
+        float va[kBlock], vb[kBlock], vp[kBlock], vg[kBlock]; int fl[kBlock];
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) {
+            const int r = r0 + k;
+            const float* rec = rows + (r < nRows ? r : r0) * kRowRec;
+            va[k] = rec[a.opA]; vb[k] = rec[a.opB]; vp[k] = rec[7]; vg[k] = rec[gy];
+            fl[k] = r < nRows ? __float_as_int(rec[11]) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) {
+            const bool valid = (fl[k] & 1) != 0;
             if (a.mode == 2) {
-                a.acc = a.acc + r[a.opA] * r[a.opB];                  /* rhs += J * f, solver.cpp:383-384 */
+                const float nv = a.acc + va[k] * vb[k];                  /* rhs += J * f, solver.cpp:383-384 */
+                a.acc = valid ? nv : a.acc;
             } else {
-                const float pen = r[7];
-                if (pen > 0.0f && isfinite(pen)) {                    /* solver.cpp:387 */
-                    a.acc = a.acc + (r[a.opA] * r[a.opB]) * pen;      /* solver.cpp:388-391 */
-                    if (a.mode == 1 && (flags & 2)) a.acc = a.acc + (a.gy >= 0 ? r[a.gy] : 0.0f); /* solver.cpp:393-397 */
-                }
+                const float pen = vp[k];
+                const bool on = valid && pen > 0.0f && isfinite(pen);    /* solver.cpp:387 */
+                float nv = a.acc + (va[k] * vb[k]) * pen;                /* solver.cpp:388-391 */
+                if (a.mode == 1 && (fl[k] & 2)) nv = nv + (a.gy >= 0 ? vg[k] : 0.0f); /* solver.cpp:393-397 */
+                a.acc = on ? nv : a.acc;
             }
         }
     }
@@ -209,6 +225,24 @@ __device__ __forceinline__ void put_row(float* r, f3 Jl, f3 Ja, float f, float p
 {
     r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
     r[6] = f; r[7] = pen; r[8] = gyro.x; r[9] = gyro.y; r[10] = gyro.z; r[11] = __int_as_float(flags);
+}
+
+/* ---- phase 1 for one Manifold contact held in registers: computeConstraint (mutating c) +
+ * computeDerivatives + row records (solver.cpp:372-399 for rows 3c..3c+2) ------------------------- */
+__device__ __forceinline__ void eval_contact_core(ContactRows& c, bool isA, const BodyLocal& L, f3 opos, q4 orot, float oinv, float fric,
+                                                  float alpha, float* rec)
+{
+    if (isA) contact_compute_constraint(c, alpha, L.pos, L.rot, L.invMass, opos, orot, oinv, fric);
+    else     contact_compute_constraint(c, alpha, opos, orot, oinv, L.pos, L.rot, L.invMass, fric);
+    f3 Jl[3], Ja[3];
+    contact_compute_derivatives(c, isA, L.rot, Jl, Ja);
+    for (int k = 0; k < 3; ++k) {
+        /* stiffness == FLT_MAX for manifold rows, motor == 0 (manifold.cpp:102-106): solver.cpp:379-381 */
+        float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
+        float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+        f3 gyro = abs3(cross3(Ja[k], L.invIw * Ja[k])) * fabsf(f);
+        put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, 3 /* valid | manifold */);
+    }
 }
 
 /* ---- phase 1: evaluate one incidence entry (<= 3 rows) for `body` ---------------------------- */
@@ -227,19 +261,8 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
         const float oinv = B.plane(BP_MASS)[other].y;
         ContactRows c;
         load_contact<COH>(M, idx, c);
-        const float fric = M.fric[m];
-        if (isA) contact_compute_constraint(c, alpha, L.pos, L.rot, L.invMass, opos, orot, oinv, fric);
-        else     contact_compute_constraint(c, alpha, opos, orot, oinv, L.pos, L.rot, L.invMass, fric);
+        eval_contact_core(c, isA, L, opos, orot, oinv, M.fric[m], alpha, rec);
         store_contact_mutations<COH>(M, idx, c, writeRows);
-        f3 Jl[3], Ja[3];
-        contact_compute_derivatives(c, isA, L.rot, Jl, Ja);
-        for (int k = 0; k < 3; ++k) {
-            /* stiffness == FLT_MAX for manifold rows, motor == 0 (manifold.cpp:102-106): solver.cpp:379-381 */
-            float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
-            float f = rclamp(desired, c.fmin[k], c.fmax[k]);
-            f3 gyro = abs3(cross3(Ja[k], L.invIw * Ja[k])) * fabsf(f);
-            put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, 3 /* valid | manifold */);
-        }
     } else if (kind == FK_JOINT) {
         const int g = idx >> 1, part = idx & 1;
         GForce& f = gf[g];
@@ -285,8 +308,14 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
     }
 }
 
-/* ---- phase 3: solve6x6 + pose update (lane 0) ---------------------------------------------------- */
-__device__ __forceinline__ void solve_pose(const float* accs, const BodyLocal& L, f3& p, q4& q)
+/* ---- phase 3: solve6x6 (solver.cpp:68-83) + pose update (solver.cpp:402-405) ---------------------------
+ * Lane-parallel evaluation of exactly the reference's expression trees:
+ *   lanes 0..2: AinvB column j = solve(ll, la.col j), then Schur column j = aa.col j - al * column j
+ *   lane  3   : x0 = solve(ll, b.l), then rhs_s = b.a - al * x0
+ *   lane  0   : y = solve(schur, rhs_s), x = x0 - AinvB * y, pose update
+ * `accs` holds the 27 accumulated entries; `xch` is a 16-float per-wave LDS exchange area.
+ * The result (p, q) is valid in lane 0 only. */
+__device__ __forceinline__ void solve_pose(const float* accs, float* xch, int lane, const BodyLocal& L, f3& p, q4& q)
 {
     m33 ll, la, al, aa;
     /* lower triangles; the strictly-upper entries are never read by solve (maths.h:104) */
@@ -294,27 +323,36 @@ __device__ __forceinline__ void solve_pose(const float* accs, const BodyLocal& L
     la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
     al = mtranspose(la); /* al accumulates (Ja_i*Jl_j)*pen = la(j,i) bit for bit (solver.cpp:389-390) */
     aa.c0 = mk3(accs[15], accs[16], accs[17]); aa.c1 = mk3(accs[16], accs[18], accs[19]); aa.c2 = mk3(accs[17], accs[19], accs[20]);
-    f3 bl = mk3(accs[21], accs[22], accs[23]), ba = mk3(accs[24], accs[25], accs[26]);
-    f3 dl, da;
-    solve_block6(ll, la, al, aa, bl, ba, dl, da);                     /* solver.cpp:402 */
-    p = L.pos - dl;                                                   /* solver.cpp:403-405 */
-    q4 dq = mkq(da.x, da.y, da.z, 0.0f);
-    q = qnormalize(L.rot - (dq * L.rot) * 0.5f);
+    const f3 bl = mk3(accs[21], accs[22], accs[23]), ba = mk3(accs[24], accs[25], accs[26]);
+    const int j = lane & 3;
+    const f3 rhs = j == 0 ? la.c0 : (j == 1 ? la.c1 : (j == 2 ? la.c2 : bl));
+    const f3 sol = solve_ldlt3(ll, rhs);             /* col0, col1, col2, x0 */
+    const f3 prod = al * sol;                        /* al * AinvB.col j  |  al * x0 */
+    const f3 base = j == 0 ? aa.c0 : (j == 1 ? aa.c1 : (j == 2 ? aa.c2 : ba));
+    const f3 out = base - prod;                      /* schur.col j  |  rhs_s */
+    if (lane < 4) {
+        xch[j * 3 + 0] = out.x; xch[j * 3 + 1] = out.y; xch[j * 3 + 2] = out.z;
+        if (lane > 0) { xch[12 + (j - 1) * 3 + 0] = sol.x; xch[12 + (j - 1) * 3 + 1] = sol.y; xch[12 + (j - 1) * 3 + 2] = sol.z; }
+    }
+    wave_sync();
+    if (lane == 0) {
+        const m33 schur = mkm(mk3(xch[0], xch[1], xch[2]), mk3(xch[3], xch[4], xch[5]), mk3(xch[6], xch[7], xch[8]));
+        const f3 rhs_s = mk3(xch[9], xch[10], xch[11]);
+        const f3 y = solve_ldlt3(schur, rhs_s);
+        const m33 AinvB = mkm(sol, mk3(xch[12], xch[13], xch[14]), mk3(xch[15], xch[16], xch[17]));
+        const f3 x0 = mk3(xch[18], xch[19], xch[20]);
+        const f3 dl = x0 - AinvB * y;
+        p = L.pos - dl;                                               /* solver.cpp:403-405 */
+        q4 dq = mkq(y.x, y.y, y.z, 0.0f);
+        q = qnormalize(L.rot - (dq * L.rot) * 0.5f);
+    }
 }
 
 /* ---- dual update of one Manifold contact (solver.cpp:411-430 for rows 3c..3c+2) ------------------- */
-template <bool COH>
-__device__ __forceinline__ void dual_contact(const BodyTable& B, const ManifoldTable& M, int s, const SolverParams& P, float alpha, bool writeRows)
+__device__ __forceinline__ void dual_contact_core(ContactRows& c, f3 posA, q4 rotA, float imA, f3 posB, q4 rotB, float imB, float fric,
+                                                  const SolverParams& P, float alpha)
 {
-    const int m = s >> 2;
-    const int2 pr = M.pair[m];
-    f3 posA, posB; q4 rotA, rotB;
-    load_pose<COH>(B, pr.x, posA, rotA);
-    load_pose<COH>(B, pr.y, posB, rotB);
-    const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
-    ContactRows c;
-    load_contact<COH>(M, s, c);
-    contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[m]);
+    contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, fric);
     bool needJ = false;
     bool active[3];
     for (int k = 0; k < 3; ++k) {
@@ -336,7 +374,14 @@ __device__ __forceinline__ void dual_contact(const BodyTable& B, const ManifoldT
             c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kManifoldPenaltyCap);
         }
     }
+}
+
+template <bool COH>
+__device__ __forceinline__ void store_contact_dual(const ManifoldTable& M, int s, const ContactRows& c, bool writeRows)
+{
     st4<COH>(M.cN + s, make_float4(c.normal.x, c.normal.y, c.normal.z, c.C0t2));
+    st4<COH>(M.cU1 + s, make_float4(c.u1.x, c.u1.y, c.u1.z, 0.f));
+    st4<COH>(M.cU2 + s, make_float4(c.u2.x, c.u2.y, c.u2.z, 0.f));
     st4<COH>(M.cLam + s, make_float4(c.lambda[0], c.lambda[1], c.lambda[2], c.penetration));
     st4<COH>(M.cPen + s, make_float4(c.penalty[0], c.penalty[1], c.penalty[2], 0.f));
     sti<COH>(&M.cFS[s].y, c.stick ? 1 : 0);
@@ -345,6 +390,21 @@ __device__ __forceinline__ void dual_contact(const BodyTable& B, const ManifoldT
         st4<COH>(M.cFmin + s, make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f));
         st4<COH>(M.cFmax + s, make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f));
     }
+}
+
+template <bool COH>
+__device__ __forceinline__ void dual_contact(const BodyTable& B, const ManifoldTable& M, int s, const SolverParams& P, float alpha, bool writeRows)
+{
+    const int m = s >> 2;
+    const int2 pr = M.pair[m];
+    f3 posA, posB; q4 rotA, rotB;
+    load_pose<COH>(B, pr.x, posA, rotA);
+    load_pose<COH>(B, pr.y, posB, rotB);
+    const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
+    ContactRows c;
+    load_contact<COH>(M, s, c);
+    dual_contact_core(c, posA, rotA, imA, posB, rotB, imB, M.fric[m], P, alpha);
+    store_contact_dual<COH>(M, s, c, writeRows);
 }
 
 /* ---- dual update of one Joint / Spring -------------------------------------------------------------- */
@@ -408,7 +468,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, Man
                                                                  const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt)
 {
     __shared__ float sRows[kWavesPerBlock][64 * kEntryRec];
-    __shared__ float sAcc[kWavesPerBlock][32];
+    __shared__ float sAcc[kWavesPerBlock][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int first = lvlStart[level], last = lvlStart[level + 1];
     const int slot = first + blockIdx.x * kWavesPerBlock + wv;
@@ -429,9 +489,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, Man
     }
     if (lane < 27) accs[lane] = a.acc;
     wave_sync();
+    f3 p; q4 q;
+    solve_pose(accs, accs + 32, lane, L, p, q);
     if (lane == 0) {
-        f3 p; q4 q;
-        solve_pose(accs, L, p, q);
         sanitize3(p, cnt);                                            /* solver.cpp:407-408 */
         sanitizeq(q, cnt);
         float4 pr = B.plane(BP_POSR)[body];

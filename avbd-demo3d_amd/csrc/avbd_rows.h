@@ -60,9 +60,33 @@ AVBD_HD void contact_basis(f3 nIn, f3& n, f3& t1, f3& t2)                       
     t2 = normalize_safe(cross3(n, t1), mk3(0.0f, 0.0f, 1.0f));
 }
 
+/* Tangents of an ALREADY NORMALISED normal: the second half of buildContactBasis (manifold.cpp:43-49). */
+AVBD_HD void contact_tangents(f3 n, f3& t1, f3& t2)
+{
+    if (fabsf(n.x) >= fabsf(n.z)) t1 = mk3(-n.y, n.x, 0.0f);
+    else t1 = mk3(0.0f, -n.z, n.y);
+    t1 = normalize_safe(t1, mk3(1.0f, 0.0f, 0.0f));
+    t2 = normalize_safe(cross3(n, t1), mk3(0.0f, 0.0f, 1.0f));
+}
+
+/* buildContactBasis(stored) with a memo: (u1, u2) are the tangents contact_tangents(stored) computed when
+ * `stored` was written.  The reference re-normalises the stored normal on every call; when that
+ * normalisation is the identity on these bits (|stored| rounds to exactly 1.0f — the usual case after the first
+ * call of a step) the whole basis equals the memo bit for bit, because it is a pure function of the same input.
+ * Otherwise the basis is recomputed exactly like the reference does and `hit` is false. */
+AVBD_HD void contact_basis_memo(f3 stored, f3 u1, f3 u2, f3& n, f3& t1, f3& t2, bool& hit)
+{
+    const float lenSq = lensq3(stored);
+    if (!(lenSq < kVecEps) && sqrtf(lenSq) == 1.0f) { n = stored; t1 = u1; t2 = u2; hit = true; return; } /* stored / 1.0f == stored */
+    hit = false;
+    n = normalize_safe(stored, mk3(0.0f, 1.0f, 0.0f));
+    contact_tangents(n, t1, t2);
+}
+
 /* ---- one contact of a Manifold = 3 rows (normal, tangent1, tangent2) ------------------- */
 struct ContactRows {
     f3    rA, rB, normal;        /* Manifold::Contact, solver.h:120-130 */
+    f3    u1, u2;                /* memo: contact_tangents(normal) for the stored normal (build-only, see contact_basis_memo) */
     float C0n, C0t1, C0t2;
     float penetration;
     bool  stick;
@@ -77,8 +101,9 @@ AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4
 {
     float biasScale = rclamp(1.0f - alpha, 0.0f, 1.0f);
     f3 n, t1, t2;
-    contact_basis(c.normal, n, t1, t2);
-    c.normal = n;
+    bool hit;
+    contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
+    c.normal = n; c.u1 = t1; c.u2 = t2;   /* stored normal and its memo move together */
     f3 pA = world_point(posA, rotA, c.rA);
     f3 pB = world_point(posB, rotB, c.rB);
     f3 d = pA - pB;
@@ -129,7 +154,8 @@ AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4
 AVBD_HD void contact_compute_derivatives(const ContactRows& c, bool isBodyA, q4 rotBody, f3 Jl[3], f3 Ja[3])
 {
     f3 n, t1, t2;
-    contact_basis(c.normal, n, t1, t2);
+    bool hit;
+    contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
     float sign = isBodyA ? 1.0f : -1.0f;
     f3 wr = qrotate(rotBody, isBodyA ? c.rA : c.rB);
     Jl[0] = n * sign;  Ja[0] = cross3(wr, n) * sign;
@@ -143,6 +169,7 @@ struct ManifoldInit {
     float combinedFriction;
     int   feature[4];
     f3    rA[4], rB[4], normal[4];
+    f3    u1[4], u2[4];          /* tangent memo of the stored (normalised) normal */
     float penetration[4], C0n[4], C0t1[4], C0t2[4];
     bool  stick[4];
     float lambda[12], penalty[12];
@@ -206,7 +233,7 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float fricti
 
         f3 n, t1, t2;
         contact_basis(m.normal[i], n, t1, t2);
-        m.normal[i] = n;
+        m.normal[i] = n; m.u1[i] = t1; m.u2[i] = t2;
         f3 pA = world_point(A.pos, A.rot, m.rA[i]);
         f3 pB = world_point(B.pos, B.rot, m.rB[i]);
         f3 d = pA - pB;

@@ -53,6 +53,8 @@ struct ManifoldTable {
     float4*   cRA;     /* rA.xyz, C0_n */
     float4*   cRB;     /* rB.xyz, C0_t.x */
     float4*   cN;      /* normal.xyz, C0_t.y */
+    float4*   cU1;     /* memo: tangent1 of the stored normal (contact_basis_memo) */
+    float4*   cU2;     /* memo: tangent2 of the stored normal */
     float4*   cLam;    /* lambda n,t1,t2, penetration */
     float4*   cPen;    /* penalty n,t1,t2, (unused) */
     int2*     cFS;     /* feature key, stick */
