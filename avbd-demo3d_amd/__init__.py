@@ -123,8 +123,8 @@ class World:
         h = C.c_void_p()
         rc = self.L.avbd_create(int(device), C.byref(h))
         if rc != 0:
-            raise AvbdError(f"avbd_create(device={device}) failed with code {rc}: no usable gfx950 device / HIP runtime "
-                            "(this framework has no CPU fallback)")
+            raise AvbdError(f"avbd_create(device={device}) failed with code {rc} ({self.L.avbd_last_error(None).decode()}): no usable gfx950 "
+                            "device / HIP runtime (this framework has no CPU fallback)")
         self.h = h
 
     # -- lifetime

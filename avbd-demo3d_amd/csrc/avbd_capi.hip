@@ -132,6 +132,8 @@ struct AvbdContext {
     DevArr<int> dFlags;        /* primalDone[bodyCap] | dualDone[bodyCap] | error word (data-flow kernel) */
     int mode = 1;              /* 1: persistent data-flow iteration kernel (default), 0: one launch per level */
     int iterBlocks = 512;      /* resident workgroups of k_iterate */
+    int iterLdsPad = 0;        /* extra dynamic LDS per workgroup: > 43 KB forces one workgroup per CU */
+    int iterSleep = 1;         /* poll back-off selector (s_sleep 1/2/4/8) */
     int numStatic = 0;
     bool statsFresh = true;
     Readback* hRb = nullptr; /* pinned */
@@ -242,8 +244,8 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, hipMemset(c->incStart.p, 0, (newCap + 1) * sizeof(int)));
     HIPCHK(c, hipMemset(c->degForce.p, 0, newCap * sizeof(int)));
     HIPCHK(c, hipMemset(c->degInc.p, 0, newCap * sizeof(int)));
-    HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 32 + 8192 * 16));
-    HIPCHK(c, hipMemset(c->dFlags.p, 0, ((size_t)2 * newCap + 32 + 8192 * 16) * sizeof(int)));
+    HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 32 + 8192 * 32));
+    HIPCHK(c, hipMemset(c->dFlags.p, 0, ((size_t)2 * newCap + 32 + 8192 * 32) * sizeof(int)));
     c->adjDirty = true;
     c->bodiesStale = true;
     return AVBD_OK;
@@ -582,8 +584,8 @@ int step_once(AvbdContext* c)
         if (blocks < 1) blocks = 1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-        hipExtLaunchKernelGGL(k_iterate, dim3(blocks), dim3(64 * kIterWaves), 0, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p);
+        hipExtLaunchKernelGGL(k_iterate, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep);
         ++c->prof.launches_primal; ++c->prof.launches_total;
         if (c->numStatic > 1 || ng > 0)
             hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
@@ -636,6 +638,8 @@ q4 HQ(const float* p) { return mkq(p[0], p[1], p[2], p[3]); }
 
 } // namespace
 
+static std::string g_createError = "null context";
+
 /* ========================================================================================== */
 extern "C" {
 
@@ -660,25 +664,27 @@ int avbd_create(int device, AvbdContext** out)
     c->device = device;
     avbd_default_params(&c->params);
     if (const char* m = std::getenv("AVBD_MODE")) c->mode = (std::strcmp(m, "levels") == 0) ? 0 : 1;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_createError = "hipStreamCreate failed"; delete c; return AVBD_E_HIP; }
     if (hipHostMalloc((void**)&c->hRb, sizeof(Readback), hipHostMallocDefault) != hipSuccess) { delete c; return AVBD_E_HIP; }
     std::memset(c->hRb, 0, sizeof(Readback));
     if (c->dCnt.alloc(1) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
     (void)hipMemset(c->dCnt.p, 0, sizeof(Counters));
     (void)hipMemset(c->dDiag.p, 0, sizeof(DiagAccum));
     (void)hipMemset(c->dNext.p, 0, sizeof(int));
-    if (ensure_capacity(c, 0) != AVBD_OK || ensure_topology_capacity(c) != AVBD_OK) { delete c; return AVBD_E_HIP; }
-    {   /* k_iterate needs every workgroup resident: size its grid from the occupancy query, with margin
-         * (MI355X_MICROARCH.md "Residency and cooperative launch": the API can over-report by one block/CU) */
+    if (ensure_capacity(c, 0) != AVBD_OK || ensure_topology_capacity(c) != AVBD_OK) { g_createError = "initial allocation failed: " + c->err; delete c; return AVBD_E_HIP; }
+    {   /* k_iterate needs every workgroup resident.  One workgroup (4 waves = one per SIMD) per CU: a spinning
+         * second wave on a SIMD steals issue slots from the wave that is on the critical path.  Padding the LDS
+         * request past half a CU's 160 KiB pins that placement, which also makes residency certain
+         * (MI355X_MICROARCH.md "Residency and cooperative launch"). */
         hipDeviceProp_t prop;
-        int perCU = 0;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_iterate, 64 * kIterWaves, 0) != hipSuccess || perCU < 1) { delete c; return AVBD_E_HIP; }
-        int use = perCU >= 3 ? 2 : 1;
-        if (perCU < 2) use = 1;
-        c->iterBlocks = std::max(1, prop.multiProcessorCount * use);
-        if (perCU == 1) c->iterBlocks = std::max(1, prop.multiProcessorCount / 2);
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_createError = "hipGetDeviceProperties failed"; delete c; return AVBD_E_HIP; }
+        c->iterBlocks = std::max(1, prop.multiProcessorCount);
+        c->iterLdsPad = 48 * 1024;
         if (const char* e = std::getenv("AVBD_ITER_BLOCKS")) c->iterBlocks = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("AVBD_ITER_LDSPAD")) c->iterLdsPad = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
+        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
     }
     *out = c;
     return AVBD_OK;
@@ -700,7 +706,7 @@ int avbd_destroy(AvbdContext* c)
     return AVBD_OK;
 }
 
-const char* avbd_last_error(const AvbdContext* c) { return c ? c->err.c_str() : "null context"; }
+const char* avbd_last_error(const AvbdContext* c) { return c ? c->err.c_str() : g_createError.c_str(); }
 
 int avbd_set_params(AvbdContext* c, const AvbdParams* p)
 {
@@ -1177,7 +1183,8 @@ __global__ void k_row_api(BodyTable B, ManifoldTable M, GForce* gf, int kind, in
             ContactRows c;
             load_contact<false>(M, s, c);
             if (mode == 0) {
-                contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[index]);
+                ContactBasis db;
+                contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[index], db);
                 store_contact_mutations<false>(M, s, c, true);
                 for (int k = 0; k < 3; ++k) { out[ci * 3 + k] = c.C[k]; out[12 + ci * 3 + k] = c.fmin[k]; out[24 + ci * 3 + k] = c.fmax[k]; out[36 + ci * 3 + k] = c.lambda[k]; }
             } else {
@@ -1347,7 +1354,7 @@ int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)
     if (!c || !out) return AVBD_E_INVALID;
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->dFlags.p + 2 * (size_t)c->bodyCap + 16, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->dFlags.p + 2 * (size_t)c->bodyCap + 16, (size_t)waves * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return AVBD_OK;
 }
 

@@ -65,7 +65,7 @@ __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& 
 
 /* dependency wait of task (body, it); returns false when the launch must be abandoned */
 __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, const int* adjStart, const int* adjRef, const int* adjOther,
-                                                  const float4* massPlane, const IterateState& S)
+                                                  const float4* massPlane, const IterateState& S, int sleepSel)
 {
     const int aBeg = adjStart[body], aEnd = adjStart[body + 1];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -87,7 +87,8 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
         while (true) {
             if (!ok) ok = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
             if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(2);
+            if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
+            else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
             if ((++spins & 1023u) == 0) {
                 bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
                             __hip_atomic_load(S.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -99,11 +100,11 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
     return true;
 }
 
-__global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
+__global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_iterate(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
                                                               const int* __restrict__ adjOther, const int* __restrict__ incStart,
-                                                              const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW)
+                                                              const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel)
 {
     __shared__ float sRows[kIterWaves][64 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
@@ -118,9 +119,10 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
     const float4* massPlane = B.plane(BP_MASS);
 
 #ifdef AVBD_DF_STATS
-    unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
     const unsigned long long tstart = tprev;
+    const unsigned long long cstart = __builtin_amdgcn_s_memtime();
 #endif
     for (long long t = w; t < nTasks; t += W) {
         DF_STAMP(7);
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
         const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
         const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
 
-        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, massPlane, S)) return;
+        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, massPlane, S, sleepSel)) return;
         DF_STAMP(0);
 
         if (fast) {
@@ -168,6 +170,10 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
                 mu1 = ld4<true>(M.cU1 + idx); mu2 = ld4<true>(M.cU2 + idx);
                 stick = ldi<true>(&M.cFS[idx].y);
             }
+#ifdef AVBD_DF_STATS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DF_STAMP(8);
+#endif
             BodyLocal L;
             L.pos = mk3(pp.x, pp.y, pp.z); L.rot = mkq(pq.x, pq.y, pq.z, pq.w);
             L.npos = mk3(snp.x, snp.y, snp.z); L.nrot = mkq(snq.x, snq.y, snq.z, snq.w);
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
                 L.invDt2 = 1.0f / (P.dt * P.dt);
             }
             AccLane a = init_acc_lane(lane, L);
+            DF_STAMP(9);
             ContactRows c;
             const f3 opos = mk3(op.x, op.y, op.z); const q4 orot = mkq(oq.x, oq.y, oq.z, oq.w);
             if (has) {
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
                 if (!(owned && doDual)) store_contact_mutations<true>(M, idx, c, writeRows);
             }
             wave_sync();
+            DF_STAMP(10);
             accumulate_rows(a, rows, nEnt);
             if (lane < 27) accs[lane] = a.acc;
             wave_sync();
@@ -278,9 +286,10 @@ __global__ __launch_bounds__(64 * kIterWaves) void k_iterate(BodyTable B, Manifo
     }
 #ifdef AVBD_DF_STATS
     if (lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(S.error + 16) + (size_t)w * 8;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(S.error + 16) + (size_t)w * 16;
         stat[6] = __builtin_amdgcn_s_memrealtime() - tstart;
-        for (int i = 0; i < 8; ++i) o[i] = stat[i];
+        stat[11] = __builtin_amdgcn_s_memtime() - cstart;
+        for (int i = 0; i < 16; ++i) o[i] = stat[i];
     }
 #endif
 }

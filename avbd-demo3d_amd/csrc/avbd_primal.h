@@ -191,32 +191,36 @@ __device__ __forceinline__ void accumulate_rows(AccLane& a, const float* rows, i
 {
     if (a.mode == 3) return;
     /* The additions must happen in row order, but the LDS reads of different rows are independent: fetch a
-     * block of rows into registers first, then run the dependent chain of adds (selects instead of branches). */
+     * block of rows into registers first, then run the dependent chain of adds, branch-free.
+     *   rhs lanes : acc += J*f            written as (J*f)*1.0f — exact
+     *   lhs lanes : acc += (Ja*Jb)*pen    only when pen > 0 and finite (solver.cpp:387)
+     *   aa lanes  : ... then += gyro (diagonal) or += 0.0f (off-diagonal) for manifold rows (solver.cpp:393-397) */
     constexpr int kBlock = 6;
     const int nRows = nEntries * 3;
-    const int gy = a.gy >= 0 ? a.gy : 0;
+    const bool isRhs = a.mode == 2, isAA = a.mode == 1, hasG = a.gy >= 0;
+    const float* pa = rows + a.opA;
+    const float* pb = rows + a.opB;
+    const float* pg = rows + (hasG ? a.gy : 0);
     for (int r0 = 0; r0 < nRows; r0 += kBlock) {
         float va[kBlock], vb[kBlock], vp[kBlock], vg[kBlock]; int fl[kBlock];
 #pragma unroll
         for (int k = 0; k < kBlock; ++k) {
-            const int r = r0 + k;
-            const float* rec = rows + (r < nRows ? r : r0) * kRowRec;
-            va[k] = rec[a.opA]; vb[k] = rec[a.opB]; vp[k] = rec[7]; vg[k] = rec[gy];
-            fl[k] = r < nRows ? __float_as_int(rec[11]) : 0;
+            const int off = (r0 + k) * kRowRec;   /* at most 2 rows past the end: still inside the wave's staging area */
+            va[k] = pa[off]; vb[k] = pb[off]; vp[k] = rows[off + 7]; vg[k] = pg[off]; fl[k] = __float_as_int(rows[off + 11]);
         }
 #pragma unroll
         for (int k = 0; k < kBlock; ++k) {
-            const bool valid = (fl[k] & 1) != 0;
-            if (a.mode == 2) {
-                const float nv = a.acc + va[k] * vb[k];                  /* rhs += J * f, solver.cpp:383-384 */
-                a.acc = valid ? nv : a.acc;
-            } else {
-                const float pen = vp[k];
-                const bool on = valid && pen > 0.0f && isfinite(pen);    /* solver.cpp:387 */
-                float nv = a.acc + (va[k] * vb[k]) * pen;                /* solver.cpp:388-391 */
-                if (a.mode == 1 && (fl[k] & 2)) nv = nv + (a.gy >= 0 ? vg[k] : 0.0f); /* solver.cpp:393-397 */
-                a.acc = on ? nv : a.acc;
-            }
+            /* bitwise (non-short-circuit) predicate algebra keeps this a straight line of v_cmp / v_cndmask */
+            const bool valid = (r0 + k < nRows) & ((fl[k] & 1) != 0);
+            const bool manifoldRow = (fl[k] & 2) != 0;
+            const float pen = vp[k];
+            const bool penOk = (pen > 0.0f) & (fabsf(pen) <= FLT_MAX);   /* pen > 0 && isfinite(pen): NaN fails both compares */
+            const float scale = isRhs ? 1.0f : pen;
+            const float nv = a.acc + (va[k] * vb[k]) * scale;
+            const float nvg = nv + (hasG ? vg[k] : 0.0f);
+            const float nv2 = (isAA & manifoldRow) ? nvg : nv;
+            const bool on = valid & (isRhs | penOk);
+            a.acc = on ? nv2 : a.acc;
         }
     }
 }
@@ -232,10 +236,11 @@ __device__ __forceinline__ void put_row(float* r, f3 Jl, f3 Ja, float f, float p
 __device__ __forceinline__ void eval_contact_core(ContactRows& c, bool isA, const BodyLocal& L, f3 opos, q4 orot, float oinv, float fric,
                                                   float alpha, float* rec)
 {
-    if (isA) contact_compute_constraint(c, alpha, L.pos, L.rot, L.invMass, opos, orot, oinv, fric);
-    else     contact_compute_constraint(c, alpha, opos, orot, oinv, L.pos, L.rot, L.invMass, fric);
+    ContactBasis db;
+    if (isA) contact_compute_constraint(c, alpha, L.pos, L.rot, L.invMass, opos, orot, oinv, fric, db);
+    else     contact_compute_constraint(c, alpha, opos, orot, oinv, L.pos, L.rot, L.invMass, fric, db);
     f3 Jl[3], Ja[3];
-    contact_compute_derivatives(c, isA, L.rot, Jl, Ja);
+    contact_compute_derivatives(c, db, isA, L.rot, Jl, Ja);
     for (int k = 0; k < 3; ++k) {
         /* stiffness == FLT_MAX for manifold rows, motor == 0 (manifold.cpp:102-106): solver.cpp:379-381 */
         float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
@@ -352,7 +357,8 @@ __device__ __forceinline__ void solve_pose(const float* accs, float* xch, int la
 __device__ __forceinline__ void dual_contact_core(ContactRows& c, f3 posA, q4 rotA, float imA, f3 posB, q4 rotB, float imB, float fric,
                                                   const SolverParams& P, float alpha)
 {
-    contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, fric);
+    ContactBasis db;
+    contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, fric, db);
     bool needJ = false;
     bool active[3];
     for (int k = 0; k < 3; ++k) {
@@ -363,8 +369,8 @@ __device__ __forceinline__ void dual_contact_core(ContactRows& c, f3 posA, q4 ro
     }
     if (needJ) {
         f3 JlA[3], JaA[3], JlB[3], JaB[3];
-        contact_compute_derivatives(c, true, rotA, JlA, JaA);
-        contact_compute_derivatives(c, false, rotB, JlB, JaB);
+        contact_compute_derivatives(c, db, true, rotA, JlA, JaA);   /* both endpoints rebuild the same basis */
+        contact_compute_derivatives(c, db, false, rotB, JlB, JaB);
         for (int k = 0; k < 3; ++k) {
             if (!active[k]) continue;
             float lw = 0.0f, aw = 0.0f;                               /* rowPenaltyGain, solver.cpp:94-125 */

@@ -96,14 +96,20 @@ struct ContactRows {
 
 /* Manifold::computeConstraint for one contact (manifold.cpp:183-243).  Mutates normal, lambda[1..2],
  * stick, penetration exactly like the reference. */
+struct ContactBasis { f3 n, t1, t2; };
+
+/* `db` receives the basis the reference's computeDerivatives would rebuild right after this call from the normal
+ * this call stores (manifold.cpp:253-254): the same memo rule applied to the new stored normal. */
 AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4 rotA, float invMassA, f3 posB, q4 rotB,
-                                        float invMassB, float combinedFriction)
+                                        float invMassB, float combinedFriction, ContactBasis& db)
 {
     float biasScale = rclamp(1.0f - alpha, 0.0f, 1.0f);
     f3 n, t1, t2;
     bool hit;
     contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
     c.normal = n; c.u1 = t1; c.u2 = t2;   /* stored normal and its memo move together */
+    if (hit) { db.n = n; db.t1 = t1; db.t2 = t2; }            /* same bits in, same basis out */
+    else { bool h2; contact_basis_memo(n, t1, t2, db.n, db.t1, db.t2, h2); }
     f3 pA = world_point(posA, rotA, c.rA);
     f3 pB = world_point(posB, rotB, c.rB);
     f3 d = pA - pB;
@@ -151,16 +157,21 @@ AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4
 /* Manifold::computeDerivatives for the three rows of one contact (manifold.cpp:247-271).  The
  * reference rebuilds the basis from the STORED normal on every call; the stored normal is the
  * one computeConstraint just wrote, so the basis below is normalised once more, as there. */
-AVBD_HD void contact_compute_derivatives(const ContactRows& c, bool isBodyA, q4 rotBody, f3 Jl[3], f3 Ja[3])
+AVBD_HD void contact_compute_derivatives(const ContactRows& c, const ContactBasis& db, bool isBodyA, q4 rotBody, f3 Jl[3], f3 Ja[3])
 {
-    f3 n, t1, t2;
-    bool hit;
-    contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
     float sign = isBodyA ? 1.0f : -1.0f;
     f3 wr = qrotate(rotBody, isBodyA ? c.rA : c.rB);
-    Jl[0] = n * sign;  Ja[0] = cross3(wr, n) * sign;
-    Jl[1] = t1 * sign; Ja[1] = cross3(wr, t1) * sign;
-    Jl[2] = t2 * sign; Ja[2] = cross3(wr, t2) * sign;
+    Jl[0] = db.n * sign;  Ja[0] = cross3(wr, db.n) * sign;
+    Jl[1] = db.t1 * sign; Ja[1] = cross3(wr, db.t1) * sign;
+    Jl[2] = db.t2 * sign; Ja[2] = cross3(wr, db.t2) * sign;
+}
+
+/* stand-alone form (row API): rebuild the basis from the stored normal like manifold.cpp:253-254 */
+AVBD_HD void contact_compute_derivatives(const ContactRows& c, bool isBodyA, q4 rotBody, f3 Jl[3], f3 Ja[3])
+{
+    ContactBasis db; bool hit;
+    contact_basis_memo(c.normal, c.u1, c.u2, db.n, db.t1, db.t2, hit);
+    contact_compute_derivatives(c, db, isBodyA, rotBody, Jl, Ja);
 }
 
 /* ---- Manifold::initialize (manifold.cpp:71-175) ----------------------------------------- */
