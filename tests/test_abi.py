@@ -1,0 +1,88 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/avbd_hip.h declares, its structs have the
+sizes the Python binding assumes, and it FAILS LOUDLY (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import harness as H
+
+pkg = H.load_product()
+HEADER = os.path.join(H.ROOT, "include", "avbd_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build()
+    return pkg.lib()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(avbd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/avbd_hip.h but not exported: {missing}"
+    assert sorted(set(pkg.EXPORTS)) == names, "the Python binding's EXPORTS list and the header disagree"
+
+
+def test_abi_version_and_defaults(lib):
+    assert lib.avbd_abi_version() == 1
+    p = np.zeros(1, pkg.PARAMS_DT)
+    assert lib.avbd_default_params(p.ctypes.data_as(C.c_void_p)) == 0
+    # Solver::defaultParams, solver.cpp:240-248
+    assert p[0]["iterations"] == 10 and p[0]["postStabilize"] == 0
+    assert p[0]["dt"] == np.float32(1.0) / np.float32(60.0)
+    assert list(p[0]["gravity"]) == [0.0, -10.0, 0.0]
+    assert p[0]["alpha"] == np.float32(0.95) and p[0]["beta"] == np.float32(100000.0) and p[0]["gamma"] == np.float32(0.99)
+
+
+def test_struct_sizes_match_the_header():
+    src = '#include <stdio.h>\n#include "avbd_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(AvbdParams), sizeof(AvbdDiagnostics),' \
+          ' sizeof(AvbdBody), sizeof(AvbdContact), sizeof(AvbdForce), sizeof(AvbdStepStats), sizeof(AvbdProfile), sizeof(void*)); return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(H.ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        sizes = [int(x) for x in subprocess.run([os.path.join(d, "t")], capture_output=True, check=True, text=True).stdout.split()]
+    want = [pkg.PARAMS_DT.itemsize, pkg.DIAG_DT.itemsize, pkg.BODY_DT.itemsize, pkg.CONTACT_DT.itemsize, pkg.FORCE_DT.itemsize,
+            pkg.STATS_DT.itemsize, pkg.PROFILE_DT.itemsize, 8]
+    assert sizes == want
+    # the harness records (oracle/harness_api.h) and the product records are the same wire layout
+    assert H.BODY_DT.itemsize == pkg.BODY_DT.itemsize and H.FORCE_DT.itemsize == pkg.FORCE_DT.itemsize
+
+
+def test_no_cpu_fallback_without_a_device(lib):
+    """In a container without /dev/kfd the product must refuse to run rather than fall back to any CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.avbd_create(0, C.byref(h))
+    assert rc in (-4, -2) and not h.value
+    with pytest.raises(pkg.AvbdError):
+        pkg.World(0)
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under avbd-demo3d_amd/ or include/ may include, link or import anything under oracle/."""
+    bad = []
+    for root in (os.path.join(H.ROOT, "avbd-demo3d_amd"), os.path.join(H.ROOT, "include")):
+        for dp, _, fns in os.walk(root):
+            for fn in fns:
+                if fn.endswith((".h", ".hip", ".cpp", ".py", "Makefile")):
+                    t = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"oracle/|liboracle|harness_api|avbd_oracle", t):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in out and "avbd_ref" not in out
