@@ -63,7 +63,8 @@ EXPORTS = [
     "avbd_num_forces", "avbd_download_forces", "avbd_upload_forces", "avbd_force_row_count",
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
-    "avbd_build_scene",
+    "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
+    "avbd_group_step", "avbd_debug_iterate_stats",
 ]
 
 
@@ -113,6 +114,32 @@ def _f32(a, shape=None):
     if shape is not None:
         a = a.reshape(shape)
     return a
+
+
+def partition_by_axis(position, inv_mass, nranks, axis=0):
+    """Equal-count slabs of the dynamic bodies along one axis (pure host code, no GPU needed)."""
+    position = np.ascontiguousarray(position, dtype=np.float32).reshape(-1, 3)
+    inv_mass = np.ascontiguousarray(inv_mass, dtype=np.float32)
+    owner = np.zeros(len(inv_mass), np.int32)
+    rc = lib().avbd_partition_by_axis(len(inv_mass), _fp(position), _fp(inv_mass), int(nranks), int(axis), owner.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc:
+        raise AvbdError(f"avbd_partition_by_axis failed: {rc}")
+    return owner
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().avbd_comm_unique_id(buf)
+    if rc:
+        raise AvbdError("RCCL is not available (avbd_comm_unique_id failed)")
+    return buf.raw
+
+
+def group_step(worlds, nsteps=1):
+    arr = (C.c_void_p * len(worlds))(*[w.h for w in worlds])
+    rc = lib().avbd_group_step(arr, len(worlds), int(nsteps))
+    if rc:
+        raise AvbdError(f"avbd_group_step failed: {rc}: " + "; ".join(lib().avbd_last_error(w.h).decode() for w in worlds))
 
 
 class World:
@@ -286,6 +313,14 @@ class World:
         outs = [np.zeros_like(a) for _ in range(4)]
         self._chk(self.L.avbd_kat_arith(self.h, a.size, _fp(a), _fp(b), *[_fp(o) for o in outs]))
         return outs
+
+    # -- sharding
+    def set_ownership(self, nranks, rank, owner):
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        self._chk(self.L.avbd_set_ownership(self.h, int(nranks), int(rank), owner.ctypes.data_as(C.POINTER(C.c_int)), len(owner)))
+
+    def comm_init(self, nranks, rank, uid):
+        self._chk(self.L.avbd_comm_init(self.h, int(nranks), int(rank), uid))
 
     # -- measurement
     def profile_enable(self, on=True):

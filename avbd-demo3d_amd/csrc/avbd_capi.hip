@@ -15,6 +15,8 @@
 #include "avbd_kernels.hip"
 #include <hip/hip_ext.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -136,6 +138,17 @@ struct AvbdContext {
     int iterSleep = 1;         /* poll back-off selector (s_sleep 1/2/4/8) */
     int numStatic = 0;
     bool statsFresh = true;
+
+    /* sharding over GPUs (one context per GPU): static ownership of the dynamic bodies */
+    int nranks = 1, rank = 0;
+    std::vector<int> hOwner;            /* per body: owning rank, -1 = replicated (static) */
+    DevArr<int> dSolved;                /* per body: 1 = dynamic and owned by this rank */
+    std::vector<int> hPerm, hRankStart; /* solved bodies grouped by rank */
+    DevArr<int> dPerm, dRankStart;
+    int maxCount = 0;                   /* rows every rank contributes to the all-gather */
+    DevArr<float4> dSend, dRecv;
+    void* comm = nullptr;               /* ncclComm_t (RCCL, loaded lazily) */
+    bool forceSharded = false;          /* AVBD_FORCE_SHARDED=1: per-iteration exchange schedule even with one rank (tests) */
     Readback* hRb = nullptr; /* pinned */
     AvbdStepStats stats{};
     int lastLevels = 0;
@@ -168,7 +181,7 @@ namespace {
 
 BodyTable body_table(AvbdContext* c)
 {
-    BodyTable t; t.planes = c->dPlanes.p; t.cap = c->bodyCap; t.n = (int)c->hBodies.size();
+    BodyTable t; t.planes = c->dPlanes.p; t.solved = c->dSolved.p; t.cap = c->bodyCap; t.n = (int)c->hBodies.size();
     return t;
 }
 
@@ -199,6 +212,9 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     HIPCHK(c, c->dPlanes.alloc((size_t)BP_COUNT * newCap));
+    HIPCHK(c, c->dSolved.alloc(newCap));
+    HIPCHK(c, hipMemset(c->dSolved.p, 0, newCap * sizeof(int)));
+    HIPCHK(c, c->dPerm.alloc(newCap));
     c->bodyCap = newCap;
 
     if (newMCap > c->mCap) {
@@ -321,6 +337,33 @@ int upload_bodies_if_stale(AvbdContext* c)
     std::vector<float4> h;
     pack_planes(c, h);
     HIPCHK(c, hipMemcpyAsync(c->dPlanes.p, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    {   /* who solves which body */
+        c->hOwner.resize((size_t)n, 0);
+        std::vector<int> solved((size_t)std::max(n, 1), 0);
+        c->hRankStart.assign((size_t)c->nranks + 1, 0);
+        for (int i = 0; i < n; ++i) {
+            const bool dyn = c->hBodies[(size_t)i].invMass > 0.0f;
+            if (!dyn) c->hOwner[(size_t)i] = -1;
+            else if (c->hOwner[(size_t)i] < 0 || c->hOwner[(size_t)i] >= c->nranks) c->hOwner[(size_t)i] = 0;
+            solved[(size_t)i] = dyn && c->hOwner[(size_t)i] == c->rank;
+            if (dyn) ++c->hRankStart[(size_t)c->hOwner[(size_t)i] + 1];
+        }
+        c->maxCount = 0;
+        for (int r = 0; r < c->nranks; ++r) { c->maxCount = std::max(c->maxCount, c->hRankStart[(size_t)r + 1]); c->hRankStart[(size_t)r + 1] += c->hRankStart[(size_t)r]; }
+        c->hPerm.assign((size_t)std::max(n, 1), 0);
+        std::vector<int> cur(c->hRankStart.begin(), c->hRankStart.end() - 1);
+        for (int i = 0; i < n; ++i) if (c->hOwner[(size_t)i] >= 0) c->hPerm[(size_t)cur[(size_t)c->hOwner[(size_t)i]]++] = i;
+        if (n) {
+            HIPCHK(c, hipMemcpyAsync(c->dSolved.p, solved.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->dPerm.p, c->hPerm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        }
+        if (c->nranks > 1 || c->forceSharded) {
+            HIPCHK(c, c->dRankStart.alloc((size_t)c->nranks + 1));
+            HIPCHK(c, hipMemcpyAsync(c->dRankStart.p, c->hRankStart.data(), ((size_t)c->nranks + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            if (c->dSend.n < (size_t)2 * std::max(1, c->maxCount)) HIPCHK(c, c->dSend.alloc((size_t)2 * std::max(1, c->maxCount)));
+            if (c->dRecv.n < (size_t)2 * std::max(1, c->maxCount) * c->nranks) HIPCHK(c, c->dRecv.alloc((size_t)2 * std::max(1, c->maxCount) * c->nranks));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bodiesStale = false;
     c->deviceAhead = false;
@@ -428,12 +471,11 @@ void collect_spans(AvbdContext* c)
 __global__ void k_count_deg(BodyTable B, ManifoldTable M, const Counters* cnt, int* degForce, int* degInc)
 {
     const int nm = cnt->numManifolds;
-    const float4* mass = B.plane(BP_MASS);
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < nm; m += gridDim.x * blockDim.x) {
         int2 p = M.pair[m]; int nc = M.nc[m];
         atomicAdd(&degForce[p.x], 1); atomicAdd(&degForce[p.y], 1);
-        if (mass[p.x].y > 0.0f) atomicAdd(&degInc[p.x], nc);
-        if (mass[p.y].y > 0.0f) atomicAdd(&degInc[p.y], nc);
+        if (B.solved[p.x]) atomicAdd(&degInc[p.x], nc);
+        if (B.solved[p.y]) atomicAdd(&degInc[p.y], nc);
     }
 }
 
@@ -492,14 +534,16 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     return AVBD_OK;
 }
 
-int step_once(AvbdContext* c)
+/* ---- one Solver::step() split into phases so that several contexts (GPUs) can be driven in lock-step ---- */
+
+/* phases 1-3 of solver.cpp:255-337 + the topology rebuild; leaves the stream ready for the iteration loop */
+int step_begin(AvbdContext* c)
 {
     int rc;
     if ((rc = upload_bodies_if_stale(c))) return rc;
     if ((rc = upload_gforces_if_stale(c))) return rc;
     BodyTable B = body_table(c);
     const int n = B.n;
-    const int ng = (int)c->hG.size();
     SolverParams P = solver_params(c);
     if (c->adjDirty && (rc = launch_topology(c, false))) return rc;
 
@@ -509,7 +553,7 @@ int step_once(AvbdContext* c)
         SpanGuard g(c, F_BROAD);
         if (n > 1) {
             const int T = (n + 255) / 256;
-            hipLaunchKernelGGL(k_broadphase, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p);
+            hipLaunchKernelGGL(k_broadphase, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
         }
     }
     {
@@ -528,68 +572,109 @@ int step_once(AvbdContext* c)
         SpanGuard g(c, F_PREDICT);
         hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
     }
+    if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
+        HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * c->bodyCap + 16) * sizeof(int), c->stream));
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
+/* iterations [itBegin, itEnd) of solver.cpp:340-431 as one persistent data-flow launch */
+int step_iterate(AvbdContext* c, int itBegin, int itEnd)
+{
+    BodyTable B = body_table(c);
+    SolverParams P = solver_params(c);
     ManifoldTable M = c->mbuf[c->cur].view();
+    IterateState S;
+    S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
+    long long tasks = (long long)B.n * (itEnd - itBegin);
+    int blocks = (int)std::min<long long>(c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
+    if (blocks < 1) blocks = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+    hipExtLaunchKernelGGL(k_iterate, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+                          c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd);
+    ++c->prof.launches_primal; ++c->prof.launches_total;
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
+/* level mode (AVBD_MODE=levels): one k_primal launch per Gauss-Seidel level, needs the schedule on the host */
+int step_iterate_levels(AvbdContext* c)
+{
+    BodyTable B = body_table(c);
+    SolverParams P = solver_params(c);
+    ManifoldTable M = c->mbuf[c->cur].view();
+    const int ng = (int)c->hG.size();
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
-    const bool needReadback = (c->mode == 0) || c->profiling;
-    if (needReadback) {
-        /* level mode: the host launches one kernel per level, so it needs the schedule (one sync per step) */
-        int rc2 = refresh_stats(c, true);
-        if (rc2) return rc2;
-    } else {
-        c->statsFresh = false;
+    const Counters& cnt = c->hRb->cnt;
+    const long long contactSlots = (long long)cnt.numManifolds * 4;
+    const int L = cnt.numLevels;
+    std::vector<int> lvl;
+    const int* lvlStart = c->hRb->lvlStart;
+    if (L > kReadbackLevels) {
+        lvl.resize(L + 1);
+        HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost));
+        lvlStart = lvl.data();
     }
+    for (int it = 0; it < totalIt; ++it) {
+        const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const int writeRows = it >= P.iterations ? 1 : 0;
+        for (int l = 0; l < L; ++l) {
+            const int count = lvlStart[l + 1] - lvlStart[l];
+            if (count <= 0) continue;
+            /* profiling: per-launch start/stop events (kernel begin → end, like a kernel trace) */
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+            hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
+                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
+            ++c->prof.launches_primal; ++c->prof.launches_total;
+        }
+        if (it < P.iterations) {
+            if (contactSlots > 0) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_DUAL, i0, i0 + 1}); }
+                hipExtLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, e0, e1, 0, B, M, c->dCnt.p, P, alphaCur);
+                ++c->prof.launches_dual; ++c->prof.launches_total;
+            }
+            if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
+/* sharded runs: this rank's solved bodies → contiguous send rows / gathered rows → the other ranks' bodies */
+int step_pack(AvbdContext* c)
+{
+    const int first = c->hRankStart[(size_t)c->rank], count = c->hRankStart[(size_t)c->rank + 1] - first;
+    if (count > 0)
+        hipLaunchKernelGGL(k_pack_poses, dim3(grid_for(count, 128, 1 << 20)), dim3(128), 0, c->stream, body_table(c), c->dPerm.p, first, count, c->dSend.p);
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
+int step_unpack(AvbdContext* c)
+{
+    if (c->maxCount > 0)
+        hipLaunchKernelGGL(k_unpack_poses, dim3(grid_for(c->maxCount, 128, 1 << 20), c->nranks), dim3(128), 0, c->stream, body_table(c), c->dPerm.p,
+                           c->dRankStart.p, c->nranks, c->rank, c->maxCount, c->dRecv.p);
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
+/* phases 5-6 of solver.cpp:434-497 */
+int step_end(AvbdContext* c, bool haveCounts)
+{
+    BodyTable B = body_table(c);
+    const int n = B.n;
+    const int ng = (int)c->hG.size();
+    SolverParams P = solver_params(c);
+    ManifoldTable M = c->mbuf[c->cur].view();
     const Counters& cnt = c->hRb->cnt;
     /* without a readback the grid sizes come from the last known counts (all kernels grid-stride) */
-    const long long contactSlots = needReadback ? (long long)cnt.numManifolds * 4 : (long long)std::max(c->stats.numManifolds + c->stats.numCandidates, n) * 4 + 4096;
-
-    if (c->mode == 0) {
-        const int L = cnt.numLevels;
-        std::vector<int> lvl;
-        const int* lvlStart = c->hRb->lvlStart;
-        if (L > kReadbackLevels) {
-            lvl.resize(L + 1);
-            HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost));
-            lvlStart = lvl.data();
-        }
-        for (int it = 0; it < totalIt; ++it) {
-            const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
-            const int writeRows = it >= P.iterations ? 1 : 0;
-            for (int l = 0; l < L; ++l) {
-                const int count = lvlStart[l + 1] - lvlStart[l];
-                if (count <= 0) continue;
-                /* profiling: per-launch start/stop events (kernel begin → end, like a kernel trace) */
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-                hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
-                                      c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
-                ++c->prof.launches_primal; ++c->prof.launches_total;
-            }
-            if (it < P.iterations) {
-                if (contactSlots > 0) {
-                    hipEvent_t e0 = nullptr, e1 = nullptr;
-                    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_DUAL, i0, i0 + 1}); }
-                    hipExtLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, e0, e1, 0, B, M, c->dCnt.p, P, alphaCur);
-                    ++c->prof.launches_dual; ++c->prof.launches_total;
-                }
-                if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
-            }
-        }
-    } else {
-        /* data-flow mode: the whole iteration loop is one persistent launch (avbd_iterate.h) */
-        IterateState S;
-        S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
-        HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * c->bodyCap + 16) * sizeof(int), c->stream));
-        long long tasks = (long long)n * totalIt;
-        int blocks = (int)std::min<long long>(c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
-        if (blocks < 1) blocks = 1;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-        hipExtLaunchKernelGGL(k_iterate, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep);
-        ++c->prof.launches_primal; ++c->prof.launches_total;
-        if (c->numStatic > 1 || ng > 0)
-            hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
-    }
+    const long long contactSlots = haveCounts ? (long long)cnt.numManifolds * 4 : (long long)std::max(c->stats.numManifolds + c->stats.numCandidates, n) * 4 + 4096;
+    if (c->mode != 0 && (c->numStatic > 1 || ng > 0))
+        hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
     {
         SpanGuard g(c, F_VELOCITY);
         hipLaunchKernelGGL(k_velocity, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p, c->dDiag.p);
@@ -600,9 +685,10 @@ int step_once(AvbdContext* c)
     HIPCHK(c, hipGetLastError());
     c->deviceAhead = true;
     if (ng) c->gDeviceAhead = true;
-    if (needReadback) {
+    if (haveCounts) {
         /* algorithmic bytes of this step's iteration loop */
-        const double nbDyn = cnt.dynamicBodies, ninc = cnt.numIncidences, ncon = cnt.numContacts;
+        const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+        const double nbDyn = c->stats.numDynamic, ninc = cnt.numIncidences, ncon = cnt.numContacts;
         if (c->mode == 0) {
             c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc);
             c->prof.algorithmic_bytes_dual += (double)P.iterations * (160.0 * ncon);
@@ -613,6 +699,37 @@ int step_once(AvbdContext* c)
     ++c->prof.steps;
     collect_spans(c);
     return AVBD_OK;
+}
+
+int rccl_allgather(AvbdContext* c); /* below, next to the communicator set-up */
+
+int step_once(AvbdContext* c)
+{
+    int rc;
+    if ((rc = step_begin(c))) return rc;
+    const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
+    const bool needReadback = (c->mode == 0) || c->profiling;
+    if (needReadback) {
+        /* level mode: the host launches one kernel per level, so it needs the schedule (one sync per step) */
+        if ((rc = refresh_stats(c, true))) return rc;
+    } else {
+        c->statsFresh = false;
+    }
+    if (c->nranks > 1 || c->forceSharded) {
+        if (c->mode == 0) return c->fail(AVBD_E_INVALID, "sharded runs need the data-flow mode");
+        if (!c->comm) return c->fail(AVBD_E_COMM, "context is sharded (avbd_set_ownership) but has no communicator: call avbd_comm_init or drive it through avbd_group_step");
+        for (int it = 0; it < totalIt; ++it) {
+            if ((rc = step_iterate(c, it, it + 1))) return rc;
+            if ((rc = step_pack(c))) return rc;
+            if ((rc = rccl_allgather(c))) return rc;
+            if ((rc = step_unpack(c))) return rc;
+        }
+    } else if (c->mode == 0) {
+        if ((rc = step_iterate_levels(c))) return rc;
+    } else {
+        if ((rc = step_iterate(c, 0, totalIt))) return rc;
+    }
+    return step_end(c, needReadback);
 }
 
 void box_mass_properties(AvbdBody& b, float density, float* I9, float* J9)
@@ -639,6 +756,7 @@ q4 HQ(const float* p) { return mkq(p[0], p[1], p[2], p[3]); }
 } // namespace
 
 static std::string g_createError = "null context";
+static void destroy_comm(void* comm);
 
 /* ========================================================================================== */
 extern "C" {
@@ -664,6 +782,7 @@ int avbd_create(int device, AvbdContext** out)
     c->device = device;
     avbd_default_params(&c->params);
     if (const char* m = std::getenv("AVBD_MODE")) c->mode = (std::strcmp(m, "levels") == 0) ? 0 : 1;
+    if (const char* f = std::getenv("AVBD_FORCE_SHARDED")) c->forceSharded = std::atoi(f) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_createError = "hipStreamCreate failed"; delete c; return AVBD_E_HIP; }
     if (hipHostMalloc((void**)&c->hRb, sizeof(Readback), hipHostMallocDefault) != hipSuccess) { delete c; return AVBD_E_HIP; }
     std::memset(c->hRb, 0, sizeof(Readback));
@@ -700,6 +819,8 @@ int avbd_destroy(AvbdContext* c)
     c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
     c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
+    c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSend.release(); c->dRecv.release();
+    if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1344,6 +1465,141 @@ int avbd_kat_arith(AvbdContext* c, int n, const float* a, const float* b, float*
     HIPCHK(c, hipMemcpy(od, d0.p, 4 * n, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(os, d1.p, 4 * n, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(om, d2.p, 4 * n, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(oa, d3.p, 4 * n, hipMemcpyDeviceToHost));
     da.release(); db.release(); d0.release(); d1.release(); d2.release(); d3.release();
+    return AVBD_OK;
+}
+
+/* ---- sharding over the GPUs of one node ------------------------------------------------------------------ */
+} // extern "C"  (reopened below)
+struct Id128 { char b[128]; }; /* ncclUniqueId, passed by value */
+namespace {
+/* RCCL is loaded lazily so that single-GPU users (and symbol checks on machines without a GPU) never need it */
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+bool load_rccl()
+{
+    if (g_rccl.lib) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather) return false;
+    g_rccl.lib = h;
+    return true;
+}
+
+int rccl_allgather(AvbdContext* c)
+{
+    /* one all-gather of {position+radius, orientation} rows per iteration: 2 float4 = 8 floats per body */
+    const size_t count = (size_t)8 * std::max(1, c->maxCount);
+    int r = g_rccl.AllGather(c->dSend.p, c->dRecv.p, count, /* ncclFloat32 */ 7, c->comm, c->stream);
+    if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclAllGather failed");
+    return AVBD_OK;
+}
+} // namespace
+
+static void destroy_comm(void* comm) { if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }
+
+extern "C" {
+
+int avbd_partition_by_axis(int n, const float* position, const float* invMass, int nranks, int axis, int* owner)
+{
+    /* equal-count slabs of the dynamic bodies along one world axis; static bodies are replicated (-1) */
+    if (n < 0 || !position || !invMass || !owner || nranks < 1 || axis < 0 || axis > 2) return AVBD_E_INVALID;
+    std::vector<int> dyn;
+    for (int i = 0; i < n; ++i) { owner[i] = -1; if (invMass[i] > 0.0f) dyn.push_back(i); }
+    std::stable_sort(dyn.begin(), dyn.end(), [&](int a, int b) { return position[3 * (size_t)a + axis] < position[3 * (size_t)b + axis]; });
+    const size_t m = dyn.size();
+    for (size_t k = 0; k < m; ++k) owner[dyn[k]] = (int)std::min<size_t>((size_t)nranks - 1, k * (size_t)nranks / std::max<size_t>(m, 1));
+    return AVBD_OK;
+}
+
+int avbd_set_ownership(AvbdContext* c, int nranks, int rank, const int* owner, int n)
+{
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || n != (int)c->hBodies.size() || (!owner && n > 0)) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = download_bodies_to_host(c);
+    if (rc) return rc;
+    if (c->stepIndex != 0) return c->fail(AVBD_E_INVALID, "ownership is static: set it before the first step");
+    c->nranks = nranks; c->rank = rank;
+    c->hOwner.assign(owner, owner + n);
+    c->bodiesStale = true; c->adjDirty = true;
+    return AVBD_OK;
+}
+
+int avbd_comm_unique_id(char id[128])
+{
+    if (!id) return AVBD_E_INVALID;
+    if (!load_rccl()) return AVBD_E_COMM;
+    Id128 u; std::memset(&u, 0, sizeof(u));
+    if (g_rccl.GetUniqueId(&u) != 0) return AVBD_E_COMM;
+    std::memcpy(id, u.b, 128);
+    return AVBD_OK;
+}
+
+int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
+{
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return AVBD_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(AVBD_E_NODEVICE, "hipSetDevice failed");
+    if (!load_rccl()) return c->fail(AVBD_E_COMM, "librccl.so could not be loaded");
+    Id128 u; std::memcpy(u.b, id, 128);
+    void* comm = nullptr;
+    int r = g_rccl.CommInitRank(&comm, nranks, u, rank);
+    if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclCommInitRank failed");
+    c->comm = comm;
+    return AVBD_OK;
+}
+
+int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
+{
+    /* Several contexts (one per shard, on one or several devices of this process) stepped in lock-step by one host
+     * thread; the per-iteration pose exchange is done with device-to-device copies instead of RCCL.  Same schedule
+     * and same results as the one-process-per-GPU RCCL path. */
+    if (!ctxs || n < 1 || nsteps < 0) return AVBD_E_INVALID;
+    for (int s = 0; s < nsteps; ++s) {
+        int rc;
+        for (int r = 0; r < n; ++r) {
+            AvbdContext* c = ctxs[r];
+            if (!c || c->nranks != n || c->rank != r || c->mode == 0) return AVBD_E_INVALID;
+            (void)hipSetDevice(c->device);
+            if ((rc = step_begin(c))) return rc;
+            c->statsFresh = false;
+        }
+        const int totalIt = ctxs[0]->params.iterations + (ctxs[0]->params.postStabilize ? 1 : 0);
+        for (int it = 0; it < totalIt; ++it) {
+            for (int r = 0; r < n; ++r) {
+                AvbdContext* c = ctxs[r];
+                (void)hipSetDevice(c->device);
+                if ((rc = step_iterate(c, it, it + 1))) return rc;
+                if ((rc = step_pack(c))) return rc;
+            }
+            for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
+            for (int dst = 0; dst < n; ++dst) {
+                AvbdContext* d = ctxs[dst];
+                (void)hipSetDevice(d->device);
+                for (int src = 0; src < n; ++src) {
+                    if (src == dst) continue;
+                    const size_t rows = (size_t)2 * std::max(1, d->maxCount);
+                    HIPCHK(d, hipMemcpyAsync(d->dRecv.p + rows * src, ctxs[src]->dSend.p, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream));
+                }
+                if ((rc = step_unpack(d))) return rc;
+            }
+        }
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(ctxs[r]->device);
+            if ((rc = step_end(ctxs[r], false))) return rc;
+        }
+    }
     return AVBD_OK;
 }
 

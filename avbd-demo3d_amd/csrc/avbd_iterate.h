@@ -53,7 +53,7 @@ __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& 
     else if (kind == FK_JOINT) { const GForce& f = gf[idx >> 1]; other = isA ? f.bodyB : f.bodyA; }
     else { const GForce& f = gf[idx]; other = isA ? f.bodyB : f.bodyA; }
     if (other < 0) return true;                                   /* world */
-    if (!(B.plane(BP_MASS)[other].y > 0.0f)) return true;         /* static partner */
+    if (!B.solved[other]) return true;                            /* static partner, or a body another GPU solves */
     return other > body;                                           /* partner is visited earlier in the sweep */
 }
 
@@ -65,7 +65,7 @@ __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& 
 
 /* dependency wait of task (body, it); returns false when the launch must be abandoned */
 __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, const int* adjStart, const int* adjRef, const int* adjOther,
-                                                  const float4* massPlane, const IterateState& S, int sleepSel)
+                                                  const int* solved, const IterateState& S, int sleepSel)
 {
     const int aBeg = adjStart[body], aEnd = adjStart[body + 1];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
             if (base == aBeg && it > 0) { word = S.dualDone + body; need = it; }
         } else if (k < aEnd) {
             const int o = adjOther[k];
-            if (o >= 0 && inc_kind(adjRef[k]) != FK_IGNORE && massPlane[o].y > 0.0f) {
+            if (o >= 0 && inc_kind(adjRef[k]) != FK_IGNORE && solved[o]) {
                 if (o > body) { word = S.primalDone + o; need = it + 1; }
                 else if (it > 0) { word = S.dualDone + o; need = it; }
             }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
                                                               const int* __restrict__ adjOther, const int* __restrict__ incStart,
-                                                              const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel)
+                                                              const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel, int itBegin, int itEnd)
 {
     __shared__ float sRows[kIterWaves][64 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     const int w = blockIdx.x * kIterWaves + wv;
     const int nd = lvlStart[cnt->numLevels];                       /* dynamic bodies in `order` */
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
-    const long long nTasks = (long long)nd * totalIt;
+    /* [itBegin, itEnd) selects the iterations of this launch: the whole loop on one GPU, one iteration per launch
+     * when body state is exchanged between GPUs after every iteration (the done-counters persist in between) */
+    const long long nTasks = (long long)nd * (itEnd < totalIt ? itEnd : totalIt);
     const float4* massPlane = B.plane(BP_MASS);
 
 #ifdef AVBD_DF_STATS
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     const unsigned long long tstart = tprev;
     const unsigned long long cstart = __builtin_amdgcn_s_memtime();
 #endif
-    for (long long t = w; t < nTasks; t += W) {
+    for (long long t = (long long)nd * itBegin + w; t < nTasks; t += W) {
         DF_STAMP(7);
         const int it = (int)(t / nd);
         const int slot = (int)(t - (long long)it * nd);
@@ -151,13 +153,13 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
             oinv = massPlane[other].y;
             fric = M.fric[m];
             sra = M.cRA[idx]; srb = M.cRB[idx];
-            owned = !(oinv > 0.0f) || other > body;
+            owned = !B.solved[other] || other > body;
         }
         const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
         const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
         const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
 
-        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, massPlane, S, sleepSel)) return;
+        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, B.solved, S, sleepSel)) return;
         DF_STAMP(0);
 
         if (fast) {
@@ -299,18 +301,17 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
 __global__ void k_dual_static(BodyTable B, ManifoldTable M, const Counters* cnt, GForce* gf, int ng, SolverParams P)
 {
     const int nm = cnt->numManifolds;
-    const float4* mass = B.plane(BP_MASS);
     const int total = nm * 4 + ng;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < nm * 4) {
             const int m = i >> 2;
             if ((i & 3) >= M.nc[m]) continue;
             const int2 pr = M.pair[m];
-            if (mass[pr.x].y > 0.0f || mass[pr.y].y > 0.0f) continue;
+            if (B.solved[pr.x] || B.solved[pr.y]) continue;
             for (int it = 0; it < P.iterations; ++it) dual_contact<false>(B, M, i, P, P.postStabilize ? 1.0f : P.alpha, true);
         } else {
             GForce& f = gf[i - nm * 4];
-            bool dynA = f.bodyA >= 0 && mass[f.bodyA].y > 0.0f, dynB = f.bodyB >= 0 && mass[f.bodyB].y > 0.0f;
+            bool dynA = f.bodyA >= 0 && B.solved[f.bodyA], dynB = f.bodyB >= 0 && B.solved[f.bodyB];
             if (dynA || dynB) continue;
             for (int it = 0; it < P.iterations; ++it) dual_gforce<false>(B, f, P, true);
         }

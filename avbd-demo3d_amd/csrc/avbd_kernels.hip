@@ -49,7 +49,7 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned* dst, float v)
  * precedes B in the reference's list).  16 B per body staged in LDS.
  * ------------------------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void k_broadphase(BodyTable B, const int* __restrict__ adjStart, const int* __restrict__ adjOther,
-                                                     int2* cand, int candCap, Counters* cnt)
+                                                     int2* cand, int candCap, Counters* cnt, int keepUnsolvedPairs)
 {
     __shared__ float4 sB[256];
     const float4* posr = B.plane(BP_POSR);
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_broadphase(BodyTable B, const int* __re
     if (i >= n) return;
     const float4 a = posr[i];
     const f3 pa = mk3(a.x, a.y, a.z);
+    const bool solvedI = B.solved[i] != 0;
     int jEnd = n - j0; if (jEnd > 256) jEnd = 256;
     if (i - j0 < jEnd) jEnd = i - j0; /* only j < i */
     for (int jj = 0; jj < jEnd; ++jj) {
@@ -77,6 +78,12 @@ __global__ __launch_bounds__(256) void k_broadphase(BodyTable B, const int* __re
         float r = a.w + b.w;
         if (dot3(dp, dp) <= r * r) {
             const int j = j0 + jj;
+            /* sharded runs: a pair belongs to this GPU when it solves one of its bodies (pairs nobody solves, e.g.
+             * static-static, are kept by rank 0 only so that diagnostics count them once) */
+            if (!solvedI && !B.solved[j]) {
+                const bool bothStatic = !(B.plane(BP_MASS)[i].y > 0.0f) && !(B.plane(BP_MASS)[j].y > 0.0f);
+                if (!(keepUnsolvedPairs && bothStatic)) continue;
+            }
             /* Rigid::isConstrainedTo: does any live force connect i and j?  scan the shorter list */
             int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
             int s, e, other;
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(128) void k_narrowphase(BodyTable B, ManifoldTable 
         atomicAdd(&degForce[a], 1);
         atomicAdd(&degForce[b], 1);
         int inc = 0;
-        if (ima > 0.0f) { atomicAdd(&degInc[a], mi.numContacts); inc += mi.numContacts; }
-        if (imb > 0.0f) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
+        if (B.solved[a]) { atomicAdd(&degInc[a], mi.numContacts); inc += mi.numContacts; }
+        if (B.solved[b]) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
         atomicAdd(&cnt->numContacts, mi.numContacts);
         atomicAdd(&cnt->numIncidences, inc);
     }
@@ -198,9 +205,8 @@ __global__ void k_gforce_prepare(BodyTable B, GForce* gf, int ng, int* degForce,
         }
     }
     int entries = f.kind == FK_JOINT ? 2 : (f.kind == FK_SPRING ? 1 : 0);
-    const float4* mass = B.plane(BP_MASS);
-    if (f.bodyA >= 0) { atomicAdd(&degForce[f.bodyA], 1); if (mass[f.bodyA].y > 0.0f) atomicAdd(&degInc[f.bodyA], entries); }
-    if (f.bodyB >= 0) { atomicAdd(&degForce[f.bodyB], 1); if (mass[f.bodyB].y > 0.0f) atomicAdd(&degInc[f.bodyB], entries); }
+    if (f.bodyA >= 0) { atomicAdd(&degForce[f.bodyA], 1); if (B.solved[f.bodyA]) atomicAdd(&degInc[f.bodyA], entries); }
+    if (f.bodyB >= 0) { atomicAdd(&degForce[f.bodyB], 1); if (B.solved[f.bodyB]) atomicAdd(&degInc[f.bodyB], entries); }
 }
 
 /* Exclusive scans of the two degree arrays (single workgroup; n+1 outputs each), and cursor reset. */
@@ -261,7 +267,7 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
     if (b >= B.n) return;
     cursor[b] = 0;
     level[b] = 0;
-    if (!(B.plane(BP_MASS)[b].y > 0.0f)) return;
+    if (!B.solved[b]) return;
     const int s = adjStart[b], e = adjStart[b + 1];
     for (int i = s + 1; i < e; ++i) {
         uint64_t k = adjKey[i]; int r = adjRef[i], o = adjOther[i];
@@ -293,17 +299,16 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
     __shared__ int sChanged, sMax;
     __shared__ int sScan[1024];
     const int n = B.n, t = threadIdx.x;
-    const float4* mass = B.plane(BP_MASS);
     for (int sweep = 0; sweep <= n; ++sweep) {
         if (t == 0) sChanged = 0;
         __syncthreads();
         int changed = 0;
         for (int b = t; b < n; b += 1024) {
-            if (!(mass[b].y > 0.0f)) continue;
+            if (!B.solved[b]) continue;
             int lv = 1;
             for (int k = adjStart[b]; k < adjStart[b + 1]; ++k) {
                 int o = adjOther[k];
-                if (o > b && inc_kind(adjRef[k]) != FK_IGNORE && mass[o].y > 0.0f) {
+                if (o > b && inc_kind(adjRef[k]) != FK_IGNORE && B.solved[o]) {
                     int lo = ((volatile int*)level)[o] + 1;
                     if (lo > lv) lv = lo;
                 }
@@ -498,6 +503,30 @@ __global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount)
     *nextCount = 0;
     diag->maxPenetration = 0; diag->maxViolation = 0; diag->maxLinearSpeed = 0; diag->maxAngularSpeed = 0; diag->maxNormalImpulse = 0;
     diag->activeContacts = 0; diag->activeManifolds = 0; diag->dynamicBodies = 0;
+}
+
+/* ---- sharded runs: exchange of body poses between GPUs once per iteration --------------------------------
+ * perm lists the solved bodies rank by rank (rank r owns perm[rankStart[r] .. rankStart[r+1])); every rank
+ * contributes maxCount rows of {position+radius, orientation} (2 float4 = 32 B per body) to the all-gather. */
+__global__ void k_pack_poses(BodyTable B, const int* perm, int first, int count, float4* send)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int b = perm[first + k];
+    send[2 * k] = B.plane(BP_POSR)[b];
+    send[2 * k + 1] = B.plane(BP_QUAT)[b];
+}
+
+__global__ void k_unpack_poses(BodyTable B, const int* perm, const int* rankStart, int nranks, int myRank, int maxCount, const float4* recv)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (r == myRank) return;
+    const int first = rankStart[r], count = rankStart[r + 1] - first;
+    if (k >= count) return;
+    const int b = perm[first + k];
+    B.plane(BP_POSR)[b] = recv[2 * ((size_t)r * maxCount + k)];
+    B.plane(BP_QUAT)[b] = recv[2 * ((size_t)r * maxCount + k) + 1];
 }
 
 /* ---- known-answer kernels --------------------------------------------------------------- */

@@ -37,6 +37,8 @@ enum BodyPlane : int {
 
 struct BodyTable {
     float4* planes; /* BP_COUNT * cap */
+    const int* solved; /* [cap] 1 = this context runs the primal visit of the body: dynamic AND owned by this rank.
+                        * Everything else (static bodies, bodies owned by another GPU) is a fixed pose during a sweep. */
     int cap;
     int n;
     __host__ __device__ float4* plane(int p) const { return planes + (size_t)p * cap; }

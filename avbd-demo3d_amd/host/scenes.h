@@ -10,6 +10,7 @@
 
 #include "solver.h"
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -77,8 +78,9 @@ static inline float avbdSceneHash01(unsigned int v)
     return (v & 0x00FFFFFFU) / 16777215.0f;
 }
 
-/* n^3 unit cubes dropped on the ground slab; `packed` starts them resting (contacts from step 1). */
-static void sceneStressN(Solver* solver, int n, bool packed = false)
+/* nx*ny*nz unit cubes dropped on the ground slab (scenes.h:87-132 generalised: the reference scene is 10,10,10);
+ * `packed` starts them resting (contacts from step 1). */
+static void sceneStressGrid(Solver* solver, int nx, int ny, int nz, bool packed = false)
 {
     sceneGround(solver);
     solver->iterations = 20;
@@ -89,19 +91,21 @@ static void sceneStressN(Solver* solver, int n, bool packed = false)
     const float baseY = packed ? 0.52f : 20.0f;
     const float wobbleXZ = 0.04f;
     const float wobbleY = packed ? 0.0f : 0.25f;
-    for (int y = 0; y < n; ++y)
-        for (int z = 0; z < n; ++z)
-            for (int x = 0; x < n; ++x) {
-                unsigned int seed = (unsigned int)(x + n * (z + n * y) + 1);
+    for (int y = 0; y < ny; ++y)
+        for (int z = 0; z < nz; ++z)
+            for (int x = 0; x < nx; ++x) {
+                unsigned int seed = (unsigned int)(x + nx * (z + nz * y) + 1);
                 float jx = (avbdSceneHash01(seed * 9781U) * 2.0f - 1.0f) * wobbleXZ;
                 float jz = (avbdSceneHash01(seed * 6271U) * 2.0f - 1.0f) * wobbleXZ;
                 float jy = avbdSceneHash01(seed * 3343U) * wobbleY;
-                float px = (x - (n - 1) * 0.5f) * pitchXZ + jx;
+                float px = (x - (nx - 1) * 0.5f) * pitchXZ + jx;
                 float py = baseY + y * pitchY + jy;
-                float pz = (z - (n - 1) * 0.5f) * pitchXZ + jz;
+                float pz = (z - (nz - 1) * 0.5f) * pitchXZ + jz;
                 new Rigid(solver, {1.0f, 1.0f, 1.0f}, 1.0f, 0.5f, {px, py, pz});
             }
 }
+
+static void sceneStressN(Solver* solver, int n, bool packed = false) { sceneStressGrid(solver, n, n, n, packed); }
 
 static void sceneStress1000(Solver* solver) { sceneStressN(solver, 10); }
 
@@ -133,6 +137,12 @@ static const int sceneCount = sizeof(scenes) / sizeof(scenes[0]);
  * 100/101 for the parametrised scenes, -1 when unknown. */
 static int buildSceneByName(Solver* solver, const char* name)
 {
+    if (!strncmp(name, "StressGrid:", 11) || !strncmp(name, "PackedGrid:", 11)) {
+        int nx = 0, ny = 0, nz = 0;
+        if (sscanf(name + 11, "%d,%d,%d", &nx, &ny, &nz) != 3 || nx < 1 || ny < 1 || nz < 1) return -1;
+        sceneStressGrid(solver, nx, ny, nz, name[0] == 'P');
+        return 102;
+    }
     if (!strncmp(name, "StressN:", 8)) { sceneStressN(solver, atoi(name + 8), false); return 100; }
     if (!strncmp(name, "Packed:", 7)) { sceneStressN(solver, atoi(name + 7), true); return 101; }
     for (int i = 0; i < sceneCount; ++i)

@@ -197,12 +197,27 @@ int  avbd_kat_collide(AvbdContext* ctx, int npairs, const float* posA, const flo
 int  avbd_kat_solve6(AvbdContext* ctx, int n, const float* A /* 36n: ll,la,al,aa column-major */, const float* b /* 6n */, float* x /* 6n */);
 int  avbd_kat_arith(AvbdContext* ctx, int n, const float* a, const float* b, float* out_div, float* out_sqrt, float* out_mul, float* out_add);
 
+/* ---- sharding over the GPUs of one node (BASELINE configs[3..4]): one context per GPU ----
+ * Dynamic bodies are owned statically by one rank each; every rank keeps ALL body poses, builds the manifolds that
+ * touch one of its bodies, sweeps its own bodies exactly (later-created first) against the last gathered poses of
+ * the others, and after EVERY solver iteration all ranks all-gather {position, orientation} (RCCL over xGMI, 32 B
+ * per body).  Across the cut this is a Jacobi coupling, so sharded results are close to, not bit-identical with,
+ * the single-GPU sweep.  There is no such mode in the reference. */
+int  avbd_partition_by_axis(int n, const float* position /* 3n */, const float* invMass /* n */, int nranks, int axis, int* owner /* n out */);
+int  avbd_set_ownership(AvbdContext* ctx, int nranks, int rank, const int* owner, int n);
+int  avbd_comm_unique_id(char id[128]);                                   /* ncclGetUniqueId on one rank, broadcast by the caller */
+int  avbd_comm_init(AvbdContext* ctx, int nranks, int rank, const char id[128]);  /* ncclCommInitRank; avbd_step then exchanges per iteration */
+/* the same sharded schedule for `n` contexts living in ONE process (exchange by device-to-device copies) */
+int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
+
 /* ---- measurement ---- */
 int  avbd_profile_enable(AvbdContext* ctx, int enable);
 int  avbd_profile_reset(AvbdContext* ctx);
 int  avbd_profile_get(AvbdContext* ctx, AvbdProfile* out);
 /* the raw hipStream_t of the context (as void*), so a caller can record its own events on it */
 void* avbd_stream(AvbdContext* ctx);
+/* debug builds (-DAVBD_DF_STATS): per-wave time breakdown of the last k_iterate launch, 16 counters per wave */
+int  avbd_debug_iterate_stats(AvbdContext* ctx, unsigned long long* out, int waves);
 
 #ifdef __cplusplus
 }

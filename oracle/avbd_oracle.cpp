@@ -1000,7 +1000,7 @@ static void ground(World& w)                     /* scenes.h:27-31 */
 static unsigned hashU(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 static float hash01(unsigned x) { return (hashU(x) & 0x00FFFFFFU) / 16777215.0f; }  /* scenes.h:108-115 */
 
-static void stressN(World& w, int n, bool packed) /* scenes.h:87-132 with NX=NY=NZ=n */
+static void stressGrid(World& w, int nx, int ny, int nz, bool packed) /* scenes.h:87-132 with NX,NY,NZ = nx,ny,nz */
 {
     ground(w);
     w.iterations = 20; w.beta = 30000.0f; w.gamma = 0.995f;
@@ -1009,22 +1009,30 @@ static void stressN(World& w, int n, bool packed) /* scenes.h:87-132 with NX=NY=
     const float startY = packed ? 0.52f : 20.0f;
     const float jitterXZ = 0.04f;
     const float jitterY = packed ? 0.0f : 0.25f;
-    for (int y = 0; y < n; ++y)
-        for (int z = 0; z < n; ++z)
-            for (int x = 0; x < n; ++x) {
-                unsigned seed = (unsigned)(x + n * (z + n * y) + 1);
+    for (int y = 0; y < ny; ++y)
+        for (int z = 0; z < nz; ++z)
+            for (int x = 0; x < nx; ++x) {
+                unsigned seed = (unsigned)(x + nx * (z + nz * y) + 1);
                 float jx = (hash01(seed * 9781U) * 2.0f - 1.0f) * jitterXZ;
                 float jz = (hash01(seed * 6271U) * 2.0f - 1.0f) * jitterXZ;
                 float jy = hash01(seed * 3343U) * jitterY;
-                float px = (x - (n - 1) * 0.5f) * spacingXZ + jx;
+                float px = (x - (nx - 1) * 0.5f) * spacingXZ + jx;
                 float py = startY + y * spacingY + jy;
-                float pz = (z - (n - 1) * 0.5f) * spacingXZ + jz;
+                float pz = (z - (nz - 1) * 0.5f) * spacingXZ + jz;
                 w.addBody(v3(1, 1, 1), 1.0f, 0.5f, v3(px, py, pz), qident(), vzero(), vzero());
             }
 }
 
+static void stressN(World& w, int n, bool packed) { stressGrid(w, n, n, n, packed); }
+
 int buildScene(World& w, const char* name)
 {
+    if (!std::strncmp(name, "StressGrid:", 11) || !std::strncmp(name, "PackedGrid:", 11)) {
+        int nx = 0, ny = 0, nz = 0;
+        if (std::sscanf(name + 11, "%d,%d,%d", &nx, &ny, &nz) != 3 || nx < 1 || ny < 1 || nz < 1) return -1;
+        stressGrid(w, nx, ny, nz, name[0] == 'P');
+        return 102;
+    }
     if (!std::strncmp(name, "StressN:", 8)) { stressN(w, std::atoi(name + 8), false); return 100; }
     if (!std::strncmp(name, "Packed:", 7)) { stressN(w, std::atoi(name + 7), true); return 101; }
     int idx = -1;
