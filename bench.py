@@ -54,6 +54,20 @@ def algorithmic_bytes(stats, iterations):
             "B_primal_iter": 100 * nb + 124 * ninc, "B_dual_iter": 160 * nc}
 
 
+def pmc_traffic(scene, fused):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r1_dataflow_window_summary.json; (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md §HBM).  PMC counters
+    cannot be read from inside the process, so this is null for any other workload or mode."""
+    path = os.path.join(ROOT, "profiles", "r1_dataflow_window_summary.json")
+    if scene != "Stress1000" or not fused or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        return round((2.0 * d["FETCH_SIZE_KB_last40"] + d["WRITE_SIZE_KB_last40"]) * 1024.0, 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(pkg, world, scene, snapshot_bodies, snapshot_forces, step_index, cpu_steps):
     """Time the CPU oracle (kind 'port') from the given snapshot on one host thread."""
     import harness as H
@@ -155,7 +169,7 @@ def main():
         achieved = bytes_per_launch / per_launch_s / 1e9
         fused = p["launches_primal"] <= 1.5 * max(1, p["steps"]) * max(1, world_size if world_size > 1 else 1) or os.environ.get("AVBD_MODE") != "levels"
         roof = {"bound": "hbm", "kernel": "k_iterate" if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "frac": round(achieved / 8000.0, 6), "traffic": pmc_traffic(scene, fused),
                 "bytes_per_launch": round(bytes_per_launch, 1), "us_per_launch": round(per_launch_s * 1e6, 3),
                 "launches_per_step": round(p["launches_primal"] / max(1, p["steps"]), 2),
                 "step_algorithmic_GBps": round(ab["B_step"] * args.steps / elapsed / 1e9, 3),
