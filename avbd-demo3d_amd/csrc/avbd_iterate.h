@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                                                               const int* __restrict__ adjOther, const int* __restrict__ incStart,
                                                               const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel, int itBegin, int itEnd)
 {
-    __shared__ float sRows[kIterWaves][64 * kEntryRec];
+    __shared__ float sRows[kIterWaves][66 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* rows = sRows[wv];
@@ -183,10 +183,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
             {
                 const m33 Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
                 const m33 Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
-                const m33 R = quat_to_mat(L.rot);
-                const m33 Rt = mtranspose(R);
-                L.Iw = R * Ib * Rt;       /* rigid.cpp:56-59 */
-                L.invIw = R * Jb * Rt;    /* rigid.cpp:51-54 */
+                world_inertia_parallel(lane, L.rot, Ib, Jb, accs + 32, L.Iw, L.invIw);   /* rigid.cpp:51-59 */
                 L.invDt2 = 1.0f / (P.dt * P.dt);
             }
             AccLane a = init_acc_lane(lane, L);
@@ -205,6 +202,8 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                 /* a contact this wave is about to update again in its dual pass needs no intermediate store unless the
                  * partner reads it first: the partner of an owned contact has already finished this iteration */
                 if (!(owned && doDual)) store_contact_mutations<true>(M, idx, c, writeRows);
+            } else if (lane < nEnt + 2) {
+                clear_row_flags(rows + lane * kEntryRec);
             }
             wave_sync();
             DF_STAMP(10);
@@ -244,6 +243,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
             for (int base = eBeg; base < eEnd; base += 64) {
                 const int nHere = min(64, eEnd - base);
                 if (lane < nHere) eval_entry<true>(inc[base + lane], B, M, gf, L, alpha, writeRows, rows + lane * kEntryRec);
+                else if (lane < nHere + 2) clear_row_flags(rows + lane * kEntryRec);
                 wave_sync();
                 accumulate_rows(a, rows, nHere);
                 wave_sync();

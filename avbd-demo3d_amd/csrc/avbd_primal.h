@@ -147,16 +147,42 @@ __device__ __forceinline__ BodyLocal load_body_local(const BodyTable& B, int bod
     return L;
 }
 
+/* World-space inertia and inverse inertia (rigid.cpp:51-59: R * I * transpose(R)), one matrix entry per lane:
+ * lanes 0..8 → Iw(i,j), lanes 9..17 → invIw(i,j) with i = l % 3, j = l / 3; entries are exchanged through 18 floats of
+ * LDS.  Same expression tree per entry as the reference's mat3 products:
+ *   (R*I)(i,k) = (R(i,0) I(0,k) + R(i,1) I(1,k)) + R(i,2) I(2,k);   (M*Rt)(i,j) = (M(i,0) R(j,0) + M(i,1) R(j,1)) + M(i,2) R(j,2) */
+__device__ __forceinline__ void world_inertia_parallel(int lane, q4 rot, m33 Ib, m33 Jb, float* xch, m33& Iw, m33& invIw)
+{
+    const m33 R = quat_to_mat(rot);
+    const m33 Rt = mtranspose(R);
+    const int e = lane < 9 ? lane : (lane < 18 ? lane - 9 : 0);
+    const int i = e % 3, j = e / 3;
+    const m33 T = lane < 9 ? Ib : Jb;
+    const f3 ri = i == 0 ? Rt.c0 : (i == 1 ? Rt.c1 : Rt.c2);       /* row i of R */
+    const f3 rj = j == 0 ? Rt.c0 : (j == 1 ? Rt.c1 : Rt.c2);       /* row j of R = column j of transpose(R) */
+    const f3 mi = mk3(dot3(ri, T.c0), dot3(ri, T.c1), dot3(ri, T.c2)); /* row i of R*T */
+    const float v = dot3(mi, rj);
+    if (lane < 18) xch[lane] = v;
+    wave_sync();
+    Iw = mkm(mk3(xch[0], xch[1], xch[2]), mk3(xch[3], xch[4], xch[5]), mk3(xch[6], xch[7], xch[8]));
+    invIw = mkm(mk3(xch[9], xch[10], xch[11]), mk3(xch[12], xch[13], xch[14]), mk3(xch[15], xch[16], xch[17]));
+    wave_sync();
+}
+
 /* ---- ordered accumulation ------------------------------------------------------------------ */
-constexpr int kRowRec = 12;                 /* Jl[3] Ja[3] f pen gyro[3] flags */
+constexpr int kRowRec = 14;                 /* Jl[3] Ja[3] f pen gyro[3] flags 1.0f 0.0f */
+constexpr int kRowFlagValid = 1, kRowFlagManifold = 2, kRowFlagPenOk = 4;
 constexpr int kEntryRec = 3 * kRowRec;
 
 /* accumulator owned by a lane: 0-5 ll lower, 6-14 la, 15-20 aa lower, 21-23 rhs.l, 24-26 rhs.a */
-struct AccLane { int opA, opB, mode, gy; float acc; }; /* mode 0: lhs, 1: lhs aa (+gyro/+0), 2: rhs, 3: idle */
+struct AccLane {
+    int opA, opB, mode, gy; float acc;   /* mode 0: lhs, 1: lhs aa (+gyro/+0), 2: rhs, 3: idle */
+    int opS, opG, onMask, gMask;         /* scale slot (pen | 1.0f), gyro slot (gyro_i | 0.0f), flag bits that enable the add / the gyro add */
+};
 
 __device__ __forceinline__ AccLane init_acc_lane(int lane, const BodyLocal& L)
 {
-    AccLane a; a.opA = 0; a.opB = 0; a.mode = 3; a.gy = -1; a.acc = 0.0f;
+    AccLane a; a.opA = 0; a.opB = 0; a.mode = 3; a.gy = -1; a.acc = 0.0f; a.opS = 7; a.opG = 13; a.onMask = kRowFlagPenOk; a.gMask = 0;
     const m33 massMat = diagm(mk3(L.mass, L.mass, L.mass));
     const m33 ll0 = zerom() + massMat * L.invDt2;                     /* solver.cpp:350-361 */
     const m33 aa0 = zerom() + L.Iw * L.invDt2;
@@ -178,11 +204,12 @@ __device__ __forceinline__ AccLane init_acc_lane(int lane, const BodyLocal& L)
         a.mode = 0; a.opA = i; a.opB = 3 + j; a.acc = 0.0f;
     } else if (lane < 21) {
         a.mode = 1; a.opA = 3 + ti; a.opB = 3 + tj; a.gy = (ti == tj) ? (8 + ti) : -1;
+        a.opG = (ti == tj) ? (8 + ti) : 13; a.gMask = kRowFlagManifold;
         a.acc = comp3(tj == 0 ? aa0.c0 : (tj == 1 ? aa0.c1 : aa0.c2), ti);
     } else if (lane < 24) {
-        const int i = lane - 21; a.mode = 2; a.opA = i; a.opB = 6; a.acc = comp3(rl0, i);
+        const int i = lane - 21; a.mode = 2; a.opA = i; a.opB = 6; a.acc = comp3(rl0, i); a.opS = 12; a.onMask = kRowFlagValid;
     } else if (lane < 27) {
-        const int i = lane - 24; a.mode = 2; a.opA = 3 + i; a.opB = 6; a.acc = comp3(ra0, i);
+        const int i = lane - 24; a.mode = 2; a.opA = 3 + i; a.opB = 6; a.acc = comp3(ra0, i); a.opS = 12; a.onMask = kRowFlagValid;
     }
     return a;
 }
@@ -190,45 +217,48 @@ __device__ __forceinline__ AccLane init_acc_lane(int lane, const BodyLocal& L)
 __device__ __forceinline__ void accumulate_rows(AccLane& a, const float* rows, int nEntries)
 {
     if (a.mode == 3) return;
-    /* The additions must happen in row order, but the LDS reads of different rows are independent: fetch a
-     * block of rows into registers first, then run the dependent chain of adds, branch-free.
-     *   rhs lanes : acc += J*f            written as (J*f)*1.0f — exact
-     *   lhs lanes : acc += (Ja*Jb)*pen    only when pen > 0 and finite (solver.cpp:387)
-     *   aa lanes  : ... then += gyro (diagonal) or += 0.0f (off-diagonal) for manifold rows (solver.cpp:393-397) */
+    /* The additions must happen in row order, but the LDS reads of different rows are independent: fetch a block of
+     * rows into registers first, then run the dependent chain of adds, branch-free.  Per lane (constant over rows):
+     *   rhs lanes : acc += (J*f)*1.0f                         when the row is valid                (solver.cpp:383-384)
+     *   lhs lanes : acc += (Ja*Jb)*pen                        when pen > 0 and finite               (solver.cpp:387-391)
+     *   aa lanes  : ... then += gyro_i (diagonal) or += 0.0f  for manifold rows                      (solver.cpp:393-397)
+     * The producer lane already encoded the row predicates in the flag word and provides the constants 1.0f / 0.0f
+     * as record slots, so each row costs 5 LDS reads, 2 mul, 2 add, 2 tests and 2 selects. */
     constexpr int kBlock = 6;
-    const int nRows = nEntries * 3;
-    const bool isRhs = a.mode == 2, isAA = a.mode == 1, hasG = a.gy >= 0;
+    const int nRows = nEntries * 3;           /* the producer zeroes the flags of the two rows past the end */
     const float* pa = rows + a.opA;
     const float* pb = rows + a.opB;
-    const float* pg = rows + (hasG ? a.gy : 0);
+    const float* ps = rows + a.opS;
+    const float* pg = rows + a.opG;
     for (int r0 = 0; r0 < nRows; r0 += kBlock) {
-        float va[kBlock], vb[kBlock], vp[kBlock], vg[kBlock]; int fl[kBlock];
+        float va[kBlock], vb[kBlock], vs[kBlock], vg[kBlock]; int fl[kBlock];
 #pragma unroll
         for (int k = 0; k < kBlock; ++k) {
-            const int off = (r0 + k) * kRowRec;   /* at most 2 rows past the end: still inside the wave's staging area */
-            va[k] = pa[off]; vb[k] = pb[off]; vp[k] = rows[off + 7]; vg[k] = pg[off]; fl[k] = __float_as_int(rows[off + 11]);
+            const int off = (r0 + k) * kRowRec;
+            va[k] = pa[off]; vb[k] = pb[off]; vs[k] = ps[off]; vg[k] = pg[off]; fl[k] = __float_as_int(rows[off + 11]);
         }
 #pragma unroll
         for (int k = 0; k < kBlock; ++k) {
-            /* bitwise (non-short-circuit) predicate algebra keeps this a straight line of v_cmp / v_cndmask */
-            const bool valid = (r0 + k < nRows) & ((fl[k] & 1) != 0);
-            const bool manifoldRow = (fl[k] & 2) != 0;
-            const float pen = vp[k];
-            const bool penOk = (pen > 0.0f) & (fabsf(pen) <= FLT_MAX);   /* pen > 0 && isfinite(pen): NaN fails both compares */
-            const float scale = isRhs ? 1.0f : pen;
-            const float nv = a.acc + (va[k] * vb[k]) * scale;
-            const float nvg = nv + (hasG ? vg[k] : 0.0f);
-            const float nv2 = (isAA & manifoldRow) ? nvg : nv;
-            const bool on = valid & (isRhs | penOk);
-            a.acc = on ? nv2 : a.acc;
+            const float nv = a.acc + (va[k] * vb[k]) * vs[k];
+            const float nvg = nv + vg[k];
+            const float nv2 = (fl[k] & a.gMask) != 0 ? nvg : nv;
+            a.acc = (fl[k] & a.onMask) != 0 ? nv2 : a.acc;
         }
     }
+}
+
+/* rows past the last entry of a block must read as invalid (the staging area keeps older tasks' records) */
+__device__ __forceinline__ void clear_row_flags(float* rec)
+{
+    rec[11] = __int_as_float(0); rec[kRowRec + 11] = __int_as_float(0); rec[2 * kRowRec + 11] = __int_as_float(0);
 }
 
 __device__ __forceinline__ void put_row(float* r, f3 Jl, f3 Ja, float f, float pen, f3 gyro, int flags)
 {
     r[0] = Jl.x; r[1] = Jl.y; r[2] = Jl.z; r[3] = Ja.x; r[4] = Ja.y; r[5] = Ja.z;
-    r[6] = f; r[7] = pen; r[8] = gyro.x; r[9] = gyro.y; r[10] = gyro.z; r[11] = __int_as_float(flags);
+    r[6] = f; r[7] = pen; r[8] = gyro.x; r[9] = gyro.y; r[10] = gyro.z;
+    const bool penOk = (pen > 0.0f) & (fabsf(pen) <= FLT_MAX);          /* pen > 0 && isfinite(pen), solver.cpp:387 */
+    r[11] = __int_as_float(flags | (penOk ? kRowFlagPenOk : 0)); r[12] = 1.0f; r[13] = 0.0f;
 }
 
 /* ---- phase 1 for one Manifold contact held in registers: computeConstraint (mutating c) +
@@ -246,7 +276,7 @@ __device__ __forceinline__ void eval_contact_core(ContactRows& c, bool isA, cons
         float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;
         float f = rclamp(desired, c.fmin[k], c.fmax[k]);
         f3 gyro = abs3(cross3(Ja[k], L.invIw * Ja[k])) * fabsf(f);
-        put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, 3 /* valid | manifold */);
+        put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, kRowFlagValid | kRowFlagManifold);
     }
 }
 
@@ -289,7 +319,7 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
             float lw = (stiff == FLT_MAX) ? ldf<COH>(&f.lambda[row]) : 0.0f;
             float desired = pen * j.C[row] + lw + f.motor[row];
             float fr = rclamp(desired, -FLT_MAX, FLT_MAX);
-            put_row(rec + k * kRowRec, Jl, Ja, fr, pen, zero3(), 1);
+            put_row(rec + k * kRowRec, Jl, Ja, fr, pen, zero3(), kRowFlagValid);
         }
     } else { /* FK_SPRING */
         GForce& f = gf[idx];
@@ -307,7 +337,7 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
         float lw = (f.stiffness[0] == FLT_MAX) ? ldf<COH>(&f.lambda[0]) : 0.0f;
         float desired = pen * s.C + lw + f.motor[0];
         float fr = rclamp(desired, f.fmin[0], f.fmax[0]);
-        put_row(rec, Jl, Ja, fr, pen, zero3(), 1);
+        put_row(rec, Jl, Ja, fr, pen, zero3(), kRowFlagValid);
         rec[kRowRec + 11] = __int_as_float(0);
         rec[2 * kRowRec + 11] = __int_as_float(0);
     }
@@ -473,7 +503,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, Man
                                                                  const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
                                                                  const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt)
 {
-    __shared__ float sRows[kWavesPerBlock][64 * kEntryRec];
+    __shared__ float sRows[kWavesPerBlock][66 * kEntryRec];
     __shared__ float sAcc[kWavesPerBlock][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int first = lvlStart[level], last = lvlStart[level + 1];
@@ -489,6 +519,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, Man
     for (int base = eBeg; base < eEnd; base += 64) {
         const int nHere = min(64, eEnd - base);
         if (lane < nHere) eval_entry<false>(inc[base + lane], B, M, gf, L, alpha, writeRows != 0, rows + lane * kEntryRec);
+        else if (lane < nHere + 2) clear_row_flags(rows + lane * kEntryRec);
         wave_sync();
         accumulate_rows(a, rows, nHere);
         wave_sync();
