@@ -65,17 +65,18 @@ __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& 
 
 /* dependency wait of task (body, it); returns false when the launch must be abandoned */
 __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, const int* adjStart, const int* adjRef, const int* adjOther,
-                                                  const int* solved, const IterateState& S, int sleepSel)
+                                                  const int* solved, const IterateState& S, int sleepSel, int which /* 0: all, 1: own previous task only, 2: neighbours only */)
 {
     const int aBeg = adjStart[body], aEnd = adjStart[body + 1];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     /* lane 63 of the first round also waits for this body's own previous task (pose + owned duals) */
-    for (int base = aBeg; base < aEnd || base == aBeg; base += 63) {
+    const int aLast = which == 1 ? aBeg : aEnd;
+    for (int base = aBeg; base < aLast || base == aBeg; base += 63) {
         const int k = base + lane;
         int need = 0; const int* word = nullptr;
         if (lane == 63) {
-            if (base == aBeg && it > 0) { word = S.dualDone + body; need = it; }
-        } else if (k < aEnd) {
+            if (base == aBeg && it > 0 && which != 2) { word = S.dualDone + body; need = it; }
+        } else if (k < aEnd && which != 1) {
             const int o = adjOther[k];
             if (o >= 0 && inc_kind(adjRef[k]) != FK_IGNORE && solved[o]) {
                 if (o > body) { word = S.primalDone + o; need = it + 1; }
@@ -159,24 +160,15 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
         const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
         const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
 
-        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, B.solved, S, sleepSel)) return;
-        DF_STAMP(0);
-
+        BodyLocal L;
+        AccLane a;
+        ContactRows c;
+        f3 wOwn = zero3(), wOther = zero3(), pOther = zero3(), opos = zero3(); q4 orot = identq();
+        bool otherFixed = false;
         if (fast) {
-            /* ---- one stage of sc1 loads: own pose, partner pose, the mutable contact fields ---- */
+            /* ---- stage 1: needs only this body's previous task: own pose, world inertia, accumulator seeds, own lever arms ---- */
+            if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, B.solved, S, sleepSel, 1)) return;
             const float4 pp = ld4<true>(B.plane(BP_POSR) + body), pq = ld4<true>(B.plane(BP_QUAT) + body);
-            float4 op = pp, oq = pq, nn = sra, lam = sra, pen = sra, mu1 = sra, mu2 = sra; int stick = 0;
-            if (has) {
-                op = ld4<true>(B.plane(BP_POSR) + other); oq = ld4<true>(B.plane(BP_QUAT) + other);
-                nn = ld4<true>(M.cN + idx); lam = ld4<true>(M.cLam + idx); pen = ld4<true>(M.cPen + idx);
-                mu1 = ld4<true>(M.cU1 + idx); mu2 = ld4<true>(M.cU2 + idx);
-                stick = ldi<true>(&M.cFS[idx].y);
-            }
-#ifdef AVBD_DF_STATS
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            DF_STAMP(8);
-#endif
-            BodyLocal L;
             L.pos = mk3(pp.x, pp.y, pp.z); L.rot = mkq(pq.x, pq.y, pq.z, pq.w);
             L.npos = mk3(snp.x, snp.y, snp.z); L.nrot = mkq(snq.x, snq.y, snq.z, snq.w);
             L.mass = smp.x; L.invMass = smp.y;
@@ -186,19 +178,52 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                 world_inertia_parallel(lane, L.rot, Ib, Jb, accs + 32, L.Iw, L.invIw);   /* rigid.cpp:51-59 */
                 L.invDt2 = 1.0f / (P.dt * P.dt);
             }
-            AccLane a = init_acc_lane(lane, L);
-            DF_STAMP(9);
-            ContactRows c;
-            const f3 opos = mk3(op.x, op.y, op.z); const q4 orot = mkq(oq.x, oq.y, oq.z, oq.w);
+            a = init_acc_lane(lane, L);
             if (has) {
                 c.rA = mk3(sra.x, sra.y, sra.z); c.C0n = sra.w;
                 c.rB = mk3(srb.x, srb.y, srb.z); c.C0t1 = srb.w;
+                wOwn = qrotate(L.rot, isA ? c.rA : c.rB);                     /* manifold.cpp:27 and :265 use the same product */
+                otherFixed = !B.solved[other];                                 /* static, or swept by another GPU: constant in this launch */
+                if (otherFixed) {
+                    const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];
+                    opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
+                    wOther = qrotate(orot, isA ? c.rB : c.rA);
+                    pOther = opos + wOther;
+                }
+            }
+        }
+
+        /* ---- stage 2: the neighbours ---- */
+        if (!wait_dependencies(body, it, lane, adjStart, adjRef, adjOther, B.solved, S, sleepSel, fast ? 2 : 0)) return;
+        DF_STAMP(0);
+
+        if (fast) {
+            /* one stage of sc1 loads: partner pose (if it moves in this launch) and the mutable contact fields */
+            float4 nn = sra, lam = sra, pen = sra, mu1 = sra, mu2 = sra; int stick = 0;
+            if (has) {
+                float4 op = sra, oq = sra;
+                if (!otherFixed) { op = ld4<true>(B.plane(BP_POSR) + other); oq = ld4<true>(B.plane(BP_QUAT) + other); }
+                nn = ld4<true>(M.cN + idx); lam = ld4<true>(M.cLam + idx); pen = ld4<true>(M.cPen + idx);
+                mu1 = ld4<true>(M.cU1 + idx); mu2 = ld4<true>(M.cU2 + idx);
+                stick = ldi<true>(&M.cFS[idx].y);
+                if (!otherFixed) {
+                    opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
+                    wOther = qrotate(orot, isA ? c.rB : c.rA);
+                    pOther = opos + wOther;
+                }
+            }
+#ifdef AVBD_DF_STATS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DF_STAMP(8);
+#endif
+            DF_STAMP(9);
+            if (has) {
                 c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
                 c.u1 = mk3(mu1.x, mu1.y, mu1.z); c.u2 = mk3(mu2.x, mu2.y, mu2.z);
                 c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
                 c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
                 c.stick = stick != 0;
-                eval_contact_core(c, isA, L, opos, orot, oinv, fric, alpha, rows + lane * kEntryRec);
+                eval_contact_pts(c, isA, L, wOwn, pOther, oinv, fric, alpha, rows + lane * kEntryRec);
                 /* a contact this wave is about to update again in its dual pass needs no intermediate store unless the
                  * partner reads it first: the partner of an owned contact has already finished this iteration */
                 if (!(owned && doDual)) store_contact_mutations<true>(M, idx, c, writeRows);
@@ -228,8 +253,10 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                 wave_sync();
                 if (has && owned) {
                     const f3 np = mk3(accs[56], accs[57], accs[58]); const q4 nq = mkq(accs[59], accs[60], accs[61], accs[62]);
-                    if (isA) dual_contact_core(c, np, nq, L.invMass, opos, orot, oinv, fric, P, alpha);
-                    else     dual_contact_core(c, opos, orot, oinv, np, nq, L.invMass, fric, P, alpha);
+                    const f3 wNew = qrotate(nq, isA ? c.rA : c.rB);
+                    const f3 pNew = np + wNew;
+                    if (isA) dual_contact_pts(c, pNew, wNew, L.invMass, pOther, wOther, oinv, fric, P, alpha);
+                    else     dual_contact_pts(c, pOther, wOther, oinv, pNew, wNew, L.invMass, fric, P, alpha);
                     store_contact_dual<true>(M, idx, c, lastDual);
                 }
                 drain_stores();

@@ -280,6 +280,53 @@ __device__ __forceinline__ void eval_contact_core(ContactRows& c, bool isA, cons
     }
 }
 
+/* The same with the lever arms already rotated: wOwn = rotate(q_own, r_own) (shared by the world point and the Jacobian,
+ * manifold.cpp:27 and :265) and pOther = pos_other + rotate(q_other, r_other). */
+__device__ __forceinline__ void eval_contact_pts(ContactRows& c, bool isA, const BodyLocal& L, f3 wOwn, f3 pOther, float oinv, float fric,
+                                                 float alpha, float* rec)
+{
+    const f3 pOwn = L.pos + wOwn;
+    ContactBasis db;
+    if (isA) contact_compute_constraint_pts(c, alpha, pOwn, pOther, L.invMass, oinv, fric, db);
+    else     contact_compute_constraint_pts(c, alpha, pOther, pOwn, oinv, L.invMass, fric, db);
+    f3 Jl[3], Ja[3];
+    contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
+    for (int k = 0; k < 3; ++k) {
+        float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;        /* solver.cpp:379-381 with stiffness FLT_MAX, motor 0 */
+        float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+        f3 gyro = abs3(cross3(Ja[k], L.invIw * Ja[k])) * fabsf(f);
+        put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, kRowFlagValid | kRowFlagManifold);
+    }
+}
+
+/* dual update from rotated lever arms (wA, wB) and world points (pA, pB) */
+__device__ __forceinline__ void dual_contact_pts(ContactRows& c, f3 pA, f3 wA, float imA, f3 pB, f3 wB, float imB, float fric, const SolverParams& P, float alpha)
+{
+    ContactBasis db;
+    contact_compute_constraint_pts(c, alpha, pA, pB, imA, imB, fric, db);
+    bool needJ = false;
+    bool active[3];
+    for (int k = 0; k < 3; ++k) {
+        float lu = rclamp(c.penalty[k] * c.C[k] + c.lambda[k], c.fmin[k], c.fmax[k]);
+        active[k] = lu > c.fmin[k] && lu < c.fmax[k];
+        c.lambda[k] = lu;
+        needJ |= active[k];
+    }
+    if (needJ) {
+        f3 JlA[3], JaA[3], JlB[3], JaB[3];
+        contact_compute_derivatives_w(db, true, wA, JlA, JaA);
+        contact_compute_derivatives_w(db, false, wB, JlB, JaB);
+        for (int k = 0; k < 3; ++k) {
+            if (!active[k]) continue;
+            float lw = 0.0f, aw = 0.0f;                               /* rowPenaltyGain, solver.cpp:94-125 */
+            lw += lensq3(JlA[k]); aw += lensq3(JaA[k]);
+            lw += lensq3(JlB[k]); aw += lensq3(JaB[k]);
+            float betaRow = row_penalty_gain(lw, aw, P.beta);
+            c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kManifoldPenaltyCap);
+        }
+    }
+}
+
 /* ---- phase 1: evaluate one incidence entry (<= 3 rows) for `body` ---------------------------- */
 template <bool COH>
 __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const ManifoldTable& M, GForce* gf, const BodyLocal& L, float alpha,

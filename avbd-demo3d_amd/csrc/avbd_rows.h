@@ -100,8 +100,9 @@ struct ContactBasis { f3 n, t1, t2; };
 
 /* `db` receives the basis the reference's computeDerivatives would rebuild right after this call from the normal
  * this call stores (manifold.cpp:253-254): the same memo rule applied to the new stored normal. */
-AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4 rotA, float invMassA, f3 posB, q4 rotB,
-                                        float invMassB, float combinedFriction, ContactBasis& db)
+/* core on the two world-space contact points pA = posA + rotate(qA, rA), pB = posB + rotate(qB, rB) (manifold.cpp:188-190) */
+AVBD_HD void contact_compute_constraint_pts(ContactRows& c, float alpha, f3 pA, f3 pB, float invMassA, float invMassB,
+                                            float combinedFriction, ContactBasis& db)
 {
     float biasScale = rclamp(1.0f - alpha, 0.0f, 1.0f);
     f3 n, t1, t2;
@@ -110,8 +111,6 @@ AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4
     c.normal = n; c.u1 = t1; c.u2 = t2;   /* stored normal and its memo move together */
     if (hit) { db.n = n; db.t1 = t1; db.t2 = t2; }            /* same bits in, same basis out */
     else { bool h2; contact_basis_memo(n, t1, t2, db.n, db.t1, db.t2, h2); }
-    f3 pA = world_point(posA, rotA, c.rA);
-    f3 pB = world_point(posB, rotB, c.rB);
     f3 d = pA - pB;
     float separation = dot3(d, n) - kNormalMargin;
     float slip1 = dot3(d, t1);
@@ -154,16 +153,27 @@ AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4
     c.penetration = rmax(0.0f, -dot3(d, n));
 }
 
+AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4 rotA, float invMassA, f3 posB, q4 rotB,
+                                        float invMassB, float combinedFriction, ContactBasis& db)
+{
+    contact_compute_constraint_pts(c, alpha, world_point(posA, rotA, c.rA), world_point(posB, rotB, c.rB), invMassA, invMassB, combinedFriction, db);
+}
+
+/* computeDerivatives from the world-space lever arm wr = rotate(q_body, r_local) (manifold.cpp:265-270) */
+AVBD_HD void contact_compute_derivatives_w(const ContactBasis& db, bool isBodyA, f3 wr, f3 Jl[3], f3 Ja[3])
+{
+    float sign = isBodyA ? 1.0f : -1.0f;
+    Jl[0] = db.n * sign;  Ja[0] = cross3(wr, db.n) * sign;
+    Jl[1] = db.t1 * sign; Ja[1] = cross3(wr, db.t1) * sign;
+    Jl[2] = db.t2 * sign; Ja[2] = cross3(wr, db.t2) * sign;
+}
+
 /* Manifold::computeDerivatives for the three rows of one contact (manifold.cpp:247-271).  The
  * reference rebuilds the basis from the STORED normal on every call; the stored normal is the
  * one computeConstraint just wrote, so the basis below is normalised once more, as there. */
 AVBD_HD void contact_compute_derivatives(const ContactRows& c, const ContactBasis& db, bool isBodyA, q4 rotBody, f3 Jl[3], f3 Ja[3])
 {
-    float sign = isBodyA ? 1.0f : -1.0f;
-    f3 wr = qrotate(rotBody, isBodyA ? c.rA : c.rB);
-    Jl[0] = db.n * sign;  Ja[0] = cross3(wr, db.n) * sign;
-    Jl[1] = db.t1 * sign; Ja[1] = cross3(wr, db.t1) * sign;
-    Jl[2] = db.t2 * sign; Ja[2] = cross3(wr, db.t2) * sign;
+    contact_compute_derivatives_w(db, isBodyA, qrotate(rotBody, isBodyA ? c.rA : c.rB), Jl, Ja);
 }
 
 /* stand-alone form (row API): rebuild the basis from the stored normal like manifold.cpp:253-254 */
