@@ -136,6 +136,7 @@ struct AvbdContext {
     int iterBlocks = 512;      /* resident workgroups of k_iterate */
     int iterLdsPad = 0;        /* extra dynamic LDS per workgroup: > 43 KB forces one workgroup per CU */
     int iterSleep = 1;         /* poll back-off selector (s_sleep 1/2/4/8) */
+    int iterForceMode = 0;     /* 0 auto, 1 latency (1 workgroup/CU), 2 throughput (2 workgroups/CU) */
     int numStatic = 0;
     bool statsFresh = true;
 
@@ -591,8 +592,17 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     if (blocks < 1) blocks = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    hipExtLaunchKernelGGL(k_iterate, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                          c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd);
+    /* latency mode (one workgroup per CU) unless every wave would have to run hundreds of tasks: then two workgroups per CU */
+    const bool throughput = c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves);
+    if (throughput) {
+        int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
+        if (blocks2 < 1) blocks2 = 1;
+        hipExtLaunchKernelGGL(k_iterate<2>, dim3(blocks2), dim3(64 * kIterWaves), 0, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd);
+    } else {
+        hipExtLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd);
+    }
     ++c->prof.launches_primal; ++c->prof.launches_total;
     HIPCHK(c, hipGetLastError());
     return AVBD_OK;
@@ -802,7 +812,8 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_BLOCKS")) c->iterBlocks = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_ITER_LDSPAD")) c->iterLdsPad = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
-        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
+        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
     }
     *out = c;

@@ -101,7 +101,10 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
     return true;
 }
 
-__global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_iterate(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
+/* WPE = wavefronts per SIMD the launch is sized for: 1 (latency mode, one workgroup per CU: the critical wave never shares
+ * its SIMD with a spinning one) or 2 (throughput mode for scenes with thousands of tasks per wave). */
+template <int WPE>
+__global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_iterate(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
                                                               const int* __restrict__ adjOther, const int* __restrict__ incStart,
