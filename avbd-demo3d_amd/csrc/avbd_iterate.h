@@ -220,22 +220,24 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
             DF_STAMP(8);
 #endif
             DF_STAMP(9);
+            bool rowsOn = true;
             if (has) {
                 c.normal = mk3(nn.x, nn.y, nn.z); c.C0t2 = nn.w;
                 c.u1 = mk3(mu1.x, mu1.y, mu1.z); c.u2 = mk3(mu2.x, mu2.y, mu2.z);
                 c.lambda[0] = lam.x; c.lambda[1] = lam.y; c.lambda[2] = lam.z; c.penetration = lam.w;
                 c.penalty[0] = pen.x; c.penalty[1] = pen.y; c.penalty[2] = pen.z;
                 c.stick = stick != 0;
-                eval_contact_pts(c, isA, L, wOwn, pOther, oinv, fric, alpha, rows + lane * kEntryRec);
+                rowsOn = eval_contact_pts(c, isA, L, wOwn, pOther, oinv, fric, alpha, rows + lane * kEntryRec);
                 /* a contact this wave is about to update again in its dual pass needs no intermediate store unless the
                  * partner reads it first: the partner of an owned contact has already finished this iteration */
                 if (!(owned && doDual)) store_contact_mutations<true>(M, idx, c, writeRows);
             } else if (lane < nEnt + 2) {
                 clear_row_flags(rows + lane * kEntryRec);
             }
+            const bool allOn = __all(rowsOn);
             wave_sync();
             DF_STAMP(10);
-            accumulate_rows(a, rows, nEnt);
+            if (allOn) accumulate_rows_all_on(a, rows, nEnt); else accumulate_rows(a, rows, nEnt);
             if (lane < 27) accs[lane] = a.acc;
             wave_sync();
             DF_STAMP(1);

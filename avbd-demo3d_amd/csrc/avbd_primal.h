@@ -247,6 +247,49 @@ __device__ __forceinline__ void accumulate_rows(AccLane& a, const float* rows, i
     }
 }
 
+/* Same sums when every row of the task is a Manifold row with a usable penalty (the normal case; the caller checks it
+ * wave-wide): no per-row predicates are needed, only the lane-constant "is this an aa entry" select. */
+__device__ __forceinline__ void accumulate_rows_all_on(AccLane& a, const float* rows, int nEntries)
+{
+    if (a.mode == 3) return;
+    constexpr int kBlock = 6;
+    const int nRows = nEntries * 3;           /* multiple of 3; rows come in blocks of 6, the tail block is handled below */
+    const bool isAA = a.mode == 1;
+    const float* pa = rows + a.opA;
+    const float* pb = rows + a.opB;
+    const float* ps = rows + a.opS;
+    const float* pg = rows + a.opG;
+    int r0 = 0;
+    for (; r0 + kBlock <= nRows; r0 += kBlock) {
+        float va[kBlock], vb[kBlock], vs[kBlock], vg[kBlock];
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) {
+            const int off = (r0 + k) * kRowRec;
+            va[k] = pa[off]; vb[k] = pb[off]; vs[k] = ps[off]; vg[k] = pg[off];
+        }
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) {
+            const float nv = a.acc + (va[k] * vb[k]) * vs[k];
+            const float nvg = nv + vg[k];
+            a.acc = isAA ? nvg : nv;
+        }
+    }
+    if (r0 < nRows) {                          /* three rows left */
+        float va[3], vb[3], vs[3], vg[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int off = (r0 + k) * kRowRec;
+            va[k] = pa[off]; vb[k] = pb[off]; vs[k] = ps[off]; vg[k] = pg[off];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float nv = a.acc + (va[k] * vb[k]) * vs[k];
+            const float nvg = nv + vg[k];
+            a.acc = isAA ? nvg : nv;
+        }
+    }
+}
+
 /* rows past the last entry of a block must read as invalid (the staging area keeps older tasks' records) */
 __device__ __forceinline__ void clear_row_flags(float* rec)
 {
@@ -282,7 +325,7 @@ __device__ __forceinline__ void eval_contact_core(ContactRows& c, bool isA, cons
 
 /* The same with the lever arms already rotated: wOwn = rotate(q_own, r_own) (shared by the world point and the Jacobian,
  * manifold.cpp:27 and :265) and pOther = pos_other + rotate(q_other, r_other). */
-__device__ __forceinline__ void eval_contact_pts(ContactRows& c, bool isA, const BodyLocal& L, f3 wOwn, f3 pOther, float oinv, float fric,
+__device__ __forceinline__ bool eval_contact_pts(ContactRows& c, bool isA, const BodyLocal& L, f3 wOwn, f3 pOther, float oinv, float fric,
                                                  float alpha, float* rec)
 {
     const f3 pOwn = L.pos + wOwn;
@@ -297,6 +340,9 @@ __device__ __forceinline__ void eval_contact_pts(ContactRows& c, bool isA, const
         f3 gyro = abs3(cross3(Ja[k], L.invIw * Ja[k])) * fabsf(f);
         put_row(rec + k * kRowRec, Jl[k], Ja[k], f, c.penalty[k], gyro, kRowFlagValid | kRowFlagManifold);
     }
+    /* all three penalties positive and finite (solver.cpp:387)? */
+    return ((c.penalty[0] > 0.0f) & (fabsf(c.penalty[0]) <= FLT_MAX)) & ((c.penalty[1] > 0.0f) & (fabsf(c.penalty[1]) <= FLT_MAX)) &
+           ((c.penalty[2] > 0.0f) & (fabsf(c.penalty[2]) <= FLT_MAX));
 }
 
 /* dual update from rotated lever arms (wA, wB) and world points (pA, pB) */
