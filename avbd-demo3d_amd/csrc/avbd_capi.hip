@@ -500,7 +500,7 @@ int launch_topology(AvbdContext* c, bool fromStep)
     hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->adjStart.p, c->adjRef.p, c->adjOther.p,
                        c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p);
     if (fromStep)
-        hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), 0, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
+        hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), kLevelsLdsBytes, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
                            c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap);
     HIPCHK(c, hipGetLastError());
     c->adjDirty = false;
@@ -552,7 +552,11 @@ int step_begin(AvbdContext* c)
     hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p);
     {
         SpanGuard g(c, F_BROAD);
-        if (n > 1) {
+        if (n > 1 && n <= 4096) {
+            const int slices = (n + 31) / 32;
+            hipLaunchKernelGGL(k_broadphase_small, dim3(grid_for((long long)n * slices, 256, 1 << 24)), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p,
+                               c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0, slices);
+        } else if (n > 1) {
             const int T = (n + 255) / 256;
             hipLaunchKernelGGL(k_broadphase, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
         }
@@ -815,6 +819,8 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
+        fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
+        if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_levels, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
     }
     *out = c;
     return AVBD_OK;

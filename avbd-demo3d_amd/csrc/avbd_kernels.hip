@@ -99,6 +99,46 @@ __global__ __launch_bounds__(256) void k_broadphase(BodyTable B, const int* __re
     }
 }
 
+/* The same pair enumeration for small scenes (a few thousand bodies): one thread per (body A, 32-body slice of the
+ * earlier-created bodies), no LDS staging — the whole position table sits in L2 — so that a 1000-body scene still
+ * spreads over the chip instead of ten workgroups. */
+__global__ __launch_bounds__(256) void k_broadphase_small(BodyTable B, const int* __restrict__ adjStart, const int* __restrict__ adjOther,
+                                                           int2* cand, int candCap, Counters* cnt, int keepUnsolvedPairs, int slices)
+{
+    const float4* posr = B.plane(BP_POSR);
+    const int n = B.n;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / slices, sl = t - i * slices;
+    if (i >= n) return;
+    const int jBeg = sl * 32;
+    int jEnd = jBeg + 32; if (jEnd > i) jEnd = i;
+    if (jBeg >= jEnd) return;
+    const float4 a = posr[i];
+    const f3 pa = mk3(a.x, a.y, a.z);
+    const bool solvedI = B.solved[i] != 0;
+    for (int j = jBeg; j < jEnd; ++j) {
+        const float4 b = posr[j];
+        f3 dp = pa - mk3(b.x, b.y, b.z);
+        float r = a.w + b.w;
+        if (dot3(dp, dp) <= r * r) {
+            if (!solvedI && !B.solved[j]) {
+                const bool bothStatic = !(B.plane(BP_MASS)[i].y > 0.0f) && !(B.plane(BP_MASS)[j].y > 0.0f);
+                if (!(keepUnsolvedPairs && bothStatic)) continue;
+            }
+            int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
+            int s, e, other;
+            if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
+            bool constrained = false;
+            for (int k = s; k < e; ++k) if (adjOther[k] == other) { constrained = true; break; }
+            if (!constrained) {
+                int slot = atomicAdd(&cnt->numCandidates, 1);
+                if (slot < candCap) cand[slot] = make_int2(i, j);
+                else atomicOr(&cnt->overflow, 1);
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * K2 narrow phase + Manifold::initialize + warm-start decay.  One lane per pair: last step's
  * manifolds (src) followed by this step's candidates.  Survivors are appended to dst.
@@ -293,12 +333,59 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
 
 /* Dependency levels of the Gauss-Seidel sweep: level(b) = 1 + max level of dynamic neighbours
  * created later than b (they precede b in the reference's body list).  Single workgroup. */
+constexpr int kLevelsLdsBodies = 8192, kLevelsLdsNbrs = 49152;
+constexpr int kLevelsLdsBytes = (kLevelsLdsBodies + kLevelsLdsNbrs) * 2;
 __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStart, const int* adjRef, const int* adjOther, int* level,
                                                   int* lvlCount, int* lvlStart, int* order, Counters* cnt, int lvlCap)
 {
     __shared__ int sChanged, sMax;
     __shared__ int sScan[1024];
+    extern __shared__ unsigned short sDyn[];      /* [kLevelsLdsBodies] levels, then [kLevelsLdsNbrs] compacted neighbour lists */
     const int n = B.n, t = threadIdx.x;
+    if (n <= kLevelsLdsBodies && adjStart[n] <= kLevelsLdsNbrs) {
+        /* small scenes: levels and the later-created swept neighbours of every body live in LDS (16-bit indices), compacted
+         * at the start of the body's own CSR segment — a sweep is then LDS reads only, no dependent global loads */
+        unsigned short* sLevel = sDyn;
+        unsigned short* sNbr = sDyn + kLevelsLdsBodies;
+        constexpr int kPer = kLevelsLdsBodies / 1024;
+        int seg[kPer], cnt_[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int b = t + q * 1024;
+            seg[q] = 0; cnt_[q] = -1;
+            if (b < n) sLevel[b] = 0;
+            if (b < n && B.solved[b]) {
+                const int s0 = adjStart[b], s1 = adjStart[b + 1];
+                int c = 0;
+                for (int k = s0; k < s1; ++k) {
+                    const int o = adjOther[k];
+                    if (o > b && inc_kind(adjRef[k]) != FK_IGNORE && B.solved[o]) sNbr[s0 + c++] = (unsigned short)o;
+                }
+                seg[q] = s0; cnt_[q] = c;
+            }
+        }
+        __syncthreads();
+        for (int sweep = 0; sweep <= n; ++sweep) {
+            if (t == 0) sChanged = 0;
+            __syncthreads();
+            int changed = 0;
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+                if (cnt_[q] < 0) continue;
+                const int b = t + q * 1024;
+                int lv = 1;
+                for (int z = 0; z < cnt_[q]; ++z) { int lo = (int)((volatile unsigned short*)sLevel)[sNbr[seg[q] + z]] + 1; if (lo > lv) lv = lo; }
+                if (lv != (int)sLevel[b]) { sLevel[b] = (unsigned short)lv; changed = 1; }
+            }
+            if (changed) sChanged = 1;
+            __syncthreads();
+            int c = sChanged;
+            __syncthreads();
+            if (!c) break;
+        }
+        for (int b = t; b < n; b += 1024) level[b] = sLevel[b];
+        __syncthreads();
+    } else {
     for (int sweep = 0; sweep <= n; ++sweep) {
         if (t == 0) sChanged = 0;
         __syncthreads();
@@ -320,6 +407,7 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
         int c = sChanged;
         __syncthreads();
         if (!c) break;
+    }
     }
     /* histogram */
     if (t == 0) sMax = 0;
