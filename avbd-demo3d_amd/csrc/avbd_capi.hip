@@ -137,6 +137,9 @@ struct AvbdContext {
     int iterLdsPad = 0;        /* extra dynamic LDS per workgroup: > 43 KB forces one workgroup per CU */
     int iterSleep = 1;         /* poll back-off selector (s_sleep 1/2/4/8) */
     int iterForceMode = 0;     /* 0 auto, 1 latency (1 workgroup/CU), 2 throughput (2 workgroups/CU) */
+    DevArr<float4> xPose, xVisit, xDual; /* stamped exchange records of the resident schedule (avbd_resident.h) */
+    unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
+    bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     int numStatic = 0;
     bool statsFresh = true;
 
@@ -248,6 +251,13 @@ int ensure_capacity(AvbdContext* c, int nBodies)
         c->candCap = newMCap;
         HIPCHK(c, c->cand.alloc(c->candCap));
     }
+    HIPCHK(c, c->xPose.alloc((size_t)3 * newCap));
+    HIPCHK(c, c->xVisit.alloc((size_t)4 * c->mCap));
+    HIPCHK(c, c->xDual.alloc((size_t)8 * c->mCap));
+    HIPCHK(c, hipMemset(c->xPose.p, 0, (size_t)3 * newCap * sizeof(float4)));
+    HIPCHK(c, hipMemset(c->xVisit.p, 0, (size_t)4 * c->mCap * sizeof(float4)));
+    HIPCHK(c, hipMemset(c->xDual.p, 0, (size_t)8 * c->mCap * sizeof(float4)));
+    c->xSerial = 0;
     c->lvlCap = newCap + 2;
     HIPCHK(c, c->adjStart.alloc(newCap + 1));
     HIPCHK(c, c->incStart.alloc(newCap + 1));
@@ -498,10 +508,10 @@ int launch_topology(AvbdContext* c, bool fromStep)
     hipLaunchKernelGGL(k_fill_adj, dim3(grid_for((long long)c->stats.numManifolds + c->stats.numCandidates + ng + 4096, 256, 2048)), dim3(256), 0, c->stream,
                        M, c->dCnt.p, c->dG.p, ng, c->adjStart.p, c->degForce.p, c->adjRef.p, c->adjOther.p, c->adjKey.p);
     hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->adjStart.p, c->adjRef.p, c->adjOther.p,
-                       c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p);
+                       c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p, c->dCnt.p);
     if (fromStep)
         hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), kLevelsLdsBytes, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
-                           c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap);
+                           c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap, c->iterBlocks * kIterWaves);
     HIPCHK(c, hipGetLastError());
     c->adjDirty = false;
     return AVBD_OK;
@@ -597,15 +607,34 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
     /* latency mode (one workgroup per CU) unless every wave would have to run hundreds of tasks: then two workgroups per CU */
-    const bool throughput = c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves);
+    /* resident schedule (one wave per body for the whole loop): whole loop in one launch on one GPU, contacts only, stamps fit */
+    ResidentExchange X{};
+    X.pose = c->xPose.p; X.visit = c->xVisit.p; X.dual = c->xDual.p;
+    const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes, poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
+    X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
+    X.maxWaves = c->iterBlocks * kIterWaves;
+    const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
+    X.enabled = (c->residentAllowed && c->iterForceMode != 2 && itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
+                 totalItAll <= 60 && totalItAll > 0 && B.n - c->numStatic <= X.maxWaves && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
+    if (X.enabled) {
+        if (c->xSerial >= (1u << 24) - 2u) {                       /* stamps are about to wrap: forget every old record */
+            HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, visitBytes, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
+            c->xSerial = 0;
+        }
+        X.base = (++c->xSerial) * 64u;
+        blocks = c->iterBlocks;                                        /* every swept body needs its wave resident */
+    }
+    const bool throughput = !X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves));
     if (throughput) {
         int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
         if (blocks2 < 1) blocks2 = 1;
         hipExtLaunchKernelGGL(k_iterate<2>, dim3(blocks2), dim3(64 * kIterWaves), 0, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd);
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
     } else {
         hipExtLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd);
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
     }
     ++c->prof.launches_primal; ++c->prof.launches_total;
     HIPCHK(c, hipGetLastError());
@@ -817,6 +846,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_LDSPAD")) c->iterLdsPad = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
+        if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);

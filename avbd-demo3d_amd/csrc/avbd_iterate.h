@@ -42,6 +42,10 @@ struct IterateState {
 constexpr int kIterWaves = 4;                      /* waves per workgroup */
 constexpr unsigned long long kSpinTimeoutTicks = 400000000ull; /* 4 s of s_memrealtime (100 MHz) */
 
+} // namespace avbd
+#include "avbd_resident.h"
+namespace avbd {
+
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 /* is this incidence entry's force owned by `body` (= body is its earliest-created dynamic endpoint)? */
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
                                                               const int* __restrict__ adjOther, const int* __restrict__ incStart,
-                                                              const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel, int itBegin, int itEnd)
+                                                              const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel, int itBegin, int itEnd,
+                                                              ResidentExchange X)
 {
     __shared__ float sRows[kIterWaves][66 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
@@ -123,6 +128,13 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
      * when body state is exchanged between GPUs after every iteration (the done-counters persist in between) */
     const long long nTasks = (long long)nd * (itEnd < totalIt ? itEnd : totalIt);
     const float4* massPlane = B.plane(BP_MASS);
+    if constexpr (WPE == 1) {
+        /* every swept body fits one resident wavefront and is a plain pile of contacts: one wave per body for the whole loop */
+        if (X.enabled && cnt->residentBad == 0) {
+            if (w < nd) iterate_resident(B, M, order[w], incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs);
+            return;
+        }
+    }
 
 #ifdef AVBD_DF_STATS
     unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

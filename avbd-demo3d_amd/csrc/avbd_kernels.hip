@@ -301,7 +301,7 @@ __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* g
 /* Per dynamic body: order its adjacency newest-first (= the reference's body->forces walk,
  * force.cpp:21-29) and expand it into the row-incidence list consumed by k_primal. */
 __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart, int* adjRef, int* adjOther, uint64_t* adjKey,
-                              const int* incStart, int* inc, int* level, int* cursor)
+                              const int* incStart, int* inc, int* level, int* cursor, Counters* cnt)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B.n) return;
@@ -316,6 +316,7 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
         adjKey[j + 1] = k; adjRef[j + 1] = r; adjOther[j + 1] = o;
     }
     int o = incStart[b];
+    bool nonManifold = false;
     for (int i = s; i < e; ++i) {
         int r = adjRef[i];
         int kind = inc_kind(r), idx = inc_index(r), isA = inc_isA(r);
@@ -328,7 +329,10 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
         } else if (kind == FK_SPRING) {
             inc[o++] = make_inc(isA, FK_SPRING, idx);
         }
+        if (kind == FK_JOINT || kind == FK_SPRING) nonManifold = true;
     }
+    /* the resident schedule (avbd_resident.h) keeps one Manifold contact per lane of the body's wavefront */
+    if (nonManifold || o - incStart[b] > 64) atomicOr(&cnt->residentBad, 1);
 }
 
 /* Dependency levels of the Gauss-Seidel sweep: level(b) = 1 + max level of dynamic neighbours
@@ -336,7 +340,7 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
 constexpr int kLevelsLdsBodies = 8192, kLevelsLdsNbrs = 49152;
 constexpr int kLevelsLdsBytes = (kLevelsLdsBodies + kLevelsLdsNbrs) * 2;
 __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStart, const int* adjRef, const int* adjOther, int* level,
-                                                  int* lvlCount, int* lvlStart, int* order, Counters* cnt, int lvlCap)
+                                                  int* lvlCount, int* lvlStart, int* order, Counters* cnt, int lvlCap, int residentWaves)
 {
     __shared__ int sChanged, sMax;
     __shared__ int sScan[1024];
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
         int lv = level[b];
         if (lv > 0 && lv < lvlCap) order[lvlStart[lv - 1] + atomicAdd(&lvlCount[lv], 1)] = b;
     }
-    if (t == 0) { cnt->numLevels = L; if (L >= lvlCap) atomicOr(&cnt->overflow, 8); }
+    if (t == 0) { cnt->numLevels = L; if (L >= lvlCap) atomicOr(&cnt->overflow, 8); if (sScan[1023] > residentWaves) atomicOr(&cnt->residentBad, 2); }
 }
 
 /* Sort the bodies of each level by index (placement only: results do not depend on it). */
@@ -587,7 +591,7 @@ __global__ void k_finish_step(Counters* cnt, DiagAccum* diag)
 __global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount)
 {
     cnt->numCandidates = 0; cnt->numContacts = 0; cnt->numIncidences = 0; cnt->warnings = 0; cnt->dynamicBodies = 0;
-    cnt->numLevels = 0;
+    cnt->numLevels = 0; cnt->residentBad = 0;
     *nextCount = 0;
     diag->maxPenetration = 0; diag->maxViolation = 0; diag->maxLinearSpeed = 0; diag->maxAngularSpeed = 0; diag->maxNormalImpulse = 0;
     diag->activeContacts = 0; diag->activeManifolds = 0; diag->dynamicBodies = 0;

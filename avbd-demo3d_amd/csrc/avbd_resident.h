@@ -1,0 +1,224 @@
+/*
+ * avbd_resident.h — "resident" schedule of the iteration loop (solver.cpp:340-431) for scenes whose swept bodies fit
+ * the machine one-to-one: every dynamic body gets ONE wavefront for the whole launch (all iterations).
+ *
+ * Same dependencies, same arithmetic and same summation order as k_iterate's task schedule (avbd_iterate.h); what
+ * changes is where state lives and how it moves between wavefronts:
+ *
+ *   - the body's pose, its incidence entries (<= 64 Manifold contacts, one per lane) and the state of the contacts it
+ *     "owns" (it is the last visitor of the contact in the sweep, so it also runs the dual update) stay in REGISTERS
+ *     from the first iteration to the last; the tables in HBM are read once before and written once after the loop;
+ *   - what another wavefront needs travels as self-validating 16-byte records: a record carries the iteration stamp
+ *     of its producer in its last word and is written / read with ONE buffer_store/load_dwordx4 ... sc1 by one lane.
+ *     A consumer polls the records themselves, so the poll that sees the stamp has the payload in its registers:
+ *     no counter, no s_waitcnt drain before publishing, no second round trip for the payload.
+ *         pose   : 3 records / body   {p.xyz,s} {q.xyz,s} {q.w,-,-,s}       producer: the body's wave after its solve
+ *         visit  : 1 record / contact {lambda1',lambda2',stick',s}          producer: first visitor (later-created body)
+ *         dual   : 2 records / contact {lambda.xyz,s} {penalty.xyz,2s+stick} producer: owner, after its dual update
+ *     (computeConstraint, manifold.cpp:183-243, mutates lambda[1..2] and stick on EVERY call, so the first visitor's
+ *     mutations are an input of the second visit; the stored normal and its tangent memo are mutated too, but only
+ *     as a function of themselves: each side replays the other side's re-normalisations locally — see replay_normal.)
+ *   - stamps are launch-unique (serial * 64 + iteration + 1), so the exchange buffers are never cleared between steps.
+ *
+ * The single-copy atomicity of one lane's aligned 16-byte access is a property of gfx950's memory pipeline (one
+ * request, one 64-byte line), not of the HIP memory model; this file is gfx950-only like the rest of csrc/.
+ * A producer can never overwrite a record before its consumer has read it: the next write of every record depends,
+ * through the Gauss-Seidel dependencies themselves, on the consumer's own progress.
+ */
+#pragma once
+#include "avbd_primal.h"
+
+#pragma clang fp contract(off)
+
+namespace avbd {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+struct ResidentExchange {
+    float4* pose;    /* [3 * bodyCap] */
+    float4* visit;   /* [4 * manifoldCap] */
+    float4* dual;    /* [8 * manifoldCap] */
+    unsigned poseBytes, visitBytes, dualBytes;
+    unsigned base;   /* stamp of "nothing published yet" for this launch */
+    int enabled;     /* host-side prerequisites hold (single GPU, no joints/springs, few enough iterations) */
+    int maxWaves;    /* wavefronts the launch keeps resident */
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
+/* aux 16 = sc1: agent scope, served from / written through to the level all XCDs share */
+__device__ __forceinline__ v4u xld(__amdgpu_buffer_rsrc_t r, int byteOff) { return __builtin_amdgcn_raw_buffer_load_b128(r, byteOff, 0, 16); }
+__device__ __forceinline__ void xst(__amdgpu_buffer_rsrc_t r, int byteOff, v4u v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, 16); }
+__device__ __forceinline__ bool stamp_reached(unsigned have, unsigned need) { return (int)(have - need) >= 0; }
+__device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float bitsf(unsigned u) { return __uint_as_float(u); }
+
+/* What one computeConstraint call does to the stored normal and its tangent memo (manifold.cpp:185-186 through
+ * contact_basis_memo): used to replay the calls the OTHER visitor / the dual made since this wave last touched the
+ * contact.  Once the normal is a fixed point of the normalisation every later call leaves it alone. */
+__device__ __forceinline__ void replay_normal(ContactRows& c, bool& fixedN)
+{
+    if (fixedN) return;
+    f3 n, t1, t2; bool hit;
+    contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
+    c.normal = n; c.u1 = t1; c.u2 = t2;
+    fixedN = hit;
+}
+
+/* One wavefront = one body for all iterations.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
+__device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, int body, const int* __restrict__ incStart,
+                                                 const int* __restrict__ inc, const SolverParams& P, int* errWord, Counters* cntW,
+                                                 const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs)
+{
+    const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
+    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+    const float4* massPlane = B.plane(BP_MASS);
+    const int eBeg = incStart[body], nEnt = incStart[body + 1] - eBeg;
+    const bool has = lane < nEnt;
+
+    /* ---- once per step: everything the loop needs, from the tables the earlier kernels of this step wrote ---- */
+    int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
+    float oinv = 0.0f, fric = 0.0f;
+    ContactRows c;
+    c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
+    for (int k = 0; k < 3; ++k) { c.lambda[k] = 0.0f; c.penalty[k] = 0.0f; c.C[k] = 0.0f; c.fmin[k] = 0.0f; c.fmax[k] = 0.0f; }
+    f3 opos = zero3(); q4 orot = identq(); f3 wOther = zero3(), pOther = zero3();
+    if (has) {
+        const int ent = inc[eBeg + lane];
+        idx = inc_index(ent); isA = inc_isA(ent) != 0;
+        const int m = idx >> 2;
+        const int2 pr = M.pair[m];
+        other = isA ? pr.y : pr.x;
+        oinv = massPlane[other].y;
+        fric = M.fric[m];
+        moving = B.solved[other] != 0;
+        owned = !moving || other > body;
+        load_contact<false>(M, idx, c);
+        const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose (solver.cpp:299-337) */
+        opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
+        wOther = qrotate(orot, isA ? c.rB : c.rA);
+        pOther = opos + wOther;
+    }
+    BodyLocal L;
+    {
+        const float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
+        const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
+        L.pos = mk3(pp.x, pp.y, pp.z); L.rot = mkq(pq.x, pq.y, pq.z, pq.w);
+        L.npos = mk3(snp.x, snp.y, snp.z); L.nrot = mkq(snq.x, snq.y, snq.z, snq.w);
+        L.mass = smp.x; L.invMass = smp.y;
+        L.invDt2 = 1.0f / (P.dt * P.dt);
+    }
+    const float radius = B.plane(BP_POSR)[body].w;
+    const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
+    const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
+    const m33 Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
+    const m33 Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
+    const int offP = other * 48, offV = idx * 16, offD = idx * 32;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+
+    for (int it = 0; it < totalIt; ++it) {
+        const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const bool doDual = it < P.iterations;
+        const unsigned stampNow = X.base + (unsigned)it + 1u;        /* what this task publishes */
+
+        /* ---- before the wait: everything that depends only on this wave's own state ---- */
+        world_inertia_parallel(lane, L.rot, Ib, Jb, accs + 32, L.Iw, L.invIw);   /* rigid.cpp:51-59 */
+        AccLane a = init_acc_lane(lane, L);
+        f3 wOwn = zero3();
+        bool needP = false, needV = false, needD = false;
+        unsigned sP = 0, sV = 0, sD = 0;
+        if (has) {
+            wOwn = qrotate(L.rot, isA ? c.rA : c.rB);                 /* manifold.cpp:27 and :265 use the same product */
+            if (moving) {
+                if (owned) { replay_normal(c, fixedN); needV = true; sV = stampNow; needP = true; sP = stampNow; }
+                else {
+                    if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
+                }
+            }
+        }
+
+        /* ---- the wait IS the load: poll the records until every stamp is current ---- */
+        {
+            bool okP = !needP, okV = !needV, okD = !needD;
+            v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vv = p0, d0 = p0, d1 = p0;
+            unsigned spins = 0;
+            while (true) {
+                const bool lp = !okP, lv = !okV, ld = !okD;
+                if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
+                if (lv) vv = xld(rV, offV);
+                if (ld) { d0 = xld(rD, offD); d1 = xld(rD, offD + 16); }
+                asm volatile("" ::: "memory");                        /* the loads are re-issued on every round */
+                if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
+                if (lv) okV = stamp_reached(vv.w, sV);
+                if (ld) okD = stamp_reached(d0.w, sD) & stamp_reached(d1.w >> 1, sD);
+                if (__all(okP & okV & okD)) break;
+                if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
+                else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 1023u) == 0) {
+                    bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+                                __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            if (needP) {
+                opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
+                wOther = qrotate(orot, isA ? c.rB : c.rA);
+                pOther = opos + wOther;
+            }
+            if (needV) { c.lambda[1] = bitsf(vv.x); c.lambda[2] = bitsf(vv.y); c.stick = vv.z != 0; }
+            if (needD) {
+                c.lambda[0] = bitsf(d0.x); c.lambda[1] = bitsf(d0.y); c.lambda[2] = bitsf(d0.z);
+                c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
+                c.stick = (d1.w & 1u) != 0;
+            }
+        }
+
+        /* ---- primal visit (solver.cpp:344-409) ---- */
+        bool rowsOn = true;
+        if (has) {
+            rowsOn = eval_contact_pts(c, isA, L, wOwn, pOther, oinv, fric, alpha, rows + lane * kEntryRec);
+            if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xst(rV, offV, r); }
+        } else if (lane < nEnt + 2) {
+            clear_row_flags(rows + lane * kEntryRec);
+        }
+        const bool allOn = __all(rowsOn);
+        wave_sync();
+        if (allOn) accumulate_rows_all_on(a, rows, nEnt); else accumulate_rows(a, rows, nEnt);
+        if (lane < 27) accs[lane] = a.acc;
+        wave_sync();
+        f3 p; q4 q;
+        solve_pose(accs, accs + 32, lane, L, p, q);
+        if (lane == 0) {
+            sanitize3(p, cntW);
+            sanitizeq(q, cntW);
+            const int o = body * 48;
+            v4u r0 = {fbits(p.x), fbits(p.y), fbits(p.z), stampNow}, r1 = {fbits(q.x), fbits(q.y), fbits(q.z), stampNow}, r2 = {fbits(q.w), 0u, 0u, stampNow};
+            xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
+            accs[56] = p.x; accs[57] = p.y; accs[58] = p.z; accs[59] = q.x; accs[60] = q.y; accs[61] = q.z; accs[62] = q.w;
+        }
+        wave_sync();
+        L.pos = mk3(accs[56], accs[57], accs[58]); L.rot = mkq(accs[59], accs[60], accs[61], accs[62]);
+        wave_sync();
+
+        /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
+        if (doDual && has && owned) {
+            const f3 wNew = qrotate(L.rot, isA ? c.rA : c.rB);
+            const f3 pNew = L.pos + wNew;
+            if (isA) dual_contact_pts(c, pNew, wNew, L.invMass, pOther, wOther, oinv, fric, P, alpha);
+            else     dual_contact_pts(c, pOther, wOther, oinv, pNew, wNew, L.invMass, fric, P, alpha);
+            if (moving) {
+                v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
+                v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), (stampNow << 1) | (c.stick ? 1u : 0u)};
+                xst(rD, offD, r0); xst(rD, offD + 16, r1);
+            }
+        }
+    }
+
+    /* ---- once per step: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
+    if (lane == 0) {
+        B.plane(BP_POSR)[body] = pack3(L.pos, radius);
+        B.plane(BP_QUAT)[body] = packq(L.rot);
+    }
+    if (has && owned) store_contact_dual<false>(M, idx, c, true);
+}
+
+} // namespace avbd

@@ -84,7 +84,8 @@ struct Counters {
     int warnings;
     int dynamicBodies;
     int levelsConverged;
-    int pad[7];
+    int residentBad;    /* bit0: a swept body has > 64 incidence entries or a non-Manifold entry, bit1: more swept bodies than resident waves */
+    int pad[6];
 };
 
 struct DiagAccum { /* uint views of non-negative floats so atomicMax orders them */
