@@ -139,6 +139,7 @@ struct AvbdContext {
     int iterForceMode = 0;     /* 0 auto, 1 latency (1 workgroup/CU), 2 throughput (2 workgroups/CU) */
     DevArr<float4> xPose, xVisit, xDual; /* stamped exchange records of the resident schedule (avbd_resident.h) */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
+    bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     int numStatic = 0;
     bool statsFresh = true;
@@ -532,6 +533,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.numBodies = (int)c->hBodies.size(); c->stats.numManifolds = cnt.numManifolds; c->stats.numContacts = cnt.numContacts;
     c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = cnt.numLevels;
     c->stats.numDynamic = cnt.dynamicBodies;
+    c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && cnt.residentBad == 0) ? 2 : 1);
     int nj = 0, ns = 0, ni = 0;
     for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
@@ -616,6 +618,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
     X.enabled = (c->residentAllowed && c->iterForceMode != 2 && itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
                  totalItAll <= 60 && totalItAll > 0 && B.n - c->numStatic <= X.maxWaves && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
+    c->residentLaunched = X.enabled != 0;
     if (X.enabled) {
         if (c->xSerial >= (1u << 24) - 2u) {                       /* stamps are about to wrap: forget every old record */
             HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));

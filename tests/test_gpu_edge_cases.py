@@ -100,3 +100,64 @@ def test_throughput_mode_and_level_mode_agree(monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
         H.assert_same_world(o, g, f"Packed:6 with {env}")
+
+
+def test_resident_and_task_schedules_are_both_exercised_and_agree(monkeypatch):
+    """Contact-only scenes with few enough bodies run the resident schedule (stats.schedule == 2); AVBD_RESIDENT=0 forces
+    the task schedule (1).  Both must reproduce the CPU oracle bit for bit, including post-stabilisation and a scene
+    that changes between steps."""
+    for scene, steps in (("Stack", 40), ("Pyramid", 25), ("Stress1000", 60)):
+        o = H.CpuWorld("orc"); o.scene(scene); o.step(steps)
+        for resident in ("1", "0"):
+            monkeypatch.setenv("AVBD_RESIDENT", resident)
+            g = H.HipWorld(); g.scene(scene); g.step(steps)
+            monkeypatch.delenv("AVBD_RESIDENT")
+            assert int(g.w.stats()["schedule"]) == (2 if resident == "1" else 1), (scene, resident, int(g.w.stats()["schedule"]))
+            H.assert_same_world(o, g, f"{scene} resident={resident}")
+
+
+def test_resident_schedule_post_stabilize_and_odd_iteration_counts():
+    for iters, post in ((1, False), (3, True), (7, False), (20, True), (59, True)):
+        o, g = pair()
+        for w in (o, g):
+            w.scene("Stack")
+            w.set_params(iterations=iters, postStabilize=post)
+        for s in range(12):
+            o.step(); g.step()
+        assert int(g.w.stats()["schedule"]) == 2
+        H.assert_same_world(o, g, f"Stack iterations={iters} postStabilize={post}")
+
+
+def test_resident_schedule_vetoed_on_device_falls_back_to_tasks():
+    """> 64 entries on one swept body: the host cannot know, the device vetoes (Counters.residentBad) and the same launch
+    runs the task schedule; a scene with a joint is not offered to the resident schedule at all."""
+    o, g = pair()
+    for w in (o, g):
+        w.add_body((40, 1, 40), 0.0, 0.5, (0, -0.5, 0))
+        w.add_body((8, 0.5, 8), 0.5, 0.6, (0, 0.27, 0))
+        for i in range(5):
+            for j in range(5):
+                w.add_body((1, 1, 1), 1.0, 0.5, ((i - 2) * 1.3, 1.6, (j - 2) * 1.3))   # dropped: the plate starts with 4 contacts
+    seen = set()
+    for s in range(35):
+        o.step(); g.step()
+        seen.add(int(g.w.stats()["schedule"]))
+        H.assert_same_world(o, g, f"plate step {s + 1}")
+    assert seen == {1, 2}, seen          # resident while the plate has few contacts, tasks once it carries > 64
+    o, g = pair()
+    for w in (o, g):
+        w.scene("Stack")
+        w.add_joint(3, 4, (0, 0.5, 0), (0, -0.5, 0))
+    o.step(10); g.step(10)
+    assert int(g.w.stats()["schedule"]) == 1
+    H.assert_same_world(o, g, "Stack + joint")
+
+
+def test_too_many_iterations_for_the_stamp_window_uses_tasks():
+    o, g = pair()
+    for w in (o, g):
+        w.scene("Stack")
+        w.set_params(iterations=64)
+    o.step(5); g.step(5)
+    assert int(g.w.stats()["schedule"]) == 1
+    H.assert_same_world(o, g, "Stack iterations=64")
