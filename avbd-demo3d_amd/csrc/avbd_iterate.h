@@ -272,8 +272,8 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                     const f3 np = mk3(accs[56], accs[57], accs[58]); const q4 nq = mkq(accs[59], accs[60], accs[61], accs[62]);
                     const f3 wNew = qrotate(nq, isA ? c.rA : c.rB);
                     const f3 pNew = np + wNew;
-                    if (isA) dual_contact_pts(c, pNew, wNew, L.invMass, pOther, wOther, oinv, fric, P, alpha);
-                    else     dual_contact_pts(c, pOther, wOther, oinv, pNew, wNew, L.invMass, fric, P, alpha);
+                    dual_contact_pts(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? L.invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
+                                     isA ? oinv : L.invMass, fric, P, alpha);
                     store_contact_dual<true>(M, idx, c, lastDual);
                 }
                 drain_stores();

@@ -330,8 +330,8 @@ __device__ __forceinline__ bool eval_contact_pts(ContactRows& c, bool isA, const
 {
     const f3 pOwn = L.pos + wOwn;
     ContactBasis db;
-    if (isA) contact_compute_constraint_pts(c, alpha, pOwn, pOther, L.invMass, oinv, fric, db);
-    else     contact_compute_constraint_pts(c, alpha, pOther, pOwn, oinv, L.invMass, fric, db);
+    /* one inlined copy for both roles: lanes of a wave mix A-side and B-side contacts, a branch would run both */
+    contact_compute_constraint_pts(c, alpha, isA ? pOwn : pOther, isA ? pOther : pOwn, isA ? L.invMass : oinv, isA ? oinv : L.invMass, fric, db);
     f3 Jl[3], Ja[3];
     contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
     for (int k = 0; k < 3; ++k) {

@@ -203,8 +203,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         if (doDual && has && owned) {
             const f3 wNew = qrotate(L.rot, isA ? c.rA : c.rB);
             const f3 pNew = L.pos + wNew;
-            if (isA) dual_contact_pts(c, pNew, wNew, L.invMass, pOther, wOther, oinv, fric, P, alpha);
-            else     dual_contact_pts(c, pOther, wOther, oinv, pNew, wNew, L.invMass, fric, P, alpha);
+            dual_contact_pts(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? L.invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
+                             isA ? oinv : L.invMass, fric, P, alpha);
             if (moving) {
                 v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
                 v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), (stampNow << 1) | (c.stick ? 1u : 0u)};
