@@ -616,7 +616,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
     X.maxWaves = c->iterBlocks * kIterWaves;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
-    X.enabled = (c->residentAllowed && c->iterForceMode != 2 && itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
+    X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave && itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
                  totalItAll <= 60 && totalItAll > 0 && B.n - c->numStatic <= X.maxWaves && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
     c->residentLaunched = X.enabled != 0;
     if (X.enabled) {
@@ -844,13 +844,13 @@ int avbd_create(int device, AvbdContext** out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_createError = "hipGetDeviceProperties failed"; delete c; return AVBD_E_HIP; }
         c->iterBlocks = std::max(1, prop.multiProcessorCount);
-        c->iterLdsPad = 48 * 1024;
+        c->iterLdsPad = kIterWaves * kResProductBytesPerWave;   /* 84 672 B: > half a CU's LDS, and the resident schedule's product lines */
         if (const char* e = std::getenv("AVBD_ITER_BLOCKS")) c->iterBlocks = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_ITER_LDSPAD")) c->iterLdsPad = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
-        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_levels, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
@@ -1655,6 +1655,15 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* debug: per-wave time breakdown of the last k_iterate launch (only in -DAVBD_DF_STATS builds) */
+int avbd_debug_task_times(AvbdContext* c, unsigned* out, int iterations)
+{
+    if (!c || !out) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dFlags.p + 2 * (size_t)c->bodyCap + 16 + 1024 * 32, (size_t)iterations * 1024 * 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
 int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)
 {
     if (!c || !out) return AVBD_E_INVALID;

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
 {
     __shared__ float sRows[kIterWaves][66 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    extern __shared__ float4 sDynamic[];   /* latency mode: pins one workgroup per CU; the resident schedule keeps its product lines here */
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform by construction: tell the compiler */
     float* rows = sRows[wv];
     float* accs = sAcc[wv];
     const int W = gridDim.x * kIterWaves;
@@ -131,7 +132,13 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     if constexpr (WPE == 1) {
         /* every swept body fits one resident wavefront and is a plain pile of contacts: one wave per body for the whole loop */
         if (X.enabled && cnt->residentBad == 0) {
-            if (w < nd) iterate_resident(B, M, order[w], incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs);
+#ifdef AVBD_RES_SPREAD
+            if (wv != 0 || (int)blockIdx.x >= nd) return;
+            iterate_resident(B, M, order[blockIdx.x], incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, reinterpret_cast<float*>(sDynamic));
+            return;
+#endif
+            if (w < nd) iterate_resident(B, M, order[w], incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs,
+                                             reinterpret_cast<float*>(sDynamic) + wv * (kResProductBytesPerWave / 4));
             return;
         }
     }

@@ -64,15 +64,112 @@ __device__ __forceinline__ void replay_normal(ContactRows& c, bool& fixedN)
     fixedN = hit;
 }
 
+
+/* ---- ordered accumulation from pre-multiplied products -------------------------------------------------------------
+ * Per-wave LDS of the resident schedule (floats):
+ *   J[row][6]            Jl.xyz Ja.xyz of every row, written by the contact lanes BEFORE the wait
+ *   S[7][kResRows]       slot arrays f | penalty | gyro.x | gyro.y | gyro.z | penalty-usable flag | zeros, written AFTER the wait
+ *   Pr[27][kResStride]   one line per accumulator entry: Ja*Jb of every row (rhs entries: J alone), written BEFORE the wait
+ * so that after the wait an accumulator lane adds (product * penalty [+ gyro]) or (J * f) row by row — the reference's
+ * order and association, (Ja*Jb)*penalty (solver.cpp:387-391) — from three 16-byte LDS reads per four rows. */
+constexpr int kResRows = 192, kResStride = 196;
+constexpr int kResJFloats = kResRows * 6, kResSFloats = 7 * kResRows;   /* slot 6: zeros (what off-diagonal entries add) */
+constexpr int kResProductBytesPerWave = 27 * kResStride * 4;
+static_assert(kResJFloats + kResSFloats <= 66 * kEntryRec, "the J and S areas reuse the row staging area of k_iterate");
+
+/* rows 0..kResRegRows-1 keep their product in a register of the accumulator lane (no LDS read after the wait);
+ * later rows (a body with more than 12 contacts) go through the lane's product line in LDS */
+constexpr int kResRegRows = 36;
+
+__device__ __forceinline__ void store_products(const AccLane& a, const float* J, float (&pr)[kResRegRows], float* prLine, int nRows)
+{
+#pragma unroll
+    for (int r = 0; r < kResRegRows; ++r) pr[r] = 0.0f;
+    const bool rhs = a.mode == 2;                                   /* idle lanes (mode 3) multiply J[.][0] by itself: harmless, unread */
+    const float* ja = J + a.opA;
+    const float* jb = J + (rhs ? a.opA : a.opB);
+#pragma unroll
+    for (int e = 0; e < kResRegRows / 3; ++e) {
+        if (e * 3 < nRows) {                                        /* wave-uniform */
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = e * 3 + k;
+                const float va = ja[r * 6], vb = jb[r * 6];
+                pr[r] = rhs ? va : va * vb;
+            }
+        }
+    }
+    for (int r = kResRegRows; r < nRows; ++r) {
+        const float va = ja[r * 6], vb = jb[r * 6];
+        prLine[r] = rhs ? va : va * vb;
+    }
+}
+
+__device__ __forceinline__ float comp4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+template <bool ALLON>
+__device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr)[kResRegRows], const float* prLine, const float* S, int nRows)
+{
+    /* every lane runs the same instruction stream (idle lanes 27..63 compute a value nobody reads): no divergent branches,
+     * only wave-uniform ones on the row count */
+    const bool isAA = a.mode == 1, diag = a.gy >= 0, rhs = a.mode == 2;
+    const float4* s4 = reinterpret_cast<const float4*>(S + (rhs ? 0 : kResRows));
+    const float4* g4 = reinterpret_cast<const float4*>(S + kResRows * (diag ? a.gy - 6 : 6));
+    const float4* o4 = reinterpret_cast<const float4*>(S + kResRows * 5);
+    constexpr int NQ = kResRegRows / 4;
+    float4 sv[NQ], gv[NQ], ov[NQ];
+    /* every operand of the first 36 rows is requested before the dependent chain of additions starts */
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        sv[q] = gv[q] = make_float4(0.f, 0.f, 0.f, 0.f); ov[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (q * 4 < nRows) {                                        /* wave-uniform */
+            sv[q] = s4[q];
+            gv[q] = g4[q];
+            if (!ALLON) ov[q] = o4[q];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kResRegRows / 3; ++e) {
+        if (e * 3 < nRows) {                                        /* wave-uniform */
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = e * 3 + k;
+                const float nv = a.acc + pr[r] * comp4(sv[r >> 2], r & 3);
+                const float nvg = nv + comp4(gv[r >> 2], r & 3);     /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
+                const float nv2 = isAA ? nvg : nv;
+                if (ALLON) a.acc = nv2; else a.acc = (rhs || comp4(ov[r >> 2], r & 3) != 0.0f) ? nv2 : a.acc;
+            }
+        }
+    }
+    /* the rare tail: rows past the register window, four at a time from the LDS product line */
+    const float4* p4 = reinterpret_cast<const float4*>(prLine);
+    for (int r4 = kResRegRows; r4 < nRows; r4 += 4) {
+        const float4 pv = p4[r4 >> 2], sw = s4[r4 >> 2], gw = g4[r4 >> 2];
+        float4 ow = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!ALLON) ow = o4[r4 >> 2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r4 + k < nRows) {                                  /* wave-uniform */
+                const float nv = a.acc + comp4(pv, k) * comp4(sw, k);
+                const float nvg = nv + comp4(gw, k);
+                const float nv2 = isAA ? nvg : nv;
+                if (ALLON) a.acc = nv2; else a.acc = (rhs || comp4(ow, k) != 0.0f) ? nv2 : a.acc;
+            }
+        }
+    }
+}
+
 /* One wavefront = one body for all iterations.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
 __device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, int body, const int* __restrict__ incStart,
                                                  const int* __restrict__ inc, const SolverParams& P, int* errWord, Counters* cntW,
-                                                 const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs)
+                                                 const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products)
 {
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     const float4* massPlane = B.plane(BP_MASS);
-    const int eBeg = incStart[body], nEnt = incStart[body + 1] - eBeg;
+    body = __builtin_amdgcn_readfirstlane(body);                     /* wave-uniform: scalar loads and scalar branches below */
+    const int eBeg = __builtin_amdgcn_readfirstlane(incStart[body]);
+    const int nEnt = __builtin_amdgcn_readfirstlane(incStart[body + 1]) - eBeg;
     const bool has = lane < nEnt;
 
     /* ---- once per step: everything the loop needs, from the tables the earlier kernels of this step wrote ---- */
@@ -113,9 +210,21 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     const m33 Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
     const m33 Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
     const int offP = other * 48, offV = idx * 16, offD = idx * 32;
+    for (int r = lane; r < kResRows; r += 64) rows[kResJFloats + 6 * kResRows + r] = 0.0f;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#ifdef AVBD_DF_STATS
+    unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = t0;
+#define RS_STAMP(i) do { unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
 
     for (int it = 0; it < totalIt; ++it) {
+#ifdef AVBD_DF_STATS
+        unsigned* trec = reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)it * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8;
+        if (lane == 0) { trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[5] = (unsigned)body; }
+#endif
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;        /* what this task publishes */
@@ -126,6 +235,10 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         f3 wOwn = zero3();
         bool needP = false, needV = false, needD = false;
         unsigned sP = 0, sV = 0, sD = 0;
+        ContactPre pre; f3 G[3];
+        float* J = rows;
+        float* S = rows + kResJFloats;
+        float* prLine = products + (lane < 27 ? lane : 0) * kResStride;
         if (has) {
             wOwn = qrotate(L.rot, isA ? c.rA : c.rB);                 /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
@@ -134,7 +247,24 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
                 }
             }
+            /* first half of this visit's computeConstraint + computeDerivatives (manifold.cpp:247-271): own state only */
+            ContactBasis db;
+            contact_constraint_pre(c, alpha, isA ? L.invMass : oinv, isA ? oinv : L.invMass, pre, db);
+            f3 Jl[3], Ja[3];
+            contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
+            for (int k = 0; k < 3; ++k) {
+                G[k] = abs3(cross3(Ja[k], L.invIw * Ja[k]));          /* solver.cpp:393-397, to be scaled by |f| */
+                float* jr = J + (lane * 3 + k) * 6;
+                jr[0] = Jl[k].x; jr[1] = Jl[k].y; jr[2] = Jl[k].z; jr[3] = Ja[k].x; jr[4] = Ja[k].y; jr[5] = Ja[k].z;
+            }
         }
+        wave_sync();
+        float pr[kResRegRows];
+        store_products(a, J, pr, prLine, nEnt * 3);
+        RS_STAMP(7);
+#ifdef AVBD_DF_STATS
+        if (lane == 0) trec[1] = (unsigned)tprev;
+#endif
 
         /* ---- the wait IS the load: poll the records until every stamp is current ---- */
         {
@@ -151,6 +281,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if (lv) okV = stamp_reached(vv.w, sV);
                 if (ld) okD = stamp_reached(d0.w, sD) & stamp_reached(d1.w >> 1, sD);
                 if (__all(okP & okV & okD)) break;
+#ifdef AVBD_DF_STATS
+                stat[14] += 1;
+#endif
                 if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
                 else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
                 if ((++spins & 1023u) == 0) {
@@ -159,6 +292,16 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 }
             }
+            RS_STAMP(0);
+#ifdef AVBD_DF_STATS
+            if (lane == 0) { trec[2] = (unsigned)tprev; trec[6] = spins; }
+            if (spins >= 2) {                                        /* a real wait: how long ago was the last awaited pose published? */
+                unsigned now = (unsigned)tprev;
+                unsigned age = needP ? now - p2.y : 0xffffffffu;
+                for (int o = 32; o > 0; o >>= 1) { unsigned other_ = __shfl_xor(age, o); age = other_ < age ? other_ : age; }
+                if (age != 0xffffffffu && age < 100000u) { stat[12] += age; stat[13] += 1; }
+            }
+#endif
             if (needP) {
                 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
                 wOther = qrotate(orot, isA ? c.rB : c.rA);
@@ -175,16 +318,27 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         /* ---- primal visit (solver.cpp:344-409) ---- */
         bool rowsOn = true;
         if (has) {
-            rowsOn = eval_contact_pts(c, isA, L, wOwn, pOther, oinv, fric, alpha, rows + lane * kEntryRec);
+            const f3 pOwn = L.pos + wOwn;
+            contact_constraint_post(c, pre, isA ? pOwn : pOther, isA ? pOther : pOwn, fric);
             if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xst(rV, offV, r); }
-        } else if (lane < nEnt + 2) {
-            clear_row_flags(rows + lane * kEntryRec);
+            for (int k = 0; k < 3; ++k) {
+                const float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;     /* solver.cpp:379-381 with stiffness FLT_MAX, motor 0 */
+                const float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+                const f3 gyro = G[k] * fabsf(f);
+                const bool penOk = (c.penalty[k] > 0.0f) & (fabsf(c.penalty[k]) <= FLT_MAX);   /* solver.cpp:387 */
+                const int r = lane * 3 + k;
+                S[r] = f; S[kResRows + r] = c.penalty[k]; S[2 * kResRows + r] = gyro.x; S[3 * kResRows + r] = gyro.y; S[4 * kResRows + r] = gyro.z;
+                S[5 * kResRows + r] = penOk ? 1.0f : 0.0f;
+                rowsOn &= penOk;
+            }
         }
         const bool allOn = __all(rowsOn);
         wave_sync();
-        if (allOn) accumulate_rows_all_on(a, rows, nEnt); else accumulate_rows(a, rows, nEnt);
+        RS_STAMP(1);
+        if (allOn) accumulate_products<true>(a, pr, prLine, S, nEnt * 3); else accumulate_products<false>(a, pr, prLine, S, nEnt * 3);
         if (lane < 27) accs[lane] = a.acc;
         wave_sync();
+        RS_STAMP(2);
         f3 p; q4 q;
         solve_pose(accs, accs + 32, lane, L, p, q);
         if (lane == 0) {
@@ -192,12 +346,17 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             sanitizeq(q, cntW);
             const int o = body * 48;
             v4u r0 = {fbits(p.x), fbits(p.y), fbits(p.z), stampNow}, r1 = {fbits(q.x), fbits(q.y), fbits(q.z), stampNow}, r2 = {fbits(q.w), 0u, 0u, stampNow};
+#ifdef AVBD_DF_STATS
+            r2.y = (unsigned)__builtin_amdgcn_s_memrealtime();
+            trec[3] = r2.y;
+#endif
             xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
             accs[56] = p.x; accs[57] = p.y; accs[58] = p.z; accs[59] = q.x; accs[60] = q.y; accs[61] = q.z; accs[62] = q.w;
         }
         wave_sync();
         L.pos = mk3(accs[56], accs[57], accs[58]); L.rot = mkq(accs[59], accs[60], accs[61], accs[62]);
         wave_sync();
+        RS_STAMP(3);
 
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
         if (doDual && has && owned) {
@@ -211,7 +370,20 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 xst(rD, offD, r0); xst(rD, offD + 16, r1);
             }
         }
+        RS_STAMP(4);
+#ifdef AVBD_DF_STATS
+        if (lane == 0) trec[4] = (unsigned)tprev;
+        stat[5] += 1;
+#endif
     }
+#ifdef AVBD_DF_STATS
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(errWord + 16) + (size_t)(blockIdx.x * kIterWaves + (threadIdx.x >> 6)) * 16;
+        stat[6] = __builtin_amdgcn_s_memrealtime() - t0;
+        stat[8] = (unsigned long long)nEnt;
+        for (int i = 0; i < 16; ++i) o[i] = stat[i];
+    }
+#endif
 
     /* ---- once per step: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
     if (lane == 0) {

@@ -100,31 +100,43 @@ struct ContactBasis { f3 n, t1, t2; };
 
 /* `db` receives the basis the reference's computeDerivatives would rebuild right after this call from the normal
  * this call stores (manifold.cpp:253-254): the same memo rule applied to the new stored normal. */
-/* core on the two world-space contact points pA = posA + rotate(qA, rA), pB = posB + rotate(qB, rB) (manifold.cpp:188-190) */
-AVBD_HD void contact_compute_constraint_pts(ContactRows& c, float alpha, f3 pA, f3 pB, float invMassA, float invMassB,
-                                            float combinedFriction, ContactBasis& db)
+/* computeConstraint is evaluated in two halves so that a caller can run the first one before the partner's state is known:
+ *   pre  (manifold.cpp:185-187, 200-204): re-normalised normal + tangents, bias terms, normal-force cap — functions of the
+ *        contact's own stored state, alpha and the two inverse masses only;
+ *   post (manifold.cpp:188-243): everything that involves the two world-space contact points. */
+struct ContactPre { f3 n, t1, t2; float biasN, biasT1, biasT2, cap; };
+
+AVBD_HD void contact_constraint_pre(ContactRows& c, float alpha, float invMassA, float invMassB, ContactPre& pre, ContactBasis& db)
 {
     float biasScale = rclamp(1.0f - alpha, 0.0f, 1.0f);
-    f3 n, t1, t2;
     bool hit;
-    contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
-    c.normal = n; c.u1 = t1; c.u2 = t2;   /* stored normal and its memo move together */
-    if (hit) { db.n = n; db.t1 = t1; db.t2 = t2; }            /* same bits in, same basis out */
-    else { bool h2; contact_basis_memo(n, t1, t2, db.n, db.t1, db.t2, h2); }
-    f3 d = pA - pB;
-    float separation = dot3(d, n) - kNormalMargin;
-    float slip1 = dot3(d, t1);
-    float slip2 = dot3(d, t2);
-
-    c.C[0] = separation + biasScale * c.C0n;
+    contact_basis_memo(c.normal, c.u1, c.u2, pre.n, pre.t1, pre.t2, hit);
+    c.normal = pre.n; c.u1 = pre.t1; c.u2 = pre.t2;   /* stored normal and its memo move together */
+    if (hit) { db.n = pre.n; db.t1 = pre.t1; db.t2 = pre.t2; }            /* same bits in, same basis out */
+    else { bool h2; contact_basis_memo(pre.n, pre.t1, pre.t2, db.n, db.t1, db.t2, h2); }
+    pre.biasN = biasScale * c.C0n;
+    pre.biasT1 = biasScale * c.C0t1;
+    pre.biasT2 = biasScale * c.C0t2;
     float invMassSum = invMassA + invMassB;
     float massScale = (invMassSum > 1.0e-6f) ? (1.0f / invMassSum) : 1.0f;
-    float cap = kNormalForceCap * massScale;
+    pre.cap = kNormalForceCap * massScale;
+}
+
+/* core on the two world-space contact points pA = posA + rotate(qA, rA), pB = posB + rotate(qB, rB) (manifold.cpp:188-190) */
+AVBD_HD void contact_constraint_post(ContactRows& c, const ContactPre& pre, f3 pA, f3 pB, float combinedFriction)
+{
+    f3 d = pA - pB;
+    float separation = dot3(d, pre.n) - kNormalMargin;
+    float slip1 = dot3(d, pre.t1);
+    float slip2 = dot3(d, pre.t2);
+
+    c.C[0] = separation + pre.biasN;
+    float cap = pre.cap;
     c.fmin[0] = -cap;
     c.fmax[0] = 0.0f;
 
-    c.C[1] = slip1 + biasScale * c.C0t1;
-    c.C[2] = slip2 + biasScale * c.C0t2;
+    c.C[1] = slip1 + pre.biasT1;
+    c.C[2] = slip2 + pre.biasT2;
 
     float warmMag = fabsf(rmin(c.lambda[0], 0.0f));
     float trial = c.penalty[0] * c.C[0] + c.lambda[0];
@@ -150,7 +162,15 @@ AVBD_HD void contact_compute_constraint_pts(ContactRows& c, float alpha, f3 pA, 
     float tanSq = c.lambda[1] * c.lambda[1] + c.lambda[2] * c.lambda[2];
     float stickSq = kStickThresh * kStickThresh;
     c.stick = (slipSq <= stickSq) && (tanSq <= limit * limit + 1.0e-8f);
-    c.penetration = rmax(0.0f, -dot3(d, n));
+    c.penetration = rmax(0.0f, -dot3(d, pre.n));
+}
+
+AVBD_HD void contact_compute_constraint_pts(ContactRows& c, float alpha, f3 pA, f3 pB, float invMassA, float invMassB,
+                                            float combinedFriction, ContactBasis& db)
+{
+    ContactPre pre;
+    contact_constraint_pre(c, alpha, invMassA, invMassB, pre, db);
+    contact_constraint_post(c, pre, pA, pB, combinedFriction);
 }
 
 AVBD_HD void contact_compute_constraint(ContactRows& c, float alpha, f3 posA, q4 rotA, float invMassA, f3 posB, q4 rotB,

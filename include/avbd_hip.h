@@ -219,6 +219,8 @@ int  avbd_profile_get(AvbdContext* ctx, AvbdProfile* out);
 void* avbd_stream(AvbdContext* ctx);
 /* debug builds (-DAVBD_DF_STATS): per-wave time breakdown of the last k_iterate launch, 16 counters per wave */
 int  avbd_debug_iterate_stats(AvbdContext* ctx, unsigned long long* out, int waves);
+/* Per-task time stamps of the resident schedule (builds with -DAVBD_DF_STATS only; zeros otherwise): out[it][1024][8] u32. */
+int  avbd_debug_task_times(AvbdContext* ctx, unsigned* out, int iterations);
 
 #ifdef __cplusplus
 }
