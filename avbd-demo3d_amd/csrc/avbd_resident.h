@@ -51,6 +51,7 @@ __device__ __forceinline__ void xst(__amdgpu_buffer_rsrc_t r, int byteOff, v4u v
 __device__ __forceinline__ bool stamp_reached(unsigned have, unsigned need) { return (int)(have - need) >= 0; }
 __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float bitsf(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ float bcast0(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
 
 /* What one computeConstraint call does to the stored normal and its tangent memo (manifold.cpp:185-186 through
  * contact_basis_memo): used to replay the calls the OTHER visitor / the dual made since this wave last touched the
@@ -121,8 +122,9 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
     /* every operand of the first 36 rows is requested before the dependent chain of additions starts */
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        sv[q] = gv[q] = make_float4(0.f, 0.f, 0.f, 0.f); ov[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (q * 4 < nRows) {                                        /* wave-uniform */
+        /* the first blocks are fetched unconditionally (their slots always exist), the later ones only when the body has
+         * that many rows; a block that is not fetched is not read below (same wave-uniform condition) */
+        if (q < 3 || q * 4 < nRows) {                               /* wave-uniform */
             sv[q] = s4[q];
             gv[q] = g4[q];
             if (!ALLON) ov[q] = o4[q];
@@ -351,11 +353,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             trec[3] = r2.y;
 #endif
             xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
-            accs[56] = p.x; accs[57] = p.y; accs[58] = p.z; accs[59] = q.x; accs[60] = q.y; accs[61] = q.z; accs[62] = q.w;
         }
-        wave_sync();
-        L.pos = mk3(accs[56], accs[57], accs[58]); L.rot = mkq(accs[59], accs[60], accs[61], accs[62]);
-        wave_sync();
+        /* lane 0's result becomes the wave's (scalar) copy of the pose */
+        L.pos = mk3(bcast0(p.x), bcast0(p.y), bcast0(p.z)); L.rot = mkq(bcast0(q.x), bcast0(q.y), bcast0(q.z), bcast0(q.w));
         RS_STAMP(3);
 
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
