@@ -124,6 +124,7 @@ struct AvbdContext {
     /* topology */
     DevArr<int> adjStart, incStart, degForce, degInc, level, order, lvlStart, lvlCount, adjRef, adjOther, inc;
     DevArr<uint64_t> adjKey;
+    DevArr<int2> adjTmp;       /* (force reference, other body) in scatter order: k_topology_small */
     DevArr<int2> cand;
     int candCap = 0, adjCap = 0, incCap = 0, lvlCap = 0;
     bool adjDirty = true;
@@ -140,6 +141,8 @@ struct AvbdContext {
     DevArr<float4> xPose, xVisit, xDual; /* stamped exchange records of the resident schedule (avbd_resident.h) */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
     bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
+    bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
+    bool topologyDidPredict = false;
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     int numStatic = 0;
     bool statsFresh = true;
@@ -300,6 +303,7 @@ int ensure_topology_capacity(AvbdContext* c)
         HIPCHK(c, c->adjRef.alloc(needAdj));
         HIPCHK(c, c->adjOther.alloc(needAdj));
         HIPCHK(c, c->adjKey.alloc(needAdj));
+        HIPCHK(c, c->adjTmp.alloc(needAdj));
         c->adjCap = needAdj;
         c->adjDirty = true;
     }
@@ -505,6 +509,17 @@ int launch_topology(AvbdContext* c, bool fromStep)
         hipLaunchKernelGGL(k_count_deg, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, B, M, c->dCnt.p, c->degForce.p, c->degInc.p);
     }
     if (ng) hipLaunchKernelGGL(k_gforce_prepare, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, c->degForce.p, c->degInc.p, P, fromStep ? 1 : 0);
+    if (fromStep && c->fusedTopology && n <= kTopoBodies && c->mode != 0) {
+        /* small scene: scans, scatter, per-body order, levels, predictor and flag reset as one workgroup in LDS */
+        hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
+                           c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
+                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap + 16);
+        c->topologyDidPredict = true;
+        HIPCHK(c, hipGetLastError());
+        c->adjDirty = false;
+        return AVBD_OK;
+    }
+    c->topologyDidPredict = false;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, n, c->degForce.p, c->degInc.p, c->adjStart.p, c->incStart.p, c->dCnt.p, c->dNext.p);
     hipLaunchKernelGGL(k_fill_adj, dim3(grid_for((long long)c->stats.numManifolds + c->stats.numCandidates + ng + 4096, 256, 2048)), dim3(256), 0, c->stream,
                        M, c->dCnt.p, c->dG.p, ng, c->adjStart.p, c->degForce.p, c->adjRef.p, c->adjOther.p, c->adjKey.p);
@@ -585,12 +600,14 @@ int step_begin(AvbdContext* c)
         SpanGuard g(c, F_TOPO);
         if ((rc = launch_topology(c, true))) return rc;
     }
-    {
-        SpanGuard g(c, F_PREDICT);
-        hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
+    if (!c->topologyDidPredict) {
+        {
+            SpanGuard g(c, F_PREDICT);
+            hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
+        }
+        if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
+            HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * c->bodyCap + 16) * sizeof(int), c->stream));
     }
-    if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
-        HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * c->bodyCap + 16) * sizeof(int), c->stream));
     HIPCHK(c, hipGetLastError());
     return AVBD_OK;
 }
@@ -850,8 +867,11 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
+        fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
+        if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_levels, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
     }

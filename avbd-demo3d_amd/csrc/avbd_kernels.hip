@@ -470,10 +470,8 @@ __global__ void k_sort_levels(const int* lvlStart, int* order, const Counters* c
 __device__ __forceinline__ void sanitize3(f3& v, Counters* cnt) { if (!finite3(v)) { atomicAdd(&cnt->warnings, 1); v = zero3(); } }
 __device__ __forceinline__ void sanitizeq(q4& q, Counters* cnt) { if (!finiteq(q)) { atomicAdd(&cnt->warnings, 1); q = identq(); } }
 
-__global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
+__device__ __forceinline__ void predict_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.n) return;
     float4 pr = B.plane(BP_POSR)[i];
     f3 pos = mk3(pr.x, pr.y, pr.z);
     q4 rot = ldq(B.plane(BP_QUAT), i);
@@ -517,6 +515,248 @@ __global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
     B.plane(BP_NQUAT)[i] = packq(nrot);
     B.plane(BP_POSR)[i] = pack3(pos, pr.w);
     B.plane(BP_QUAT)[i] = packq(rot);
+}
+
+__global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    predict_body(B, i, P, cnt);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Small scenes (<= 4096 bodies, <= 6144 adjacency entries): the whole per-step topology — what k_scan, k_fill_adj,
+ * k_sort_expand and k_levels do in four launches — plus the predictor and the reset of the data-flow flags, as ONE
+ * workgroup working in LDS.  Five dependent launches of a few microseconds each become phases separated by
+ * workgroup barriers.  Same outputs (adjStart/adjRef/adjOther sorted newest-first, incStart/inc, level order).
+ * ------------------------------------------------------------------------------------------ */
+constexpr int kTopoBodies = 4096, kTopoEntries = 6144;
+constexpr int kTopoIntWords = (kTopoBodies + 1) * 2 + kTopoBodies;            /* adjStart | incStart | cursor */
+constexpr int kTopoLdsBytes = kTopoIntWords * 4 + 8 /* align */ + kTopoEntries * 8 /* keys, later neighbour lists */ +
+                              kTopoBodies * 2 /* levels */ + kTopoEntries * 2 * 3 /* entry body | rank | rows */;
+
+__global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTable M, const GForce* gf, int ng, Counters* cnt, const int* nextCount,
+                                                          int* degForce, int* degInc, int* adjStart, int* incStart, int* adjRef, int* adjOther,
+                                                          uint64_t* adjKey, int2* adjTmp, int* inc, int* level, int* lvlCount, int* lvlStart, int* order, int lvlCap,
+                                                          int residentWaves, SolverParams P, int* flags, int nFlags)
+{
+
+    extern __shared__ int sTopo[];
+    __shared__ unsigned long long sScan64[1024];
+    __shared__ int sChanged, sMax, sBad, sHist[1024];
+    const int n = B.n, t = threadIdx.x;
+    int* sAdj = sTopo;
+    int* sInc = sTopo + (kTopoBodies + 1);
+    int* sCur = sTopo + 2 * (kTopoBodies + 1);
+    unsigned long long* sKey = reinterpret_cast<unsigned long long*>(sTopo + ((kTopoIntWords + 1) & ~1));
+    unsigned short* sNbr = reinterpret_cast<unsigned short*>(sKey);                   /* reused once the keys are dead */
+    unsigned short* sLevel = reinterpret_cast<unsigned short*>(sKey + kTopoEntries);
+    unsigned short* sEntBody = sLevel + kTopoBodies;
+    unsigned short* sEntRank = sEntBody + kTopoEntries;
+    unsigned short* sEntRows = sEntRank + kTopoEntries;
+    const int nm = *nextCount;
+    if (t == 0) { cnt->numManifolds = nm; sBad = 0; }
+
+    /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below ---- */
+    for (int b = t; b < n; b += 1024) predict_body(B, b, P, cnt);
+    for (int i = t; i < nFlags; i += 1024) flags[i] = 0;
+
+    /* ---- phase 1: exclusive scans of the two degree arrays (one 64-bit scan: high word rows, low word forces) ---- */
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = min(n, lo + chunk);
+    unsigned long long mine = 0;
+    for (int i = lo; i < hi; ++i) mine += ((unsigned long long)(unsigned)degInc[i] << 32) | (unsigned)degForce[i];
+    sScan64[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long v = (t >= off) ? sScan64[t - off] : 0ull;
+        __syncthreads();
+        sScan64[t] += v;
+        __syncthreads();
+    }
+    {
+        unsigned long long base = sScan64[t] - mine;
+        for (int i = lo; i < hi; ++i) {
+            const int da = degForce[i], db = degInc[i];
+            const int a0 = (int)(unsigned)base, b0 = (int)(base >> 32);
+            sAdj[i] = a0; sInc[i] = b0; adjStart[i] = a0; incStart[i] = b0; sCur[i] = 0;
+            base += ((unsigned long long)(unsigned)db << 32) | (unsigned)da;
+            degForce[i] = 0; degInc[i] = 0;                          /* the next narrow phase counts from zero */
+        }
+        if (t == 1023) {
+            const int ea = (int)(unsigned)sScan64[1023], eb = (int)(sScan64[1023] >> 32);
+            sAdj[n] = ea; sInc[n] = eb; adjStart[n] = ea; incStart[n] = eb;
+        }
+    }
+    __syncthreads();
+    const int E = sAdj[n];
+    const bool inLds = E <= kTopoEntries;
+
+    /* ---- phase 2: scatter every force into the CSR segments of its two bodies ---- */
+    for (int item = t; item < nm + ng; item += 1024) {
+        int a, b, kind, index, rows; uint64_t key;
+        if (item < nm) { const int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; rows = M.nc[item]; }
+        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = f.kind; index = item - nm; key = f.key; rows = kind == FK_JOINT ? 2 : (kind == FK_SPRING ? 1 : 0); }
+        if (a >= 0) {
+            const int pos = sAdj[a] + atomicAdd(&sCur[a], 1);
+            adjTmp[pos] = make_int2(make_inc(1, kind, index), b);
+            if (inLds) { sKey[pos] = key; sEntBody[pos] = (unsigned short)a; sEntRows[pos] = (unsigned short)rows; } else adjKey[pos] = key;
+        }
+        if (b >= 0) {
+            const int pos = sAdj[b] + atomicAdd(&sCur[b], 1);
+            adjTmp[pos] = make_int2(make_inc(0, kind, index), a);
+            if (inLds) { sKey[pos] = key; sEntBody[pos] = (unsigned short)b; sEntRows[pos] = (unsigned short)rows; } else adjKey[pos] = key;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 3: newest-first order inside every swept body's segment, then the row-incidence list ---- */
+    if (inLds) {
+        /* one thread per ENTRY: rank of an entry = entries of the same body with a larger key */
+        for (int pos = t; pos < E; pos += 1024) {
+            const int b = sEntBody[pos];
+            int rank = pos - sAdj[b];                                 /* unswept bodies keep the scatter order (never visited in order) */
+            if (B.solved[b]) {
+                const unsigned long long k = sKey[pos];
+                const int s0 = sAdj[b], s1 = sAdj[b + 1];
+                rank = 0;
+                for (int j = s0; j < s1; ++j) rank += sKey[j] > k ? 1 : 0;
+            }
+            sEntRank[pos] = (unsigned short)rank;
+        }
+        __syncthreads();
+        for (int pos = t; pos < E; pos += 1024) {
+            const int b = sEntBody[pos];
+            const int s0 = sAdj[b], s1 = sAdj[b + 1];
+            const int rank = sEntRank[pos];
+            const int2 ro = adjTmp[pos];
+            adjRef[s0 + rank] = ro.x; adjOther[s0 + rank] = ro.y;
+            if (B.solved[b]) {
+                /* row-incidence entries of this force start after those of every force that precedes it in the list */
+                int off = 0;
+                for (int j = s0; j < s1; ++j) off += sEntRank[j] < rank ? sEntRows[j] : 0;
+                const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
+                int* out = inc + sInc[b] + off;
+                if (kind == FK_MANIFOLD) { const int nc = sEntRows[pos]; for (int c = 0; c < nc; ++c) out[c] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
+                else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); sBad = 1; }
+                else if (kind == FK_SPRING) { out[0] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
+            }
+        }
+    } else {
+        /* more entries than the LDS staging holds (dense packings): one thread per BODY, insertion sort in global memory */
+        for (int b = t; b < n; b += 1024) {
+            const int s0 = sAdj[b], s1 = sAdj[b + 1];
+            if (B.solved[b]) {
+                for (int i = s0 + 1; i < s1; ++i) {
+                    const uint64_t k = adjKey[i]; const int2 ro = adjTmp[i];
+                    int j = i - 1;
+                    while (j >= s0 && adjKey[j] < k) { adjKey[j + 1] = adjKey[j]; adjTmp[j + 1] = adjTmp[j]; --j; }
+                    adjKey[j + 1] = k; adjTmp[j + 1] = ro;
+                }
+            }
+            int o = sInc[b];
+            for (int i = s0; i < s1; ++i) {
+                const int2 ro = adjTmp[i];
+                adjRef[i] = ro.x; adjOther[i] = ro.y;
+                if (!B.solved[b]) continue;
+                const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
+                if (kind == FK_MANIFOLD) { const int nc = M.nc[idx]; for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
+                else if (kind == FK_JOINT) { inc[o++] = make_inc(isA, FK_JOINT, idx * 2); inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1); sBad = 1; }
+                else if (kind == FK_SPRING) { inc[o++] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
+            }
+        }
+    }
+    for (int b = t; b < n; b += 1024) {
+        sLevel[b] = 0;
+        if (B.solved[b] && sInc[b + 1] - sInc[b] > 64) sBad = 1;      /* the resident schedule keeps one contact per lane */
+    }
+    __syncthreads();
+
+    /* ---- phase 4: dependency levels (level = 1 + max level of the later-created swept neighbours), relaxed in LDS ---- */
+    constexpr int kPer = kTopoBodies / 1024;
+    int seg[kPer], cnt_[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int b = t + q * 1024;
+        seg[q] = 0; cnt_[q] = -1;
+        if (b < n && B.solved[b]) {
+            const int s0 = sAdj[b], s1 = sAdj[b + 1];
+            int c = 0;
+            if (inLds) {                                              /* compact the relevant neighbours once, 16-bit, in the dead key area */
+                for (int k = s0; k < s1; ++k) {
+                    const int2 ro = adjTmp[k];                        /* any order will do here */
+                    if (ro.y > b && inc_kind(ro.x) != FK_IGNORE && B.solved[ro.y]) sNbr[s0 + c++] = (unsigned short)ro.y;
+                }
+            }
+            seg[q] = s0; cnt_[q] = inLds ? c : (s1 - s0);
+        }
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep <= n; ++sweep) {
+        if (t == 0) sChanged = 0;
+        __syncthreads();
+        int changed = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            if (cnt_[q] < 0) continue;
+            const int b = t + q * 1024;
+            int lv = 1;
+            if (inLds) {
+                for (int z = 0; z < cnt_[q]; ++z) { int lo2 = (int)sLevel[sNbr[seg[q] + z]] + 1; if (lo2 > lv) lv = lo2; }
+            } else {
+                for (int z = 0; z < cnt_[q]; ++z) {
+                    const int2 ro = adjTmp[seg[q] + z];
+                    if (ro.y > b && inc_kind(ro.x) != FK_IGNORE && B.solved[ro.y]) { int lo2 = (int)sLevel[ro.y] + 1; if (lo2 > lv) lv = lo2; }
+                }
+            }
+            if (lv != (int)sLevel[b]) { sLevel[b] = (unsigned short)lv; changed = 1; }
+        }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        const int c = sChanged;
+        __syncthreads();
+        if (!c) break;
+    }
+
+    /* ---- phase 5: bodies grouped by level (counting sort; levels of a small scene fit one histogram word per thread) ---- */
+    if (t == 0) sMax = 0;
+    sHist[t] = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int b = t; b < n; b += 1024) {
+        const int lv = sLevel[b];
+        level[b] = lv;
+        if (lv > 0) { if (lv < 1024) atomicAdd(&sHist[lv], 1); if (lv > mx) mx = lv; }
+    }
+    atomicMax(&sMax, mx);
+    __syncthreads();
+    const int L = sMax;                                               /* levels are 1..L */
+    if (L >= 1024 || L >= lvlCap) { if (t == 0) { cnt->numLevels = 0; atomicOr(&cnt->overflow, 8); } return; }
+    /* exclusive scan of sHist[1..L]: thread t owns level t+1 */
+    const int hv = (t < L) ? sHist[t + 1] : 0;
+    sScan64[t] = (unsigned long long)hv;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long v = (t >= off) ? sScan64[t - off] : 0ull;
+        __syncthreads();
+        sScan64[t] += v;
+        __syncthreads();
+    }
+    const int startL = (int)sScan64[t] - hv;
+    if (t < L) { lvlStart[t] = startL; sHist[t + 1] = startL; }       /* sHist becomes the fill cursor of its level */
+    if (t == 0) lvlStart[L] = (int)sScan64[1023];
+    __syncthreads();
+    for (int b = t; b < n; b += 1024) {
+        const int lv = sLevel[b];
+        if (lv > 0) order[atomicAdd(&sHist[lv], 1)] = b;
+    }
+    if (t == 0) {
+        cnt->numLevels = L;
+        int bad = sBad ? 1 : 0;
+        if ((int)sScan64[1023] > residentWaves) bad |= 2;
+        if (bad) atomicOr(&cnt->residentBad, bad);
+    }
+
 }
 
 /* K5 primal, K6 dual and the fused data-flow iteration kernel live in avbd_primal.h / avbd_iterate.h */

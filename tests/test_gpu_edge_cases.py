@@ -161,3 +161,17 @@ def test_too_many_iterations_for_the_stamp_window_uses_tasks():
     o.step(5); g.step(5)
     assert int(g.w.stats()["schedule"]) == 1
     H.assert_same_world(o, g, "Stack iterations=64")
+
+
+def test_fused_topology_kernel_fast_and_slow_paths(monkeypatch):
+    """k_topology_small stages at most 6144 adjacency entries in LDS; a packing of 3376 cubes has more and takes its
+    in-kernel global-memory path (Packed:15: 3376 cubes, > 3072 manifolds); AVBD_FUSED_TOPOLOGY=0 is the multi-launch chain.  All three agree with the oracle."""
+    for scene, steps in (("Packed:15", 12), ("Stress1000", 40)):
+        o = H.CpuWorld("orc"); o.scene(scene); o.step(steps)
+        for fused in ("1", "0"):
+            monkeypatch.setenv("AVBD_FUSED_TOPOLOGY", fused)
+            g = H.HipWorld(); g.scene(scene); g.step(steps)
+            monkeypatch.delenv("AVBD_FUSED_TOPOLOGY")
+            H.assert_same_world(o, g, f"{scene} fused_topology={fused}")
+        if scene == "Packed:15":
+            assert 2 * int(g.w.stats()["numManifolds"]) > 6144
