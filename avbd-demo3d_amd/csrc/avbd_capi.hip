@@ -592,7 +592,7 @@ int step_begin(AvbdContext* c)
         SpanGuard g(c, F_NARROW);
         ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
         long long est = (long long)c->stats.numManifolds + std::max(c->stats.numCandidates, n) + 4096;
-        hipLaunchKernelGGL(k_narrowphase, dim3(grid_for(est * 2, 128, 8192)), dim3(128), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
+        hipLaunchKernelGGL(k_narrowphase, dim3(grid_for(est * 2, 32, 32768)), dim3(32), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
                            c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex);
         c->cur ^= 1;
     }

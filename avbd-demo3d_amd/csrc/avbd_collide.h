@@ -115,9 +115,12 @@ AVBD_HD bool add_contact(const BoxPose& A, const BoxPose& B, RawContact* cs, int
     return true;
 }
 
+/* working storage of the manifold builders: indexed dynamically, so a kernel keeps it in LDS (scratch otherwise) */
+struct CollideScratch { f3 clip0[kMaxPolyVerts], clip1[kMaxPolyVerts]; f3 mids[kMaxContacts]; };
+
 /* collision.cpp:313-394 — reference-face clipping manifold. */
 AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& boxA, const Obb& boxB, bool refIsA,
-                                int refAxis, f3 nAB, RawContact* cs)
+                                int refAxis, f3 nAB, RawContact* cs, CollideScratch& ws)
 {
     const Obb& refBox = refIsA ? boxA : boxB;
     const Obb& incBox = refIsA ? boxB : boxA;
@@ -142,7 +145,7 @@ AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& b
         }
     }
 
-    f3 clip0[kMaxPolyVerts], clip1[kMaxPolyVerts];
+    f3* clip0 = ws.clip0; f3* clip1 = ws.clip1;
     {   /* buildIncidentFace, collision.cpp:118-134 */
         f3 iax = obb_axis(incBox, incAxis);
         float s = dot3(iax, fN) > 0.0f ? -1.0f : 1.0f;
@@ -166,7 +169,7 @@ AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& b
     count = clip_polygon(clip1, count, n3, o3, clip0); if (!count) return 0;
 
     int cc = 0;
-    f3 mids[kMaxContacts];
+    f3* mids = ws.mids;
     int prefix = (refIsA ? 0 : 1) << 24;
     prefix |= (refAxis & 0xFF) << 16;
     prefix |= (incAxis & 0xFF) << 8;
@@ -229,7 +232,7 @@ AVBD_HD void closest_on_segments(f3 p0, f3 p1, f3 q0, f3 q1, f3& c0, f3& c1)
 
 /* collision.cpp:396-416 */
 AVBD_HD int build_edge_contact(const BoxPose& A, const BoxPose& B, const Obb& boxA, const Obb& boxB, int axA, int axB,
-                               f3 nAB, RawContact* cs)
+                               f3 nAB, RawContact* cs, CollideScratch& ws)
 {
     f3 a0, a1, b0, b1;
     support_edge(boxA, axA, nAB, a0, a1);
@@ -237,14 +240,14 @@ AVBD_HD int build_edge_contact(const BoxPose& A, const BoxPose& B, const Obb& bo
     f3 xA, xB;
     closest_on_segments(a0, a1, b0, b1, xA, xB);
     int cc = 0;
-    f3 mids[kMaxContacts];
+    f3* mids = ws.mids;
     int key = (2 << 24) | ((axA & 0xFF) << 8) | (axB & 0xFF);
     add_contact(A, B, cs, cc, mids, xA, xB, key, -nAB);
     return cc;
 }
 
 /* Manifold::collide, collision.cpp:420-489 with flip=false. */
-AVBD_HD int collide_boxes(const BoxPose& A, const BoxPose& B, RawContact* cs)
+AVBD_HD int collide_boxes(const BoxPose& A, const BoxPose& B, RawContact* cs, CollideScratch& ws)
 {
     Obb boxA = make_obb(A), boxB = make_obb(B);
     f3 delta = boxB.center - boxA.center;
@@ -267,9 +270,16 @@ AVBD_HD int collide_boxes(const BoxPose& A, const BoxPose& B, RawContact* cs)
         const float relTol = 0.95f, absTol = 0.01f;          /* collision.cpp:463-467 */
         if (relTol * bestEdge.sep > bestFace.sep + absTol) best = bestEdge;
     }
-    if (best.type == 2) return build_edge_contact(A, B, boxA, boxB, best.iA, best.iB, best.nAB, cs);
-    if (best.type == 0) return build_face_manifold(A, B, boxA, boxB, true, best.iA, best.nAB, cs);
-    return build_face_manifold(A, B, boxA, boxB, false, best.iB, best.nAB, cs);
+    if (best.type == 2) return build_edge_contact(A, B, boxA, boxB, best.iA, best.iB, best.nAB, cs, ws);
+    /* one inlined copy of the face builder for both roles (lanes of a wave mix them) */
+    const bool refIsA = best.type == 0;
+    return build_face_manifold(A, B, boxA, boxB, refIsA, refIsA ? best.iA : best.iB, best.nAB, cs, ws);
+}
+
+AVBD_HD int collide_boxes(const BoxPose& A, const BoxPose& B, RawContact* cs)
+{
+    CollideScratch ws;
+    return collide_boxes(A, B, cs, ws);
 }
 
 } // namespace avbd

@@ -155,14 +155,18 @@ __device__ __forceinline__ BoxPose load_box(const BodyTable& B, int i, float& fr
     return p;
 }
 
-__global__ __launch_bounds__(128) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
+__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
                                                       int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
 {
     const int nOld = cnt->numManifolds;
     int nCand = cnt->numCandidates; if (nCand > candCap) nCand = candCap;
     const int total = nOld + nCand;
+    /* 32 pairs per workgroup: with ~5000 pairs and 1024 SIMDs a half-filled wavefront costs nothing and halves the branch
+     * divergence; the dynamically indexed per-pair state lives in LDS instead of scratch */
+    __shared__ ManifoldInit sMi[32];
+    __shared__ ManifoldOld sOld[32];
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-        ManifoldInit mi;
+        ManifoldInit& mi = sMi[threadIdx.x];
         int a, b; uint64_t key;
         if (item < nOld) {
             int2 pr = src.pair[item]; a = pr.x; b = pr.y; key = src.key[item];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(128) void k_narrowphase(BodyTable B, ManifoldTable 
         float fa, fb, ima, imb;
         BoxPose A = load_box(B, a, fa, ima);
         BoxPose Bp = load_box(B, b, fb, imb);
-        if (!manifold_initialize(mi, A, fa, Bp, fb)) continue;
+        if (!manifold_initialize(mi, sOld[threadIdx.x], A, fa, Bp, fb)) continue;
 
         /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
         const int rows = mi.numContacts * 3;

@@ -216,16 +216,28 @@ struct ManifoldInit {
     float lambda[12], penalty[12];
 };
 
+/* the previous step's contacts while the new ones are matched against them (manifold.cpp:76-84); a separate object so
+ * that a kernel can keep it (and ManifoldInit) in LDS: both are indexed dynamically and would otherwise live in scratch */
+struct ManifoldOld {
+    RawContact raw[4];           /* what collide_boxes found this step */
+    CollideScratch ws;
+    int   feature[4];
+    f3    rA[4], rB[4], normal[4];
+    bool  stick[4], used[4];
+    float lambda[12], penalty[12];
+};
+
 /* `m` holds the previous step's contacts on entry (numContacts = 0 for a fresh manifold) and the
  * new manifold on exit.  Returns false when the pair no longer touches (the reference deletes it). */
-AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float frictionA, const BoxPose& B, float frictionB)
+AVBD_HD bool manifold_initialize(ManifoldInit& m, ManifoldOld& old, const BoxPose& A, float frictionA, const BoxPose& B, float frictionB)
 {
     m.combinedFriction = sqrtf(frictionA * frictionB);
 
     int   oldN = m.numContacts;
-    int   oldFeature[4]; f3 oldRA[4], oldRB[4], oldNormal[4]; bool oldStick[4];
-    float oldLambda[12], oldPenalty[12];
-    bool  oldUsed[4] = {false, false, false, false};
+    int* oldFeature = old.feature; f3* oldRA = old.rA; f3* oldRB = old.rB; f3* oldNormal = old.normal; bool* oldStick = old.stick;
+    float* oldLambda = old.lambda; float* oldPenalty = old.penalty;
+    bool* oldUsed = old.used;
+    for (int i = 0; i < 4; ++i) oldUsed[i] = false;
     for (int i = 0; i < 4; ++i) {
         if (i < oldN) {
             oldFeature[i] = m.feature[i]; oldRA[i] = m.rA[i]; oldRB[i] = m.rB[i]; oldNormal[i] = m.normal[i]; oldStick[i] = m.stick[i];
@@ -233,8 +245,8 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float fricti
         }
     }
 
-    RawContact raw[4];
-    m.numContacts = collide_boxes(A, B, raw);
+    RawContact* raw = old.raw;
+    m.numContacts = collide_boxes(A, B, raw, old.ws);
     if (m.numContacts == 0) return false;
 
     for (int i = 0; i < 4; ++i) {
@@ -284,6 +296,12 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float fricti
         m.penetration[i] = rmax(0.0f, -dot3(d, n));
     }
     return true;
+}
+
+AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float frictionA, const BoxPose& B, float frictionB)
+{
+    ManifoldOld old;
+    return manifold_initialize(m, old, A, frictionA, B, frictionB);
 }
 
 /* ---- Joint (6 rows) — joint.cpp:68-139, bug-compatible angular Jacobian sign --- */
