@@ -11,10 +11,12 @@ measured in its contact-rich steady window: the scene is first simulated `--pres
 all state resident in HBM, bracketed by barrier + device synchronize; value = steps / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (k_iterate: the persistent data-flow launch that runs the whole iteration loop;
-                k_primal with AVBD_MODE=levels): algorithmic bytes per launch (SURVEY.md §8d model, recomputed
-                from the live scene every step) / mean launch duration from HIP events recorded around every
-                launch on the solver's own stream, against 8 TB/s HBM peak.
+  roofline      dominant kernel (k_iterate: the persistent launch that runs the whole iteration loop — resident
+                schedule, one wavefront per body; k_primal with AVBD_MODE=levels): algorithmic bytes per launch
+                (SURVEY.md §8d model, recomputed from the live scene every step) / mean launch duration from HIP
+                events recorded around every launch on the solver's own stream, against 8 TB/s HBM peak.
+                The kernel is bound by a dependency chain (203 sequential body solves per step), not by bytes:
+                DESIGN.md §5 gives the per-hop latency budget that actually bounds it.
   cpu_baseline  the CPU oracle (port of the reference, bit-identical to it) timed on this box's host, one
                 thread, started from the SAME state as the timed GPU window; when it covers the whole window the
                 final states are compared bit for bit ("parity": "bit-exact").
@@ -56,9 +58,9 @@ def algorithmic_bytes(stats, iterations):
 
 def pmc_traffic(scene, fused):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r1_dataflow_window_summary.json; (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md §HBM).  PMC counters
+    (profiles/r1_resident_window_summary.json; (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md §HBM).  PMC counters
     cannot be read from inside the process, so this is null for any other workload or mode."""
-    path = os.path.join(ROOT, "profiles", "r1_dataflow_window_summary.json")
+    path = os.path.join(ROOT, "profiles", "r1_resident_window_summary.json")
     if scene != "Stress1000" or not fused or not os.path.exists(path):
         return None
     try:
