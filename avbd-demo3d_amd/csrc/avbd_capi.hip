@@ -141,6 +141,7 @@ struct AvbdContext {
     DevArr<float4> xPose, xVisit, xDual; /* stamped exchange records of the resident schedule (avbd_resident.h) */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
     bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
+    bool fusedFront = true;        /* AVBD_FUSED_FRONT=0: separate broadphase and narrow-phase launches */
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
@@ -577,6 +578,17 @@ int step_begin(AvbdContext* c)
 
     ++c->stepIndex;
     hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p);
+    if (c->fusedFront && n > 1 && n <= 4096) {
+        /* small scene: persistent manifolds and the broadphase (+ its own candidates) side by side in one launch */
+        SpanGuard g(c, F_NARROW);
+        ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
+        const int slices = (n + 31) / 32;
+        const int persistBlocks = std::max(1, std::min(4096, (c->stats.numManifolds + c->stats.numCandidates + n + 31) / 32));
+        const int broadBlocks = (int)(((long long)n * slices + 31) / 32);
+        hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(32), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
+                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices);
+        c->cur ^= 1;
+    } else {
     {
         SpanGuard g(c, F_BROAD);
         if (n > 1 && n <= 4096) {
@@ -595,6 +607,7 @@ int step_begin(AvbdContext* c)
         hipLaunchKernelGGL(k_narrowphase, dim3(grid_for(est * 2, 32, 32768)), dim3(32), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
                            c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex);
         c->cur ^= 1;
+    }
     }
     {
         SpanGuard g(c, F_TOPO);
@@ -868,6 +881,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);

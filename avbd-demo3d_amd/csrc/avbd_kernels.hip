@@ -155,6 +155,74 @@ __device__ __forceinline__ BoxPose load_box(const BodyTable& B, int i, float& fr
     return p;
 }
 
+/* one pair: last step's manifold `item` of `src` (item >= 0) or a fresh candidate (a, b); survivors are appended to dst */
+__device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTable& src, const ManifoldTable& dst, int item, int a, int b, int step,
+                                            ManifoldInit& mi, ManifoldOld& old, Counters* cnt, int* nextCount, int* degForce, int* degInc, const SolverParams& P)
+{
+    uint64_t key;
+    if (item >= 0) {
+        int2 pr = src.pair[item]; a = pr.x; b = pr.y; key = src.key[item];
+        mi.numContacts = src.nc[item];
+        for (int c = 0; c < 4; ++c) {
+            if (c < mi.numContacts) {
+                int s = item * 4 + c;
+                float4 ra = src.cRA[s], rb = src.cRB[s], nn = src.cN[s], lam = src.cLam[s], pen = src.cPen[s];
+                int2 fs = src.cFS[s];
+                mi.feature[c] = fs.x; mi.stick[c] = fs.y != 0;
+                mi.rA[c] = mk3(ra.x, ra.y, ra.z); mi.rB[c] = mk3(rb.x, rb.y, rb.z); mi.normal[c] = mk3(nn.x, nn.y, nn.z);
+                mi.lambda[c * 3 + 0] = lam.x; mi.lambda[c * 3 + 1] = lam.y; mi.lambda[c * 3 + 2] = lam.z;
+                mi.penalty[c * 3 + 0] = pen.x; mi.penalty[c * 3 + 1] = pen.y; mi.penalty[c * 3 + 2] = pen.z;
+            }
+        }
+    } else {
+        key = make_manifold_key(step, a, b);
+        mi.numContacts = 0;
+    }
+    float fa, fb, ima, imb;
+    BoxPose A = load_box(B, a, fa, ima);
+    BoxPose Bp = load_box(B, b, fb, imb);
+    if (!manifold_initialize(mi, old, A, fa, Bp, fb)) return;
+
+    /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
+    const int rows = mi.numContacts * 3;
+    for (int r = 0; r < 12; ++r) {
+        if (r < rows) {
+            if (!P.postStabilize) mi.lambda[r] *= P.alpha * P.gamma;
+            mi.penalty[r] = rclamp(mi.penalty[r] * P.gamma, kPenaltyMin, kPenaltyMax);
+        }
+    }
+
+    int slot = atomicAdd(nextCount, 1);
+    if (slot >= dst.cap) { atomicOr(&cnt->overflow, 2); return; }
+    dst.pair[slot] = make_int2(a, b);
+    dst.key[slot] = key;
+    dst.nc[slot] = mi.numContacts;
+    dst.fric[slot] = mi.combinedFriction;
+    for (int c = 0; c < 4; ++c) {
+        if (c < mi.numContacts) {
+            int s = slot * 4 + c;
+            dst.cRA[s] = pack3(mi.rA[c], mi.C0n[c]);
+            dst.cRB[s] = pack3(mi.rB[c], mi.C0t1[c]);
+            dst.cN[s] = pack3(mi.normal[c], mi.C0t2[c]);
+            dst.cU1[s] = pack3(mi.u1[c], 0.f);
+            dst.cU2[s] = pack3(mi.u2[c], 0.f);
+            dst.cLam[s] = make_float4(mi.lambda[c * 3], mi.lambda[c * 3 + 1], mi.lambda[c * 3 + 2], mi.penetration[c]);
+            dst.cPen[s] = make_float4(mi.penalty[c * 3], mi.penalty[c * 3 + 1], mi.penalty[c * 3 + 2], 0.0f);
+            dst.cFS[s] = make_int2(mi.feature[c], mi.stick[c] ? 1 : 0);
+            dst.cC[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst.cFmin[s] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+            dst.cFmax[s] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+        }
+    }
+    atomicAdd(&degForce[a], 1);
+    atomicAdd(&degForce[b], 1);
+    int inc = 0;
+    if (B.solved[a]) { atomicAdd(&degInc[a], mi.numContacts); inc += mi.numContacts; }
+    if (B.solved[b]) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
+    atomicAdd(&cnt->numContacts, mi.numContacts);
+    atomicAdd(&cnt->numIncidences, inc);
+}
+
 __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
                                                       int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
 {
@@ -166,70 +234,67 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __shared__ ManifoldInit sMi[32];
     __shared__ ManifoldOld sOld[32];
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-        ManifoldInit& mi = sMi[threadIdx.x];
-        int a, b; uint64_t key;
-        if (item < nOld) {
-            int2 pr = src.pair[item]; a = pr.x; b = pr.y; key = src.key[item];
-            mi.numContacts = src.nc[item];
-            for (int c = 0; c < 4; ++c) {
-                if (c < mi.numContacts) {
-                    int s = item * 4 + c;
-                    float4 ra = src.cRA[s], rb = src.cRB[s], nn = src.cN[s], lam = src.cLam[s], pen = src.cPen[s];
-                    int2 fs = src.cFS[s];
-                    mi.feature[c] = fs.x; mi.stick[c] = fs.y != 0;
-                    mi.rA[c] = mk3(ra.x, ra.y, ra.z); mi.rB[c] = mk3(rb.x, rb.y, rb.z); mi.normal[c] = mk3(nn.x, nn.y, nn.z);
-                    mi.lambda[c * 3 + 0] = lam.x; mi.lambda[c * 3 + 1] = lam.y; mi.lambda[c * 3 + 2] = lam.z;
-                    mi.penalty[c * 3 + 0] = pen.x; mi.penalty[c * 3 + 1] = pen.y; mi.penalty[c * 3 + 2] = pen.z;
+        int a = 0, b = 0;
+        if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
+        narrow_pair(B, src, dst, item < nOld ? item : -1, a, b, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+    }
+}
+
+/* Small scenes: broadphase and narrow phase as ONE launch.  The first `persistBlocks` workgroups re-collide last step's
+ * manifolds (they do not depend on the broadphase); every other workgroup enumerates 32 (body, 32-body slice) pair sets,
+ * keeps its sphere-overlapping, unconstrained pairs in LDS and then collides them itself, one pair per lane.  Creation
+ * keys make the order in which manifolds are appended irrelevant (avbd_types.h: make_manifold_key). */
+constexpr int kFrontHits = 1024;   /* 32 threads x 32 pairs: a workgroup can never find more */
+__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
+                                                      const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
+                                                      int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
+{
+    __shared__ ManifoldInit sMi[32];
+    __shared__ ManifoldOld sOld[32];
+    __shared__ int2 sHits[kFrontHits];
+    __shared__ int sNumHits;
+    if ((int)blockIdx.x < persistBlocks) {
+        const int nOld = cnt->numManifolds;
+        for (int item = blockIdx.x * 32 + threadIdx.x; item < nOld; item += persistBlocks * 32)
+            narrow_pair(B, src, dst, item, 0, 0, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+        return;
+    }
+    if (threadIdx.x == 0) sNumHits = 0;
+    __syncthreads();
+    const float4* posr = B.plane(BP_POSR);
+    const int n = B.n;
+    const int t = ((int)blockIdx.x - persistBlocks) * 32 + threadIdx.x;
+    const int i = t / slices, sl = t - i * slices;
+    const int jBeg = sl * 32;
+    int jEnd = jBeg + 32; if (jEnd > i) jEnd = i;
+    if (i < n && jBeg < jEnd) {
+        const float4 a = posr[i];
+        const f3 pa = mk3(a.x, a.y, a.z);
+        const bool solvedI = B.solved[i] != 0;
+        for (int j = jBeg; j < jEnd; ++j) {
+            const float4 b = posr[j];
+            f3 dp = pa - mk3(b.x, b.y, b.z);
+            float r = a.w + b.w;
+            if (dot3(dp, dp) <= r * r) {
+                if (!solvedI && !B.solved[j]) {
+                    const bool bothStatic = !(B.plane(BP_MASS)[i].y > 0.0f) && !(B.plane(BP_MASS)[j].y > 0.0f);
+                    if (!(keepUnsolvedPairs && bothStatic)) continue;
                 }
-            }
-        } else {
-            int2 pr = cand[item - nOld]; a = pr.x; b = pr.y;
-            key = make_manifold_key(step, a, b);
-            mi.numContacts = 0;
-        }
-        float fa, fb, ima, imb;
-        BoxPose A = load_box(B, a, fa, ima);
-        BoxPose Bp = load_box(B, b, fb, imb);
-        if (!manifold_initialize(mi, sOld[threadIdx.x], A, fa, Bp, fb)) continue;
-
-        /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
-        const int rows = mi.numContacts * 3;
-        for (int r = 0; r < 12; ++r) {
-            if (r < rows) {
-                if (!P.postStabilize) mi.lambda[r] *= P.alpha * P.gamma;
-                mi.penalty[r] = rclamp(mi.penalty[r] * P.gamma, kPenaltyMin, kPenaltyMax);
+                int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
+                int s, e, other;
+                if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
+                bool constrained = false;
+                for (int k = s; k < e; ++k) if (adjOther[k] == other) { constrained = true; break; }
+                if (!constrained) sHits[atomicAdd(&sNumHits, 1)] = make_int2(i, j);
             }
         }
-
-        int slot = atomicAdd(nextCount, 1);
-        if (slot >= dst.cap) { atomicOr(&cnt->overflow, 2); continue; }
-        dst.pair[slot] = make_int2(a, b);
-        dst.key[slot] = key;
-        dst.nc[slot] = mi.numContacts;
-        dst.fric[slot] = mi.combinedFriction;
-        for (int c = 0; c < 4; ++c) {
-            if (c < mi.numContacts) {
-                int s = slot * 4 + c;
-                dst.cRA[s] = pack3(mi.rA[c], mi.C0n[c]);
-                dst.cRB[s] = pack3(mi.rB[c], mi.C0t1[c]);
-                dst.cN[s] = pack3(mi.normal[c], mi.C0t2[c]);
-                dst.cU1[s] = pack3(mi.u1[c], 0.f);
-                dst.cU2[s] = pack3(mi.u2[c], 0.f);
-                dst.cLam[s] = make_float4(mi.lambda[c * 3], mi.lambda[c * 3 + 1], mi.lambda[c * 3 + 2], mi.penetration[c]);
-                dst.cPen[s] = make_float4(mi.penalty[c * 3], mi.penalty[c * 3 + 1], mi.penalty[c * 3 + 2], 0.0f);
-                dst.cFS[s] = make_int2(mi.feature[c], mi.stick[c] ? 1 : 0);
-                dst.cC[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst.cFmin[s] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
-                dst.cFmax[s] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
-            }
-        }
-        atomicAdd(&degForce[a], 1);
-        atomicAdd(&degForce[b], 1);
-        int inc = 0;
-        if (B.solved[a]) { atomicAdd(&degInc[a], mi.numContacts); inc += mi.numContacts; }
-        if (B.solved[b]) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
-        atomicAdd(&cnt->numContacts, mi.numContacts);
-        atomicAdd(&cnt->numIncidences, inc);
+    }
+    __syncthreads();
+    const int nHits = sNumHits;
+    if (threadIdx.x == 0 && nHits) atomicAdd(&cnt->numCandidates, nHits);
+    for (int h = threadIdx.x; h < nHits; h += 32) {
+        const int2 pr = sHits[h];
+        narrow_pair(B, src, dst, -1, pr.x, pr.y, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
     }
 }
 
