@@ -753,10 +753,9 @@ int step_end(AvbdContext* c, bool haveCounts)
         hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
     {
         SpanGuard g(c, F_VELOCITY);
-        hipLaunchKernelGGL(k_velocity, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p, c->dDiag.p);
-        if (contactSlots > 0)
-            hipLaunchKernelGGL(k_diag_contacts, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dDiag.p);
-        hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p);
+        const int velBlocks = grid_for(n, 128, 1 << 20);
+        const int diagBlocks = contactSlots > 0 ? grid_for(contactSlots, 128, 1 << 20) : 1;
+        hipLaunchKernelGGL(k_tail, dim3(velBlocks + diagBlocks), dim3(128), 0, c->stream, B, M, P, c->dCnt.p, c->dDiag.p, velBlocks);
     }
     HIPCHK(c, hipGetLastError());
     c->deviceAhead = true;

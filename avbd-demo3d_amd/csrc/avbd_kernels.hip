@@ -837,10 +837,8 @@ namespace avbd {
 /* ------------------------------------------------------------------------------------------
  * K7 velocities — solver.cpp:434-469
  * ------------------------------------------------------------------------------------------ */
-__global__ void k_velocity(BodyTable B, SolverParams P, Counters* cnt, DiagAccum* diag)
+__device__ __forceinline__ void velocity_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt, DiagAccum* diag)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.n) return;
     if (!(B.plane(BP_MASS)[i].y > 0.0f)) return;
     const float linearDamping = 0.995f, angularDamping = 0.97f;
     f3 v = ld3(B.plane(BP_LINV), i), w = ld3(B.plane(BP_ANGV), i);
@@ -864,14 +862,21 @@ __global__ void k_velocity(BodyTable B, SolverParams P, Counters* cnt, DiagAccum
     atomic_max_nonneg(&diag->maxAngularSpeed, len3(w));
 }
 
+__global__ void k_velocity(BodyTable B, SolverParams P, Counters* cnt, DiagAccum* diag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    velocity_body(B, i, P, cnt, diag);
+}
+
 /* ------------------------------------------------------------------------------------------
  * K8 diagnostics — solver.cpp:472-497 (max and integer sums only: order-independent)
  * ------------------------------------------------------------------------------------------ */
-__global__ void k_diag_contacts(BodyTable B, ManifoldTable M, const Counters* cnt, DiagAccum* diag)
+__device__ __forceinline__ void diag_contacts(const BodyTable& B, const ManifoldTable& M, const Counters* cnt, DiagAccum* diag, int first, int stride)
 {
     const int nm = cnt->numManifolds;
     const int total = nm * 4;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+    for (int s = first; s < total; s += stride) {
         const int m = s >> 2, ci = s & 3;
         const int nc = M.nc[m];
         if (ci == 0) { atomicAdd(&diag->activeManifolds, 1); atomicAdd(&diag->activeContacts, nc); }
@@ -888,6 +893,23 @@ __global__ void k_diag_contacts(BodyTable B, ManifoldTable M, const Counters* cn
         atomic_max_nonneg(&diag->maxPenetration, pen);
         atomic_max_nonneg(&diag->maxViolation, viol);
         atomic_max_nonneg(&diag->maxNormalImpulse, fabsf(M.cLam[s].x));
+    }
+}
+
+__global__ void k_diag_contacts(BodyTable B, ManifoldTable M, const Counters* cnt, DiagAccum* diag)
+{
+    diag_contacts(B, M, cnt, diag, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+/* velocities (first `velBlocks` workgroups), contact diagnostics (the rest) and the dynamic-body count in one launch */
+__global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* cnt, DiagAccum* diag, int velBlocks)
+{
+    if ((int)blockIdx.x < velBlocks) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i == 0) diag->dynamicBodies = cnt->dynamicBodies;        /* counted by the predictor, long finished */
+        if (i < B.n) velocity_body(B, i, P, cnt, diag);
+    } else {
+        diag_contacts(B, M, cnt, diag, (blockIdx.x - velBlocks) * blockDim.x + threadIdx.x, (gridDim.x - velBlocks) * blockDim.x);
     }
 }
 
