@@ -1688,6 +1688,15 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* debug: per-wave time breakdown of the last k_iterate launch (only in -DAVBD_DF_STATS builds) */
+int avbd_debug_topology_times(AvbdContext* c, unsigned long long* out7)
+{
+    if (!c || !out7) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out7, c->dFlags.p + 2 * (size_t)c->bodyCap + 16 + 1024 * 32 + 20 * 1024 * 8, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
 int avbd_debug_task_times(AvbdContext* c, unsigned* out, int iterations)
 {
     if (!c || !out) return AVBD_E_INVALID;

@@ -602,17 +602,33 @@ __global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
 constexpr int kTopoBodies = 4096, kTopoEntries = 6144;
 constexpr int kTopoIntWords = (kTopoBodies + 1) * 2 + kTopoBodies;            /* adjStart | incStart | cursor */
 constexpr int kTopoLdsBytes = kTopoIntWords * 4 + 8 /* align */ + kTopoEntries * 8 /* keys, later neighbour lists */ +
-                              kTopoBodies * 2 /* levels */ + kTopoEntries * 2 * 3 /* entry body | rank | rows */;
+                              kTopoBodies * 2 /* levels */ + kTopoEntries * 2 * 3 /* entry body | rank | rows */ + kTopoBodies /* swept? */;
+
+/* inclusive scan over the 1024 threads of the workgroup: wave shuffles + one 16-entry exchange (two barriers) */
+__device__ __forceinline__ unsigned long long block_scan_inclusive_u64(unsigned long long v, unsigned long long* sWaveTotals /* [16] */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned lo = __shfl_up((unsigned)v, off), hi = __shfl_up((unsigned)(v >> 32), off);
+        if (lane >= off) v += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) sWaveTotals[wv] = v;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < wv; ++w) base += sWaveTotals[w];
+    __syncthreads();
+    return v + base;
+}
 
 __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTable M, const GForce* gf, int ng, Counters* cnt, const int* nextCount,
                                                           int* degForce, int* degInc, int* adjStart, int* incStart, int* adjRef, int* adjOther,
                                                           uint64_t* adjKey, int2* adjTmp, int* inc, int* level, int* lvlCount, int* lvlStart, int* order, int lvlCap,
                                                           int residentWaves, SolverParams P, int* flags, int nFlags)
 {
-
     extern __shared__ int sTopo[];
-    __shared__ unsigned long long sScan64[1024];
-    __shared__ int sChanged, sMax, sBad, sHist[1024];
+    __shared__ unsigned long long sWaveTotals[16];
+    __shared__ int sMax, sBad, sTotal, sHist[1024];
     const int n = B.n, t = threadIdx.x;
     int* sAdj = sTopo;
     int* sInc = sTopo + (kTopoBodies + 1);
@@ -623,28 +639,29 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     unsigned short* sEntBody = sLevel + kTopoBodies;
     unsigned short* sEntRank = sEntBody + kTopoEntries;
     unsigned short* sEntRows = sEntRank + kTopoEntries;
+    unsigned char* sSwept = reinterpret_cast<unsigned char*>(sEntRows + kTopoEntries);
+#ifdef AVBD_DF_STATS
+    unsigned long long* tstamp = reinterpret_cast<unsigned long long*>(flags + nFlags + 1024 * 32 + 20 * 1024 * 8);
+    if (t == 0) tstamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nm = *nextCount;
     if (t == 0) { cnt->numManifolds = nm; sBad = 0; }
 
     /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below ---- */
-    for (int b = t; b < n; b += 1024) predict_body(B, b, P, cnt);
+    for (int b = t; b < n; b += 1024) { predict_body(B, b, P, cnt); sSwept[b] = B.solved[b] ? 1 : 0; sLevel[b] = 0; }
     for (int i = t; i < nFlags; i += 1024) flags[i] = 0;
 
+#ifdef AVBD_DF_STATS
+    __syncthreads(); if (t == 0) tstamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     /* ---- phase 1: exclusive scans of the two degree arrays (one 64-bit scan: high word rows, low word forces) ---- */
     const int chunk = (n + 1023) / 1024;
     const int lo = t * chunk, hi = min(n, lo + chunk);
     unsigned long long mine = 0;
     for (int i = lo; i < hi; ++i) mine += ((unsigned long long)(unsigned)degInc[i] << 32) | (unsigned)degForce[i];
-    sScan64[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned long long v = (t >= off) ? sScan64[t - off] : 0ull;
-        __syncthreads();
-        sScan64[t] += v;
-        __syncthreads();
-    }
     {
-        unsigned long long base = sScan64[t] - mine;
+        const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
+        unsigned long long base = incl - mine;
         for (int i = lo; i < hi; ++i) {
             const int da = degForce[i], db = degInc[i];
             const int a0 = (int)(unsigned)base, b0 = (int)(base >> 32);
@@ -653,7 +670,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             degForce[i] = 0; degInc[i] = 0;                          /* the next narrow phase counts from zero */
         }
         if (t == 1023) {
-            const int ea = (int)(unsigned)sScan64[1023], eb = (int)(sScan64[1023] >> 32);
+            const int ea = (int)(unsigned)incl, eb = (int)(incl >> 32);
             sAdj[n] = ea; sInc[n] = eb; adjStart[n] = ea; incStart[n] = eb;
         }
     }
@@ -661,6 +678,9 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     const int E = sAdj[n];
     const bool inLds = E <= kTopoEntries;
 
+#ifdef AVBD_DF_STATS
+    __syncthreads(); if (t == 0) tstamp[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     /* ---- phase 2: scatter every force into the CSR segments of its two bodies ---- */
     for (int item = t; item < nm + ng; item += 1024) {
         int a, b, kind, index, rows; uint64_t key;
@@ -679,13 +699,17 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     }
     __syncthreads();
 
-    /* ---- phase 3: newest-first order inside every swept body's segment, then the row-incidence list ---- */
+#ifdef AVBD_DF_STATS
+    __syncthreads(); if (t == 0) tstamp[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    /* ---- phase 3: newest-first order inside every swept body's segment, the row-incidence list, and the later-created
+     *      swept neighbours of every swept body (what the level relaxation needs) ---- */
     if (inLds) {
         /* one thread per ENTRY: rank of an entry = entries of the same body with a larger key */
         for (int pos = t; pos < E; pos += 1024) {
             const int b = sEntBody[pos];
             int rank = pos - sAdj[b];                                 /* unswept bodies keep the scatter order (never visited in order) */
-            if (B.solved[b]) {
+            if (sSwept[b]) {
                 const unsigned long long k = sKey[pos];
                 const int s0 = sAdj[b], s1 = sAdj[b + 1];
                 rank = 0;
@@ -693,6 +717,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             }
             sEntRank[pos] = (unsigned short)rank;
         }
+        for (int b = t; b < n; b += 1024) sCur[b] = 0;                 /* becomes the neighbour count */
         __syncthreads();
         for (int pos = t; pos < E; pos += 1024) {
             const int b = sEntBody[pos];
@@ -700,7 +725,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             const int rank = sEntRank[pos];
             const int2 ro = adjTmp[pos];
             adjRef[s0 + rank] = ro.x; adjOther[s0 + rank] = ro.y;
-            if (B.solved[b]) {
+            if (sSwept[b]) {
                 /* row-incidence entries of this force start after those of every force that precedes it in the list */
                 int off = 0;
                 for (int j = s0; j < s1; ++j) off += sEntRank[j] < rank ? sEntRows[j] : 0;
@@ -709,13 +734,15 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                 if (kind == FK_MANIFOLD) { const int nc = sEntRows[pos]; for (int c = 0; c < nc; ++c) out[c] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
                 else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); sBad = 1; }
                 else if (kind == FK_SPRING) { out[0] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
+                /* the key area is dead now (nothing below reads it): compact the neighbour lists into it, any order */
+                if (ro.y > b && kind != FK_IGNORE && sSwept[ro.y]) sNbr[s0 + atomicAdd(&sCur[b], 1)] = (unsigned short)ro.y;
             }
         }
     } else {
         /* more entries than the LDS staging holds (dense packings): one thread per BODY, insertion sort in global memory */
         for (int b = t; b < n; b += 1024) {
             const int s0 = sAdj[b], s1 = sAdj[b + 1];
-            if (B.solved[b]) {
+            if (sSwept[b]) {
                 for (int i = s0 + 1; i < s1; ++i) {
                     const uint64_t k = adjKey[i]; const int2 ro = adjTmp[i];
                     int j = i - 1;
@@ -727,66 +754,70 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             for (int i = s0; i < s1; ++i) {
                 const int2 ro = adjTmp[i];
                 adjRef[i] = ro.x; adjOther[i] = ro.y;
-                if (!B.solved[b]) continue;
+                if (!sSwept[b]) continue;
                 const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
                 if (kind == FK_MANIFOLD) { const int nc = M.nc[idx]; for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
                 else if (kind == FK_JOINT) { inc[o++] = make_inc(isA, FK_JOINT, idx * 2); inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1); sBad = 1; }
                 else if (kind == FK_SPRING) { inc[o++] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
             }
+            sCur[b] = s1 - s0;                                          /* the sweeps below filter the whole segment */
         }
     }
-    for (int b = t; b < n; b += 1024) {
-        sLevel[b] = 0;
-        if (B.solved[b] && sInc[b + 1] - sInc[b] > 64) sBad = 1;      /* the resident schedule keeps one contact per lane */
-    }
+    for (int b = t; b < n; b += 1024)
+        if (sSwept[b] && sInc[b + 1] - sInc[b] > 64) sBad = 1;         /* the resident schedule keeps one contact per lane */
     __syncthreads();
 
+#ifdef AVBD_DF_STATS
+    __syncthreads(); if (t == 0) tstamp[4] = __builtin_amdgcn_s_memrealtime();
+#endif
     /* ---- phase 4: dependency levels (level = 1 + max level of the later-created swept neighbours), relaxed in LDS ---- */
-    constexpr int kPer = kTopoBodies / 1024;
+    constexpr int kPer = kTopoBodies / 1024, kNbReg = 8;
     int seg[kPer], cnt_[kPer];
+    unsigned short nb[kPer][kNbReg];                                  /* the first neighbours of each body: registers, not LDS */
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         const int b = t + q * 1024;
         seg[q] = 0; cnt_[q] = -1;
-        if (b < n && B.solved[b]) {
-            const int s0 = sAdj[b], s1 = sAdj[b + 1];
-            int c = 0;
-            if (inLds) {                                              /* compact the relevant neighbours once, 16-bit, in the dead key area */
-                for (int k = s0; k < s1; ++k) {
-                    const int2 ro = adjTmp[k];                        /* any order will do here */
-                    if (ro.y > b && inc_kind(ro.x) != FK_IGNORE && B.solved[ro.y]) sNbr[s0 + c++] = (unsigned short)ro.y;
-                }
-            }
-            seg[q] = s0; cnt_[q] = inLds ? c : (s1 - s0);
-        }
+        if (b < n && sSwept[b]) { seg[q] = sAdj[b]; cnt_[q] = sCur[b]; }
+#pragma unroll
+        for (int z = 0; z < kNbReg; ++z) nb[q][z] = (inLds && z < cnt_[q]) ? sNbr[seg[q] + z] : (unsigned short)0;
     }
+    __shared__ int sChangedAlt[2];
+    if (t == 0) { sChangedAlt[0] = 0; sChangedAlt[1] = 0; }
     __syncthreads();
     for (int sweep = 0; sweep <= n; ++sweep) {
-        if (t == 0) sChanged = 0;
-        __syncthreads();
         int changed = 0;
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
+            if (q * 1024 >= n) break;                                   /* wave-uniform: a 1000-body scene runs one of the four copies */
             if (cnt_[q] < 0) continue;
             const int b = t + q * 1024;
             int lv = 1;
             if (inLds) {
-                for (int z = 0; z < cnt_[q]; ++z) { int lo2 = (int)sLevel[sNbr[seg[q] + z]] + 1; if (lo2 > lv) lv = lo2; }
+                int lvz[kNbReg];
+#pragma unroll
+                for (int z = 0; z < kNbReg; ++z) lvz[z] = (int)sLevel[nb[q][z]];             /* independent reads */
+#pragma unroll
+                for (int z = 0; z < kNbReg; ++z) if (z < cnt_[q] && lvz[z] + 1 > lv) lv = lvz[z] + 1;
+                for (int z = kNbReg; z < cnt_[q]; ++z) { int lo2 = (int)sLevel[sNbr[seg[q] + z]] + 1; if (lo2 > lv) lv = lo2; }
             } else {
                 for (int z = 0; z < cnt_[q]; ++z) {
                     const int2 ro = adjTmp[seg[q] + z];
-                    if (ro.y > b && inc_kind(ro.x) != FK_IGNORE && B.solved[ro.y]) { int lo2 = (int)sLevel[ro.y] + 1; if (lo2 > lv) lv = lo2; }
+                    if (ro.y > b && inc_kind(ro.x) != FK_IGNORE && sSwept[ro.y]) { int lo2 = (int)sLevel[ro.y] + 1; if (lo2 > lv) lv = lo2; }
                 }
             }
             if (lv != (int)sLevel[b]) { sLevel[b] = (unsigned short)lv; changed = 1; }
         }
-        if (changed) sChanged = 1;
+        if (changed) sChangedAlt[sweep & 1] = 1;
+        if (t == 0) sChangedAlt[(sweep + 1) & 1] = 0;                  /* the flag of the next sweep; nobody reads or sets it now */
         __syncthreads();
-        const int c = sChanged;
+        if (!sChangedAlt[sweep & 1]) break;
         __syncthreads();
-        if (!c) break;
     }
 
+#ifdef AVBD_DF_STATS
+    __syncthreads(); if (t == 0) tstamp[5] = __builtin_amdgcn_s_memrealtime();
+#endif
     /* ---- phase 5: bodies grouped by level (counting sort; levels of a small scene fit one histogram word per thread) ---- */
     if (t == 0) sMax = 0;
     sHist[t] = 0;
@@ -803,29 +834,24 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     if (L >= 1024 || L >= lvlCap) { if (t == 0) { cnt->numLevels = 0; atomicOr(&cnt->overflow, 8); } return; }
     /* exclusive scan of sHist[1..L]: thread t owns level t+1 */
     const int hv = (t < L) ? sHist[t + 1] : 0;
-    sScan64[t] = (unsigned long long)hv;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned long long v = (t >= off) ? sScan64[t - off] : 0ull;
-        __syncthreads();
-        sScan64[t] += v;
-        __syncthreads();
-    }
-    const int startL = (int)sScan64[t] - hv;
+    const int incl = (int)block_scan_inclusive_u64((unsigned long long)hv, sWaveTotals);
+    const int startL = incl - hv;
     if (t < L) { lvlStart[t] = startL; sHist[t + 1] = startL; }       /* sHist becomes the fill cursor of its level */
-    if (t == 0) lvlStart[L] = (int)sScan64[1023];
+    if (t == 1023) { lvlStart[L] = incl; sTotal = incl; }
     __syncthreads();
     for (int b = t; b < n; b += 1024) {
         const int lv = sLevel[b];
         if (lv > 0) order[atomicAdd(&sHist[lv], 1)] = b;
     }
+#ifdef AVBD_DF_STATS
+    __syncthreads(); if (t == 0) tstamp[6] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (t == 0) {
         cnt->numLevels = L;
         int bad = sBad ? 1 : 0;
-        if ((int)sScan64[1023] > residentWaves) bad |= 2;
+        if (sTotal > residentWaves) bad |= 2;
         if (bad) atomicOr(&cnt->residentBad, bad);
     }
-
 }
 
 /* K5 primal, K6 dual and the fused data-flow iteration kernel live in avbd_primal.h / avbd_iterate.h */

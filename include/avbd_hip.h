@@ -221,6 +221,8 @@ void* avbd_stream(AvbdContext* ctx);
 int  avbd_debug_iterate_stats(AvbdContext* ctx, unsigned long long* out, int waves);
 /* Per-task time stamps of the resident schedule (builds with -DAVBD_DF_STATS only; zeros otherwise): out[it][1024][8] u32. */
 int  avbd_debug_task_times(AvbdContext* ctx, unsigned* out, int iterations);
+/* phase boundaries of the last k_topology_small launch (s_memrealtime ticks, -DAVBD_DF_STATS builds only) */
+int  avbd_debug_topology_times(AvbdContext* ctx, unsigned long long* out7);
 
 #ifdef __cplusplus
 }
