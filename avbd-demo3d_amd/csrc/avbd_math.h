@@ -126,6 +126,28 @@ AVBD_HD f3 solve_ldlt3(m33 A, f3 b)
     return x;
 }
 
+/* The same solve without early returns: every operation of the full path is executed (a tiny pivot just produces inf/nan
+ * that the final select discards), so a wavefront runs one straight instruction stream.  Same results bit for bit. */
+AVBD_HD f3 solve_ldlt3_branchless(m33 A, f3 b)
+{
+    f3 L0 = A.c0;
+    bool bad = fabsf(L0.x) < FLT_EPSILON;
+    float d0 = L0.x;
+    float L10 = L0.y / d0;
+    float L20 = L0.z / d0;
+    f3 L1 = A.c1 - L0 * L10;
+    bad |= fabsf(L1.y) < FLT_EPSILON;
+    float d1 = L1.y;
+    float L21 = L1.z / d1;
+    f3 L2 = A.c2 - L0 * L20 - L1 * L21;
+    bad |= fabsf(L2.z) < FLT_EPSILON;
+    float d2 = L2.z;
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    f3 z; z.x = y.x / d0; z.y = y.y / d1; z.z = y.z / d2;
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    return bad ? zero3() : x;
+}
+
 /* solver.cpp:68-83 — Schur-complement 6x6 solve built from five 3x3 LDL^T solves. */
 AVBD_HD void solve_block6(m33 ll, m33 la, m33 al, m33 aa, f3 bl, f3 ba, f3& xl, f3& xa)
 {

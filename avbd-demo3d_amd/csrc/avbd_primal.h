@@ -445,18 +445,20 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
  * The result (p, q) is valid in lane 0 only. */
 __device__ __forceinline__ void solve_pose(const float* accs, float* xch, int lane, const BodyLocal& L, f3& p, q4& q)
 {
-    m33 ll, la, al, aa;
+    m33 ll, la, al;
     /* lower triangles; the strictly-upper entries are never read by solve (maths.h:104) */
     ll.c0 = mk3(accs[0], accs[1], accs[2]); ll.c1 = mk3(accs[1], accs[3], accs[4]); ll.c2 = mk3(accs[2], accs[4], accs[5]);
     la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
     al = mtranspose(la); /* al accumulates (Ja_i*Jl_j)*pen = la(j,i) bit for bit (solver.cpp:389-390) */
-    aa.c0 = mk3(accs[15], accs[16], accs[17]); aa.c1 = mk3(accs[16], accs[18], accs[19]); aa.c2 = mk3(accs[17], accs[19], accs[20]);
-    const f3 bl = mk3(accs[21], accs[22], accs[23]), ba = mk3(accs[24], accs[25], accs[26]);
     const int j = lane & 3;
-    const f3 rhs = j == 0 ? la.c0 : (j == 1 ? la.c1 : (j == 2 ? la.c2 : bl));
-    const f3 sol = solve_ldlt3(ll, rhs);             /* col0, col1, col2, x0 */
+    /* each of the four lanes fetches its own right-hand side / Schur base straight from the accumulator area */
+    const int ro = j < 3 ? 6 + 3 * j : 21;
+    const f3 rhs = mk3(accs[ro], accs[ro + 1], accs[ro + 2]);
+    const f3 sol = solve_ldlt3_branchless(ll, rhs);  /* col0, col1, col2, x0 */
     const f3 prod = al * sol;                        /* al * AinvB.col j  |  al * x0 */
-    const f3 base = j == 0 ? aa.c0 : (j == 1 ? aa.c1 : (j == 2 ? aa.c2 : ba));
+    const int b0 = j == 0 ? 15 : (j == 1 ? 16 : (j == 2 ? 17 : 24)), b1 = j == 0 ? 16 : (j == 1 ? 18 : (j == 2 ? 19 : 25)),
+              b2 = j == 0 ? 17 : (j == 1 ? 19 : (j == 2 ? 20 : 26));
+    const f3 base = mk3(accs[b0], accs[b1], accs[b2]);
     const f3 out = base - prod;                      /* schur.col j  |  rhs_s */
     if (lane < 4) {
         xch[j * 3 + 0] = out.x; xch[j * 3 + 1] = out.y; xch[j * 3 + 2] = out.z;
@@ -466,7 +468,7 @@ __device__ __forceinline__ void solve_pose(const float* accs, float* xch, int la
     if (lane == 0) {
         const m33 schur = mkm(mk3(xch[0], xch[1], xch[2]), mk3(xch[3], xch[4], xch[5]), mk3(xch[6], xch[7], xch[8]));
         const f3 rhs_s = mk3(xch[9], xch[10], xch[11]);
-        const f3 y = solve_ldlt3(schur, rhs_s);
+        const f3 y = solve_ldlt3_branchless(schur, rhs_s);
         const m33 AinvB = mkm(sol, mk3(xch[12], xch[13], xch[14]), mk3(xch[15], xch[16], xch[17]));
         const f3 x0 = mk3(xch[18], xch[19], xch[20]);
         const f3 dl = x0 - AinvB * y;
