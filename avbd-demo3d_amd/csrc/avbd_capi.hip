@@ -144,6 +144,7 @@ struct AvbdContext {
     bool fusedFront = true;        /* AVBD_FUSED_FRONT=0: separate broadphase and narrow-phase launches */
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
+    int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     int numStatic = 0;
     bool statsFresh = true;
@@ -645,6 +646,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes, poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
     X.maxWaves = c->iterBlocks * kIterWaves;
+    X.quietPermille = c->residentQuiet;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
     X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave && itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
                  totalItAll <= 60 && totalItAll > 0 && B.n - c->numStatic <= X.maxWaves && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
@@ -879,6 +881,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -42,6 +42,7 @@ struct ResidentExchange {
     unsigned base;   /* stamp of "nothing published yet" for this launch */
     int enabled;     /* host-side prerequisites hold (single GPU, no joints/springs, few enough iterations) */
     int maxWaves;    /* wavefronts the launch keeps resident */
+    int quietPermille; /* share of the previous iteration's wait a wave spends asleep before it starts polling */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -214,6 +215,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     const int offP = other * 48, offV = idx * 16, offD = idx * 32;
     for (int r = lane; r < kResRows; r += 64) rows[kResJFloats + 6 * kResRows + r] = 0.0f;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned prevWait = 0;                                           /* ticks (10 ns) this wave waited in the previous iteration */
 #ifdef AVBD_DF_STATS
     unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = t0;
@@ -270,6 +272,14 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 
         /* ---- the wait IS the load: poll the records until every stamp is current ---- */
         {
+            /* A wave that waited w last iteration will wait about w again (the dependency pattern repeats every sweep): it
+             * stays off the memory system for the first part of that time.  Polls of idle waves were measured to lengthen
+             * everybody's hand-off latency. */
+            const unsigned long long tWait0 = __builtin_amdgcn_s_memrealtime();
+            if (needP | needV | needD) {
+                const unsigned quiet = (prevWait * (unsigned)X.quietPermille) / 1000u;
+                while ((unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0) < quiet) __builtin_amdgcn_s_sleep(8);
+            }
             bool okP = !needP, okV = !needV, okD = !needD;
             v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vv = p0, d0 = p0, d1 = p0;
             unsigned spins = 0;
@@ -304,6 +314,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if (age != 0xffffffffu && age < 100000u) { stat[12] += age; stat[13] += 1; }
             }
 #endif
+            prevWait = (unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0);
             if (needP) {
                 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
                 wOther = qrotate(orot, isA ? c.rB : c.rA);

@@ -175,3 +175,17 @@ def test_fused_topology_kernel_fast_and_slow_paths(monkeypatch):
             H.assert_same_world(o, g, f"{scene} fused_topology={fused}")
         if scene == "Packed:15":
             assert 2 * int(g.w.stats()["numManifolds"]) > 6144
+
+
+def test_front_end_and_polling_knobs_do_not_change_results(monkeypatch):
+    """AVBD_FUSED_FRONT=0 (separate broadphase / narrow-phase launches) and the quiet share of the resident schedule's wait
+    (0 = poll at once, 900 = sleep through 90 % of the previous wait) are placement/timing choices only."""
+    o = H.CpuWorld("orc"); o.scene("Pyramid"); o.step(40)
+    for env in ({"AVBD_FUSED_FRONT": "0"}, {"AVBD_RESIDENT_QUIET": "0"}, {"AVBD_RESIDENT_QUIET": "900"},
+                {"AVBD_FUSED_FRONT": "0", "AVBD_FUSED_TOPOLOGY": "0", "AVBD_RESIDENT": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = H.HipWorld(); g.scene("Pyramid"); g.step(40)
+        for k in env:
+            monkeypatch.delenv(k)
+        H.assert_same_world(o, g, f"Pyramid with {env}")
