@@ -84,6 +84,25 @@ def cpu_baseline(pkg, world, scene, snapshot_bodies, snapshot_forces, step_index
     return o, dt
 
 
+def reference_baseline(scene, start_step, steps, end_bodies):
+    """Time the REAL reference (oracle/_ref/libavbd_ref.so = the unmodified sources of /root/reference compiled by
+    oracle/Makefile) on the same window: it cannot load a snapshot, so it simulates the scene from step 0 untimed, then
+    `steps` timed steps; its state after them is compared bit for bit with the GPU's when the windows coincide."""
+    import harness as H
+    if not os.path.exists(H.lib_path("ref")):
+        return None
+    r = H.CpuWorld("ref")
+    r.scene(scene)
+    r.step(start_step)
+    t0 = time.perf_counter()
+    r.step(steps)
+    dt = time.perf_counter() - t0
+    same = None
+    if end_bodies is not None:
+        same = H.same_bits(r.bodies(), end_bodies.view(H.BODY_DT))
+    return steps / dt, dt / steps * 1e3, same
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +112,7 @@ def main():
     ap.add_argument("--presim", type=int, default=None, help="untimed steps before warm-up (default 400 for falling scenes)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--no-reference", action="store_true", help="cpu_baseline from the port only (skip the run of oracle/_ref)")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +213,18 @@ def main():
                    "sample": f"{cpu_steps} steps of {scene} from the GPU run's own state at step {snap_step} (oracle/liboracle.so, "
                              f"-O2 -ffp-contract=off, 1 thread of {os.cpu_count()} host cores)",
                    "ms_per_step": round(dt / cpu_steps * 1e3, 3), "parity": parity}
+            # the real reference on the same window, when its build travelled with the snapshot (oracle/_ref)
+            if not args.no_reference and args.scene is None and snap_step <= 1000:
+                ref = reference_baseline(scene, snap_step, args.steps if args.steps <= 200 else 200, end_b if args.steps <= 200 else None)
+                if ref is not None:
+                    port = cpu
+                    cpu = {"value": round(ref[0], 3), "unit": "steps/s", "cores": 1, "kind": "reference",
+                           "sample": f"{min(args.steps, 200)} steps of {scene}, steps {snap_step}..{snap_step + min(args.steps, 200)} of the reference's own run "
+                                     f"from step 0 (oracle/_ref/libavbd_ref.so: the unmodified reference sources, g++ -O2 -ffp-contract=off, "
+                                     f"1 thread of {os.cpu_count()} host cores)",
+                           "ms_per_step": round(ref[1], 3),
+                           "parity": "not-compared" if ref[2] is None else ("bit-exact" if ref[2] else "MISMATCH"),
+                           "port": {"value": port["value"], "ms_per_step": port["ms_per_step"], "parity": port["parity"]}}
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             cpu = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
 
