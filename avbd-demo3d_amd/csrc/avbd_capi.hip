@@ -881,6 +881,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;

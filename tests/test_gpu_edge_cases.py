@@ -189,3 +189,17 @@ def test_front_end_and_polling_knobs_do_not_change_results(monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
         H.assert_same_world(o, g, f"Pyramid with {env}")
+
+
+def test_resident_stamp_window_wraps_cleanly(monkeypatch):
+    """Stamps are launch serial * 64 + iteration; at serial 2^24 the exchange buffers are cleared and the serial restarts.
+    Start 10 launches before the wrap and step across it."""
+    monkeypatch.setenv("AVBD_RESIDENT_SERIAL", str((1 << 24) - 12))
+    o, g = pair()
+    monkeypatch.delenv("AVBD_RESIDENT_SERIAL")
+    for w in (o, g):
+        w.scene("Stack")
+    for s in range(30):
+        o.step(); g.step()
+        H.assert_same_world(o, g, f"Stack across the stamp wrap, step {s + 1}")
+    assert int(g.w.stats()["schedule"]) == 2
