@@ -1,0 +1,66 @@
+"""BASELINE.json configs 3-5 at their full sizes on ONE MI355X, exact mode: 8 000 cubes, 64 000 cubes, 64 000 cubes + 10 000
+weld joints.  The CPU oracle needs ~0.5 s/step at 8 k and ~20 s/step at 64 k (O(n^2) broadphase), so the direct bit-for-bit
+comparisons run a handful of steps of the contact-rich packed variant; size-independent properties (determinism across
+runs, nothing non-finite, nothing through the ground) cover longer runs."""
+import numpy as np
+import pytest
+
+import harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+def add_config5_joints(w, count=10000):
+    """Joint(cube[2k], cube[2k+1], (0.5,0,0), (-0.5,0,0)) for the first `count` x-adjacent pairs
+    (body 0 is the ground, cubes follow in creation order, x is the innermost loop of the scene builder)."""
+    for k in range(count):
+        w.add_joint(1 + 2 * k, 2 + 2 * k, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+
+
+def test_config3_8000_cubes_bit_exact_vs_oracle():
+    o, g = H.CpuWorld("orc"), H.HipWorld()
+    for w in (o, g):
+        w.scene("Packed:20")
+    assert g.w.num_bodies() == 8001
+    for s in range(12):
+        o.step(); g.step()
+        H.assert_same_world_fast(o, g, f"Packed:20 step {s + 1}")
+    st = g.w.stats()
+    assert int(st["numManifolds"]) > 5000 and int(st["schedule"]) == 1
+
+
+def test_config3_8000_cubes_long_run_is_deterministic_and_finite():
+    runs = []
+    for _ in range(2):
+        g = H.HipWorld(); g.scene("Packed:20"); g.step(120)
+        runs.append(g.bodies())
+    assert H.same_bits(runs[0], runs[1])
+    b = runs[0]
+    assert np.isfinite(b["pos"]).all() and np.isfinite(b["quat"]).all() and np.isfinite(b["linVel"]).all()
+    assert float(b["pos"][1:, 1].min()) > 0.3          # nothing fell through the ground slab
+
+
+def test_config5_64000_cubes_with_10k_weld_joints_bit_exact_vs_oracle():
+    o, g = H.CpuWorld("orc"), H.HipWorld()
+    for w in (o, g):
+        w.scene("Packed:40")
+        add_config5_joints(w)
+    assert g.w.num_bodies() == 64001
+    for s in range(2):
+        o.step(); g.step()
+        H.assert_same_world_fast(o, g, f"Packed:40 + 10k joints, step {s + 1}")
+    st = g.w.stats()
+    assert int(st["numJoints"]) == 10000 and int(st["numManifolds"]) > 40000
+
+
+def test_config4_64000_cubes_with_joints_is_deterministic_and_finite():
+    """40 steps of the falling 64 000-cube scene with the 10 000 welds: two runs agree bit for bit and nothing is non-finite
+    (the reference's weld rows are bug-compatible — SURVEY.md §7-5 — so no claim is made about their residuals)."""
+    finals = []
+    for _ in range(2):
+        g = H.HipWorld(); g.scene("StressN:40"); add_config5_joints(g)
+        g.step(40)
+        finals.append(g.bodies())
+    assert H.same_bits(finals[0], finals[1])
+    b = finals[0]
+    assert np.isfinite(b["pos"]).all() and np.isfinite(b["quat"]).all() and np.isfinite(b["linVel"]).all()
