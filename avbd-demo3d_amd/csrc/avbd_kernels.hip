@@ -8,8 +8,7 @@
  *   K4  k_predict           solver.cpp:299-337
  *   K5  k_primal            solver.cpp:344-409   one wavefront per body, one Gauss-Seidel level per launch
  *   K6  k_dual / k_dual_gforce   solver.cpp:411-430
- *   K7  k_velocity          solver.cpp:434-469
- *   K8  k_diag_contacts     solver.cpp:472-497
+ *   K7/K8 k_tail            solver.cpp:434-497 (velocities + contact diagnostics)
  *
  * Exactness: the primal sweep of the reference is sequential over bodies (newest first) and each
  * body accumulates its rows force by force, row by row.  Here bodies are grouped into dependency
@@ -518,21 +517,6 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
     if (t == 0) { cnt->numLevels = L; if (L >= lvlCap) atomicOr(&cnt->overflow, 8); if (sScan[1023] > residentWaves) atomicOr(&cnt->residentBad, 2); }
 }
 
-/* Sort the bodies of each level by index (placement only: results do not depend on it). */
-__global__ void k_sort_levels(const int* lvlStart, int* order, const Counters* cnt)
-{
-    const int L = cnt->numLevels;
-    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
-        int s = lvlStart[l], e = lvlStart[l + 1];
-        if (e - s > 4096) continue;
-        for (int i = s + 1; i < e; ++i) {
-            int v = order[i], j = i - 1;
-            while (j >= s && order[j] > v) { order[j + 1] = order[j]; --j; }
-            order[j + 1] = v;
-        }
-    }
-}
-
 /* ------------------------------------------------------------------------------------------
  * K4 predict — solver.cpp:299-337
  * ------------------------------------------------------------------------------------------ */
@@ -888,13 +872,6 @@ __device__ __forceinline__ void velocity_body(const BodyTable& B, int i, const S
     atomic_max_nonneg(&diag->maxAngularSpeed, len3(w));
 }
 
-__global__ void k_velocity(BodyTable B, SolverParams P, Counters* cnt, DiagAccum* diag)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.n) return;
-    velocity_body(B, i, P, cnt, diag);
-}
-
 /* ------------------------------------------------------------------------------------------
  * K8 diagnostics — solver.cpp:472-497 (max and integer sums only: order-independent)
  * ------------------------------------------------------------------------------------------ */
@@ -922,11 +899,6 @@ __device__ __forceinline__ void diag_contacts(const BodyTable& B, const Manifold
     }
 }
 
-__global__ void k_diag_contacts(BodyTable B, ManifoldTable M, const Counters* cnt, DiagAccum* diag)
-{
-    diag_contacts(B, M, cnt, diag, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
 /* velocities (first `velBlocks` workgroups), contact diagnostics (the rest) and the dynamic-body count in one launch */
 __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* cnt, DiagAccum* diag, int velBlocks)
 {
@@ -937,11 +909,6 @@ __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* c
     } else {
         diag_contacts(B, M, cnt, diag, (blockIdx.x - velBlocks) * blockDim.x + threadIdx.x, (gridDim.x - velBlocks) * blockDim.x);
     }
-}
-
-__global__ void k_finish_step(Counters* cnt, DiagAccum* diag)
-{
-    diag->dynamicBodies = cnt->dynamicBodies;
 }
 
 /* start-of-step reset of the per-step counters */

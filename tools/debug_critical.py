@@ -1,6 +1,6 @@
 """Critical-path trace of the resident schedule from per-task time stamps (library built with -DAVBD_DF_STATS)."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import harness as H
 scene = sys.argv[1] if len(sys.argv) > 1 else "Stress1000"
