@@ -514,7 +514,9 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
         int lv = level[b];
         if (lv > 0 && lv < lvlCap) order[lvlStart[lv - 1] + atomicAdd(&lvlCount[lv], 1)] = b;
     }
-    if (t == 0) { cnt->numLevels = L; if (L >= lvlCap) atomicOr(&cnt->overflow, 8); if (sScan[1023] > residentWaves) atomicOr(&cnt->residentBad, 2); }
+    /* Counters / DiagAccum words are updated with atomics by other workgroups (possibly on other XCDs, whose L2s are not
+     * coherent with this one): a plain store here could write a stale copy of its neighbours back over them. */
+    if (t == 0) { atomicExch(&cnt->numLevels, L); if (L >= lvlCap) atomicOr(&cnt->overflow, 8); if (sScan[1023] > residentWaves) atomicOr(&cnt->residentBad, 2); }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     if (t == 0) tstamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int nm = *nextCount;
-    if (t == 0) { cnt->numManifolds = nm; sBad = 0; }
+    if (t == 0) { atomicExch(&cnt->numManifolds, nm); sBad = 0; }   /* atomics only on Counters words inside a kernel that also adds to them */
 
     /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below ---- */
     for (int b = t; b < n; b += 1024) { predict_body(B, b, P, cnt); sSwept[b] = B.solved[b] ? 1 : 0; sLevel[b] = 0; }
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     atomicMax(&sMax, mx);
     __syncthreads();
     const int L = sMax;                                               /* levels are 1..L */
-    if (L >= 1024 || L >= lvlCap) { if (t == 0) { cnt->numLevels = 0; atomicOr(&cnt->overflow, 8); } return; }
+    if (L >= 1024 || L >= lvlCap) { if (t == 0) { atomicExch(&cnt->numLevels, 0); atomicOr(&cnt->overflow, 8); } return; }
     /* exclusive scan of sHist[1..L]: thread t owns level t+1 */
     const int hv = (t < L) ? sHist[t + 1] : 0;
     const int incl = (int)block_scan_inclusive_u64((unsigned long long)hv, sWaveTotals);
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     __syncthreads(); if (t == 0) tstamp[6] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (t == 0) {
-        cnt->numLevels = L;
+        atomicExch(&cnt->numLevels, L);
         int bad = sBad ? 1 : 0;
         if (sTotal > residentWaves) bad |= 2;
         if (bad) atomicOr(&cnt->residentBad, bad);
@@ -904,7 +906,9 @@ __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* c
 {
     if ((int)blockIdx.x < velBlocks) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i == 0) diag->dynamicBodies = cnt->dynamicBodies;        /* counted by the predictor, long finished */
+        /* counted by the predictor, long finished; an atomic because the other workgroups of this launch update the same
+         * cache line with atomics from other XCDs (a plain store's write-back could put stale neighbours over them) */
+        if (i == 0) atomicExch(&diag->dynamicBodies, cnt->dynamicBodies);
         if (i < B.n) velocity_body(B, i, P, cnt, diag);
     } else {
         diag_contacts(B, M, cnt, diag, (blockIdx.x - velBlocks) * blockDim.x + threadIdx.x, (gridDim.x - velBlocks) * blockDim.x);
