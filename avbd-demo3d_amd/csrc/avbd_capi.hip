@@ -139,6 +139,10 @@ struct AvbdContext {
     int iterSleep = 1;         /* poll back-off selector (s_sleep 1/2/4/8) */
     int iterForceMode = 0;     /* 0 auto, 1 latency (1 workgroup/CU), 2 throughput (2 workgroups/CU) */
     DevArr<float4> xPose, xVisit, xDual; /* stamped exchange records of the resident schedule (avbd_resident.h) */
+    DevArr<float4> xPrivN, xPrivPose;   /* resident schedule with several bodies per wave: state parked between a body's tasks */
+    size_t privNCap = 0, privPoseCap = 0;
+    bool residentMultiAllowed = true;   /* AVBD_RESIDENT_MULTI=0: scenes with more swept bodies than waves use the task schedule */
+    bool residentMultiLaunched = false;
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
     bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
     bool fusedFront = true;        /* AVBD_FUSED_FRONT=0: separate broadphase and narrow-phase launches */
@@ -550,7 +554,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.numBodies = (int)c->hBodies.size(); c->stats.numManifolds = cnt.numManifolds; c->stats.numContacts = cnt.numContacts;
     c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = cnt.numLevels;
     c->stats.numDynamic = cnt.dynamicBodies;
-    c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && cnt.residentBad == 0) ? 2 : 1);
+    c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && (cnt.residentBad & 1) == 0 && ((cnt.residentBad & 2) == 0 || c->residentMultiLaunched)) ? ((cnt.residentBad & 2) ? 3 : 2) : 1);
     int nj = 0, ns = 0, ni = 0;
     for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
@@ -648,8 +652,21 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.maxWaves = c->iterBlocks * kIterWaves;
     X.quietPermille = c->residentQuiet;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
-    X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave && itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
-                 totalItAll <= 60 && totalItAll > 0 && B.n - c->numStatic <= X.maxWaves && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
+    const int dynBodies = B.n - c->numStatic;
+    const bool fitsOne = dynBodies <= X.maxWaves;
+    const bool fitsMulti = c->residentMultiAllowed && dynBodies <= 16 * X.maxWaves;   /* beyond that a wave would own > 16 bodies: throughput-bound, task schedule */
+    X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave &&
+                 itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
+                 totalItAll <= 60 && totalItAll > 0 && (fitsOne || fitsMulti) && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
+    X.multi = 0;
+    if (X.enabled && !fitsOne) {
+        const size_t needN = (size_t)3 * c->incCap, needP = (size_t)2 * c->bodyCap;
+        if (c->privNCap < needN) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivN.alloc(needN)); c->privNCap = needN; }
+        if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
+        X.multi = 1;
+    }
+    X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p;
+    c->residentMultiLaunched = X.multi != 0;
     c->residentLaunched = X.enabled != 0;
     if (X.enabled) {
         if (c->xSerial >= (1u << 24) - 2u) {                       /* stamps are about to wrap: forget every old record */
@@ -881,6 +898,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
@@ -907,6 +925,7 @@ int avbd_destroy(AvbdContext* c)
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
     c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSend.release(); c->dRecv.release();
+    c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->adjTmp.release();
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);
     (void)hipStreamDestroy(c->stream);

@@ -131,14 +131,11 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     const float4* massPlane = B.plane(BP_MASS);
     if constexpr (WPE == 1) {
         /* every swept body fits one resident wavefront and is a plain pile of contacts: one wave per body for the whole loop */
-        if (X.enabled && cnt->residentBad == 0) {
-#ifdef AVBD_RES_SPREAD
-            if (wv != 0 || (int)blockIdx.x >= nd) return;
-            iterate_resident(B, M, order[blockIdx.x], incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, reinterpret_cast<float*>(sDynamic));
-            return;
-#endif
-            if (w < nd) iterate_resident(B, M, order[w], incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs,
-                                             reinterpret_cast<float*>(sDynamic) + wv * (kResProductBytesPerWave / 4));
+        const int veto = cnt->residentBad;                            /* bit0: not a pile of <= 64 contacts per body; bit1: more bodies than waves */
+        if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi)) {
+            float* products = reinterpret_cast<float*>(sDynamic) + wv * (kResProductBytesPerWave / 4);
+            if (veto & 2) iterate_resident<true>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products);
+            else if (w < nd) iterate_resident<false>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products);
             return;
         }
     }

@@ -43,6 +43,9 @@ struct ResidentExchange {
     int enabled;     /* host-side prerequisites hold (single GPU, no joints/springs, few enough iterations) */
     int maxWaves;    /* wavefronts the launch keeps resident */
     int quietPermille; /* share of the previous iteration's wait a wave spends asleep before it starts polling */
+    float4* privN;     /* [3 * incidence capacity] MULTI: a first visitor's own copy of (normal, u1, u2) between its tasks */
+    float4* privPose;  /* [2 * bodyCap]            MULTI: the pose between the body's tasks */
+    int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -162,57 +165,95 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
     }
 }
 
-/* One wavefront = one body for all iterations.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
-__device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, int body, const int* __restrict__ incStart,
-                                                 const int* __restrict__ inc, const SolverParams& P, int* errWord, Counters* cntW,
-                                                 const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products)
+/* One wavefront = one body for all iterations (MULTI = false: the body's state stays in registers from the first iteration to
+ * the last), or one wavefront = every W-th body of the level-sorted order (MULTI = true, scenes with more swept bodies than
+ * resident waves: the state of a body is parked between its tasks — owned contacts in the Manifold tables, which only their
+ * owner writes; the first visitor's copy of normal + tangent memo and the pose in arrays private to the wave).  Tasks are
+ * taken in the order t = it * slots + slot, a linear extension of the dependency order, so the smallest unfinished task is
+ * always at the head of a resident wave's list.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
+template <bool MULTI>
+__device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, const int* __restrict__ order, int nd, int w, int W,
+                                                 const int* __restrict__ incStart, const int* __restrict__ inc, const SolverParams& P, int* errWord,
+                                                 Counters* cntW, const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products)
 {
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     const float4* massPlane = B.plane(BP_MASS);
-    body = __builtin_amdgcn_readfirstlane(body);                     /* wave-uniform: scalar loads and scalar branches below */
-    const int eBeg = __builtin_amdgcn_readfirstlane(incStart[body]);
-    const int nEnt = __builtin_amdgcn_readfirstlane(incStart[body + 1]) - eBeg;
-    const bool has = lane < nEnt;
 
-    /* ---- once per step: everything the loop needs, from the tables the earlier kernels of this step wrote ---- */
+    /* ---- the state of the task in hand ---- */
+    int body = 0, eBeg = 0, nEnt = 0;
+    bool has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
     c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
     for (int k = 0; k < 3; ++k) { c.lambda[k] = 0.0f; c.penalty[k] = 0.0f; c.C[k] = 0.0f; c.fmin[k] = 0.0f; c.fmax[k] = 0.0f; }
     f3 opos = zero3(); q4 orot = identq(); f3 wOther = zero3(), pOther = zero3();
-    if (has) {
-        const int ent = inc[eBeg + lane];
-        idx = inc_index(ent); isA = inc_isA(ent) != 0;
-        const int m = idx >> 2;
-        const int2 pr = M.pair[m];
-        other = isA ? pr.y : pr.x;
-        oinv = massPlane[other].y;
-        fric = M.fric[m];
-        moving = B.solved[other] != 0;
-        owned = !moving || other > body;
-        load_contact<false>(M, idx, c);
-        const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose (solver.cpp:299-337) */
-        opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
-        wOther = qrotate(orot, isA ? c.rB : c.rA);
-        pOther = opos + wOther;
-    }
     BodyLocal L;
-    {
-        const float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
-        const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
-        L.pos = mk3(pp.x, pp.y, pp.z); L.rot = mkq(pq.x, pq.y, pq.z, pq.w);
-        L.npos = mk3(snp.x, snp.y, snp.z); L.nrot = mkq(snq.x, snq.y, snq.z, snq.w);
-        L.mass = smp.x; L.invMass = smp.y;
-        L.invDt2 = 1.0f / (P.dt * P.dt);
-    }
-    const float radius = B.plane(BP_POSR)[body].w;
-    const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
-    const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
-    const m33 Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
-    const m33 Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
-    const int offP = other * 48, offV = idx * 16, offD = idx * 32;
+    L.invDt2 = 1.0f / (P.dt * P.dt);
+    float radius = 0.0f;
+    m33 Ib, Jb;
+    int offP = 0, offV = 0, offD = 0;
+
+    /* everything a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
+     * wrote (first iteration), or what this same wave parked after the body's previous task (MULTI, later iterations) */
+    auto load_task = [&](int slot, int it) {
+        body = __builtin_amdgcn_readfirstlane(order[slot]);           /* wave-uniform: scalar loads and scalar branches below */
+        eBeg = __builtin_amdgcn_readfirstlane(incStart[body]);
+        nEnt = __builtin_amdgcn_readfirstlane(incStart[body + 1]) - eBeg;
+        has = lane < nEnt;
+        fixedN = false;
+        if (has) {
+            const int ent = inc[eBeg + lane];
+            idx = inc_index(ent); isA = inc_isA(ent) != 0;
+            const int m = idx >> 2;
+            const int2 pr = M.pair[m];
+            other = isA ? pr.y : pr.x;
+            oinv = massPlane[other].y;
+            fric = M.fric[m];
+            moving = B.solved[other] != 0;
+            owned = !moving || other > body;
+            load_contact<false>(M, idx, c);                           /* owned contacts: also what this wave's last dual left there */
+            if (MULTI && it > 0 && !owned) {                          /* this visitor's own copy of the normal and its memo */
+                const float4 pn = X.privN[(size_t)(eBeg + lane) * 3], p1 = X.privN[(size_t)(eBeg + lane) * 3 + 1], p2 = X.privN[(size_t)(eBeg + lane) * 3 + 2];
+                c.normal = mk3(pn.x, pn.y, pn.z); c.u1 = mk3(p1.x, p1.y, p1.z); c.u2 = mk3(p2.x, p2.y, p2.z);
+            }
+            const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose (solver.cpp:299-337); constant for unswept partners */
+            opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
+            wOther = qrotate(orot, isA ? c.rB : c.rA);
+            pOther = opos + wOther;
+        }
+        {
+            float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
+            radius = pp.w;
+            if (MULTI && it > 0) { pp = X.privPose[(size_t)body * 2]; pq = X.privPose[(size_t)body * 2 + 1]; }
+            const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
+            L.pos = mk3(pp.x, pp.y, pp.z); L.rot = mkq(pq.x, pq.y, pq.z, pq.w);
+            L.npos = mk3(snp.x, snp.y, snp.z); L.nrot = mkq(snq.x, snq.y, snq.z, snq.w);
+            L.mass = smp.x; L.invMass = smp.y;
+        }
+        const float4 i0 = B.plane(BP_I0)[body], i1 = B.plane(BP_I1)[body], i2 = B.plane(BP_I2)[body];
+        const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
+        Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
+        Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
+        offP = other * 48; offV = idx * 16; offD = idx * 32;
+    };
+    /* MULTI: park the body's state until its next task; the last task leaves the step's final state (rows included) */
+    auto save_task = [&](bool last) {
+        if (has) {
+            if (owned) store_contact_dual<false>(M, idx, c, last);
+            else {
+                X.privN[(size_t)(eBeg + lane) * 3] = make_float4(c.normal.x, c.normal.y, c.normal.z, 0.f);
+                X.privN[(size_t)(eBeg + lane) * 3 + 1] = make_float4(c.u1.x, c.u1.y, c.u1.z, 0.f);
+                X.privN[(size_t)(eBeg + lane) * 3 + 2] = make_float4(c.u2.x, c.u2.y, c.u2.z, 0.f);
+            }
+        }
+        if (lane == 0) {
+            if (last) { B.plane(BP_POSR)[body] = pack3(L.pos, radius); B.plane(BP_QUAT)[body] = packq(L.rot); }
+            else { X.privPose[(size_t)body * 2] = pack3(L.pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(L.rot); }
+        }
+    };
+
     for (int r = lane; r < kResRows; r += 64) rows[kResJFloats + 6 * kResRows + r] = 0.0f;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned prevWait = 0;                                           /* ticks (10 ns) this wave waited in the previous iteration */
@@ -225,6 +266,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #endif
 
     for (int it = 0; it < totalIt; ++it) {
+      for (int slot = w; slot < nd; slot += W) {                       /* MULTI = false: exactly one slot (the caller checks w < nd) */
+        if (MULTI || it == 0) load_task(slot, it);
 #ifdef AVBD_DF_STATS
         unsigned* trec = reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)it * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8;
         if (lane == 0) { trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[5] = (unsigned)body; }
@@ -276,7 +319,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
              * stays off the memory system for the first part of that time.  Polls of idle waves were measured to lengthen
              * everybody's hand-off latency. */
             const unsigned long long tWait0 = __builtin_amdgcn_s_memrealtime();
-            if (needP | needV | needD) {
+            if (!MULTI && (needP | needV | needD)) {
                 const unsigned quiet = (prevWait * (unsigned)X.quietPermille) / 1000u;
                 while ((unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0) < quiet) __builtin_amdgcn_s_sleep(8);
             }
@@ -386,6 +429,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         if (lane == 0) trec[4] = (unsigned)tprev;
         stat[5] += 1;
 #endif
+        if (MULTI) save_task(it == totalIt - 1);
+        else break;
+      }
     }
 #ifdef AVBD_DF_STATS
     if (lane == 0) {
@@ -397,11 +443,13 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #endif
 
     /* ---- once per step: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
-    if (lane == 0) {
-        B.plane(BP_POSR)[body] = pack3(L.pos, radius);
-        B.plane(BP_QUAT)[body] = packq(L.rot);
+    if (!MULTI) {
+        if (lane == 0) {
+            B.plane(BP_POSR)[body] = pack3(L.pos, radius);
+            B.plane(BP_QUAT)[body] = packq(L.rot);
+        }
+        if (has && owned) store_contact_dual<false>(M, idx, c, true);
     }
-    if (has && owned) store_contact_dual<false>(M, idx, c, true);
 }
 
 } // namespace avbd

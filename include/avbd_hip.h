@@ -109,7 +109,8 @@ typedef struct AvbdStepStats {
     int numJoints, numSprings, numIgnores;
     int warnings;           /* non-finite sanitizer hits this step (solver.cpp:51-66) */
     int schedule;           /* how the iteration loop of that step ran: 0 one launch per level, 1 data-flow tasks (k_iterate),
-                               2 resident (one wavefront per body for the whole loop, avbd_resident.h) */
+                               2 resident (one wavefront per body for the whole loop, avbd_resident.h),
+                               3 resident with several bodies per wavefront (more swept bodies than resident waves) */
 } AvbdStepStats;
 
 /* Accumulated device time per kernel family since the last avbd_profile_reset, measured with HIP

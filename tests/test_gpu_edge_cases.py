@@ -203,3 +203,17 @@ def test_resident_stamp_window_wraps_cleanly(monkeypatch):
         o.step(); g.step()
         H.assert_same_world(o, g, f"Stack across the stamp wrap, step {s + 1}")
     assert int(g.w.stats()["schedule"]) == 2
+
+
+def test_resident_schedule_with_several_bodies_per_wave(monkeypatch):
+    """More swept bodies than resident wavefronts (1728 > 1024): every wave takes every W-th body of the level order and
+    parks a body's state between its tasks (stats.schedule == 3).  AVBD_RESIDENT_MULTI=0 sends the scene to the task
+    schedule instead (1).  Post-stabilisation changes which task is a body's last."""
+    for post in (0, 1):
+        o = H.CpuWorld("orc"); o.scene("Packed:12"); o.set_params(postStabilize=post, iterations=6); o.step(14)
+        for multi, sched in (("1", 3), ("0", 1)):
+            monkeypatch.setenv("AVBD_RESIDENT_MULTI", multi)
+            g = H.HipWorld(); g.scene("Packed:12"); g.set_params(postStabilize=post, iterations=6); g.step(14)
+            monkeypatch.delenv("AVBD_RESIDENT_MULTI")
+            assert int(g.w.stats()["schedule"]) == sched
+            H.assert_same_world_fast(o, g, f"Packed:12 postStabilize={post} multi={multi}", check_rows=True)
