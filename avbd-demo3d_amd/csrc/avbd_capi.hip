@@ -143,9 +143,11 @@ struct AvbdContext {
     size_t privNCap = 0, privPoseCap = 0;
     bool residentMultiAllowed = true;   /* AVBD_RESIDENT_MULTI=0: scenes with more swept bodies than waves use the task schedule */
     bool residentMultiLaunched = false;
+    int residentMultiMax = 64;          /* AVBD_RESIDENT_MULTI_MAX: most bodies one wave may own */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
     bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
     bool fusedFront = true;        /* AVBD_FUSED_FRONT=0: separate broadphase and narrow-phase launches */
+    bool orderByIndex = true;      /* data-flow schedules sweep in descending creation index; AVBD_ORDER=levels: dependency levels (always in AVBD_MODE=levels) */
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
@@ -519,7 +521,7 @@ int launch_topology(AvbdContext* c, bool fromStep)
         /* small scene: scans, scatter, per-body order, levels, predictor and flag reset as one workgroup in LDS */
         hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
-                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap + 16);
+                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap + 16, c->orderByIndex ? 1 : 0);
         c->topologyDidPredict = true;
         HIPCHK(c, hipGetLastError());
         c->adjDirty = false;
@@ -531,9 +533,13 @@ int launch_topology(AvbdContext* c, bool fromStep)
                        M, c->dCnt.p, c->dG.p, ng, c->adjStart.p, c->degForce.p, c->adjRef.p, c->adjOther.p, c->adjKey.p);
     hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->adjStart.p, c->adjRef.p, c->adjOther.p,
                        c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p, c->dCnt.p);
-    if (fromStep)
-        hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), kLevelsLdsBytes, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
-                           c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap, c->iterBlocks * kIterWaves);
+    if (fromStep) {
+        if (c->mode != 0 && c->orderByIndex)
+            hipLaunchKernelGGL(k_order_by_index, dim3(1), dim3(1024), 0, c->stream, B, c->level.p, c->lvlStart.p, c->order.p, c->dCnt.p, c->iterBlocks * kIterWaves);
+        else
+            hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), kLevelsLdsBytes, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
+                               c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap, c->iterBlocks * kIterWaves);
+    }
     HIPCHK(c, hipGetLastError());
     c->adjDirty = false;
     return AVBD_OK;
@@ -654,7 +660,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
     const int dynBodies = B.n - c->numStatic;
     const bool fitsOne = dynBodies <= X.maxWaves;
-    const bool fitsMulti = c->residentMultiAllowed && dynBodies <= 16 * X.maxWaves;   /* beyond that a wave would own > 16 bodies: throughput-bound, task schedule */
+    const bool fitsMulti = c->residentMultiAllowed && dynBodies <= c->residentMultiMax * X.maxWaves;   /* beyond: throughput-bound, task schedule with two workgroups per CU */
     X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave &&
                  itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
                  totalItAll <= 60 && totalItAll > 0 && (fitsOne || fitsMulti) && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
@@ -899,8 +905,10 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
+        if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -607,10 +607,45 @@ __device__ __forceinline__ unsigned long long block_scan_inclusive_u64(unsigned 
     return v + base;
 }
 
+/* Large scenes, data-flow schedules: the sweep order only has to be a linear extension of "later-created swept neighbours
+ * first", and descending creation index IS one — no level relaxation (a single workgroup needs one sweep per level: 15 ms
+ * at 64 000 bodies / 128 levels).  All swept bodies form one "level"; the level schedule (AVBD_MODE=levels) keeps k_levels. */
+__global__ __launch_bounds__(1024) void k_order_by_index(BodyTable B, int* level, int* lvlStart, int* order, Counters* cnt, int residentWaves)
+{
+    __shared__ unsigned long long sWaveTotals[16];
+    __shared__ int sTotal;
+    const int n = B.n, t = threadIdx.x;
+    int running = 0;
+    /* pass 1: how many swept bodies */
+    int mine = 0;
+    for (int b = t; b < n; b += 1024) mine += B.solved[b] ? 1 : 0;
+    const int inclAll = (int)block_scan_inclusive_u64((unsigned long long)mine, sWaveTotals);
+    if (t == 1023) sTotal = inclAll;
+    __syncthreads();
+    const int nd = sTotal;
+    /* pass 2: ascending rank by blocks of 1024 bodies; slot = nd - 1 - rank (newest first) */
+    for (int base = 0; base < n; base += 1024) {
+        const int b = base + t;
+        const int f = (b < n && B.solved[b]) ? 1 : 0;
+        const int incl = (int)block_scan_inclusive_u64((unsigned long long)f, sWaveTotals);
+        if (b < n) level[b] = f;
+        if (f) order[nd - 1 - (running + incl - 1)] = b;
+        if (t == 1023) sTotal = incl;
+        __syncthreads();
+        running += sTotal;
+        __syncthreads();
+    }
+    if (t == 0) {
+        lvlStart[0] = 0; lvlStart[1] = nd;
+        atomicExch(&cnt->numLevels, nd > 0 ? 1 : 0);
+        if (nd > residentWaves) atomicOr(&cnt->residentBad, 2);
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTable M, const GForce* gf, int ng, Counters* cnt, const int* nextCount,
                                                           int* degForce, int* degInc, int* adjStart, int* incStart, int* adjRef, int* adjOther,
                                                           uint64_t* adjKey, int2* adjTmp, int* inc, int* level, int* lvlCount, int* lvlStart, int* order, int lvlCap,
-                                                          int residentWaves, SolverParams P, int* flags, int nFlags)
+                                                          int residentWaves, SolverParams P, int* flags, int nFlags, int byIndex)
 {
     extern __shared__ int sTopo[];
     __shared__ unsigned long long sWaveTotals[16];
@@ -756,6 +791,31 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
 #ifdef AVBD_DF_STATS
     __syncthreads(); if (t == 0) tstamp[4] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (byIndex) {
+        /* data-flow schedules only need a linear extension of "later-created swept neighbours first": descending creation
+         * index is one, and costs one scan instead of one relaxation sweep per level */
+        int running = 0;
+        for (int base = 0; base < n; base += 1024) {
+            const int b = base + t;
+            const int f = (b < n && sSwept[b]) ? 1 : 0;
+            const int incl = (int)block_scan_inclusive_u64((unsigned long long)f, sWaveTotals);
+            if (b < n) { level[b] = f; sLevel[b] = (unsigned short)(running + incl - 1); }   /* ascending rank, parked in sLevel */
+            if (t == 1023) sTotal = incl;
+            __syncthreads();
+            running += sTotal;
+            __syncthreads();
+        }
+        const int ndAll = running;
+        for (int b = t; b < n; b += 1024) if (sSwept[b]) order[ndAll - 1 - (int)sLevel[b]] = b;
+        if (t == 0) {
+            lvlStart[0] = 0; lvlStart[1] = ndAll;
+            atomicExch(&cnt->numLevels, ndAll > 0 ? 1 : 0);
+            int bad = sBad ? 1 : 0;
+            if (ndAll > residentWaves) bad |= 2;
+            if (bad) atomicOr(&cnt->residentBad, bad);
+        }
+        return;
+    }
     /* ---- phase 4: dependency levels (level = 1 + max level of the later-created swept neighbours), relaxed in LDS ---- */
     constexpr int kPer = kTopoBodies / 1024, kNbReg = 8;
     int seg[kPer], cnt_[kPer];

@@ -105,7 +105,8 @@ typedef struct AvbdStepStats {
     int numContacts;        /* Nc */
     int numIncidences;      /* Ninc = sum over contacts of dynamic endpoints */
     int numCandidates;      /* sphere-overlap pairs tested by SAT this step that were not persistent */
-    int numLevels;          /* Gauss-Seidel dependency levels of the primal sweep */
+    int numLevels;          /* Gauss-Seidel dependency levels of the primal sweep (AVBD_MODE=levels or AVBD_ORDER=levels; the
+                               data-flow schedules sweep in descending creation index and report 1) */
     int numJoints, numSprings, numIgnores;
     int warnings;           /* non-finite sanitizer hits this step (solver.cpp:51-66) */
     int schedule;           /* how the iteration loop of that step ran: 0 one launch per level, 1 data-flow tasks (k_iterate),

@@ -179,9 +179,11 @@ def test_fused_topology_kernel_fast_and_slow_paths(monkeypatch):
 
 def test_front_end_and_polling_knobs_do_not_change_results(monkeypatch):
     """AVBD_FUSED_FRONT=0 (separate broadphase / narrow-phase launches) and the quiet share of the resident schedule's wait
-    (0 = poll at once, 900 = sleep through 90 % of the previous wait) are placement/timing choices only."""
+    (0 = poll at once, 900 = sleep through 90 % of the previous wait) are placement/timing choices only, and so is the sweep
+    order handed to the data-flow schedules (descending creation index by default, dependency levels with AVBD_ORDER=levels)."""
     o = H.CpuWorld("orc"); o.scene("Pyramid"); o.step(40)
-    for env in ({"AVBD_FUSED_FRONT": "0"}, {"AVBD_RESIDENT_QUIET": "0"}, {"AVBD_RESIDENT_QUIET": "900"},
+    for env in ({"AVBD_FUSED_FRONT": "0"}, {"AVBD_RESIDENT_QUIET": "0"}, {"AVBD_RESIDENT_QUIET": "900"}, {"AVBD_ORDER": "levels"},
+                {"AVBD_ORDER": "levels", "AVBD_RESIDENT": "0"}, {"AVBD_ORDER": "levels", "AVBD_FUSED_TOPOLOGY": "0", "AVBD_RESIDENT": "0"},
                 {"AVBD_FUSED_FRONT": "0", "AVBD_FUSED_TOPOLOGY": "0", "AVBD_RESIDENT": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
