@@ -150,6 +150,7 @@ struct AvbdContext {
     bool orderByIndex = true;      /* data-flow schedules sweep in descending creation index; AVBD_ORDER=levels: dependency levels (always in AVBD_MODE=levels) */
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
+    bool residentSpread = true;    /* AVBD_RESIDENT_SPREAD=0: slot = linear wave index */
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     int numStatic = 0;
@@ -657,6 +658,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
     X.maxWaves = c->iterBlocks * kIterWaves;
     X.quietPermille = c->residentQuiet;
+    X.spread = c->residentSpread ? 1 : 0;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
     const int dynBodies = B.n - c->numStatic;
     const bool fitsOne = dynBodies <= X.maxWaves;
@@ -907,6 +909,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
+        if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
@@ -1725,6 +1728,16 @@ int avbd_debug_topology_times(AvbdContext* c, unsigned long long* out7)
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out7, c->dFlags.p + 2 * (size_t)c->bodyCap + 16 + 1024 * 32 + 20 * 1024 * 8, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
+int avbd_debug_front_times(AvbdContext* c, unsigned long long* out4)
+{
+    if (!c || !out4) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ManifoldBuf& m = c->mbuf[c->cur];
+    HIPCHK(c, hipMemcpy(out4, reinterpret_cast<unsigned long long*>(m.cC.p + (size_t)m.cap * 4 - 8), 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return AVBD_OK;
 }
 

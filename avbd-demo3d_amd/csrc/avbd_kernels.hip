@@ -156,7 +156,8 @@ __device__ __forceinline__ BoxPose load_box(const BodyTable& B, int i, float& fr
 
 /* one pair: last step's manifold `item` of `src` (item >= 0) or a fresh candidate (a, b); survivors are appended to dst */
 __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTable& src, const ManifoldTable& dst, int item, int a, int b, int step,
-                                            ManifoldInit& mi, ManifoldOld& old, Counters* cnt, int* nextCount, int* degForce, int* degInc, const SolverParams& P)
+                                            ManifoldInit& mi, ManifoldOld& old, Counters* cnt, int* nextCount, int* degForce, int* degInc, const SolverParams& P,
+                                            unsigned long long* dbg = nullptr)
 {
     uint64_t key;
     if (item >= 0) {
@@ -180,7 +181,13 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
     float fa, fb, ima, imb;
     BoxPose A = load_box(B, a, fa, ima);
     BoxPose Bp = load_box(B, b, fb, imb);
+#ifdef AVBD_DF_STATS
+    if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A.pos.x == 12345.0f);
+#endif
     if (!manifold_initialize(mi, old, A, fa, Bp, fb)) return;
+#ifdef AVBD_DF_STATS
+    if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
     const int rows = mi.numContacts * 3;
@@ -220,6 +227,9 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
     if (B.solved[b]) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
     atomicAdd(&cnt->numContacts, mi.numContacts);
     atomicAdd(&cnt->numIncidences, inc);
+#ifdef AVBD_DF_STATS
+    if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
@@ -253,9 +263,17 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __shared__ int2 sHits[kFrontHits];
     __shared__ int sNumHits;
     if ((int)blockIdx.x < persistBlocks) {
+#ifdef AVBD_DF_STATS
+        unsigned long long* dbg = (blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<unsigned long long*>(dst.cC + (size_t)dst.cap * 4 - 8) : nullptr;
+        if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
+#endif
         const int nOld = cnt->numManifolds;
         for (int item = blockIdx.x * 32 + threadIdx.x; item < nOld; item += persistBlocks * 32)
-            narrow_pair(B, src, dst, item, 0, 0, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+            narrow_pair(B, src, dst, item, 0, 0, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P
+#ifdef AVBD_DF_STATS
+                        , dbg
+#endif
+                        );
         return;
     }
     if (threadIdx.x == 0) sNumHits = 0;

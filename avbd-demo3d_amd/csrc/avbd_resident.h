@@ -45,6 +45,7 @@ struct ResidentExchange {
     int quietPermille; /* share of the previous iteration's wait a wave spends asleep before it starts polling */
     float4* privN;     /* [3 * incidence capacity] MULTI: a first visitor's own copy of (normal, u1, u2) between its tasks */
     float4* privPose;  /* [2 * bodyCap]            MULTI: the pose between the body's tasks */
+    int spread;        /* one body per wave: slot = wave-in-workgroup * workgroups + workgroup instead of the linear wave index */
     int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
 };
 

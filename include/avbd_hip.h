@@ -225,6 +225,8 @@ int  avbd_debug_iterate_stats(AvbdContext* ctx, unsigned long long* out, int wav
 int  avbd_debug_task_times(AvbdContext* ctx, unsigned* out, int iterations);
 /* phase boundaries of the last k_topology_small launch (s_memrealtime ticks, -DAVBD_DF_STATS builds only) */
 int  avbd_debug_topology_times(AvbdContext* ctx, unsigned long long* out7);
+/* s_memrealtime at start / after loads / after Manifold::initialize / at the end of the first pair of k_front_small (stats builds) */
+int  avbd_debug_front_times(AvbdContext* ctx, unsigned long long* out4);
 
 #ifdef __cplusplus
 }
