@@ -163,6 +163,7 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
     if (item >= 0) {
         int2 pr = src.pair[item]; a = pr.x; b = pr.y; key = src.key[item];
         mi.numContacts = src.nc[item];
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c < mi.numContacts) {
                 int s = item * 4 + c;
@@ -191,6 +192,7 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
 
     /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
     const int rows = mi.numContacts * 3;
+#pragma unroll
     for (int r = 0; r < 12; ++r) {
         if (r < rows) {
             if (!P.postStabilize) mi.lambda[r] *= P.alpha * P.gamma;
@@ -204,6 +206,7 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
     dst.key[slot] = key;
     dst.nc[slot] = mi.numContacts;
     dst.fric[slot] = mi.combinedFriction;
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c < mi.numContacts) {
             int s = slot * 4 + c;
@@ -240,12 +243,12 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int total = nOld + nCand;
     /* 32 pairs per workgroup: with ~5000 pairs and 1024 SIMDs a half-filled wavefront costs nothing and halves the branch
      * divergence; the dynamically indexed per-pair state lives in LDS instead of scratch */
-    __shared__ ManifoldInit sMi[32];
     __shared__ ManifoldOld sOld[32];
+    ManifoldInit miPriv;
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         int a = 0, b = 0;
         if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
-        narrow_pair(B, src, dst, item < nOld ? item : -1, a, b, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+        narrow_pair(B, src, dst, item < nOld ? item : -1, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
     }
 }
 
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                                                       const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
                                                       int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
 {
-    __shared__ ManifoldInit sMi[32];
+    ManifoldInit miPriv;             /* statically indexed after unrolling: registers; the dynamically indexed state is in sOld */
     __shared__ ManifoldOld sOld[32];
     __shared__ int2 sHits[kFrontHits];
     __shared__ int sNumHits;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
         const int nOld = cnt->numManifolds;
         for (int item = blockIdx.x * 32 + threadIdx.x; item < nOld; item += persistBlocks * 32)
-            narrow_pair(B, src, dst, item, 0, 0, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P
+            narrow_pair(B, src, dst, item, 0, 0, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P
 #ifdef AVBD_DF_STATS
                         , dbg
 #endif
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (threadIdx.x == 0 && nHits) atomicAdd(&cnt->numCandidates, nHits);
     for (int h = threadIdx.x; h < nHits; h += 32) {
         const int2 pr = sHits[h];
-        narrow_pair(B, src, dst, -1, pr.x, pr.y, step, sMi[threadIdx.x], sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+        narrow_pair(B, src, dst, -1, pr.x, pr.y, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
     }
 }
 

@@ -238,6 +238,7 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, ManifoldOld& old, const BoxPos
     float* oldLambda = old.lambda; float* oldPenalty = old.penalty;
     bool* oldUsed = old.used;
     for (int i = 0; i < 4; ++i) oldUsed[i] = false;
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i < oldN) {
             oldFeature[i] = m.feature[i]; oldRA[i] = m.rA[i]; oldRB[i] = m.rB[i]; oldNormal[i] = m.normal[i]; oldStick[i] = m.stick[i];
@@ -249,6 +250,7 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, ManifoldOld& old, const BoxPos
     m.numContacts = collide_boxes(A, B, raw, old.ws);
     if (m.numContacts == 0) return false;
 
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i >= m.numContacts) break;
         int base = i * 3;
