@@ -126,6 +126,9 @@ struct AvbdContext {
     DevArr<uint64_t> adjKey;
     DevArr<int2> adjTmp;       /* (force reference, other body) in scatter order: k_topology_small */
     DevArr<int2> cand;
+    /* grid broadphase (scenes above 4096 bodies): radius classes from the host mirror, hashed cell table */
+    DevArr<unsigned char> dIsBig; DevArr<int> dBigList, dCellHead, dCellNext;
+    int nBig = 0, gridBuckets = 0; float gridCell = 0.0f; bool gridBroadphase = true;   /* AVBD_BROADPHASE=n2: always the O(n^2) tiles */
     int candCap = 0, adjCap = 0, incCap = 0, lvlCap = 0;
     bool adjDirty = true;
 
@@ -389,6 +392,34 @@ int upload_bodies_if_stale(AvbdContext* c)
             if (c->dRecv.n < (size_t)2 * std::max(1, c->maxCount) * c->nranks) HIPCHK(c, c->dRecv.alloc((size_t)2 * std::max(1, c->maxCount) * c->nranks));
         }
     }
+    if (c->gridBroadphase && n > kTopoBodies) {
+        /* radius classes (radii never change after creation): cell edge = 2.002 x the largest radius that is at most 4x the
+         * median; anything larger (the ground slab) is "big" and tested against every body */
+        std::vector<float> rad((size_t)n);
+        for (int i = 0; i < n; ++i) rad[(size_t)i] = c->hBodies[(size_t)i].radius;
+        std::vector<float> sorted(rad);
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const float limit = 4.0f * sorted[(size_t)n / 2];
+        std::vector<unsigned char> big((size_t)n, 0);
+        std::vector<int> bigList;
+        float rSmall = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            if (rad[(size_t)i] > limit || !(rad[(size_t)i] == rad[(size_t)i])) { big[(size_t)i] = 1; bigList.push_back(i); }
+            else rSmall = std::max(rSmall, rad[(size_t)i]);
+        }
+        c->nBig = (int)bigList.size();
+        c->gridCell = std::max(1.0e-3f, 2.002f * rSmall);
+        int buckets = 1024;
+        while (buckets < 2 * n && buckets < (1 << 18)) buckets <<= 1;
+        c->gridBuckets = buckets;
+        HIPCHK(c, c->dIsBig.alloc((size_t)n)); HIPCHK(c, c->dBigList.alloc((size_t)std::max(1, c->nBig)));
+        HIPCHK(c, c->dCellHead.alloc((size_t)buckets)); HIPCHK(c, c->dCellNext.alloc((size_t)n));
+        HIPCHK(c, hipMemcpyAsync(c->dIsBig.p, big.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
+        if (c->nBig) HIPCHK(c, hipMemcpyAsync(c->dBigList.p, bigList.data(), (size_t)c->nBig * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   /* the vectors above die with this scope */
+    } else {
+        c->gridBuckets = 0;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bodiesStale = false;
     c->deviceAhead = false;
@@ -607,6 +638,13 @@ int step_begin(AvbdContext* c)
             const int slices = (n + 31) / 32;
             hipLaunchKernelGGL(k_broadphase_small, dim3(grid_for((long long)n * slices, 256, 1 << 24)), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p,
                                c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0, slices);
+        } else if (n > 1 && c->gridBuckets > 0 && c->nBig <= 64) {
+            const float invCell = 1.0f / c->gridCell;
+            const unsigned mask = (unsigned)c->gridBuckets - 1u;
+            HIPCHK(c, hipMemsetAsync(c->dCellHead.p, 0xff, (size_t)c->gridBuckets * sizeof(int), c->stream));   /* -1: empty bucket */
+            hipLaunchKernelGGL(k_grid_build, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0, c->stream, B, c->dIsBig.p, invCell, mask, c->dCellHead.p, c->dCellNext.p);
+            hipLaunchKernelGGL(k_grid_pairs, dim3(grid_for((long long)n * 27, 256, 1 << 24)), dim3(256), 0, c->stream, B, c->dIsBig.p, c->dBigList.p, c->nBig, invCell, mask,
+                               c->dCellHead.p, c->dCellNext.p, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
         } else if (n > 1) {
             const int T = (n + 255) / 256;
             hipLaunchKernelGGL(k_broadphase, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
@@ -911,6 +949,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
+        if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;
         if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
@@ -936,6 +975,7 @@ int avbd_destroy(AvbdContext* c)
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
     c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSend.release(); c->dRecv.release();
+    c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->adjTmp.release();
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);

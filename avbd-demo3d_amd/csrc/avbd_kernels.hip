@@ -139,6 +139,114 @@ __global__ __launch_bounds__(256) void k_broadphase_small(BodyTable B, const int
 }
 
 /* ------------------------------------------------------------------------------------------
+ * K1g grid broadphase, scenes above 4096 bodies: the SAME pair set as the O(n^2) loop — every pair
+ * (A later-created, B earlier) whose bounding spheres overlap and that shares no force — found through a hashed uniform
+ * grid.  The creation keys make the order in which candidates are appended irrelevant.  Bodies whose radius exceeds the
+ * cell (the ground slab) are on a short "big" list and are tested against everybody; the others are binned by centre into
+ * cells of edge >= 2 * largest small radius, so two overlapping small spheres are never more than one cell apart on any axis.
+ * Different cells may share a bucket of the hash table (that only adds pairs to the exact sphere test); a body scans each
+ * distinct bucket once.
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int grid_coord(float x, float invCell) { return (int)floorf(x * invCell); }
+__device__ __forceinline__ unsigned grid_bucket(int ix, int iy, int iz, unsigned mask)
+{
+    /* lattice coordinates are small consecutive integers: mix them properly (murmur3 finaliser) before masking */
+    unsigned h = (unsigned)ix * 73856093u + (unsigned)iy * 19349663u + (unsigned)iz * 83492791u;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h & mask;
+}
+
+/* every small body pushes itself on the linked list of its bucket (heads start at -1; order inside a bucket is irrelevant) */
+__global__ void k_grid_build(BodyTable B, const unsigned char* __restrict__ isBig, float invCell, unsigned mask, int* __restrict__ cellHead, int* __restrict__ cellNext)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    if (isBig[i]) { cellNext[i] = -1; return; }
+    const float4 p = B.plane(BP_POSR)[i];
+    const unsigned h = grid_bucket(grid_coord(p.x, invCell), grid_coord(p.y, invCell), grid_coord(p.z, invCell), mask);
+    cellNext[i] = atomicExch(&cellHead[h], i);
+}
+
+/* the pair test of solver.cpp:262-270 + Rigid::isConstrainedTo (rigid.cpp:61-69) for one ordered pair i > j */
+__device__ __forceinline__ bool broadphase_pair_passes(const BodyTable& B, int i, int j, const int* __restrict__ adjStart, const int* __restrict__ adjOther,
+                                                       int keepUnsolvedPairs)
+{
+    const float4* posr = B.plane(BP_POSR);
+    const float4 a = posr[i], b = posr[j];
+    const f3 dp = mk3(a.x, a.y, a.z) - mk3(b.x, b.y, b.z);
+    const float r = a.w + b.w;
+    if (!(dot3(dp, dp) <= r * r)) return false;
+    if (!B.solved[i] && !B.solved[j]) {
+        const bool bothStatic = !(B.plane(BP_MASS)[i].y > 0.0f) && !(B.plane(BP_MASS)[j].y > 0.0f);
+        if (!(keepUnsolvedPairs && bothStatic)) return false;
+    }
+    const int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
+    int s, e, other;
+    if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
+    for (int k = s; k < e; ++k) if (adjOther[k] == other) return false;
+    return true;
+}
+
+/* one thread per (body, one of the 27 cells around it): the centre thread also takes the body's pairs with the big bodies.
+ * Appending is what bounds a broadphase here (a falling 64 000-cube grid yields 250 000 candidates per step, and atomics on
+ * one word retire at ~10 ns each): every thread first COUNTS its candidates, the workgroup reserves its range with ONE atomic,
+ * then the threads run their (cheap, cache-resident) tests again and write. */
+__global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned char* __restrict__ isBig, const int* __restrict__ bigList, int nBig, float invCell, unsigned mask,
+                             const int* __restrict__ cellHead, const int* __restrict__ cellNext, const int* __restrict__ adjStart,
+                             const int* __restrict__ adjOther, int2* cand, int candCap, Counters* cnt, int keepUnsolvedPairs)
+{
+    __shared__ int sCount, sBase;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / 27), k = (int)(t - (long long)i * 27);
+    const bool live = i < B.n;
+    const bool big = live && isBig[i];
+    if (threadIdx.x == 0) sCount = 0;
+    int head = -1;
+    if (live && !big) {
+        const float4 p = B.plane(BP_POSR)[i];
+        const int cx = grid_coord(p.x, invCell), cy = grid_coord(p.y, invCell), cz = grid_coord(p.z, invCell);
+        const unsigned h = grid_bucket(cx + (k % 3) - 1, cy + ((k / 3) % 3) - 1, cz + (k / 9) - 1, mask);
+        /* different cells may share a bucket: the bucket is scanned by the first of the 27 threads that maps to it */
+        bool first = true;
+        for (int q = 0; q < k; ++q) first &= grid_bucket(cx + (q % 3) - 1, cy + ((q / 3) % 3) - 1, cz + (q / 9) - 1, mask) != h;
+        if (first) head = cellHead[h];
+    }
+    __syncthreads();
+    int offset = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int mine = 0;
+        if (live && k == 13) {                                        /* pairs with a big body: once per unordered pair */
+            for (int g = 0; g < nBig; ++g) {
+                const int o = bigList[g];
+                if (o == i || (big && !(i < o))) continue;
+                const int hi = i > o ? i : o, lo = i > o ? o : i;
+                if (broadphase_pair_passes(B, hi, lo, adjStart, adjOther, keepUnsolvedPairs)) {
+                    if (pass) { const int slot = offset + mine; if (slot < candCap) cand[slot] = make_int2(hi, lo); }
+                    ++mine;
+                }
+            }
+        }
+        for (int j = head; j >= 0; j = cellNext[j]) {
+            if (j < i && broadphase_pair_passes(B, i, j, adjStart, adjOther, keepUnsolvedPairs)) {
+                if (pass) { const int slot = offset + mine; if (slot < candCap) cand[slot] = make_int2(i, j); }
+                ++mine;
+            }
+        }
+        if (pass) break;
+        offset = mine ? atomicAdd(&sCount, mine) : 0;                 /* LDS: position inside the workgroup's range */
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = sCount;
+            const int base = total ? atomicAdd(&cnt->numCandidates, total) : 0;
+            if (base + total > candCap) atomicOr(&cnt->overflow, 1);
+            sBase = base;
+        }
+        __syncthreads();
+        offset += sBase;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * K2 narrow phase + Manifold::initialize + warm-start decay.  One lane per pair: last step's
  * manifolds (src) followed by this step's candidates.  Survivors are appended to dst.
  * ------------------------------------------------------------------------------------------ */
