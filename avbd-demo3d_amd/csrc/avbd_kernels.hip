@@ -36,10 +36,11 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* max over non-negative floats through their uint bit patterns; NaNs are skipped */
+/* max over non-negative floats through their uint bit patterns; NaNs are skipped; -0.0f (what max(0.0f, -separation) yields
+ * for a separation of exactly +0) counts as +0.0f — as a uint it would beat every positive float */
 __device__ __forceinline__ void atomic_max_nonneg(unsigned* dst, float v)
 {
-    if (v == v) atomicMax(dst, __float_as_uint(v));
+    if (v == v) atomicMax(dst, __float_as_uint(v + 0.0f));
 }
 
 /* ------------------------------------------------------------------------------------------

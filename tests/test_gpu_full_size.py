@@ -64,3 +64,30 @@ def test_config4_64000_cubes_with_joints_is_deterministic_and_finite():
     assert H.same_bits(finals[0], finals[1])
     b = finals[0]
     assert np.isfinite(b["pos"]).all() and np.isfinite(b["quat"]).all() and np.isfinite(b["linVel"]).all()
+
+
+def test_grid_broadphase_matches_the_n2_loop_on_mixed_sizes(monkeypatch):
+    """Above 4096 bodies the broadphase is a hashed grid.  Mixed radii put several bodies on its "big" list
+    (ground slab, two long static beams that overlap each other, one large dynamic crate); AVBD_BROADPHASE=n2 is the
+    O(n^2) tile kernel.  Both must reproduce the oracle's (O(n^2)) manifold set and state bit for bit."""
+    rng = np.random.default_rng(7)
+    n = 4600
+    size = rng.uniform(0.5, 1.4, (n, 3)).astype(np.float32)
+    pos = np.stack([rng.uniform(-30, 30, n), rng.uniform(0.8, 9.0, n), rng.uniform(-30, 30, n)], 1).astype(np.float32)
+
+    def build(w):
+        w.add_body((100, 1, 100), 0.0, 0.5, (0, -0.5, 0))
+        w.add_body((40, 2, 2), 0.0, 0.6, (0, 1.0, 10))                 # static beam
+        w.add_body((2, 2, 40), 0.0, 0.6, (5, 1.5, 0))                  # static beam crossing the first one
+        w.add_body((8, 8, 8), 0.3, 0.5, (-12, 4.2, -12))               # big dynamic crate
+        for k in range(n):
+            w.add_body(tuple(float(x) for x in size[k]), 1.0, 0.5, tuple(float(x) for x in pos[k]))
+        w.set_params(iterations=6)
+
+    o = H.CpuWorld("orc"); build(o); o.step(12)
+    for mode in ("grid", "n2"):
+        monkeypatch.setenv("AVBD_BROADPHASE", mode)
+        g = H.HipWorld(); build(g); g.step(12)
+        monkeypatch.delenv("AVBD_BROADPHASE")
+        H.assert_same_world_fast(o, g, f"mixed sizes, broadphase={mode}")
+    assert int(g.w.stats()["numManifolds"]) > 800 and int(g.w.stats()["numCandidates"]) > 0
