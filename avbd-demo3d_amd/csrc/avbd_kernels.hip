@@ -1039,7 +1039,7 @@ namespace avbd {
 /* ------------------------------------------------------------------------------------------
  * K7 velocities — solver.cpp:434-469
  * ------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ void velocity_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt, DiagAccum* diag)
+__device__ __forceinline__ void velocity_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt, float& speedLin, float& speedAng)
 {
     if (!(B.plane(BP_MASS)[i].y > 0.0f)) return;
     const float linearDamping = 0.995f, angularDamping = 0.97f;
@@ -1060,21 +1060,26 @@ __device__ __forceinline__ void velocity_body(const BodyTable& B, int i, const S
     sanitize3(w, cnt);
     B.plane(BP_LINV)[i] = pack3(v, 0.f);
     B.plane(BP_ANGV)[i] = pack3(w, 0.f);
-    atomic_max_nonneg(&diag->maxLinearSpeed, len3(v));
-    atomic_max_nonneg(&diag->maxAngularSpeed, len3(w));
+    speedLin = len3(v);                                              /* solver.cpp:472-497: maxima over the dynamic bodies */
+    speedAng = len3(w);
 }
 
 /* ------------------------------------------------------------------------------------------
  * K8 diagnostics — solver.cpp:472-497 (max and integer sums only: order-independent)
  * ------------------------------------------------------------------------------------------ */
+/* per-thread partial results, reduced over the wavefront with shuffles: one set of atomics per wave instead of five per contact
+ * (480 000 contact slots at 64 000 cubes) */
 __device__ __forceinline__ void diag_contacts(const BodyTable& B, const ManifoldTable& M, const Counters* cnt, DiagAccum* diag, int first, int stride)
 {
     const int nm = cnt->numManifolds;
     const int total = nm * 4;
+    float maxPen = 0.0f, maxViol = 0.0f, maxImp = 0.0f;
+    int manifolds = 0, contacts = 0;
+    bool nan = false;
     for (int s = first; s < total; s += stride) {
         const int m = s >> 2, ci = s & 3;
         const int nc = M.nc[m];
-        if (ci == 0) { atomicAdd(&diag->activeManifolds, 1); atomicAdd(&diag->activeContacts, nc); }
+        if (ci == 0) { ++manifolds; contacts += nc; }
         if (ci >= nc) continue;
         const int2 pr = M.pair[m];
         float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s];
@@ -1085,9 +1090,23 @@ __device__ __forceinline__ void diag_contacts(const BodyTable& B, const Manifold
         float separation = dot3(pA - pB, mk3(nn.x, nn.y, nn.z));
         float pen = rmax(0.0f, -separation);
         float viol = rmax(0.0f, kPenetrationSlop - separation);
-        atomic_max_nonneg(&diag->maxPenetration, pen);
-        atomic_max_nonneg(&diag->maxViolation, viol);
-        atomic_max_nonneg(&diag->maxNormalImpulse, fabsf(M.cLam[s].x));
+        float imp = fabsf(M.cLam[s].x);
+        /* NaNs are skipped like in atomic_max_nonneg; all three quantities are >= 0 */
+        if (pen == pen) maxPen = pen > maxPen ? pen : maxPen;
+        if (viol == viol) maxViol = viol > maxViol ? viol : maxViol;
+        if (imp == imp) maxImp = imp > maxImp ? imp : maxImp;
+        (void)nan;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float p2 = __shfl_xor(maxPen, o), v2 = __shfl_xor(maxViol, o), i2 = __shfl_xor(maxImp, o);
+        maxPen = p2 > maxPen ? p2 : maxPen; maxViol = v2 > maxViol ? v2 : maxViol; maxImp = i2 > maxImp ? i2 : maxImp;
+        manifolds += __shfl_xor(manifolds, o); contacts += __shfl_xor(contacts, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (manifolds) { atomicAdd(&diag->activeManifolds, manifolds); atomicAdd(&diag->activeContacts, contacts); }
+        if (maxPen > 0.0f) atomic_max_nonneg(&diag->maxPenetration, maxPen);
+        if (maxViol > 0.0f) atomic_max_nonneg(&diag->maxViolation, maxViol);
+        if (maxImp > 0.0f) atomic_max_nonneg(&diag->maxNormalImpulse, maxImp);
     }
 }
 
@@ -1099,7 +1118,18 @@ __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* c
         /* counted by the predictor, long finished; an atomic because the other workgroups of this launch update the same
          * cache line with atomics from other XCDs (a plain store's write-back could put stale neighbours over them) */
         if (i == 0) atomicExch(&diag->dynamicBodies, cnt->dynamicBodies);
-        if (i < B.n) velocity_body(B, i, P, cnt, diag);
+        float sl = 0.0f, sa = 0.0f;
+        if (i < B.n) velocity_body(B, i, P, cnt, sl, sa);
+        if (!(sl == sl)) sl = 0.0f;                                   /* NaNs are skipped, like in atomic_max_nonneg */
+        if (!(sa == sa)) sa = 0.0f;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float l2 = __shfl_xor(sl, o), a2 = __shfl_xor(sa, o);
+            sl = l2 > sl ? l2 : sl; sa = a2 > sa ? a2 : sa;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (sl > 0.0f) atomic_max_nonneg(&diag->maxLinearSpeed, sl);
+            if (sa > 0.0f) atomic_max_nonneg(&diag->maxAngularSpeed, sa);
+        }
     } else {
         diag_contacts(B, M, cnt, diag, (blockIdx.x - velBlocks) * blockDim.x + threadIdx.x, (gridDim.x - velBlocks) * blockDim.x);
     }
