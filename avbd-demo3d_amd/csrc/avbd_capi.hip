@@ -1143,6 +1143,84 @@ int avbd_add_force(AvbdContext* c, const AvbdForce* r)
     return add_gforce(c, g);
 }
 
+/* ---- snapshots: the complete solver state as one little-endian file --------------------------------
+ * header { magic "AVBDSNP1", sizeof(AvbdBody), sizeof(AvbdForce), nBodies, nForces, stepIndex, AvbdParams } then the
+ * AvbdBody and AvbdForce arrays exactly as avbd_download_bodies / avbd_download_forces return them (force list newest
+ * first).  A context that loads a snapshot continues bit for bit like the one that saved it. */
+namespace {
+struct SnapshotHeader { char magic[8]; int bodyBytes, forceBytes, nBodies, nForces, stepIndex, reserved; AvbdParams params; };
+}
+
+int avbd_set_step_index(AvbdContext* c, int stepIndex)
+{
+    if (!c || stepIndex < 0) return AVBD_E_INVALID;
+    c->stepIndex = stepIndex;
+    return AVBD_OK;
+}
+
+int avbd_save_snapshot(AvbdContext* c, const char* path)
+{
+    if (!c || !path) return AVBD_E_INVALID;
+    const int nb = avbd_num_bodies(c), nf = avbd_num_forces(c);
+    if (nb < 0 || nf < 0) return c->fail(AVBD_E_INVALID, "avbd_save_snapshot: cannot count the state");
+    std::vector<AvbdBody> bodies((size_t)std::max(nb, 1));
+    std::vector<AvbdForce> forces((size_t)std::max(nf, 1));
+    int rc;
+    if (nb && (rc = avbd_download_bodies(c, bodies.data(), nb)) < 0) return rc;
+    if (nf && (rc = avbd_download_forces(c, forces.data(), nf)) < 0) return rc;
+    SnapshotHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "AVBDSNP1", 8);
+    h.bodyBytes = (int)sizeof(AvbdBody); h.forceBytes = (int)sizeof(AvbdForce); h.nBodies = nb; h.nForces = nf; h.stepIndex = c->stepIndex; h.params = c->params;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return c->fail(AVBD_E_INVALID, "avbd_save_snapshot: cannot open the file for writing");
+    bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1;
+    if (ok && nb) ok = std::fwrite(bodies.data(), sizeof(AvbdBody), (size_t)nb, f) == (size_t)nb;
+    if (ok && nf) ok = std::fwrite(forces.data(), sizeof(AvbdForce), (size_t)nf, f) == (size_t)nf;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? AVBD_OK : c->fail(AVBD_E_INVALID, "avbd_save_snapshot: short write");
+}
+
+int avbd_load_snapshot(AvbdContext* c, const char* path)
+{
+    if (!c || !path) return AVBD_E_INVALID;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return c->fail(AVBD_E_INVALID, "avbd_load_snapshot: cannot open the file");
+    SnapshotHeader h;
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "AVBDSNP1", 8) == 0 && h.bodyBytes == (int)sizeof(AvbdBody) &&
+              h.forceBytes == (int)sizeof(AvbdForce) && h.nBodies >= 0 && h.nForces >= 0 && h.nBodies <= (1 << 20) - 2;
+    std::vector<AvbdBody> bodies; std::vector<AvbdForce> forces;
+    if (ok) {
+        bodies.resize((size_t)std::max(h.nBodies, 1)); forces.resize((size_t)std::max(h.nForces, 1));
+        if (h.nBodies) ok = std::fread(bodies.data(), sizeof(AvbdBody), (size_t)h.nBodies, f) == (size_t)h.nBodies;
+        if (ok && h.nForces) ok = std::fread(forces.data(), sizeof(AvbdForce), (size_t)h.nForces, f) == (size_t)h.nForces;
+    }
+    std::fclose(f);
+    if (!ok) return c->fail(AVBD_E_INVALID, "avbd_load_snapshot: not a snapshot of this ABI version, or truncated");
+    int rc;
+    if ((rc = avbd_clear(c))) return rc;
+    if ((rc = avbd_set_params(c, &h.params))) return rc;
+    for (int i = 0; i < h.nBodies; ++i) {
+        const AvbdBody& b = bodies[(size_t)i];
+        float I9[9], J9[9];
+        for (int k = 0; k < 9; ++k) { I9[k] = 0.0f; J9[k] = 0.0f; }
+        if (b.invMass > 0.0f) {                                       /* rigid.cpp:31-40 from the stored mass: same bits as at creation */
+            const float Ixx = (1.0f / 12.0f) * b.mass * (b.size[1] * b.size[1] + b.size[2] * b.size[2]);
+            const float Iyy = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[2] * b.size[2]);
+            const float Izz = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[1] * b.size[1]);
+            I9[0] = Ixx; I9[4] = Iyy; I9[8] = Izz;
+            J9[0] = 1.0f / Ixx; J9[4] = 1.0f / Iyy; J9[8] = 1.0f / Izz;
+        } else ++c->numStatic;
+        c->hBodies.push_back(b);
+        c->hI.insert(c->hI.end(), I9, I9 + 9);
+        c->hJ.insert(c->hJ.end(), J9, J9 + 9);
+    }
+    c->bodiesStale = true; c->adjDirty = true;
+    if ((rc = avbd_upload_forces(c, forces.data(), h.nForces))) return rc;
+    c->stepIndex = h.stepIndex;
+    return AVBD_OK;
+}
+
 int avbd_step(AvbdContext* c, int nsteps)
 {
     if (!c || nsteps < 0) return AVBD_E_INVALID;

@@ -6,7 +6,8 @@
  *
  * Build-only flags (do not exist in the reference): --quiet (no per-step trace; one timing JSON line),
  * --dump <file> (raw AvbdBody array after the last step), --device <n>, --batch (run all steps on the
- * device without per-step downloads; implies --quiet).
+ * device without per-step downloads; implies --quiet), --save-state <file> / --load-state <file>
+ * (checkpoint after the last step / resume from a checkpoint instead of building --scene: SURVEY.md §8 f3).
  */
 #include "solver.h"
 #include "joint.h"
@@ -24,6 +25,8 @@ int main(int argc, char** argv)
 {
     const char* requested = nullptr;
     const char* dumpPath = nullptr;
+    const char* savePath = nullptr;
+    const char* loadPath = nullptr;
     int steps = 300; /* main.cpp:192 */
     bool quiet = false, batch = false;
     for (int i = 1; i < argc; ++i) {
@@ -33,6 +36,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--quiet")) quiet = true;
         else if (!strcmp(argv[i], "--batch")) { batch = true; quiet = true; }
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dumpPath = argv[++i];
+        else if (!strcmp(argv[i], "--save-state") && i + 1 < argc) savePath = argv[++i];
+        else if (!strcmp(argv[i], "--load-state") && i + 1 < argc) loadPath = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) setenv("AVBD_DEVICE", argv[++i], 1);
     }
 
@@ -41,10 +46,15 @@ int main(int argc, char** argv)
 
     /* unknown names silently select scene 0 "Empty" (main.cpp:211-219) */
     const char* shown = sceneNames[0];
-    int idx = requested ? buildSceneByName(solver, requested) : -1;
-    if (idx < 0) scenes[0](solver);
-    else if (idx < sceneCount) shown = sceneNames[idx];
-    else shown = requested;
+    if (loadPath) {
+        solver->loadSnapshot(loadPath);
+        shown = loadPath;
+    } else {
+        int idx = requested ? buildSceneByName(solver, requested) : -1;
+        if (idx < 0) scenes[0](solver);
+        else if (idx < sceneCount) shown = sceneNames[idx];
+        else shown = requested;
+    }
 
     if (!quiet) printf("Running in headless mode: scene '%s', steps=%d\n", shown, steps);
     auto t0 = std::chrono::steady_clock::now();
@@ -75,6 +85,7 @@ int main(int argc, char** argv)
         printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\"}\n", shown, steps, ms,
                steps ? ms / steps : 0.0);
     }
+    if (savePath) solver->saveSnapshot(savePath);
     if (dumpPath) {
         int n = solver->bodyCount();
         std::vector<AvbdBody> hb((size_t)n);

@@ -178,6 +178,11 @@ struct Solver {
     void flush();           /* create queued bodies/forces on the device now */
     void pull();            /* download body state + diagnostics into the mirrors */
     void syncForces();      /* rebuild solver->forces / body->forces mirrors from the device (newest first) */
+    /* checkpoint / resume (absent in the reference): the whole device state as one file.  loadSnapshot
+     * replaces the scene: bodies get fresh Rigid mirrors (same creation order, hence the same ids relative to each other),
+     * contact manifolds and joints/springs live on the device (syncForces() mirrors the manifolds on demand). */
+    void saveSnapshot(const char* path);
+    void loadSnapshot(const char* path);
     AvbdContext* context() const { return ctx; }
     int bodyCount() const { return numBodies; }
     Rigid* bodyByIndex(int i) const;

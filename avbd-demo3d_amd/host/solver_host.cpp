@@ -402,6 +402,50 @@ void Solver::pull()
     stepIndex = avbd_step_index(ctx);
 }
 
+void Solver::saveSnapshot(const char* path)
+{
+    flush();
+    pushParams();
+    if (hostSync) pushEditedBodies();
+    int rc = avbd_save_snapshot(ctx, path);
+    if (rc) fail("avbd_save_snapshot", rc);
+}
+
+void Solver::loadSnapshot(const char* path)
+{
+    clear();
+    int rc = avbd_load_snapshot(ctx, path);
+    if (rc) fail("avbd_load_snapshot", rc);
+    const int n = avbd_num_bodies(ctx);
+    std::vector<AvbdBody> st((size_t)(n > 0 ? n : 1));
+    if (n > 0 && (rc = avbd_download_bodies(ctx, st.data(), n)) < 0) fail("avbd_download_bodies", rc);
+    for (int i = 0; i < n; ++i) {
+        const AvbdBody& o = st[(size_t)i];
+        const float vol = o.size[0] * o.size[1] * o.size[2];
+        /* the mirror's density is informational (mass = volume * density need not round-trip); the mass properties
+         * themselves are taken from the record */
+        Rigid* b = new Rigid(this, vec3(o.size[0], o.size[1], o.size[2]), vol > 0.0f ? o.mass / vol : 0.0f, o.friction,
+                             vec3(o.position[0], o.position[1], o.position[2]));
+        b->mass = o.mass; b->invMass = o.invMass; b->radius = o.radius;
+        if (o.invMass > 0.0f) {
+            float Ixx = (1.0f / 12.0f) * o.mass * (o.size[1] * o.size[1] + o.size[2] * o.size[2]);
+            float Iyy = (1.0f / 12.0f) * o.mass * (o.size[0] * o.size[0] + o.size[2] * o.size[2]);
+            float Izz = (1.0f / 12.0f) * o.mass * (o.size[0] * o.size[0] + o.size[1] * o.size[1]);
+            b->inertiaTensor = mat3(vec3(Ixx, 0, 0), vec3(0, Iyy, 0), vec3(0, 0, Izz));
+            b->invInertiaTensor = mat3(vec3(1.0f / Ixx, 0, 0), vec3(0, 1.0f / Iyy, 0), vec3(0, 0, 1.0f / Izz));
+        }
+        unpackBody(b, o);
+    }
+    flushedBodies = n;                                                  /* they already live on the device */
+    impl->shadow = st;
+    impl->shadow.resize((size_t)n);
+    AvbdParams p;
+    if ((rc = avbd_get_params(ctx, &p))) fail("avbd_get_params", rc);
+    dt = p.dt; gravity = vec3(p.gravity[0], p.gravity[1], p.gravity[2]); iterations = p.iterations; alpha = p.alpha; beta = p.beta; gamma = p.gamma;
+    postStabilize = p.postStabilize != 0;
+    stepIndex = avbd_step_index(ctx);
+}
+
 void Solver::stepMany(int n)
 {
     flush();

@@ -187,6 +187,14 @@ int  avbd_download_forces(AvbdContext* ctx, AvbdForce* out, int capacity);
 /* replace every force by `n` records given newest first (snapshot restore / teacher forcing) */
 int  avbd_upload_forces(AvbdContext* ctx, const AvbdForce* in, int n);
 
+/* ---- snapshots (the reference has no checkpoint/resume) ------------------------------------
+ * One little-endian file: header (magic, record sizes, counts, Solver::stepIndex, parameters) + the AvbdBody and AvbdForce
+ * arrays of avbd_download_bodies / avbd_download_forces.  avbd_load_snapshot replaces the whole content of the context;
+ * stepping on continues bit for bit like the context that saved.  CLI: --save-state <file>, --load-state <file>. */
+int  avbd_save_snapshot(AvbdContext* ctx, const char* path);
+int  avbd_load_snapshot(AvbdContext* ctx, const char* path);
+int  avbd_set_step_index(AvbdContext* ctx, int stepIndex);
+
 /* ---- row API on the device for one force of the downloaded list (index into newest-first order):
  * Force::computeConstraint / computeDerivatives (solver.h:104-106).  compute_constraint applies the
  * reference's in-place mutations to the device-resident force and returns its rows. ---- */

@@ -1,5 +1,7 @@
 """Edge cases of the boundary on the device: empty / tiny scenes, bodies and forces added between steps, clear() and
 rebuild, static-only scenes, a body with more than 64 incidence entries (generic path of k_iterate), both schedules."""
+import os
+
 import numpy as np
 import pytest
 
@@ -219,3 +221,33 @@ def test_resident_schedule_with_several_bodies_per_wave(monkeypatch):
             monkeypatch.delenv("AVBD_RESIDENT_MULTI")
             assert int(g.w.stats()["schedule"]) == sched
             H.assert_same_world_fast(o, g, f"Packed:12 postStabilize={post} multi={multi}", check_rows=True)
+
+
+def test_snapshot_save_load_continues_bit_for_bit(tmp_path):
+    """SURVEY.md §8 f3 (checkpoint / resume, absent in the reference): a context that loads a snapshot goes on exactly like
+    the one that saved it — contacts only (resident schedule) and with joints + springs (task schedule)."""
+    for scene, pre, post in (("Pyramid", 45, 30), ("Soft Body (WIP)", 30, 25), ("Stress1000", 200, 40)):
+        a = H.HipWorld(); a.scene(scene); a.step(pre)
+        path = tmp_path / f"{scene.split()[0]}.snap"
+        a.w.save_snapshot(path)
+        b = H.HipWorld(); b.scene("Stack")                       # whatever was there is replaced
+        b.w.load_snapshot(path)
+        assert b.w.step_index() == a.w.step_index() == pre
+        H.assert_same_world(a, b, f"{scene}: right after the load", check_rows=True, check_diag=False)
+        a.step(post); b.step(post)
+        H.assert_same_world(a, b, f"{scene}: {post} steps after the load")
+    with pytest.raises(Exception):
+        b.w.load_snapshot(tmp_path / "missing.snap")
+
+
+def test_cli_save_state_load_state(tmp_path):
+    import subprocess
+    exe = os.path.join(H.ROOT, "avbd-demo3d_amd", "avbd_demo3d")
+    snap = str(tmp_path / "stack.snap")
+    full = subprocess.run([exe, "--nogfx", "--scene", "Stack", "--steps", "70"], capture_output=True, text=True, check=True).stdout.splitlines()
+    subprocess.run([exe, "--nogfx", "--scene", "Stack", "--steps", "40", "--save-state", snap], capture_output=True, text=True, check=True)
+    tail = subprocess.run([exe, "--nogfx", "--load-state", snap, "--steps", "30"], capture_output=True, text=True, check=True).stdout.splitlines()
+    body = lambda lines: [l for l in lines if l.startswith("  Body") or l.startswith("  Diagnostics")]
+    a, b = body(full), body(tail)
+    n = len(b)
+    assert n > 0 and a[-n:] == b
