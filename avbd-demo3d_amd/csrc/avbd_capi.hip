@@ -146,6 +146,7 @@ struct AvbdContext {
     size_t privNCap = 0, privPoseCap = 0;
     bool residentMultiAllowed = true;   /* AVBD_RESIDENT_MULTI=0: scenes with more swept bodies than waves use the task schedule */
     bool residentMultiLaunched = false;
+    bool residentSharded = true;        /* AVBD_RESIDENT_SHARDED=0: sharded runs (one launch per iteration) use the task schedule */
     int residentMultiMax = 64;          /* AVBD_RESIDENT_MULTI_MAX: most bodies one wave may own */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
     bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
@@ -592,7 +593,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.numBodies = (int)c->hBodies.size(); c->stats.numManifolds = cnt.numManifolds; c->stats.numContacts = cnt.numContacts;
     c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = cnt.numLevels;
     c->stats.numDynamic = cnt.dynamicBodies;
-    c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && (cnt.residentBad & 1) == 0 && ((cnt.residentBad & 2) == 0 || c->residentMultiLaunched)) ? ((cnt.residentBad & 2) ? 3 : 2) : 1);
+    c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && (cnt.residentBad & 1) == 0 && ((cnt.residentBad & 2) == 0 || c->residentMultiLaunched)) ? (((cnt.residentBad & 2) || c->residentMultiLaunched) ? 3 : 2) : 1);
     int nj = 0, ns = 0, ni = 0;
     for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
@@ -698,30 +699,34 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.quietPermille = c->residentQuiet;
     X.spread = c->residentSpread ? 1 : 0;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
-    const int dynBodies = B.n - c->numStatic;
-    const bool fitsOne = dynBodies <= X.maxWaves;
+    const bool wholeLoop = itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded;
+    const bool sharded = c->nranks > 1 || c->forceSharded;
+    const int dynBodies = sharded ? c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank] : B.n - c->numStatic;
+    const bool fitsOne = wholeLoop && dynBodies <= X.maxWaves;
     const bool fitsMulti = c->residentMultiAllowed && dynBodies <= c->residentMultiMax * X.maxWaves;   /* beyond: throughput-bound, task schedule with two workgroups per CU */
     X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave &&
-                 itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded && c->hG.empty() &&
+                 (wholeLoop || (sharded && c->residentSharded)) && c->hG.empty() &&
                  totalItAll <= 60 && totalItAll > 0 && (fitsOne || fitsMulti) && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
-    X.multi = 0;
+    X.multi = 0; X.forceMulti = 0; X.planesAlways = 0;
     if (X.enabled && !fitsOne) {
         const size_t needN = (size_t)3 * c->incCap, needP = (size_t)2 * c->bodyCap;
         if (c->privNCap < needN) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivN.alloc(needN)); c->privNCap = needN; }
         if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
         X.multi = 1;
+        if (!wholeLoop) { X.forceMulti = 1; X.planesAlways = 1; }
     }
     X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p;
     c->residentMultiLaunched = X.multi != 0;
     c->residentLaunched = X.enabled != 0;
     if (X.enabled) {
-        if (c->xSerial >= (1u << 24) - 2u) {                       /* stamps are about to wrap: forget every old record */
+        if (itBegin == 0 && c->xSerial >= (1u << 24) - 2u) {      /* stamps are about to wrap: forget every old record */
             HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));
             HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, visitBytes, c->stream));
             HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
             c->xSerial = 0;
         }
-        X.base = (++c->xSerial) * 64u;
+        if (itBegin == 0) ++c->xSerial;                                /* one stamp window per step, shared by its launches */
+        X.base = c->xSerial * 64u;
         blocks = c->iterBlocks;                                        /* every swept body needs its wave resident */
     }
     const bool throughput = !X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves));
@@ -945,6 +950,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_SHARDED")) c->residentSharded = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;

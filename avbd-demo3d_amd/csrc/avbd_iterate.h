@@ -134,12 +134,12 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
         const int veto = cnt->residentBad;                            /* bit0: not a pile of <= 64 contacts per body; bit1: more bodies than waves */
         if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi)) {
             float* products = reinterpret_cast<float*>(sDynamic) + wv * (kResProductBytesPerWave / 4);
-            if (veto & 2) iterate_resident<true>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products);
+            if ((veto & 2) || X.forceMulti) iterate_resident<true>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
             else {
                 /* one body per wave: the four waves of a CU take slots a quarter of the sweep order apart, so that they are
                  * busy at different times (waves of one CU share its LDS, L1 and instruction front end) */
                 const int slot = X.spread ? wv * (int)gridDim.x + (int)blockIdx.x : w;
-                if (slot < nd) iterate_resident<false>(B, M, order, nd, slot, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products);
+                if (slot < nd) iterate_resident<false>(B, M, order, nd, slot, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
             }
             return;
         }

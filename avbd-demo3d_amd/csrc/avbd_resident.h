@@ -47,6 +47,8 @@ struct ResidentExchange {
     float4* privPose;  /* [2 * bodyCap]            MULTI: the pose between the body's tasks */
     int spread;        /* one body per wave: slot = wave-in-workgroup * workgroups + workgroup instead of the linear wave index */
     int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
+    int forceMulti;    /* launches that cover part of the iteration loop (sharded runs) park state even with one body per wave */
+    int planesAlways;  /* sharded runs: the pose planes are what k_pack_poses sends after every iteration */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -175,7 +177,8 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
 template <bool MULTI>
 __device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, const int* __restrict__ order, int nd, int w, int W,
                                                  const int* __restrict__ incStart, const int* __restrict__ inc, const SolverParams& P, int* errWord,
-                                                 Counters* cntW, const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products)
+                                                 Counters* cntW, const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products,
+                                                 int itBegin, int itEnd)
 {
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
@@ -250,8 +253,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             }
         }
         if (lane == 0) {
-            if (last) { B.plane(BP_POSR)[body] = pack3(L.pos, radius); B.plane(BP_QUAT)[body] = packq(L.rot); }
-            else { X.privPose[(size_t)body * 2] = pack3(L.pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(L.rot); }
+            if (last || X.planesAlways) { B.plane(BP_POSR)[body] = pack3(L.pos, radius); B.plane(BP_QUAT)[body] = packq(L.rot); }
+            if (!last) { X.privPose[(size_t)body * 2] = pack3(L.pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(L.rot); }
         }
     };
 
@@ -266,7 +269,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #define RS_STAMP(i) do { } while (0)
 #endif
 
-    for (int it = 0; it < totalIt; ++it) {
+    /* [itBegin, itEnd): the whole loop on one GPU; one iteration per launch when poses are exchanged between GPUs after every
+     * iteration (MULTI only: the parked state and the stamped records carry over from launch to launch) */
+    for (int it = (MULTI ? itBegin : 0); it < (MULTI && itEnd < totalIt ? itEnd : totalIt); ++it) {
       for (int slot = w; slot < nd; slot += W) {                       /* MULTI = false: exactly one slot (the caller checks w < nd) */
         if (MULTI || it == 0) load_task(slot, it);
 #ifdef AVBD_DF_STATS
