@@ -146,6 +146,7 @@ struct AvbdContext {
     size_t privNCap = 0, privPoseCap = 0;
     bool residentMultiAllowed = true;   /* AVBD_RESIDENT_MULTI=0: scenes with more swept bodies than waves use the task schedule */
     bool residentMultiLaunched = false;
+    bool packFused = false;             /* the last k_iterate launch filled dSend itself */
     bool residentSharded = true;        /* AVBD_RESIDENT_SHARDED=0: sharded runs (one launch per iteration) use the task schedule */
     int residentMultiMax = 64;          /* AVBD_RESIDENT_MULTI_MAX: most bodies one wave may own */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
@@ -165,7 +166,7 @@ struct AvbdContext {
     std::vector<int> hOwner;            /* per body: owning rank, -1 = replicated (static) */
     DevArr<int> dSolved;                /* per body: 1 = dynamic and owned by this rank */
     std::vector<int> hPerm, hRankStart; /* solved bodies grouped by rank */
-    DevArr<int> dPerm, dRankStart;
+    DevArr<int> dPerm, dRankStart, dSendSlot;
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
     void* comm = nullptr;               /* ncclComm_t (RCCL, loaded lazily) */
@@ -385,6 +386,13 @@ int upload_bodies_if_stale(AvbdContext* c)
         if (n) {
             HIPCHK(c, hipMemcpyAsync(c->dSolved.p, solved.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->dPerm.p, c->hPerm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            {   /* row of each body this rank solves inside its all-gather block */
+                std::vector<int> slot((size_t)n, 0);
+                const int first = c->hRankStart[(size_t)c->rank];
+                for (int k = first; k < c->hRankStart[(size_t)c->rank + 1]; ++k) slot[(size_t)c->hPerm[(size_t)k]] = k - first;
+                if (c->dSendSlot.n < (size_t)c->bodyCap) HIPCHK(c, c->dSendSlot.alloc((size_t)c->bodyCap));
+                HIPCHK(c, hipMemcpy(c->dSendSlot.p, slot.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+            }
         }
         if (c->nranks > 1 || c->forceSharded) {
             HIPCHK(c, c->dRankStart.alloc((size_t)c->nranks + 1));
@@ -716,7 +724,9 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         if (!wholeLoop) { X.forceMulti = 1; X.planesAlways = 1; }
     }
     X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p;
+    X.send = (sharded && c->dSend.p && c->dSendSlot.p) ? c->dSend.p : nullptr; X.sendSlot = c->dSendSlot.p;
     c->residentMultiLaunched = X.multi != 0;
+    c->packFused = X.send != nullptr;
     c->residentLaunched = X.enabled != 0;
     if (X.enabled) {
         if (itBegin == 0 && c->xSerial >= (1u << 24) - 2u) {      /* stamps are about to wrap: forget every old record */
@@ -793,6 +803,7 @@ int step_iterate_levels(AvbdContext* c)
 int step_pack(AvbdContext* c)
 {
     const int first = c->hRankStart[(size_t)c->rank], count = c->hRankStart[(size_t)c->rank + 1] - first;
+    if (c->packFused) return AVBD_OK;                                   /* k_iterate wrote the rows when it published each pose */
     if (count > 0)
         hipLaunchKernelGGL(k_pack_poses, dim3(grid_for(count, 128, 1 << 20)), dim3(128), 0, c->stream, body_table(c), c->dPerm.p, first, count, c->dSend.p);
     HIPCHK(c, hipGetLastError());
@@ -980,7 +991,7 @@ int avbd_destroy(AvbdContext* c)
     c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
     c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
-    c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSend.release(); c->dRecv.release();
+    c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release();
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->adjTmp.release();
     if (c->comm) destroy_comm(c->comm);

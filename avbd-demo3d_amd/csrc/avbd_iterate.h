@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                 sanitizeq(q, cntW);
                 st4<true>(B.plane(BP_POSR) + body, pack3(p, smp.w));
                 st4<true>(B.plane(BP_QUAT) + body, packq(q));
+                if (X.send) { const int k = X.sendSlot[body]; X.send[2 * k] = pack3(p, smp.w); X.send[2 * k + 1] = packq(q); }   /* this rank's all-gather rows */
                 accs[56] = p.x; accs[57] = p.y; accs[58] = p.z; accs[59] = q.x; accs[60] = q.y; accs[61] = q.z; accs[62] = q.w;
             }
             DF_STAMP(2);
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                 sanitizeq(q, cntW);
                 st4<true>(B.plane(BP_POSR) + body, pack3(p, smp.w));
                 st4<true>(B.plane(BP_QUAT) + body, packq(q));
+                if (X.send) { const int k = X.sendSlot[body]; X.send[2 * k] = pack3(p, smp.w); X.send[2 * k + 1] = packq(q); }   /* this rank's all-gather rows */
             }
             DF_STAMP(2);
             drain_stores();

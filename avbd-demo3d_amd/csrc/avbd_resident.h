@@ -48,7 +48,9 @@ struct ResidentExchange {
     int spread;        /* one body per wave: slot = wave-in-workgroup * workgroups + workgroup instead of the linear wave index */
     int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
     int forceMulti;    /* launches that cover part of the iteration loop (sharded runs) park state even with one body per wave */
-    int planesAlways;  /* sharded runs: the pose planes are what k_pack_poses sends after every iteration */
+    int planesAlways;  /* sharded runs: other kernels of the step read the pose planes after every iteration */
+    float4* send;      /* sharded runs: this rank's rows of the all-gather, filled by the wave that publishes the pose */
+    const int* sendSlot; /* [bodyCap] row of a body this rank solves */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -254,6 +256,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         }
         if (lane == 0) {
             if (last || X.planesAlways) { B.plane(BP_POSR)[body] = pack3(L.pos, radius); B.plane(BP_QUAT)[body] = packq(L.rot); }
+            if (X.send) { const int k = X.sendSlot[body]; X.send[2 * k] = pack3(L.pos, radius); X.send[2 * k + 1] = packq(L.rot); }
             if (!last) { X.privPose[(size_t)body * 2] = pack3(L.pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(L.rot); }
         }
     };
