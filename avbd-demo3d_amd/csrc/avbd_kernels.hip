@@ -447,33 +447,54 @@ __global__ void k_gforce_prepare(BodyTable B, GForce* gf, int ng, int* degForce,
     if (f.bodyB >= 0) { atomicAdd(&degForce[f.bodyB], 1); if (B.solved[f.bodyB]) atomicAdd(&degInc[f.bodyB], entries); }
 }
 
-/* Exclusive scans of the two degree arrays (single workgroup; n+1 outputs each), and cursor reset. */
+/* inclusive scan over the 1024 threads of the workgroup: wave shuffles + one 16-entry exchange (two barriers) */
+__device__ __forceinline__ unsigned long long block_scan_inclusive_u64(unsigned long long v, unsigned long long* sWaveTotals /* [16] */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned lo = __shfl_up((unsigned)v, off), hi = __shfl_up((unsigned)(v >> 32), off);
+        if (lane >= off) v += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) sWaveTotals[wv] = v;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < wv; ++w) base += sWaveTotals[w];
+    __syncthreads();
+    return v + base;
+}
+
+/* Exclusive scans of the two degree arrays (single workgroup; n+1 outputs each), and cursor reset.  Tiles of 4096 bodies:
+ * every thread takes four consecutive bodies (coalesced), one shuffle-based workgroup scan per tile, running offsets carried
+ * from tile to tile (the chunk-per-thread form of this kernel took 250 us at 64 000 bodies: uncoalesced). */
 __global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc, int* adjStart, int* incStart, Counters* cnt, const int* nextCount)
 {
-    __shared__ int sA[1024], sB[1024];
+    __shared__ unsigned long long sWaveTotals[16];
+    __shared__ unsigned long long sTile;
     const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk, hi = min(n, lo + chunk);
-    int a = 0, b = 0;
-    for (int i = lo; i < hi; ++i) { a += degForce[i]; b += degInc[i]; }
-    sA[t] = a; sB[t] = b;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int va = 0, vb = 0;
-        if (t >= off) { va = sA[t - off]; vb = sB[t - off]; }
+    unsigned long long running = 0;                                   /* high word: incidence entries, low word: forces */
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * t;
+        unsigned long long v[4];
+        unsigned long long mine = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            v[k] = i < n ? (((unsigned long long)(unsigned)degInc[i] << 32) | (unsigned)degForce[i]) : 0ull;
+            mine += v[k];
+        }
+        const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
+        unsigned long long off = running + incl - mine;
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            if (i < n) { adjStart[i] = (int)(unsigned)off; incStart[i] = (int)(off >> 32); degForce[i] = 0; degInc[i] = 0; /* become fill cursors */ }
+            off += v[k];
+        }
+        if (t == 1023) sTile = incl;
         __syncthreads();
-        sA[t] += va; sB[t] += vb;
+        running += sTile;
         __syncthreads();
     }
-    int baseA = sA[t] - a, baseB = sB[t] - b;
-    for (int i = lo; i < hi; ++i) {
-        int da = degForce[i], db = degInc[i];
-        adjStart[i] = baseA; incStart[i] = baseB;
-        baseA += da; baseB += db;
-        degForce[i] = 0; degInc[i] = 0; /* become fill cursors */
-    }
-    if (t == 1023) { adjStart[n] = sA[1023]; incStart[n] = sB[1023]; }
-    if (t == 0) cnt->numManifolds = *nextCount;
+    if (t == 0) { adjStart[n] = (int)(unsigned)running; incStart[n] = (int)(running >> 32); cnt->numManifolds = *nextCount; }
 }
 
 __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* gf, int ng, const int* adjStart, int* cursor,
@@ -720,23 +741,6 @@ constexpr int kTopoIntWords = (kTopoBodies + 1) * 2 + kTopoBodies;            /*
 constexpr int kTopoLdsBytes = kTopoIntWords * 4 + 8 /* align */ + kTopoEntries * 8 /* keys, later neighbour lists */ +
                               kTopoBodies * 2 /* levels */ + kTopoEntries * 2 * 3 /* entry body | rank | rows */ + kTopoBodies /* swept? */;
 
-/* inclusive scan over the 1024 threads of the workgroup: wave shuffles + one 16-entry exchange (two barriers) */
-__device__ __forceinline__ unsigned long long block_scan_inclusive_u64(unsigned long long v, unsigned long long* sWaveTotals /* [16] */)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned lo = __shfl_up((unsigned)v, off), hi = __shfl_up((unsigned)(v >> 32), off);
-        if (lane >= off) v += ((unsigned long long)hi << 32) | lo;
-    }
-    if (lane == 63) sWaveTotals[wv] = v;
-    __syncthreads();
-    unsigned long long base = 0;
-    for (int w = 0; w < wv; ++w) base += sWaveTotals[w];
-    __syncthreads();
-    return v + base;
-}
-
 /* Large scenes, data-flow schedules: the sweep order only has to be a linear extension of "later-created swept neighbours
  * first", and descending creation index IS one — no level relaxation (a single workgroup needs one sweep per level: 15 ms
  * at 64 000 bodies / 128 levels).  All swept bodies form one "level"; the level schedule (AVBD_MODE=levels) keeps k_levels. */
@@ -753,13 +757,18 @@ __global__ __launch_bounds__(1024) void k_order_by_index(BodyTable B, int* level
     if (t == 1023) sTotal = inclAll;
     __syncthreads();
     const int nd = sTotal;
-    /* pass 2: ascending rank by blocks of 1024 bodies; slot = nd - 1 - rank (newest first) */
-    for (int base = 0; base < n; base += 1024) {
-        const int b = base + t;
-        const int f = (b < n && B.solved[b]) ? 1 : 0;
-        const int incl = (int)block_scan_inclusive_u64((unsigned long long)f, sWaveTotals);
-        if (b < n) level[b] = f;
-        if (f) order[nd - 1 - (running + incl - 1)] = b;
+    /* pass 2: ascending rank by tiles of 4096 bodies (four consecutive bodies per thread); slot = nd - 1 - rank (newest first) */
+    for (int base = 0; base < n; base += 4096) {
+        const int b0 = base + 4 * t;
+        int f[4], mine4 = 0;
+        for (int k = 0; k < 4; ++k) { f[k] = (b0 + k < n && B.solved[b0 + k]) ? 1 : 0; mine4 += f[k]; }
+        const int incl = (int)block_scan_inclusive_u64((unsigned long long)mine4, sWaveTotals);
+        int rank = running + incl - mine4;
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + k;
+            if (b < n) level[b] = f[k];
+            if (f[k]) order[nd - 1 - rank++] = b;
+        }
         if (t == 1023) sTotal = incl;
         __syncthreads();
         running += sTotal;
