@@ -148,6 +148,8 @@ struct AvbdContext {
     bool residentMultiLaunched = false;
     bool packFused = false;             /* the last k_iterate launch filled dSend itself */
     bool residentSharded = true;        /* AVBD_RESIDENT_SHARDED=0: sharded runs (one launch per iteration) use the task schedule */
+    bool residentForceLite = false;     /* AVBD_RESIDENT_FORCE_LITE=1: the two-workgroups-per-CU launch for every scene size */
+    int residentLiteFrom = 1;           /* AVBD_RESIDENT_LITE_FROM=<k>: more than k bodies per wave → two workgroups per CU (0: never) */
     int residentMultiMax = 64;          /* AVBD_RESIDENT_MULTI_MAX: most bodies one wave may own */
     unsigned xSerial = 0;      /* launch serial: stamp base = serial * 64 */
     bool residentLaunched = false; /* the last k_iterate launch had the resident schedule enabled (the device may still veto it) */
@@ -705,12 +707,13 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
     X.maxWaves = c->iterBlocks * kIterWaves;
     X.quietPermille = c->residentQuiet;
+    X.prStride = kResStride;
     X.spread = c->residentSpread ? 1 : 0;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
     const bool wholeLoop = itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded;
     const bool sharded = c->nranks > 1 || c->forceSharded;
     const int dynBodies = sharded ? c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank] : B.n - c->numStatic;
-    const bool fitsOne = wholeLoop && dynBodies <= X.maxWaves;
+    const bool fitsOne = wholeLoop && dynBodies <= X.maxWaves && !c->residentForceLite;
     const bool fitsMulti = c->residentMultiAllowed && dynBodies <= c->residentMultiMax * X.maxWaves;   /* beyond: throughput-bound, task schedule with two workgroups per CU */
     X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave &&
                  (wholeLoop || (sharded && c->residentSharded)) && c->hG.empty() &&
@@ -739,11 +742,15 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         X.base = c->xSerial * 64u;
         blocks = c->iterBlocks;                                        /* every swept body needs its wave resident */
     }
-    const bool throughput = !X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves));
+    /* several bodies per wave and more than residentLiteFrom of them: two workgroups per CU (twice the waves, short product lines) */
+    const bool lite = X.enabled && X.multi && (c->residentForceLite || (c->residentLiteFrom > 0 && dynBodies > c->residentLiteFrom * X.maxWaves));
+    if (lite) { X.prStride = kResStrideLite; X.maxWaves *= 2; }
+    const bool throughput = lite || (!X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
     if (throughput) {
         int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
         if (blocks2 < 1) blocks2 = 1;
-        hipExtLaunchKernelGGL(k_iterate<2>, dim3(blocks2), dim3(64 * kIterWaves), 0, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+        if (lite) blocks2 = 2 * c->iterBlocks;
+        hipExtLaunchKernelGGL(k_iterate<2>, dim3(blocks2), dim3(64 * kIterWaves), kIterWaves * kResProductBytesPerWaveLite, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
                               c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
     } else {
         hipExtLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
@@ -962,6 +969,8 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_SHARDED")) c->residentSharded = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_FORCE_LITE")) c->residentForceLite = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_LITE_FROM")) c->residentLiteFrom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
@@ -972,6 +981,8 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
+        fe = hipFuncSetAttribute((const void*)k_iterate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
+        if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate<2>, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);

@@ -129,12 +129,15 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
      * when body state is exchanged between GPUs after every iteration (the done-counters persist in between) */
     const long long nTasks = (long long)nd * (itEnd < totalIt ? itEnd : totalIt);
     const float4* massPlane = B.plane(BP_MASS);
-    if constexpr (WPE == 1) {
-        /* every swept body fits one resident wavefront and is a plain pile of contacts: one wave per body for the whole loop */
-        const int veto = cnt->residentBad;                            /* bit0: not a pile of <= 64 contacts per body; bit1: more bodies than waves */
-        if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi)) {
-            float* products = reinterpret_cast<float*>(sDynamic) + wv * (kResProductBytesPerWave / 4);
-            if ((veto & 2) || X.forceMulti) iterate_resident<true>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
+    {
+        /* a plain pile of contacts: the resident schedule (avbd_resident.h).  veto bits set by the topology kernels —
+         * bit0: a swept body has > 64 contacts or a joint/spring, bit1: more swept bodies than resident waves,
+         * bit2: a swept body has > 33 contacts (too many for the short product lines of the two-workgroups-per-CU launch) */
+        const int veto = cnt->residentBad;
+        const bool lite = WPE == 2;
+        if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi) && (!lite || (veto & 4) == 0)) {
+            float* products = reinterpret_cast<float*>(sDynamic) + wv * 27 * X.prStride;
+            if (lite || (veto & 2) || X.forceMulti) iterate_resident<true>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
             else {
                 /* one body per wave: the four waves of a CU take slots a quarter of the sweep order apart, so that they are
                  * busy at different times (waves of one CU share its LDS, L1 and instruction front end) */

@@ -24,6 +24,8 @@
 
 namespace avbd {
 
+constexpr int kResLiteMaxEntriesDecl = 33;   /* = kResLiteMaxEntries (avbd_resident.h), needed before that header is included */
+
 __device__ __forceinline__ f3 ld3(const float4* p, int i) { float4 v = p[i]; return mk3(v.x, v.y, v.z); }
 __device__ __forceinline__ q4 ldq(const float4* p, int i) { float4 v = p[i]; return mkq(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float4 pack3(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -552,6 +554,7 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
     }
     /* the resident schedule (avbd_resident.h) keeps one Manifold contact per lane of the body's wavefront */
     if (nonManifold || o - incStart[b] > 64) atomicOr(&cnt->residentBad, 1);
+    else if (o - incStart[b] > kResLiteMaxEntriesDecl) atomicOr(&cnt->residentBad, 4);
 }
 
 /* Dependency levels of the Gauss-Seidel sweep: level(b) = 1 + max level of dynamic neighbours
@@ -925,6 +928,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     }
     for (int b = t; b < n; b += 1024)
         if (sSwept[b] && sInc[b + 1] - sInc[b] > 64) sBad = 1;         /* the resident schedule keeps one contact per lane */
+        else if (sSwept[b] && sInc[b + 1] - sInc[b] > kResLiteMaxEntriesDecl) atomicOr(&cnt->residentBad, 4);
     __syncthreads();
 
 #ifdef AVBD_DF_STATS

@@ -46,6 +46,7 @@ struct ResidentExchange {
     float4* privN;     /* [3 * incidence capacity] MULTI: a first visitor's own copy of (normal, u1, u2) between its tasks */
     float4* privPose;  /* [2 * bodyCap]            MULTI: the pose between the body's tasks */
     int spread;        /* one body per wave: slot = wave-in-workgroup * workgroups + workgroup instead of the linear wave index */
+    int prStride;      /* floats per product line: kResStride, or kResStrideLite when two workgroups share a CU */
     int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
     int forceMulti;    /* launches that cover part of the iteration loop (sharded runs) park state even with one body per wave */
     int planesAlways;  /* sharded runs: other kernels of the step read the pose planes after every iteration */
@@ -82,9 +83,13 @@ __device__ __forceinline__ void replay_normal(ContactRows& c, bool& fixedN)
  *   Pr[27][kResStride]   one line per accumulator entry: Ja*Jb of every row (rhs entries: J alone), written BEFORE the wait
  * so that after the wait an accumulator lane adds (product * penalty [+ gyro]) or (J * f) row by row — the reference's
  * order and association, (Ja*Jb)*penalty (solver.cpp:387-391) — from three 16-byte LDS reads per four rows. */
-constexpr int kResRows = 192, kResStride = 196;
+constexpr int kResRows = 192, kResStride = 160;      /* a product line holds rows 36..191 (the first 36 live in registers) */
 constexpr int kResJFloats = kResRows * 6, kResSFloats = 7 * kResRows;   /* slot 6: zeros (what off-diagonal entries add) */
 constexpr int kResProductBytesPerWave = 27 * kResStride * 4;
+/* two workgroups per CU (k_iterate<2>): product lines only for rows 36..99, i.e. bodies with at most 33 contacts
+ * (4 x 7 344 B + 45 KB of row staging = 75 KB per workgroup) */
+constexpr int kResStrideLite = 68, kResLiteMaxEntries = 33;
+constexpr int kResProductBytesPerWaveLite = 27 * kResStrideLite * 4;
 static_assert(kResJFloats + kResSFloats <= 66 * kEntryRec, "the J and S areas reuse the row staging area of k_iterate");
 
 /* rows 0..kResRegRows-1 keep their product in a register of the accumulator lane (no LDS read after the wait);
@@ -111,7 +116,7 @@ __device__ __forceinline__ void store_products(const AccLane& a, const float* J,
     }
     for (int r = kResRegRows; r < nRows; ++r) {
         const float va = ja[r * 6], vb = jb[r * 6];
-        prLine[r] = rhs ? va : va * vb;
+        prLine[r - kResRegRows] = rhs ? va : va * vb;
     }
 }
 
@@ -155,7 +160,7 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
     /* the rare tail: rows past the register window, four at a time from the LDS product line */
     const float4* p4 = reinterpret_cast<const float4*>(prLine);
     for (int r4 = kResRegRows; r4 < nRows; r4 += 4) {
-        const float4 pv = p4[r4 >> 2], sw = s4[r4 >> 2], gw = g4[r4 >> 2];
+        const float4 pv = p4[(r4 - kResRegRows) >> 2], sw = s4[r4 >> 2], gw = g4[r4 >> 2];
         float4 ow = make_float4(1.f, 1.f, 1.f, 1.f);
         if (!ALLON) ow = o4[r4 >> 2];
 #pragma unroll
@@ -294,7 +299,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         ContactPre pre; f3 G[3];
         float* J = rows;
         float* S = rows + kResJFloats;
-        float* prLine = products + (lane < 27 ? lane : 0) * kResStride;
+        float* prLine = products + (lane < 27 ? lane : 0) * X.prStride;
         if (has) {
             wOwn = qrotate(L.rot, isA ? c.rA : c.rB);                 /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
