@@ -1,6 +1,11 @@
 /*
- * avbd_resident.h — "resident" schedule of the iteration loop (solver.cpp:340-431) for scenes whose swept bodies fit
- * the machine one-to-one: every dynamic body gets ONE wavefront for the whole launch (all iterations).
+ * avbd_resident.h — "resident" schedule of the iteration loop (solver.cpp:340-431) for piles of contacts (no joints or
+ * springs, at most 64 contacts per body).  Three forms of the same code (iterate_resident<MULTI>):
+ *   - up to 1024 swept bodies: every body gets ONE wavefront for the whole launch (all iterations), state in registers;
+ *   - more bodies: every wave takes every W-th body of the sweep order and parks a body's state between its tasks
+ *     (two workgroups per CU, 2048 waves, when every body has at most 33 contacts);
+ *   - sharded runs: one launch per iteration; state is parked between the launches the same way.
+ * The description below is written for the first form.
  *
  * Same dependencies, same arithmetic and same summation order as k_iterate's task schedule (avbd_iterate.h); what
  * changes is where state lives and how it moves between wavefronts:
@@ -18,7 +23,8 @@
  *     (computeConstraint, manifold.cpp:183-243, mutates lambda[1..2] and stick on EVERY call, so the first visitor's
  *     mutations are an input of the second visit; the stored normal and its tangent memo are mutated too, but only
  *     as a function of themselves: each side replays the other side's re-normalisations locally — see replay_normal.)
- *   - stamps are launch-unique (serial * 64 + iteration + 1), so the exchange buffers are never cleared between steps.
+ *   - stamps are unique per step (serial * 64 + iteration + 1; the launches of a sharded step share the serial), so the
+ *     exchange buffers are never cleared between steps (only when the serial wraps, every 2^24 steps).
  *
  * The single-copy atomicity of one lane's aligned 16-byte access is a property of gfx950's memory pipeline (one
  * request, one 64-byte line), not of the HIP memory model; this file is gfx950-only like the rest of csrc/.
