@@ -146,6 +146,7 @@ struct AvbdContext {
     size_t privNCap = 0, privPoseCap = 0;
     bool residentMultiAllowed = true;   /* AVBD_RESIDENT_MULTI=0: scenes with more swept bodies than waves use the task schedule */
     bool residentMultiLaunched = false;
+    hipEvent_t iterDone = nullptr;      /* recorded behind every k_iterate of avbd_group_step (contexts sharing a device take turns) */
     bool packFused = false;             /* the last k_iterate launch filled dSend itself */
     bool residentSharded = true;        /* AVBD_RESIDENT_SHARDED=0: sharded runs (one launch per iteration) use the task schedule */
     bool residentForceLite = false;     /* AVBD_RESIDENT_FORCE_LITE=1: the two-workgroups-per-CU launch for every scene size */
@@ -1003,6 +1004,7 @@ int avbd_destroy(AvbdContext* c)
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
     c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release();
+    if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->adjTmp.release();
     if (c->comm) destroy_comm(c->comm);
@@ -1843,7 +1845,17 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
             for (int r = 0; r < n; ++r) {
                 AvbdContext* c = ctxs[r];
                 (void)hipSetDevice(c->device);
+                /* k_iterate needs ALL its workgroups resident: two such launches must never be dispatched onto one device at
+                 * the same time (each could end up with half of its workgroups on the chip, waiting for the rest).  Contexts that
+                 * share a device run their iteration kernels one after the other. */
+                for (int q = 0; q < r; ++q)
+                    if (ctxs[q]->device == c->device) {
+                        if (!ctxs[q]->iterDone) HIPCHK(c, hipEventCreateWithFlags(&ctxs[q]->iterDone, hipEventDisableTiming));
+                        HIPCHK(c, hipStreamWaitEvent(c->stream, ctxs[q]->iterDone, 0));
+                    }
                 if ((rc = step_iterate(c, it, it + 1))) return rc;
+                if (!c->iterDone) HIPCHK(c, hipEventCreateWithFlags(&c->iterDone, hipEventDisableTiming));
+                HIPCHK(c, hipEventRecord(c->iterDone, c->stream));
                 if ((rc = step_pack(c))) return rc;
             }
             for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }

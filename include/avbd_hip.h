@@ -123,6 +123,11 @@ typedef struct AvbdProfile {
     double algorithmic_bytes_primal, algorithmic_bytes_dual; /* summed per launch, SURVEY §8d model */
 } AvbdProfile;
 
+/* Threading / concurrency: one context = one device + one stream; calls on a context are not thread-safe.  The iteration
+ * kernel needs all its workgroups resident on the device, so two contexts that share a device must not be stepped
+ * CONCURRENTLY from different host threads (stepping them one after the other, or through avbd_group_step, is fine):
+ * two half-resident launches would wait for each other until the bounded spin reports AVBD_E_TIMEOUT-like failure. */
+
 /* ---- lifetime: `new Solver` / `delete solver` (solver.cpp:127-143) ---------------------- */
 int  avbd_create(int device, AvbdContext** out);
 int  avbd_destroy(AvbdContext* ctx);
