@@ -126,7 +126,7 @@ typedef struct AvbdProfile {
 /* Threading / concurrency: one context = one device + one stream; calls on a context are not thread-safe.  The iteration
  * kernel needs all its workgroups resident on the device, so two contexts that share a device must not be stepped
  * CONCURRENTLY from different host threads (stepping them one after the other, or through avbd_group_step, is fine):
- * two half-resident launches would wait for each other until the bounded spin reports AVBD_E_TIMEOUT-like failure. */
+ * two half-resident launches would wait for each other until the bounded spin (4 s) gives up and the step returns AVBD_E_HIP ("dependency wait timed out"). */
 
 /* ---- lifetime: `new Solver` / `delete solver` (solver.cpp:127-143) ---------------------- */
 int  avbd_create(int device, AvbdContext** out);
