@@ -565,7 +565,7 @@ int launch_topology(AvbdContext* c, bool fromStep)
         /* small scene: scans, scatter, per-body order, levels, predictor and flag reset as one workgroup in LDS */
         hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
-                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap + 16, c->orderByIndex ? 1 : 0);
+                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap /* not the error word behind them: a failure stays visible until the next synchronising call */, c->orderByIndex ? 1 : 0);
         c->topologyDidPredict = true;
         HIPCHK(c, hipGetLastError());
         c->adjDirty = false;
@@ -614,7 +614,10 @@ int refresh_stats(AvbdContext* c, bool withLevels)
         std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
         return c->fail(AVBD_E_CAPACITY, buf);
     }
-    if (iterError) return c->fail(AVBD_E_HIP, "k_iterate: dependency wait timed out (grid not resident?)");
+    if (iterError) {
+        (void)hipMemsetAsync(c->dFlags.p + 2 * (size_t)c->bodyCap, 0, sizeof(int), c->stream);   /* reported once */
+        return c->fail(AVBD_E_HIP, "k_iterate: dependency wait timed out (grid not resident?)");
+    }
     return AVBD_OK;
 }
 
@@ -681,7 +684,7 @@ int step_begin(AvbdContext* c)
             hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
         }
         if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
-            HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * c->bodyCap + 16) * sizeof(int), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, (size_t)2 * c->bodyCap * sizeof(int), c->stream));   /* the error word behind them is sticky */
     }
     HIPCHK(c, hipGetLastError());
     return AVBD_OK;

@@ -804,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     unsigned short* sEntRows = sEntRank + kTopoEntries;
     unsigned char* sSwept = reinterpret_cast<unsigned char*>(sEntRows + kTopoEntries);
 #ifdef AVBD_DF_STATS
-    unsigned long long* tstamp = reinterpret_cast<unsigned long long*>(flags + nFlags + 1024 * 32 + 20 * 1024 * 8);
+    unsigned long long* tstamp = reinterpret_cast<unsigned long long*>(flags + nFlags + 16 + 1024 * 32 + 20 * 1024 * 8);
     if (t == 0) tstamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int nm = *nextCount;
