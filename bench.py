@@ -230,6 +230,19 @@ def main():
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             cpu = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
 
+    # SURVEY.md §8d also asks for the whole 600-step run from scratch (free fall + landing + steady state), untimed parts none
+    whole = None
+    if rank == 0 and not sharded and args.scene is None:
+        w2 = pkg.World(local_rank)
+        w2.scene(scene)
+        w2.synchronize()
+        t0 = time.perf_counter()
+        w2.step(600)
+        w2.synchronize()
+        tw = time.perf_counter() - t0
+        whole = {"steps": 600, "steps_per_s": round(600 / tw, 3), "ms_per_step": round(tw / 600 * 1e3, 5)}
+        w2.close()
+
     if rank == 0:
         # sharded runs step ONE scene of N x 1000 cubes: count it as N Stress1000-equivalent steps per step
         total_steps = args.steps * world_size
@@ -243,7 +256,8 @@ def main():
                                "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)",
                        "parallelism": "1 GPU" if not sharded else f"{world_size} z-slabs, RCCL all-gather of 32 B/body after every iteration; value = {world_size} x scene steps/s (1000-cube equivalents)",
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
-                       "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"]},
+                       "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
+                       "whole_run_from_scratch": whole},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
