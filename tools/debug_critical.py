@@ -54,6 +54,17 @@ for p in path:
 for k, v in agg.items():
     v = np.array(v, float); ok = ~np.isnan(v)
     print(f"{k:32s} n={ok.sum():4d} mean {np.nanmean(v):6.2f} p50 {np.nanmedian(v):6.2f} max {np.nanmax(v):6.2f} sum {np.nansum(v):8.1f}")
+# same-XCD vs cross-XCD hand-offs (workgroups are dealt round-robin over the 8 XCDs; wave index = 4 * workgroup + wave)
+allh = {"same": [], "cross": []}
+for it in range(IT):
+    for b in b2w:
+        for o in nbr[b]:
+            if o > b:
+                d = tm(it, b, 2) - tm(it, o, 3)
+                if 0 < d < 3.0 and int(t[it, b2w[b], 6]) >= 2:
+                    allh["same" if (b2w[b] // 4) % 8 == (b2w[o] // 4) % 8 else "cross"].append(d)
+for k, v in allh.items():
+    if v: print(f"pose hand-offs that ended a real wait, {k}-XCD: n={len(v)} mean {np.mean(v):.3f} p50 {np.median(v):.3f} us")
 kinds = collections.Counter(p["dep"] for p in path)
 print("dep kinds", kinds)
 for p in path[:40]:
