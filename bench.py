@@ -56,6 +56,40 @@ def algorithmic_bytes(stats, iterations):
             "B_primal_iter": 100 * nb + 124 * ninc, "B_dual_iter": 160 * nc}
 
 
+def dependency_chain_hops(forces, bodies, total_iterations):
+    """Length (in body solves) of the longest dependency chain of the exact Gauss-Seidel sweep over `total_iterations`
+    iterations on the current contact graph: task (b, it) needs (o, it) of every later-created swept neighbour o and
+    (e, it-1) of every earlier-created one (whose task also runs the dual of the shared contact) and (b, it-1).
+    This chain, not bytes, is what bounds k_iterate."""
+    dyn = bodies["invMass"] > 0
+    n = len(bodies)
+    later = [[] for _ in range(n)]
+    earlier = [[] for _ in range(n)]
+    for a, b, nc in zip(forces["bodyA"], forces["bodyB"], forces["numContacts"]):
+        a, b = int(a), int(b)
+        if nc <= 0 or a < 0 or b < 0 or not (dyn[a] and dyn[b]):
+            continue
+        lo, hi = (a, b) if a < b else (b, a)
+        later[lo].append(hi)
+        earlier[hi].append(lo)
+    prev = np.zeros(n, np.int64)
+    longest = 0
+    for _ in range(total_iterations):
+        cur = np.zeros(n, np.int64)
+        for b in range(n - 1, -1, -1):                       # the sweep visits later-created bodies first
+            if not dyn[b]:
+                continue
+            d = prev[b]
+            for o in later[b]:
+                d = max(d, cur[o])
+            for e in earlier[b]:
+                d = max(d, prev[e])
+            cur[b] = d + 1
+        prev = cur
+        longest = int(cur.max()) if n else 0
+    return longest
+
+
 def pmc_traffic(scene, fused):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r1_resident_window_summary.json; (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md §HBM).  PMC counters
@@ -199,6 +233,14 @@ def main():
                 "step_algorithmic_GBps": round(ab["B_step"] * args.steps / elapsed / 1e9, 3),
                 "kernel_ms_per_step": {k[3:]: round(float(p[k]) / max(1, p["steps"]), 4) for k in
                                        ("ms_broadphase", "ms_narrowphase", "ms_topology", "ms_predict", "ms_primal", "ms_dual", "ms_velocity")}}
+
+    if roof is not None and rank == 0 and not sharded and int(stats["numBodies"]) <= 20000:
+        try:
+            hops = dependency_chain_hops(w.forces(), w.bodies(), iterations)
+            roof["dependency_chain"] = {"sequential_body_solves_per_step": hops,
+                                        "us_per_solve_and_handoff": round(roof["us_per_launch"] / max(1, hops), 3)}
+        except Exception as e:                                # informative only
+            roof["dependency_chain"] = {"error": repr(e)}
 
     # ---- CPU baseline on the same window ----------------------------------------------------
     cpu = None
