@@ -251,3 +251,24 @@ def test_cli_save_state_load_state(tmp_path):
     a, b = body(full), body(tail)
     n = len(b)
     assert n > 0 and a[-n:] == b
+
+
+def test_non_finite_state_is_sanitised_like_the_reference():
+    """solver.cpp:41-66: non-finite velocities / poses are reset (and counted) instead of spreading.  Inject them through the
+    body upload on both sides and keep comparing bit for bit."""
+    o, g = pair()
+    for w in (o, g):
+        w.scene("Pyramid")
+    o.step(12); g.step(12)
+    b = g.bodies().copy()
+    b["linVel"][5] = (np.nan, 1.0, np.inf)
+    b["angVel"][9] = (np.inf, 0.0, -np.inf)
+    b["linVel"][20] = (-np.inf, np.nan, 0.0)
+    f = o.forces()
+    o.set_bodies(b); o.set_forces(f)
+    g.set_bodies(b); g.set_forces(f)
+    for s in range(6):
+        o.step(); g.step()
+        H.assert_same_world(o, g, f"after injecting non-finite velocities, step {s + 1}", check_diag=(s > 0))
+    gb = g.bodies()
+    assert np.isfinite(gb["pos"]).all() and np.isfinite(gb["linVel"]).all() and np.isfinite(gb["angVel"]).all()
