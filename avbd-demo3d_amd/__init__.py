@@ -64,7 +64,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times",
+    "avbd_group_step", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times",
 ]
 
 
@@ -227,6 +227,12 @@ class World:
 
     def synchronize(self):
         self._chk(self.L.avbd_synchronize(self.h))
+
+    def remove_body(self, index):
+        self._chk(self.L.avbd_remove_body(self.h, int(index)))
+
+    def remove_force(self, list_index):
+        self._chk(self.L.avbd_remove_force(self.h, int(list_index)))
 
     def save_snapshot(self, path):
         self._chk(self.L.avbd_save_snapshot(self.h, str(path).encode()))

@@ -1184,6 +1184,32 @@ namespace {
 struct SnapshotHeader { char magic[8]; int bodyBytes, forceBytes, nBodies, nForces, stepIndex, reserved; AvbdParams params; };
 }
 
+static int restore_state(AvbdContext* c, const AvbdParams& params, int stepIndex, const AvbdBody* bodies, int nBodies, const AvbdForce* forces, int nForces)
+{
+    int rc;
+    if ((rc = avbd_clear(c))) return rc;
+    if ((rc = avbd_set_params(c, &params))) return rc;
+    for (int i = 0; i < nBodies; ++i) {
+        const AvbdBody& b = bodies[(size_t)i];
+        float I9[9], J9[9];
+        for (int k = 0; k < 9; ++k) { I9[k] = 0.0f; J9[k] = 0.0f; }
+        if (b.invMass > 0.0f) {                                       /* rigid.cpp:31-40 from the stored mass: same bits as at creation */
+            const float Ixx = (1.0f / 12.0f) * b.mass * (b.size[1] * b.size[1] + b.size[2] * b.size[2]);
+            const float Iyy = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[2] * b.size[2]);
+            const float Izz = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[1] * b.size[1]);
+            I9[0] = Ixx; I9[4] = Iyy; I9[8] = Izz;
+            J9[0] = 1.0f / Ixx; J9[4] = 1.0f / Iyy; J9[8] = 1.0f / Izz;
+        } else ++c->numStatic;
+        c->hBodies.push_back(b);
+        c->hI.insert(c->hI.end(), I9, I9 + 9);
+        c->hJ.insert(c->hJ.end(), J9, J9 + 9);
+    }
+    c->bodiesStale = true; c->adjDirty = true;
+    if ((rc = avbd_upload_forces(c, forces, nForces))) return rc;
+    c->stepIndex = stepIndex;
+    return AVBD_OK;
+}
+
 int avbd_set_step_index(AvbdContext* c, int stepIndex)
 {
     if (!c || stepIndex < 0) return AVBD_E_INVALID;
@@ -1230,28 +1256,49 @@ int avbd_load_snapshot(AvbdContext* c, const char* path)
     }
     std::fclose(f);
     if (!ok) return c->fail(AVBD_E_INVALID, "avbd_load_snapshot: not a snapshot of this ABI version, or truncated");
+    return restore_state(c, h.params, h.stepIndex, bodies.data(), h.nBodies, forces.data(), h.nForces);
+}
+
+/* Removal (`delete body` / `delete force` in the reference, rigid.cpp:43-49, force.cpp:31-69): the device state is compact and
+ * indexed by creation order, so a removal rebuilds it from its own snapshot with the element left out.  Removing a body also
+ * removes every force attached to it (the reference leaves them dangling — undefined behaviour there).  Bodies created after
+ * the removed one move down by one index; relative order, hence every result-relevant order, is preserved. */
+int avbd_remove_body(AvbdContext* c, int index)
+{
+    if (!c) return AVBD_E_INVALID;
+    const int nb = avbd_num_bodies(c), nf = avbd_num_forces(c);
+    if (index < 0 || index >= nb) return c->fail(AVBD_E_INVALID, "avbd_remove_body: index out of range");
+    std::vector<AvbdBody> bodies((size_t)nb);
+    std::vector<AvbdForce> forces((size_t)std::max(nf, 1));
     int rc;
-    if ((rc = avbd_clear(c))) return rc;
-    if ((rc = avbd_set_params(c, &h.params))) return rc;
-    for (int i = 0; i < h.nBodies; ++i) {
-        const AvbdBody& b = bodies[(size_t)i];
-        float I9[9], J9[9];
-        for (int k = 0; k < 9; ++k) { I9[k] = 0.0f; J9[k] = 0.0f; }
-        if (b.invMass > 0.0f) {                                       /* rigid.cpp:31-40 from the stored mass: same bits as at creation */
-            const float Ixx = (1.0f / 12.0f) * b.mass * (b.size[1] * b.size[1] + b.size[2] * b.size[2]);
-            const float Iyy = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[2] * b.size[2]);
-            const float Izz = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[1] * b.size[1]);
-            I9[0] = Ixx; I9[4] = Iyy; I9[8] = Izz;
-            J9[0] = 1.0f / Ixx; J9[4] = 1.0f / Iyy; J9[8] = 1.0f / Izz;
-        } else ++c->numStatic;
-        c->hBodies.push_back(b);
-        c->hI.insert(c->hI.end(), I9, I9 + 9);
-        c->hJ.insert(c->hJ.end(), J9, J9 + 9);
+    if ((rc = avbd_download_bodies(c, bodies.data(), nb)) < 0) return rc;
+    if (nf && (rc = avbd_download_forces(c, forces.data(), nf)) < 0) return rc;
+    bodies.erase(bodies.begin() + index);
+    std::vector<AvbdForce> kept;
+    for (int i = 0; i < nf; ++i) {
+        AvbdForce f = forces[(size_t)i];
+        if (f.bodyA == index || f.bodyB == index) continue;
+        if (f.bodyA > index) --f.bodyA;
+        if (f.bodyB > index) --f.bodyB;
+        kept.push_back(f);
     }
-    c->bodiesStale = true; c->adjDirty = true;
-    if ((rc = avbd_upload_forces(c, forces.data(), h.nForces))) return rc;
-    c->stepIndex = h.stepIndex;
-    return AVBD_OK;
+    const AvbdParams p = c->params;
+    return restore_state(c, p, c->stepIndex, bodies.data(), nb - 1, kept.data(), (int)kept.size());
+}
+
+int avbd_remove_force(AvbdContext* c, int list_index)
+{
+    if (!c) return AVBD_E_INVALID;
+    const int nb = avbd_num_bodies(c), nf = avbd_num_forces(c);
+    if (list_index < 0 || list_index >= nf) return c->fail(AVBD_E_INVALID, "avbd_remove_force: index out of range");
+    std::vector<AvbdBody> bodies((size_t)std::max(nb, 1));
+    std::vector<AvbdForce> forces((size_t)nf);
+    int rc;
+    if (nb && (rc = avbd_download_bodies(c, bodies.data(), nb)) < 0) return rc;
+    if ((rc = avbd_download_forces(c, forces.data(), nf)) < 0) return rc;
+    forces.erase(forces.begin() + list_index);
+    const AvbdParams p = c->params;
+    return restore_state(c, p, c->stepIndex, bodies.data(), nb, forces.data(), nf - 1);
 }
 
 int avbd_step(AvbdContext* c, int nsteps)

@@ -7,7 +7,8 @@
  * Build-only flags (do not exist in the reference): --quiet (no per-step trace; one timing JSON line),
  * --dump <file> (raw AvbdBody array after the last step), --device <n>, --batch (run all steps on the
  * device without per-step downloads; implies --quiet), --save-state <file> / --load-state <file>
- * (checkpoint after the last step / resume from a checkpoint instead of building --scene: SURVEY.md §8 f3).
+ * (checkpoint after the last step / resume from a checkpoint instead of building --scene: SURVEY.md §8 f3),
+ * --remove-body <creation index> --remove-at <step> (`delete body` before that step, through the host mirror).
  */
 #include "solver.h"
 #include "joint.h"
@@ -27,6 +28,7 @@ int main(int argc, char** argv)
     const char* dumpPath = nullptr;
     const char* savePath = nullptr;
     const char* loadPath = nullptr;
+    int removeBody = -1, removeAt = -1;   /* --remove-body <creation index> --remove-at <step>: `delete body` mid-run */
     int steps = 300; /* main.cpp:192 */
     bool quiet = false, batch = false;
     for (int i = 1; i < argc; ++i) {
@@ -38,6 +40,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dumpPath = argv[++i];
         else if (!strcmp(argv[i], "--save-state") && i + 1 < argc) savePath = argv[++i];
         else if (!strcmp(argv[i], "--load-state") && i + 1 < argc) loadPath = argv[++i];
+        else if (!strcmp(argv[i], "--remove-body") && i + 1 < argc) removeBody = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--remove-at") && i + 1 < argc) removeAt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) setenv("AVBD_DEVICE", argv[++i], 1);
     }
 
@@ -64,6 +68,7 @@ int main(int argc, char** argv)
         solver->pull();
     } else {
         for (int step = 0; step < steps; ++step) {
+            if (step == removeAt && removeBody >= 0) delete solver->bodyByIndex(removeBody);
             solver->step();
             if (quiet) continue;
             printf("Step %d:\n", step);

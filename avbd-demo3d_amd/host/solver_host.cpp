@@ -25,6 +25,7 @@ struct Solver::Impl {
     std::vector<AvbdBody> shadow;       /* body state as last seen by the device */
     std::vector<Manifold*> manifolds;   /* mirrors created by syncForces() */
     bool clearing = false;
+    bool syncing = false;               /* syncForces() is replacing the manifold mirrors */
 };
 
 /* ------------------------------------------------------------------ Rigid ----------------- */
@@ -56,37 +57,41 @@ Rigid::Rigid(Solver* s, const vec3& size_, float density_, float friction_, cons
 
 Rigid::~Rigid()
 {
-    if (!solver->impl->clearing && index < solver->flushedBodies)
-        solver->fail("deleting a single body that already lives on the device is not supported; use Solver::clear()", AVBD_E_INVALID);
-    Rigid** p = &solver->bodies;
+    Solver* s = solver;
+    const bool onDevice = !s->impl->clearing && index < s->flushedBodies;
+    if (onDevice) {
+        /* `delete body` of a body that lives on the device (rigid.cpp:43-49): the device state is rebuilt without it and without
+         * the forces attached to it.  Joint / Spring mirrors attached to this body stay alive as plain host objects (the
+         * reference leaves them dangling); they no longer exist for the solver. */
+        s->flush();
+        int rc = avbd_remove_body(s->ctx, index);
+        if (rc) s->fail("avbd_remove_body", rc);
+        auto& uf = s->impl->userForces;
+        for (size_t i = 0; i < uf.size();) {
+            if (uf[i]->bodyA == this || uf[i]->bodyB == this) {
+                if (i < s->impl->flushedForces) --s->impl->flushedForces;
+                uf[i]->deviceKind = -2;                                  /* gone from the device */
+                uf.erase(uf.begin() + (long)i);
+            } else ++i;
+        }
+        for (Force* f : uf) f->listIndex = -1;
+        for (Manifold* m : s->impl->manifolds) m->listIndex = -1;
+        s->impl->shadow.erase(s->impl->shadow.begin() + index);
+        --s->flushedBodies;
+    }
+    /* forces that still point at this body lose the pointer (a dangling pointer in the reference) */
+    for (Force* f = s->forces; f; f = f->next) { if (f->bodyA == this) f->bodyA = nullptr; else if (f->bodyB == this) f->bodyB = nullptr; }
+    Rigid** p = &s->bodies;
     while (*p && *p != this) p = &(*p)->next;
     if (*p) *p = next;
-    if (!solver->impl->clearing) { /* an unflushed body: drop it from the creation list */
-        auto& v = solver->impl->byIndex;
+    if (!s->impl->clearing) { /* drop it from the creation list */
+        auto& v = s->impl->byIndex;
         for (size_t i = 0; i < v.size(); ++i)
             if (v[i] == this) { v.erase(v.begin() + (long)i); break; }
         for (size_t i = 0; i < v.size(); ++i) v[i]->index = (int)i;
-        solver->numBodies = (int)v.size();
+        s->numBodies = (int)v.size();
+        if (onDevice) s->syncForces();                                    /* manifold mirrors and list links of the smaller scene */
     }
-}
-
-mat3 Rigid::getInvInertiaTensorWorld() const
-{
-    mat3 R = mat3_from_quat(orientation);
-    return R * invInertiaTensor * transpose(R);
-}
-
-mat3 Rigid::getInertiaTensorWorld() const
-{
-    mat3 R = mat3_from_quat(orientation);
-    return R * inertiaTensor * transpose(R);
-}
-
-bool Rigid::isConstrainedTo(Rigid* other) const
-{
-    for (Force* f = forces; f != nullptr; f = (f->bodyA == this) ? f->nextA : f->nextB)
-        if (f->bodyB == other || f->bodyA == other) return true;
-    return false;
 }
 
 /* ------------------------------------------------------------------ Force ----------------- */
@@ -119,17 +124,28 @@ static void unlinkForce(Force* f)
 
 Force::~Force()
 {
-    unlinkForce(this);
-    if (!isManifold() && !solver->impl->clearing) {
-        auto& v = solver->impl->userForces;
-        for (size_t i = 0; i < v.size(); ++i) {
-            if (v[i] != this) continue;
-            if (i < solver->impl->flushedForces)
-                solver->fail("deleting a single force that already lives on the device is not supported; use Solver::clear()", AVBD_E_INVALID);
-            v.erase(v.begin() + (long)i);
-            break;
+    Solver* s = solver;
+    if (!s->impl->clearing && !s->impl->syncing && deviceKind != -2) {
+        auto& v = s->impl->userForces;
+        size_t k = v.size();
+        if (!isManifold()) for (size_t i = 0; i < v.size(); ++i) if (v[i] == this) { k = i; break; }
+        const bool userOnDevice = k < s->impl->flushedForces;
+        if (userOnDevice || (isManifold() && listIndex >= 0)) {
+            /* `delete force` of a force that lives on the device (force.cpp:31-69): rebuilt without it */
+            if (listIndex < 0) s->syncForces();
+            int rc = avbd_remove_force(s->ctx, listIndex);
+            if (rc) s->fail("avbd_remove_force", rc);
+            if (userOnDevice) --s->impl->flushedForces;
+            for (Force* f : v) f->listIndex = -1;
+            for (Manifold* m : s->impl->manifolds) m->listIndex = -1;
+        }
+        if (k < v.size()) v.erase(v.begin() + (long)k);
+        if (isManifold()) {
+            auto& mm = s->impl->manifolds;
+            for (size_t i = 0; i < mm.size(); ++i) if ((Force*)mm[i] == this) { mm.erase(mm.begin() + (long)i); break; }
         }
     }
+    unlinkForce(this);
 }
 
 void Force::deviceComputeConstraint(float alpha)
@@ -486,9 +502,9 @@ void Solver::syncForces()
         if (rc < 0) fail("avbd_download_forces", rc);
     }
     /* drop the old manifold mirrors and every list link, then rebuild oldest → newest with head insertion */
-    impl->clearing = true;
+    impl->syncing = true;
     for (Manifold* m : impl->manifolds) delete m;
-    impl->clearing = false;
+    impl->syncing = false;
     impl->manifolds.clear();
     forces = nullptr;
     for (Rigid* b : impl->byIndex) b->forces = nullptr;

@@ -200,6 +200,14 @@ int  avbd_save_snapshot(AvbdContext* ctx, const char* path);
 int  avbd_load_snapshot(AvbdContext* ctx, const char* path);
 int  avbd_set_step_index(AvbdContext* ctx, int stepIndex);
 
+/* ---- removal: `delete body` (rigid.cpp:43-49) / `delete force` (force.cpp:31-69) ------------------------------
+ * The device state is compact and ordered by creation, so a removal rebuilds it without the element (cost: one download and
+ * one upload of the whole state — an editing operation, not a per-step one).  Removing a body removes the forces attached to
+ * it as well (the reference leaves them dangling); later-created bodies move down one index.  `list_index` counts the force
+ * list newest first, as avbd_download_forces returns it. */
+int  avbd_remove_body(AvbdContext* ctx, int body_index);
+int  avbd_remove_force(AvbdContext* ctx, int list_index);
+
 /* ---- row API on the device for one force of the downloaded list (index into newest-first order):
  * Force::computeConstraint / computeDerivatives (solver.h:104-106).  compute_constraint applies the
  * reference's in-place mutations to the device-resident force and returns its rows. ---- */

@@ -272,3 +272,67 @@ def test_non_finite_state_is_sanitised_like_the_reference():
         H.assert_same_world(o, g, f"after injecting non-finite velocities, step {s + 1}", check_diag=(s > 0))
     gb = g.bodies()
     assert np.isfinite(gb["pos"]).all() and np.isfinite(gb["linVel"]).all() and np.isfinite(gb["angVel"]).all()
+
+
+def _pile(w, skip=None, joints=()):
+    w.add_body((30, 1, 30), 0.0, 0.5, (0, -0.5, 0))
+    k = 1
+    for layer in range(3):
+        for i in range(2):
+            for j in range(2):
+                if k != skip:
+                    w.add_body((1, 1, 1), 1.0, 0.5, ((i - 0.5) * 1.02, 0.5 + layer * 1.001, (j - 0.5) * 1.02))
+                k += 1
+    for a, b in joints:
+        w.add_joint(a, b, (0.5, 0, 0), (-0.5, 0, 0))
+    w.set_params(iterations=8)
+
+
+def test_remove_body_rebuilds_the_state_without_it():
+    """`delete body` of the reference: avbd_remove_body drops the body and the forces attached to it and renumbers the later
+    bodies.  Checked against the oracle started from the same filtered state in a scene built without that body."""
+    g = H.HipWorld(); _pile(g); g.step(20)
+    victim = 6
+    b, f = g.bodies(), g.forces()
+    g.w.remove_body(victim)
+    assert g.w.num_bodies() == len(b) - 1
+    keep = [i for i in range(len(f)) if victim not in (int(f["bodyA"][i]), int(f["bodyB"][i]))]
+    f2 = f[keep].copy()
+    for name in ("bodyA", "bodyB"):
+        f2[name] = np.where(f2[name] > victim, f2[name] - 1, f2[name])
+    b2 = np.delete(b, victim)
+    o = H.CpuWorld("orc"); _pile(o, skip=victim)
+    o.set_bodies(b2); o.set_forces(f2)
+    # (initial / inertial poses are scratch of the predictor: rewritten at the start of every step, not part of set_bodies)
+    for s in range(15):
+        o.step(); g.step()
+        H.assert_same_world(o, g, f"{s + 1} steps after the removal", check_diag=(s > 0))
+
+
+def test_remove_force_drops_one_joint():
+    g = H.HipWorld(); _pile(g, joints=((1, 2), (3, 4))); g.step(10)
+    b, f = g.bodies(), g.forces()
+    joint_rows = [i for i in range(len(f)) if int(f["kind"][i]) == 1 and {int(f["bodyA"][i]), int(f["bodyB"][i])} == {3, 4}]
+    assert len(joint_rows) == 1
+    g.w.remove_force(joint_rows[0])
+    f2 = np.delete(f, joint_rows[0])
+    o = H.CpuWorld("orc"); _pile(o, joints=((1, 2),))
+    o.set_bodies(b); o.set_forces(f2)
+    for s in range(10):
+        o.step(); g.step()
+        H.assert_same_world(o, g, f"{s + 1} steps after removing the joint", check_diag=(s > 0))
+
+
+def test_cli_delete_body_through_the_host_mirror(tmp_path):
+    """`delete body` in the source-compatible host API (a body that already lives on the device): same final state as
+    avbd_remove_body through the C ABI at the same step."""
+    import subprocess
+    exe = os.path.join(H.ROOT, "avbd-demo3d_amd", "avbd_demo3d")
+    dump = str(tmp_path / "final.bin")
+    subprocess.run([exe, "--nogfx", "--scene", "Pyramid", "--steps", "40", "--remove-body", "17", "--remove-at", "25", "--quiet", "--dump", dump],
+                   capture_output=True, text=True, check=True)
+    got = np.fromfile(dump, dtype=H.load_product().BODY_DT)
+    g = H.HipWorld(); g.scene("Pyramid"); g.step(25); g.w.remove_body(17); g.step(15)
+    want = g.w.bodies()
+    assert len(got) == len(want) == 55
+    assert H.same_bits(got, want)
