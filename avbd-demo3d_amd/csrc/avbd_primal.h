@@ -413,6 +413,9 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
             float desired = pen * j.C[row] + lw + f.motor[row];
             float fr = rclamp(desired, -FLT_MAX, FLT_MAX);
             put_row(rec + k * kRowRec, Jl, Ja, fr, pen, zero3(), kRowFlagValid);
+            /* API visibility of Force::C after a post-stabilisation visit (the last computeConstraint of the step, joint.cpp:68-106);
+             * both endpoints store, the later visitor's value stays — its stores are ordered behind the earlier visitor's publish */
+            if (writeRows) stf<COH>(&f.C[row], j.C[row]);
         }
     } else { /* FK_SPRING */
         GForce& f = gf[idx];
@@ -431,6 +434,7 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
         float desired = pen * s.C + lw + f.motor[0];
         float fr = rclamp(desired, f.fmin[0], f.fmax[0]);
         put_row(rec, Jl, Ja, fr, pen, zero3(), kRowFlagValid);
+        if (writeRows) stf<COH>(&f.C[0], s.C);                          /* as for joints (spring.cpp:33-58) */
         rec[kRowRec + 11] = __int_as_float(0);
         rec[2 * kRowRec + 11] = __int_as_float(0);
     }
