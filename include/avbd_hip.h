@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AVBD_ABI_VERSION 1
+#define AVBD_ABI_VERSION 2   /* 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 is a subset) */
 
 enum {
     AVBD_OK = 0,
