@@ -707,7 +707,18 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     /* resident schedule (one wave per body for the whole loop): whole loop in one launch on one GPU, contacts only, stamps fit */
     ResidentExchange X{};
     X.pose = c->xPose.p; X.visit = c->xVisit.p; X.dual = c->xDual.p;
-    const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes, poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
+    /* dual records: two per contact slot, then two per joint half */
+    const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes + (size_t)4 * c->gCap * sizeof(float4), poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
+    if (c->xDual.n * sizeof(float4) < dualBytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->xDual.alloc(dualBytes / sizeof(float4)));
+        HIPCHK(c, hipMemset(c->xDual.p, 0, dualBytes));
+        X.dual = c->xDual.p;
+    }
+    X.jointRecBase = 4 * c->mCap;
+    bool noSprings = true, anyJoint = false;
+    for (const GForce& g : c->hG) { noSprings &= g.kind != FK_SPRING; anyJoint |= g.kind == FK_JOINT; }
+    X.joints = anyJoint ? 1 : 0;
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
     X.maxWaves = c->iterBlocks * kIterWaves;
     X.quietPermille = c->residentQuiet;
@@ -720,7 +731,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     const bool fitsOne = wholeLoop && dynBodies <= X.maxWaves && !c->residentForceLite;
     const bool fitsMulti = c->residentMultiAllowed && dynBodies <= c->residentMultiMax * X.maxWaves;   /* beyond: throughput-bound, task schedule with two workgroups per CU */
     X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave &&
-                 (wholeLoop || (sharded && c->residentSharded)) && c->hG.empty() &&
+                 (wholeLoop || (sharded && c->residentSharded)) && noSprings &&
                  totalItAll <= 60 && totalItAll > 0 && (fitsOne || fitsMulti) && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
     X.multi = 0; X.forceMulti = 0; X.planesAlways = 0;
     if (X.enabled && !fitsOne) {
@@ -754,10 +765,12 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
         if (blocks2 < 1) blocks2 = 1;
         if (lite) blocks2 = 2 * c->iterBlocks;
-        hipExtLaunchKernelGGL(k_iterate<2>, dim3(blocks2), dim3(64 * kIterWaves), kIterWaves * kResProductBytesPerWaveLite, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+        auto kern = X.joints ? k_iterate<2, true> : k_iterate<2, false>;
+        hipExtLaunchKernelGGL(kern, dim3(blocks2), dim3(64 * kIterWaves), kIterWaves * kResProductBytesPerWaveLite, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
                               c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
     } else {
-        hipExtLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+        auto kern = X.joints ? k_iterate<1, true> : k_iterate<1, false>;
+        hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
                               c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
     }
     ++c->prof.launches_primal; ++c->prof.launches_total;
@@ -983,9 +996,11 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;
         if (const char* e = std::getenv("AVBD_FUSED_TOPOLOGY")) c->fusedTopology = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
-        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
-        fe = hipFuncSetAttribute((const void*)k_iterate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
+        fe = hipFuncSetAttribute((const void*)k_iterate<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate<2>, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }

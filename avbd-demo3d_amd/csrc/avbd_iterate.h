@@ -107,7 +107,7 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
 
 /* WPE = wavefronts per SIMD the launch is sized for: 1 (latency mode, one workgroup per CU: the critical wave never shares
  * its SIMD with a spinning one) or 2 (throughput mode for scenes with thousands of tasks per wave). */
-template <int WPE>
+template <int WPE, bool JOINTS>
 __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_iterate(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
@@ -137,12 +137,15 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
         const bool lite = WPE == 2;
         if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi) && (!lite || (veto & 4) == 0)) {
             float* products = reinterpret_cast<float*>(sDynamic) + wv * 27 * X.prStride;
-            if (lite || (veto & 2) || X.forceMulti) iterate_resident<true>(B, M, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
-            else {
-                /* one body per wave: the four waves of a CU take slots a quarter of the sweep order apart, so that they are
-                 * busy at different times (waves of one CU share its LDS, L1 and instruction front end) */
-                const int slot = X.spread ? wv * (int)gridDim.x + (int)blockIdx.x : w;
-                if (slot < nd) iterate_resident<false>(B, M, order, nd, slot, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
+            const bool multi = lite || (veto & 2) || X.forceMulti;
+            /* one body per wave: the four waves of a CU take slots a quarter of the sweep order apart, so that they are
+             * busy at different times (waves of one CU share its LDS, L1 and instruction front end) */
+            const int slot = X.spread ? wv * (int)gridDim.x + (int)blockIdx.x : w;
+            /* JOINTS is a property of the launch (the host instantiates the joint-aware resident code only for scenes that have
+             * joints: it costs registers on the path that bounds the contacts-only headline workload) */
+            if (multi) iterate_resident<true, JOINTS>(B, M, gf, order, nd, w, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
+            else if (slot < nd) {
+                if constexpr (WPE == 1) iterate_resident<false, JOINTS>(B, M, gf, order, nd, slot, W, incStart, inc, P, S.error, cntW, X, sleepSel, lane, rows, accs, products, itBegin, itEnd);
             }
             return;
         }

@@ -550,7 +550,7 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
         } else if (kind == FK_SPRING) {
             inc[o++] = make_inc(isA, FK_SPRING, idx);
         }
-        if (kind == FK_JOINT || kind == FK_SPRING) nonManifold = true;
+        if (kind == FK_SPRING) nonManifold = true;                     /* joints are fine for the resident schedule, springs are not */
     }
     /* the resident schedule (avbd_resident.h) keeps one Manifold contact per lane of the body's wavefront */
     if (nonManifold || o - incStart[b] > 64) atomicOr(&cnt->residentBad, 1);
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                 const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
                 int* out = inc + sInc[b] + off;
                 if (kind == FK_MANIFOLD) { const int nc = sEntRows[pos]; for (int c = 0; c < nc; ++c) out[c] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
-                else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); sBad = 1; }
+                else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); }
                 else if (kind == FK_SPRING) { out[0] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
                 /* the key area is dead now (nothing below reads it): compact the neighbour lists into it, any order */
                 if (ro.y > b && kind != FK_IGNORE && sSwept[ro.y]) sNbr[s0 + atomicAdd(&sCur[b], 1)] = (unsigned short)ro.y;
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                 if (!sSwept[b]) continue;
                 const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
                 if (kind == FK_MANIFOLD) { const int nc = M.nc[idx]; for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
-                else if (kind == FK_JOINT) { inc[o++] = make_inc(isA, FK_JOINT, idx * 2); inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1); sBad = 1; }
+                else if (kind == FK_JOINT) { inc[o++] = make_inc(isA, FK_JOINT, idx * 2); inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1); }
                 else if (kind == FK_SPRING) { inc[o++] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
             }
             sCur[b] = s1 - s0;                                          /* the sweeps below filter the whole segment */

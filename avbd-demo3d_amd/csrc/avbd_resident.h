@@ -1,6 +1,7 @@
 /*
- * avbd_resident.h — "resident" schedule of the iteration loop (solver.cpp:340-431) for piles of contacts (no joints or
- * springs, at most 64 contacts per body).  Three forms of the same code (iterate_resident<MULTI>):
+ * avbd_resident.h — "resident" schedule of the iteration loop (solver.cpp:340-431) for scenes of contacts and joints (no
+ * springs, at most 64 incidence entries per body; a lane holds one contact or one half of a joint).  Three forms of the same
+ * code (iterate_resident<MULTI, JOINTS>):
  *   - up to 1024 swept bodies: every body gets ONE wavefront for the whole launch (all iterations), state in registers;
  *   - more bodies: every wave takes every W-th body of the sweep order and parks a body's state between its tasks
  *     (two workgroups per CU, 2048 waves, when every body has at most 33 contacts);
@@ -53,6 +54,8 @@ struct ResidentExchange {
     float4* privPose;  /* [2 * bodyCap]            MULTI: the pose between the body's tasks */
     int spread;        /* one body per wave: slot = wave-in-workgroup * workgroups + workgroup instead of the linear wave index */
     int prStride;      /* floats per product line: kResStride, or kResStrideLite when two workgroups share a CU */
+    int joints;        /* the scene has Joint forces: instantiate the joint-aware code */
+    int jointRecBase;  /* record index of joint half 0 of GForce 0 in `dual` (= 4 * manifold capacity) */
     int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
     int forceMulti;    /* launches that cover part of the iteration loop (sharded runs) park state even with one body per wave */
     int planesAlways;  /* sharded runs: other kernels of the step read the pose planes after every iteration */
@@ -85,12 +88,12 @@ __device__ __forceinline__ void replay_normal(ContactRows& c, bool& fixedN)
 /* ---- ordered accumulation from pre-multiplied products -------------------------------------------------------------
  * Per-wave LDS of the resident schedule (floats):
  *   J[row][6]            Jl.xyz Ja.xyz of every row, written by the contact lanes BEFORE the wait
- *   S[7][kResRows]       slot arrays f | penalty | gyro.x | gyro.y | gyro.z | penalty-usable flag | zeros, written AFTER the wait
+ *   S[8][kResRows]       slot arrays f | penalty | gyro.x | gyro.y | gyro.z | penalty-usable flag | zeros | Manifold-row flag, written AFTER the wait
  *   Pr[27][kResStride]   one line per accumulator entry: Ja*Jb of every row (rhs entries: J alone), written BEFORE the wait
  * so that after the wait an accumulator lane adds (product * penalty [+ gyro]) or (J * f) row by row — the reference's
  * order and association, (Ja*Jb)*penalty (solver.cpp:387-391) — from three 16-byte LDS reads per four rows. */
 constexpr int kResRows = 192, kResStride = 160;      /* a product line holds rows 36..191 (the first 36 live in registers) */
-constexpr int kResJFloats = kResRows * 6, kResSFloats = 7 * kResRows;   /* slot 6: zeros (what off-diagonal entries add) */
+constexpr int kResJFloats = kResRows * 6, kResSFloats = 8 * kResRows;   /* slot 6: zeros (what off-diagonal entries add), slot 7: Manifold row? */
 constexpr int kResProductBytesPerWave = 27 * kResStride * 4;
 /* two workgroups per CU (k_iterate<2>): product lines only for rows 36..99, i.e. bodies with at most 33 contacts
  * (4 x 7 344 B + 45 KB of row staging = 75 KB per workgroup) */
@@ -128,17 +131,20 @@ __device__ __forceinline__ void store_products(const AccLane& a, const float* J,
 
 __device__ __forceinline__ float comp4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-template <bool ALLON>
+template <bool ALLON, bool JOINTS>
 __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr)[kResRegRows], const float* prLine, const float* S, int nRows)
 {
     /* every lane runs the same instruction stream (idle lanes 27..63 compute a value nobody reads): no divergent branches,
-     * only wave-uniform ones on the row count */
+     * only wave-uniform ones on the row count.  ALLON: every row is a Manifold row with a usable penalty (the normal case);
+     * otherwise two per-row flags gate the add (penalty usable, solver.cpp:387) and the geometric-stiffness term (Manifold
+     * rows only, solver.cpp:393). */
     const bool isAA = a.mode == 1, diag = a.gy >= 0, rhs = a.mode == 2;
     const float4* s4 = reinterpret_cast<const float4*>(S + (rhs ? 0 : kResRows));
     const float4* g4 = reinterpret_cast<const float4*>(S + kResRows * (diag ? a.gy - 6 : 6));
     const float4* o4 = reinterpret_cast<const float4*>(S + kResRows * 5);
+    const float4* m4 = reinterpret_cast<const float4*>(S + kResRows * 7);
     constexpr int NQ = kResRegRows / 4;
-    float4 sv[NQ], gv[NQ], ov[NQ];
+    float4 sv[NQ], gv[NQ], ov[NQ], mv[NQ];
     /* every operand of the first 36 rows is requested before the dependent chain of additions starts */
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -147,7 +153,7 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
         if (q < 3 || q * 4 < nRows) {                               /* wave-uniform */
             sv[q] = s4[q];
             gv[q] = g4[q];
-            if (!ALLON) ov[q] = o4[q];
+            if (!ALLON) { ov[q] = o4[q]; if (JOINTS) mv[q] = m4[q]; }
         }
     }
 #pragma unroll
@@ -158,8 +164,11 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
                 const int r = e * 3 + k;
                 const float nv = a.acc + pr[r] * comp4(sv[r >> 2], r & 3);
                 const float nvg = nv + comp4(gv[r >> 2], r & 3);     /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
-                const float nv2 = isAA ? nvg : nv;
-                if (ALLON) a.acc = nv2; else a.acc = (rhs || comp4(ov[r >> 2], r & 3) != 0.0f) ? nv2 : a.acc;
+                if (ALLON) a.acc = isAA ? nvg : nv;
+                else {
+                    const float nv2 = (isAA && (!JOINTS || comp4(mv[r >> 2], r & 3) != 0.0f)) ? nvg : nv;
+                    a.acc = (rhs || comp4(ov[r >> 2], r & 3) != 0.0f) ? nv2 : a.acc;
+                }
             }
         }
     }
@@ -167,17 +176,29 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
     const float4* p4 = reinterpret_cast<const float4*>(prLine);
     for (int r4 = kResRegRows; r4 < nRows; r4 += 4) {
         const float4 pv = p4[(r4 - kResRegRows) >> 2], sw = s4[r4 >> 2], gw = g4[r4 >> 2];
-        float4 ow = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (!ALLON) ow = o4[r4 >> 2];
+        float4 ow = make_float4(1.f, 1.f, 1.f, 1.f), mw = ow;
+        if (!ALLON) { ow = o4[r4 >> 2]; if (JOINTS) mw = m4[r4 >> 2]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (r4 + k < nRows) {                                  /* wave-uniform */
                 const float nv = a.acc + comp4(pv, k) * comp4(sw, k);
                 const float nvg = nv + comp4(gw, k);
-                const float nv2 = isAA ? nvg : nv;
-                if (ALLON) a.acc = nv2; else a.acc = (rhs || comp4(ow, k) != 0.0f) ? nv2 : a.acc;
+                if (ALLON) a.acc = isAA ? nvg : nv;
+                else {
+                    const float nv2 = (isAA && comp4(mw, k) != 0.0f) ? nvg : nv;
+                    a.acc = (rhs || comp4(ow, k) != 0.0f) ? nv2 : a.acc;
+                }
             }
         }
+    }
+}
+
+/* what the owner of a joint half leaves in the GForce record: between its tasks (MULTI) and at the end of the step */
+__device__ __forceinline__ void store_joint_half(GForce& f, int part, const ContactRows& c, bool withRows)
+{
+    for (int k = 0; k < 3; ++k) {
+        f.lambda[part * 3 + k] = c.lambda[k]; f.penalty[part * 3 + k] = c.penalty[k];
+        if (withRows) { f.C[part * 3 + k] = c.C[k]; f.fmin[part * 3 + k] = -FLT_MAX; f.fmax[part * 3 + k] = FLT_MAX; }
     }
 }
 
@@ -187,8 +208,8 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
  * owner writes; the first visitor's copy of normal + tangent memo and the pose in arrays private to the wave).  Tasks are
  * taken in the order t = it * slots + slot, a linear extension of the dependency order, so the smallest unfinished task is
  * always at the head of a resident wave's list.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
-template <bool MULTI>
-__device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, const int* __restrict__ order, int nd, int w, int W,
+template <bool MULTI, bool JOINTS>
+__device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, GForce* gf, const int* __restrict__ order, int nd, int w, int W,
                                                  const int* __restrict__ incStart, const int* __restrict__ inc, const SolverParams& P, int* errWord,
                                                  Counters* cntW, const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products,
                                                  int itBegin, int itEnd)
@@ -201,6 +222,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     int body = 0, eBeg = 0, nEnt = 0;
     bool has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
+    bool isJoint = false, hasA = true;                               /* a lane holds one Manifold contact or one half (3 rows) of a Joint */
+    q4 jq0 = identq(); f3 jStiff = zero3(), jMotor = zero3(); int jPart = 0;
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
     c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
@@ -220,9 +243,32 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         nEnt = __builtin_amdgcn_readfirstlane(incStart[body + 1]) - eBeg;
         has = lane < nEnt;
         fixedN = false;
+        isJoint = false;
         if (has) {
             const int ent = inc[eBeg + lane];
             idx = inc_index(ent); isA = inc_isA(ent) != 0;
+            isJoint = JOINTS && inc_kind(ent) == FK_JOINT;         /* JOINTS = false: contacts only, the joint code below is compiled out */
+        }
+        if (JOINTS && has && isJoint) {
+            /* one half of a Joint (joint.cpp:68-139): rows 3*part .. 3*part+2; lambda / penalty live in the GForce record, which
+             * only the owner writes during the launch (and where it parks them between its tasks) */
+            const GForce& f = gf[idx >> 1];
+            jPart = idx & 1;
+            hasA = f.bodyA >= 0;
+            other = isA ? f.bodyB : f.bodyA;
+            moving = other >= 0 && B.solved[other] != 0;
+            owned = !moving || other > body;
+            c.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); c.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
+            jq0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+            for (int k = 0; k < 3; ++k) { c.lambda[k] = f.lambda[jPart * 3 + k]; c.penalty[k] = f.penalty[jPart * 3 + k]; c.C[k] = f.C[jPart * 3 + k]; }
+            jStiff = mk3(f.stiffness[jPart * 3], f.stiffness[jPart * 3 + 1], f.stiffness[jPart * 3 + 2]);
+            jMotor = mk3(f.motor[jPart * 3], f.motor[jPart * 3 + 1], f.motor[jPart * 3 + 2]);
+            opos = zero3(); orot = identq();
+            if (other >= 0) {
+                const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];
+                opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
+            } else other = 0;                                          /* world anchor: a fixed partner, never polled */
+        } else if (has) {
             const int m = idx >> 2;
             const int2 pr = M.pair[m];
             other = isA ? pr.y : pr.x;
@@ -253,11 +299,13 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
         Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
         Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
-        offP = other * 48; offV = idx * 16; offD = idx * 32;
+        offP = other * 48; offV = idx * 16; offD = ((JOINTS && isJoint) ? X.jointRecBase + idx : idx) * 32;
     };
     /* MULTI: park the body's state until its next task; the last task leaves the step's final state (rows included) */
     auto save_task = [&](bool last) {
-        if (has) {
+        if (JOINTS && has && isJoint) {
+            if (owned) store_joint_half(gf[idx >> 1], jPart, c, last);
+        } else if (has) {
             if (owned) store_contact_dual<false>(M, idx, c, last);
             else {
                 X.privN[(size_t)(eBeg + lane) * 3] = make_float4(c.normal.x, c.normal.y, c.normal.z, 0.f);
@@ -306,7 +354,23 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         float* J = rows;
         float* S = rows + kResJFloats;
         float* prLine = products + (lane < 27 ? lane : 0) * X.prStride;
-        if (has) {
+        if (JOINTS && has && isJoint) {
+            if (moving) {
+                needP = true;
+                if (owned) sP = stampNow;
+                else if (it > 0) { needD = true; sD = X.base + (unsigned)it; sP = sD; }
+                else needP = false;
+            }
+            /* Jacobians of this body's three rows (joint.cpp:108-139): functions of its own orientation only */
+            JointRows jr0; jr0.rA = c.rA; jr0.rB = c.rB; jr0.q0 = jq0;
+            for (int k = 0; k < 3; ++k) {
+                f3 Jl, Ja;
+                joint_compute_derivatives(jr0, isA, false, L.rot, jPart * 3 + k, Jl, Ja);
+                G[k] = zero3();
+                float* jr = J + (lane * 3 + k) * 6;
+                jr[0] = Jl.x; jr[1] = Jl.y; jr[2] = Jl.z; jr[3] = Ja.x; jr[4] = Ja.y; jr[5] = Ja.z;
+            }
+        } else if (has) {
             wOwn = qrotate(L.rot, isA ? c.rA : c.rB);                 /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
                 if (owned) { replay_normal(c, fixedN); needV = true; sV = stampNow; needP = true; sP = stampNow; }
@@ -380,20 +444,40 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             prevWait = (unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0);
             if (needP) {
                 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
-                wOther = qrotate(orot, isA ? c.rB : c.rA);
-                pOther = opos + wOther;
+                if (!(JOINTS && isJoint)) {
+                    wOther = qrotate(orot, isA ? c.rB : c.rA);
+                    pOther = opos + wOther;
+                }
             }
             if (needV) { c.lambda[1] = bitsf(vv.x); c.lambda[2] = bitsf(vv.y); c.stick = vv.z != 0; }
             if (needD) {
                 c.lambda[0] = bitsf(d0.x); c.lambda[1] = bitsf(d0.y); c.lambda[2] = bitsf(d0.z);
                 c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
-                c.stick = (d1.w & 1u) != 0;
+                c.stick = (d1.w & 1u) != 0;                           /* (unused by joints) */
             }
         }
 
         /* ---- primal visit (solver.cpp:344-409) ---- */
         bool rowsOn = true;
-        if (has) {
+        if (JOINTS && has && isJoint) {
+            /* Joint::computeConstraint (joint.cpp:68-106) + the row forces of solver.cpp:372-385 for this half */
+            JointRows jr1; jr1.rA = c.rA; jr1.rB = c.rB; jr1.q0 = jq0;
+            if (isA) joint_compute_constraint(jr1, hasA, L.pos, L.rot, opos, orot);
+            else     joint_compute_constraint(jr1, hasA, opos, orot, L.pos, L.rot);
+            for (int k = 0; k < 3; ++k) {
+                const float stiff = comp3(jStiff, k);
+                c.C[k] = jr1.C[jPart * 3 + k];
+                const float lw = (stiff == FLT_MAX) ? c.lambda[k] : 0.0f;
+                const float desired = c.penalty[k] * c.C[k] + lw + comp3(jMotor, k);
+                const float f = rclamp(desired, -FLT_MAX, FLT_MAX);
+                const bool penOk = (c.penalty[k] > 0.0f) & (fabsf(c.penalty[k]) <= FLT_MAX);
+                const int r = lane * 3 + k;
+                S[r] = f; S[kResRows + r] = c.penalty[k]; S[2 * kResRows + r] = 0.0f; S[3 * kResRows + r] = 0.0f; S[4 * kResRows + r] = 0.0f;
+                S[5 * kResRows + r] = penOk ? 1.0f : 0.0f;
+                S[7 * kResRows + r] = 0.0f;                             /* not a Manifold row: no geometric-stiffness term (solver.cpp:393) */
+            }
+            rowsOn = false;                                            /* the predicate-free accumulation is for all-Manifold bodies */
+        } else if (has) {
             const f3 pOwn = L.pos + wOwn;
             contact_constraint_post(c, pre, isA ? pOwn : pOther, isA ? pOther : pOwn, fric);
             if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xst(rV, offV, r); }
@@ -405,13 +489,14 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 const int r = lane * 3 + k;
                 S[r] = f; S[kResRows + r] = c.penalty[k]; S[2 * kResRows + r] = gyro.x; S[3 * kResRows + r] = gyro.y; S[4 * kResRows + r] = gyro.z;
                 S[5 * kResRows + r] = penOk ? 1.0f : 0.0f;
+                if (JOINTS) S[7 * kResRows + r] = 1.0f;
                 rowsOn &= penOk;
             }
         }
         const bool allOn = __all(rowsOn);
         wave_sync();
         RS_STAMP(1);
-        if (allOn) accumulate_products<true>(a, pr, prLine, S, nEnt * 3); else accumulate_products<false>(a, pr, prLine, S, nEnt * 3);
+        if (allOn) accumulate_products<true, JOINTS>(a, pr, prLine, S, nEnt * 3); else accumulate_products<false, JOINTS>(a, pr, prLine, S, nEnt * 3);
         if (lane < 27) accs[lane] = a.acc;
         wave_sync();
         RS_STAMP(2);
@@ -432,8 +517,36 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         L.pos = mk3(bcast0(p.x), bcast0(p.y), bcast0(p.z)); L.rot = mkq(bcast0(q.x), bcast0(q.y), bcast0(q.z), bcast0(q.w));
         RS_STAMP(3);
 
+        /* ---- dual update of the joint halves this body owns (solver.cpp:411-430 with Joint rows) ---- */
+        if (JOINTS && doDual && has && owned && isJoint) {
+            JointRows jr2; jr2.rA = c.rA; jr2.rB = c.rB; jr2.q0 = jq0;
+            const q4 rotA = isA ? L.rot : orot, rotB = isA ? orot : L.rot;
+            if (isA) joint_compute_constraint(jr2, hasA, L.pos, L.rot, opos, orot);
+            else     joint_compute_constraint(jr2, hasA, opos, orot, L.pos, L.rot);
+            for (int k = 0; k < 3; ++k) {
+                const int row = jPart * 3 + k;
+                c.C[k] = jr2.C[row];
+                if (comp3(jStiff, k) != FLT_MAX) continue;
+                const float lu = rclamp(c.penalty[k] * c.C[k] + c.lambda[k], -FLT_MAX, FLT_MAX);
+                const bool active = lu > -FLT_MAX && lu < FLT_MAX;
+                c.lambda[k] = lu;
+                if (active) {
+                    float lw = 0.0f, aw = 0.0f;
+                    f3 Jl, Ja;
+                    if (hasA) { joint_compute_derivatives(jr2, true, false, rotA, row, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+                    joint_compute_derivatives(jr2, false, false, rotB, row, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+                    const float betaRow = row_penalty_gain(lw, aw, P.beta);
+                    c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kPenaltyMax);
+                }
+            }
+            if (moving) {
+                v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
+                v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), stampNow << 1};
+                xst(rD, offD, r0); xst(rD, offD + 16, r1);
+            }
+        }
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
-        if (doDual && has && owned) {
+        if (doDual && has && owned && !(JOINTS && isJoint)) {
             const f3 wNew = qrotate(L.rot, isA ? c.rA : c.rB);
             const f3 pNew = L.pos + wNew;
             dual_contact_pts(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? L.invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
@@ -468,7 +581,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             B.plane(BP_POSR)[body] = pack3(L.pos, radius);
             B.plane(BP_QUAT)[body] = packq(L.rot);
         }
-        if (has && owned) store_contact_dual<false>(M, idx, c, true);
+        if (has && owned) { if (JOINTS && isJoint) store_joint_half(gf[idx >> 1], jPart, c, true); else store_contact_dual<false>(M, idx, c, true); }
     }
 }
 

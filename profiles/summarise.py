@@ -24,7 +24,9 @@ def one(pattern):
 
 
 def short(name):
-    return name.split("(")[0].split("::")[-1].split(" ")[-1]
+    """'void avbd::k_iterate<1, false>(avbd::BodyTable, ...)' -> 'k_iterate<1, false>'"""
+    head = name.split("(")[0]
+    return head.split("::")[-1] if "::" in head else head.split(" ")[-1]
 
 
 summary = {}

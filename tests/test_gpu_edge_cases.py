@@ -132,7 +132,7 @@ def test_resident_schedule_post_stabilize_and_odd_iteration_counts():
 
 def test_resident_schedule_vetoed_on_device_falls_back_to_tasks():
     """> 64 entries on one swept body: the host cannot know, the device vetoes (Counters.residentBad) and the same launch
-    runs the task schedule; a scene with a joint is not offered to the resident schedule at all."""
+    runs the task schedule; a scene with a spring is not offered to the resident schedule at all (joints are)."""
     o, g = pair()
     for w in (o, g):
         w.add_body((40, 1, 40), 0.0, 0.5, (0, -0.5, 0))
@@ -151,8 +151,15 @@ def test_resident_schedule_vetoed_on_device_falls_back_to_tasks():
         w.scene("Stack")
         w.add_joint(3, 4, (0, 0.5, 0), (0, -0.5, 0))
     o.step(10); g.step(10)
-    assert int(g.w.stats()["schedule"]) == 1
+    assert int(g.w.stats()["schedule"]) == 2                      # joints are taken by the resident schedule ...
     H.assert_same_world(o, g, "Stack + joint")
+    o, g = pair()
+    for w in (o, g):
+        w.scene("Stack")
+        w.add_spring(3, 5, (0, 0.5, 0), (0, -0.5, 0), 800.0)
+    o.step(10); g.step(10)
+    assert int(g.w.stats()["schedule"]) == 1                      # ... springs are not: the scene is not offered to it
+    H.assert_same_world(o, g, "Stack + spring")
 
 
 def test_too_many_iterations_for_the_stamp_window_uses_tasks():

@@ -44,3 +44,51 @@ def test_random_scenes_bit_exact(first):
         for s in range(18):
             o.step(); g.step()
             H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
+
+
+def build_jointed(w, seed, big=False):
+    r = np.random.default_rng(seed)
+    n = int(r.integers(20, 160)) if not big else int(r.integers(1100, 1900))
+    w.add_body((80, 1.0, 80), 0.0, 0.5, (0, -0.5, 0))
+    span = 4 if not big else 14
+    for k in range(n):
+        size = tuple(float(x) for x in r.uniform(0.4, 1.4, 3))
+        pos = (float(r.uniform(-span, span)), float(r.uniform(0.4, 7)), float(r.uniform(-span, span)))
+        q = r.normal(size=4); q = tuple(float(x) for x in q / np.linalg.norm(q))
+        w.add_body(size, float(r.uniform(0.3, 3.0)), float(r.uniform(0.1, 1.0)), pos, q, tuple(float(x) for x in r.uniform(-2, 2, 3)),
+                   tuple(float(x) for x in r.uniform(-3, 3, 3)))
+    for _ in range(int(r.integers(3, 25))):
+        a, b = int(r.integers(1, n)), int(r.integers(1, n))
+        if a == b:
+            continue
+        kind = r.integers(0, 4)
+        if kind == 0: w.add_joint(a, b, (0.4, 0, 0), (-0.4, 0, 0))
+        elif kind == 1: w.add_joint(-1, b, (float(r.uniform(-3, 3)), 3.0, float(r.uniform(-3, 3))), (0, 0.3, 0))      # world anchor
+        elif kind == 2: w.add_joint(a, b, (0, 0.3, 0), (0, -0.3, 0), lin_stiff=float(r.uniform(1e3, 1e5)), ang_stiff=H.FLT_MAX)  # soft rows
+        else: w.add_ignore(a, b)
+    w.set_params(iterations=int(r.integers(1, 25)), postStabilize=int(r.integers(0, 2)), beta=float(r.uniform(1e4, 2e5)))
+
+
+@pytest.mark.parametrize("first", [300, 320])
+def test_random_jointed_scenes_run_the_resident_schedule_bit_exact(first):
+    """Joints (hard, soft, world-anchored) and ignore-collision markers but no springs: the resident schedule takes them
+    (a lane holds one half = three rows of a joint); every step compared with the oracle."""
+    for seed in range(first, first + 20):
+        o, g = H.CpuWorld("orc"), H.HipWorld()
+        for w in (o, g):
+            build_jointed(w, seed)
+        for s in range(18):
+            o.step(); g.step()
+            H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
+        assert int(g.w.stats()["schedule"]) == 2 and int(g.w.stats()["numJoints"]) > 0
+
+
+def test_jointed_scene_with_several_bodies_per_wave():
+    for seed in (9001, 9003):
+        o, g = H.CpuWorld("orc"), H.HipWorld()
+        for w in (o, g):
+            build_jointed(w, seed, big=True)
+        for s in range(10):
+            o.step(); g.step()
+            H.assert_same_world_fast(o, g, f"seed {seed} step {s + 1}", check_rows=True)
+        assert int(g.w.stats()["schedule"]) == 3
