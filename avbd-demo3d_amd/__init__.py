@@ -64,7 +64,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times",
+    "avbd_group_step", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick",
 ]
 
 
@@ -233,6 +233,16 @@ class World:
 
     def remove_force(self, list_index):
         self._chk(self.L.avbd_remove_force(self.h, int(list_index)))
+
+    def pick(self, origins, directions):
+        """Solver::pick (solver.cpp:145-228) for a batch of rays → (body indices, -1 = miss; local hit points)."""
+        o = _f32(origins, (-1, 3)); d = _f32(directions, (-1, 3))
+        if o.shape != d.shape:
+            raise ValueError("origins and directions must have the same shape")
+        n = o.shape[0]
+        bodies = np.full(n, -1, np.int32); local = np.zeros((n, 3), np.float32)
+        self._chk(self.L.avbd_pick(self.h, n, _fp(o), _fp(d), bodies.ctypes.data_as(C.POINTER(C.c_int)), _fp(local)))
+        return bodies, local
 
     def save_snapshot(self, path):
         self._chk(self.L.avbd_save_snapshot(self.h, str(path).encode()))

@@ -1744,6 +1744,27 @@ int avbd_force_compute_derivatives(AvbdContext* c, int force_index, int body, in
 }
 
 /* ---- known-answer entry points ---------------------------------------------------------- */
+int avbd_pick(AvbdContext* c, int nrays, const float* origins, const float* directions, int* bodies, float* locals)
+{
+    if (!c || nrays < 0 || (nrays && (!origins || !directions || !bodies || !locals))) return AVBD_E_INVALID;
+    if (nrays == 0) return AVBD_OK;
+    (void)hipSetDevice(c->device);
+    int rc = upload_bodies_if_stale(c);
+    if (rc) return rc;
+    DevArr<float> dO, dD, dL; DevArr<int> dB;
+    HIPCHK(c, dO.alloc(3 * nrays)); HIPCHK(c, dD.alloc(3 * nrays)); HIPCHK(c, dL.alloc(3 * nrays)); HIPCHK(c, dB.alloc(nrays));
+    HIPCHK(c, hipMemcpyAsync(dO.p, origins, 12 * (size_t)nrays, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dD.p, directions, 12 * (size_t)nrays, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(dL.p, 0, 12 * (size_t)nrays, c->stream));
+    hipLaunchKernelGGL(k_pick, dim3(nrays), dim3(256), 0, c->stream, body_table(c), nrays, dO.p, dD.p, dB.p, dL.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(bodies, dB.p, 4 * (size_t)nrays, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(locals, dL.p, 12 * (size_t)nrays, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dO.release(); dD.release(); dL.release(); dB.release();
+    return AVBD_OK;
+}
+
 int avbd_kat_collide(AvbdContext* c, int n, const float* posA, const float* quatA, const float* sizeA, const float* posB, const float* quatB,
                      const float* sizeB, AvbdContact* out, int* counts)
 {

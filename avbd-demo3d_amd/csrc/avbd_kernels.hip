@@ -1224,6 +1224,69 @@ __global__ void k_kat_solve6(int n, const float* A, const float* b, float* x)
     x[6 * i] = xl.x; x[6 * i + 1] = xl.y; x[6 * i + 2] = xl.z; x[6 * i + 3] = xa.x; x[6 * i + 4] = xa.y; x[6 * i + 5] = xa.z;
 }
 
+/* Solver::pick (solver.cpp:145-228): nearest dynamic box hit by a ray.  One workgroup per ray; each lane runs the reference's
+ * slab test on every 256th body, the workgroup keeps the smallest (t, newest body) — the reference walks its list newest
+ * first and replaces only on a strictly smaller t — and the lane that holds it writes the body-local hit point. */
+__global__ void __launch_bounds__(256) k_pick(BodyTable B, int nrays, const float* origins, const float* dirs, int* bodyOut, float* localOut)
+{
+    const int ray = blockIdx.x;
+    if (ray >= nrays) return;
+    __shared__ unsigned long long sKey[256];
+    const float epsilon = 1.0e-6f;
+    const f3 origin = mk3(origins[3 * ray], origins[3 * ray + 1], origins[3 * ray + 2]);
+    f3 rayDir = mk3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    const float dirLenSq = lensq3(rayDir);
+    unsigned long long best = ~0ull;
+    f3 bestLocal = zero3();
+    if (!(dirLenSq < epsilon)) {
+        rayDir = rayDir / sqrtf(dirLenSq);
+        const float4* posr = B.plane(BP_POSR); const float4* quat = B.plane(BP_QUAT);
+        const float4* size = B.plane(BP_SIZE); const float4* mass = B.plane(BP_MASS);
+        for (int i = threadIdx.x; i < B.n; i += 256) {
+            if (mass[i].y <= 0.0f) continue;
+            const float4 p = posr[i], q = quat[i], s = size[i];
+            const q4 invRot = qconj(mkq(q.x, q.y, q.z, q.w));
+            const f3 lo = qrotate(invRot, origin - mk3(p.x, p.y, p.z));
+            const f3 ld = qrotate(invRot, rayDir);
+            const f3 half = mk3(s.x, s.y, s.z) * 0.5f;
+            float tEnter = 0.0f, tExit = FLT_MAX;
+            bool hit = true;
+            for (int axis = 0; axis < 3 && hit; ++axis) {
+                const float o = comp3(lo, axis), d = comp3(ld, axis);
+                const float minB = -comp3(half, axis), maxB = comp3(half, axis);
+                if (fabsf(d) < epsilon) {
+                    if (o < minB || o > maxB) hit = false;
+                    continue;
+                }
+                const float invD = 1.0f / d;
+                float t0 = (minB - o) * invD, t1 = (maxB - o) * invD;
+                if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+                tEnter = rmax(tEnter, t0);
+                tExit = rmin(tExit, t1);
+                if (tEnter > tExit) hit = false;
+            }
+            if (!hit) continue;
+            const float tHit = (tEnter >= 0.0f) ? tEnter : tExit;
+            if (tHit < 0.0f || !(tHit < FLT_MAX)) continue;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(tHit + 0.0f) << 32) | (unsigned)(0x7fffffff - i);
+            if (key < best) { best = key; bestLocal = lo + ld * tHit; }
+        }
+    }
+    sKey[threadIdx.x] = best;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && sKey[threadIdx.x + s] < sKey[threadIdx.x]) sKey[threadIdx.x] = sKey[threadIdx.x + s];
+        __syncthreads();
+    }
+    const unsigned long long win = sKey[0];
+    if (win == ~0ull) {
+        if (threadIdx.x == 0) bodyOut[ray] = -1;
+    } else if (best == win) {
+        bodyOut[ray] = 0x7fffffff - (int)(unsigned)(win & 0xffffffffu);
+        localOut[3 * ray] = bestLocal.x; localOut[3 * ray + 1] = bestLocal.y; localOut[3 * ray + 2] = bestLocal.z;
+    }
+}
+
 __global__ void k_kat_arith(int n, const float* a, const float* b, float* od, float* os, float* om, float* oa)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

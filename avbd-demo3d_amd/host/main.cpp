@@ -8,7 +8,9 @@
  * --dump <file> (raw AvbdBody array after the last step), --device <n>, --batch (run all steps on the
  * device without per-step downloads; implies --quiet), --save-state <file> / --load-state <file>
  * (checkpoint after the last step / resume from a checkpoint instead of building --scene: SURVEY.md §8 f3),
- * --remove-body <creation index> --remove-at <step> (`delete body` before that step, through the host mirror).
+ * --remove-body <creation index> --remove-at <step> (`delete body` before that step, through the host mirror),
+ * --pick ox,oy,oz,dx,dy,dz (after the last step: Solver::pick along that ray; prints one `Pick:` line with the body id,
+ * creation index and body-local hit point, floats as hex so the line can be compared bit for bit).
  */
 #include "solver.h"
 #include "joint.h"
@@ -28,6 +30,7 @@ int main(int argc, char** argv)
     const char* dumpPath = nullptr;
     const char* savePath = nullptr;
     const char* loadPath = nullptr;
+    const char* pickRay = nullptr;
     int removeBody = -1, removeAt = -1;   /* --remove-body <creation index> --remove-at <step>: `delete body` mid-run */
     int steps = 300; /* main.cpp:192 */
     bool quiet = false, batch = false;
@@ -42,6 +45,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--load-state") && i + 1 < argc) loadPath = argv[++i];
         else if (!strcmp(argv[i], "--remove-body") && i + 1 < argc) removeBody = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--remove-at") && i + 1 < argc) removeAt = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--pick") && i + 1 < argc) pickRay = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) setenv("AVBD_DEVICE", argv[++i], 1);
     }
 
@@ -89,6 +93,14 @@ int main(int argc, char** argv)
         double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\"}\n", shown, steps, ms,
                steps ? ms / steps : 0.0);
+    }
+    if (pickRay) {
+        float r[6] = {0, 0, 0, 0, 0, 0};
+        sscanf(pickRay, "%f,%f,%f,%f,%f,%f", &r[0], &r[1], &r[2], &r[3], &r[4], &r[5]);
+        vec3 local(0.0f, 0.0f, 0.0f);
+        Rigid* hit = solver->pick(vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), local);
+        if (hit) printf("Pick: body id=%d index=%d local=(%a, %a, %a)\n", hit->id, hit->index, local.x, local.y, local.z);
+        else printf("Pick: none\n");
     }
     if (savePath) solver->saveSnapshot(savePath);
     if (dumpPath) {

@@ -165,7 +165,7 @@ struct Solver {
     explicit Solver(AvbdContext* borrowed);/* drives an existing context; does not destroy it */
     ~Solver();
 
-    Rigid* pick(const vec3& origin, const vec3& dir, vec3& local); /* GUI-only in the reference: returns nullptr */
+    Rigid* pick(const vec3& origin, const vec3& dir, vec3& local); /* solver.cpp:145-228 on the device (avbd_pick) */
     void clear();
     void defaultParams();
     void step();

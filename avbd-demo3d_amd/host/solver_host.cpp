@@ -286,7 +286,19 @@ Solver::~Solver()
     delete impl;
 }
 
-Rigid* Solver::pick(const vec3&, const vec3&, vec3&) { return nullptr; }
+Rigid* Solver::pick(const vec3& origin, const vec3& dir, vec3& local)      /* solver.cpp:145-228, evaluated on the device */
+{
+    flush();
+    if (hostSync) pushEditedBodies();
+    const float o[3] = {origin.x, origin.y, origin.z}, d[3] = {dir.x, dir.y, dir.z};
+    float l[3] = {0.0f, 0.0f, 0.0f};
+    int body = -1;
+    int rc = avbd_pick(ctx, 1, o, d, &body, l);
+    if (rc) fail("avbd_pick", rc);
+    if (body < 0 || body >= (int)impl->byIndex.size()) return nullptr;
+    local = vec3(l[0], l[1], l[2]);
+    return impl->byIndex[(size_t)body];
+}
 
 void Solver::clear()                                                       /* solver.cpp:230-238 */
 {

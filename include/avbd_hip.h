@@ -215,6 +215,14 @@ int  avbd_force_row_count(AvbdContext* ctx, int force_index, int* rows);
 int  avbd_force_compute_constraint(AvbdContext* ctx, int force_index, float alpha, float* C, float* fmin, float* fmax, float* lambda);
 int  avbd_force_compute_derivatives(AvbdContext* ctx, int force_index, int body, int row, float J_linear[3], float J_angular[3]);
 
+/* ---- Solver::pick (solver.cpp:145-228): for each of `nrays` rays (origin xyz, direction xyz — any non-zero length),
+ * the creation index of the nearest DYNAMIC body whose box the ray enters (ties: the newer body, as the reference's
+ * newest-first list walk resolves them) and the hit point in that body's local frame; -1 (and a zero point) for a miss
+ * or a direction shorter than 1e-3.  Evaluated on the device against the current body poses, bit-identical with the
+ * reference's slab test. ---- */
+int  avbd_pick(AvbdContext* ctx, int nrays, const float* origins /* 3*nrays */, const float* directions /* 3*nrays */,
+               int* bodies /* nrays */, float* locals /* 3*nrays */);
+
 /* ---- known-answer entry points evaluated on the device (one lane) ---- */
 int  avbd_kat_collide(AvbdContext* ctx, int npairs, const float* posA, const float* quatA, const float* sizeA,
                       const float* posB, const float* quatB, const float* sizeB, AvbdContact* out /* 4*npairs */, int* counts);

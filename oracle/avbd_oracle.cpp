@@ -469,6 +469,48 @@ void World::defaultParams()                    /* solver.cpp:240-253 */
     std::memset(&last, 0, sizeof(last));
 }
 
+/* solver.cpp:145-228 — ray pick of the nearest dynamic box.  The reference walks its body list, which is newest
+ * first (rigid.cpp:20-21), and keeps a hit only when strictly nearer, so equal distances go to the newer body. */
+int World::pick(V3 origin, V3 dir, V3& local) const
+{
+    const float epsilon = 1.0e-6f;
+    float dirLenSq = lengthSq(dir);
+    if (dirLenSq < epsilon) return -1;
+    V3 rayDir = dir / sqrtf(dirLenSq);
+    float bestT = FLT_MAX;
+    int bestBody = -1;
+    V3 bestLocal = vzero();
+    for (int i = (int)bodies.size() - 1; i >= 0; --i) {
+        const Body& b = bodies[i];
+        if (b.invMass <= 0.0f) continue;
+        Q4 invRot = conj(b.rot);
+        V3 lo = rotate(invRot, origin - b.pos);
+        V3 ld = rotate(invRot, rayDir);
+        V3 half = b.size * 0.5f;
+        float tEnter = 0.0f, tExit = FLT_MAX;
+        bool hit = true;
+        for (int axis = 0; axis < 3; ++axis) {
+            float o = comp(lo, axis), d = comp(ld, axis), lim = comp(half, axis);
+            if (fabsf(d) < epsilon) {
+                if (o < -lim || o > lim) { hit = false; break; }
+                continue;
+            }
+            float invD = 1.0f / d;
+            float t0 = (-lim - o) * invD, t1 = (lim - o) * invD;
+            if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+            tEnter = tEnter > t0 ? tEnter : t0;   /* maths.h:102 max */
+            tExit = tExit < t1 ? tExit : t1;      /* maths.h:101 min */
+            if (tEnter > tExit) { hit = false; break; }
+        }
+        if (!hit) continue;
+        float tHit = (tEnter >= 0.0f) ? tEnter : tExit;
+        if (tHit < 0.0f) continue;
+        if (tHit < bestT) { bestT = tHit; bestBody = i; bestLocal = lo + ld * tHit; }
+    }
+    if (bestBody >= 0) local = bestLocal;
+    return bestBody;
+}
+
 void World::clear()                            /* solver.cpp:230-238; Rigid::next_id is NOT reset (rigid.cpp:10) */
 {
     bodies.clear(); pool.clear(); forceList.clear(); freeSlots.clear();

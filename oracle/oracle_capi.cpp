@@ -182,6 +182,15 @@ int orc_collide(const float* posA, const float* qA, const float* sizeA, const fl
     return n;
 }
 
+int orc_pick(void* h, const float* origin, const float* dir, float* local)
+{
+    V3 l = {0.0f, 0.0f, 0.0f};
+    V3 o = {origin[0], origin[1], origin[2]}, d = {dir[0], dir[1], dir[2]};
+    int r = ((World*)h)->pick(o, d, l);
+    local[0] = l.x; local[1] = l.y; local[2] = l.z;
+    return r;
+}
+
 void orc_solve3(const float* A, const float* b, float* x)
 {
     M3 M; M.c[0] = v3p(A); M.c[1] = v3p(A + 3); M.c[2] = v3p(A + 6);

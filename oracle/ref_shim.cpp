@@ -286,6 +286,16 @@ void ref_solve6(const float* A, const float* b, float* x)
     put3(x, r.l); put3(x + 3, r.a);
 }
 
+/* Solver::pick (solver.cpp:145-228) → creation index of the picked body or -1. */
+int ref_pick(void* h, const float* origin, const float* dir, float* local)
+{
+    RefWorld* w = (RefWorld*)h;
+    vec3 l(0.0f, 0.0f, 0.0f);
+    Rigid* b = w->solver->pick(v3(origin), v3(dir), l);
+    put3(local, l);
+    return b ? indexOf(w, b) : -1;
+}
+
 /* Body-frame → world inertia (rigid.cpp:51-59) for a box body at a given orientation. */
 void ref_world_inertia(const float* size, float density, const float* q, float* I9, float* invI9)
 {

@@ -108,11 +108,50 @@ def main():
     np.savez_compressed(os.path.join(HERE, "kat_vectors.npz"), posA=pA, quatA=qA, sizeA=sA, posB=pB, quatB=qB, sizeB=sB,
                         collide_counts=counts, collide_contacts=contacts, solve6_A=np.array(As), solve6_b=np.array(bs), solve6_x=np.array(xs))
 
+    pick_vectors()
+
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("golden fixtures written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print(f"  {fn:45s} {os.path.getsize(os.path.join(HERE, fn)):>9d} B")
+
+
+def pick_rays(rng, n):
+    """Rays at the Pyramid scene: mostly aimed at the pile from outside, plus axis-parallel, inside-a-box, unnormalised,
+    degenerate and missing ones (same generator for the fixture and for live comparisons)."""
+    o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32)
+    for k in range(n):
+        target = np.array([rng.uniform(-6, 6), rng.uniform(0, 6), rng.uniform(-1, 1)])
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        origin = target + u * rng.uniform(8, 20)
+        direction = (target - origin) * rng.uniform(0.01, 30.0)
+        m = k % 10
+        if m == 0:      # axis-parallel: exercises the |d| < epsilon slab branch
+            axis = k // 10 % 3
+            direction = np.zeros(3); direction[axis] = -1.0 if origin[axis] > target[axis] else 1.0
+            origin = target.copy(); origin[axis] -= direction[axis] * 15.0
+        elif m == 1:    # starts inside the pile
+            origin = np.array([rng.uniform(-4, 4), rng.uniform(0.1, 3), rng.uniform(-0.4, 0.4)])
+        elif m == 2 and k % 20 == 2:
+            direction = direction * 1e-6    # shorter than sqrt(1e-6): no pick
+        elif m == 3 and k % 20 == 3:
+            direction = -direction          # points away
+        o[k] = origin; d[k] = direction
+    return o, d
+
+
+def pick_vectors():
+    """Solver::pick of the unmodified reference on the Pyramid scene after 60 steps (the state of snapshot_Pyramid_step60)."""
+    w = H.CpuWorld("ref")
+    w.scene("Pyramid")
+    w.step(60)
+    o, d = pick_rays(np.random.default_rng(77), 400)
+    body = np.zeros(len(o), np.int32); local = np.zeros((len(o), 3), np.float32)
+    for k in range(len(o)):
+        body[k], local[k] = w.pick(o[k], d[k])
+    np.savez_compressed(os.path.join(HERE, "pick_vectors.npz"), origins=o, directions=d, body=body, local=local)
+    return body
 
 
 def joint_scene(w):
@@ -132,4 +171,8 @@ def joint_scene(w):
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["pick"]:      # only the pick fixture (the others are unchanged by it)
+        b = pick_vectors()
+        print("pick_vectors.npz:", int((b >= 0).sum()), "hits of", len(b))
+    else:
+        main()

@@ -85,7 +85,7 @@ def load(prefix):
               "set_diag_logging", "print_step", "solve3", "solve6", "world_inertia"):
         g(n).restype = None
     for n in ("scene", "add_body", "add_joint", "add_spring", "add_ignore", "num_bodies", "num_forces",
-              "step_index", "collide"):
+              "step_index", "collide", "pick"):
         g(n).restype = C.c_int
     _libs[prefix] = lib
     return lib
@@ -136,6 +136,12 @@ class CpuWorld:
 
     def add_spring(self, a, b, rA, rB, stiffness, rest=-1.0):
         return self._c("add_spring")(self.h, a, b, _f(rA), _f(rB), C.c_float(stiffness), C.c_float(rest))
+
+    def pick(self, origin, direction):
+        """Solver::pick → (creation index or -1, local hit point)."""
+        local = np.zeros(3, np.float32)
+        b = self._c("pick")(self.h, _f(origin), _f(direction), local.ctypes.data_as(C.POINTER(C.c_float)))
+        return b, local
 
     def add_ignore(self, a, b):
         return self._c("add_ignore")(self.h, a, b)

@@ -343,3 +343,61 @@ def test_cli_delete_body_through_the_host_mirror(tmp_path):
     want = g.w.bodies()
     assert len(got) == len(want) == 55
     assert H.same_bits(got, want)
+
+
+def test_pick_ties_static_bodies_and_empty_world():
+    """avbd_pick: ties go to the newer body, static bodies and empty worlds give no pick, rays are batched."""
+    o, g = pair()
+    assert g.w.pick([(0, 5, 0)], [(0, -1, 0)])[0][0] == -1           # nothing in the world yet
+    for w in (o, g):
+        w.add_body((30, 1, 30), 0.0, 0.5, (0, -0.5, 0))
+    assert g.w.pick([(0, 5, 0)], [(0, -1, 0)])[0][0] == -1           # only a static body
+    for w in (o, g):
+        w.add_body((1, 1, 1), 1.0, 0.5, (0, 2.0, 0))
+        w.add_body((1, 1, 1), 1.0, 0.5, (0, 2.0, 0))
+        w.add_body((1, 2, 1), 1.0, 0.5, (3, 2.0, 0), (0, 0, 0.3826834, 0.9238795))
+    rays = [((0, 10, 0), (0, -1, 0)), ((0, 2.1, 0.2), (1, 0, 0)), ((10, 2, 0), (-3, 0, 0)), ((0, 10, 5), (0, -1, 0)),
+            ((-10, 2, 0), (1, 0, 0)), ((3, 9, 0), (0, -2, 0)), ((0, 2, 0), (0, 0, 0)), ((0, 2, 0), (1e-4, 0, 0))]
+    body, local = g.w.pick([r[0] for r in rays], [r[1] for r in rays])
+    for k, (ro, rd) in enumerate(rays):
+        b, l = o.pick(ro, rd)
+        assert body[k] == b, k
+        assert H.same_bits(local[k], l), k
+    assert list(body[:5]) == [2, 2, 3, -1, 2]
+
+
+def test_pick_after_stepping_a_large_pile_matches_the_oracle():
+    o, g = pair()
+    for w in (o, g):
+        w.scene("Packed:6")
+    o.step(15); g.step(15)
+    rng = np.random.default_rng(3)
+    origins = rng.uniform(-10, 10, (256, 3)).astype(np.float32) + np.float32([0, 12, 0])
+    targets = rng.uniform(-3, 3, (256, 3)).astype(np.float32) + np.float32([0, 3, 0])
+    body, local = g.w.pick(origins, targets - origins)
+    assert (body >= 0).sum() > 100
+    for k in range(256):
+        b, l = o.pick(origins[k], targets[k] - origins[k])
+        assert body[k] == b and H.same_bits(local[k], l), k
+
+
+def test_cli_pick_through_the_host_mirror():
+    """Solver::pick of the source-compatible host API: same body and bit-identical local point as the C ABI call."""
+    import subprocess
+    exe = os.path.join(H.ROOT, "avbd-demo3d_amd", "avbd_demo3d")
+    out = subprocess.run([exe, "--nogfx", "--scene", "Pyramid", "--steps", "30", "--quiet", "--pick", "0.3,20,0.1,0.01,-1,0.02"],
+                         capture_output=True, text=True, check=True).stdout
+    line = [l for l in out.splitlines() if l.startswith("Pick:")][0]
+    g = H.HipWorld(); g.scene("Pyramid"); g.step(30)
+    body, local = g.w.pick([(0.3, 20, 0.1)], [(0.01, -1, 0.02)])
+    assert body[0] >= 0
+    want = "Pick: body id=%d index=%d local=(%s, %s, %s)" % (body[0], body[0], *[float(v).hex() for v in local[0]])
+    import re
+    m = re.match(r"Pick: body id=(\d+) index=(\d+) local=\((.*), (.*), (.*)\)", line)
+    assert m, line
+    assert int(m.group(2)) == body[0]
+    got = np.float32([float.fromhex(m.group(k)) for k in (3, 4, 5)])
+    assert H.same_bits(got, local[0]), (line, want)
+    miss = subprocess.run([exe, "--nogfx", "--scene", "Pyramid", "--steps", "1", "--quiet", "--pick", "0,50,0,0,1,0"],
+                          capture_output=True, text=True, check=True).stdout
+    assert "Pick: none" in miss

@@ -84,3 +84,14 @@ def test_cli_trace_bytes():
         want = gzip.open(os.path.join(G, f"trace_{scene}_300.txt.gz"), "rb").read()
         got = subprocess.run([exe, "--nogfx", "--scene", scene, "--steps", "300"], capture_output=True, check=True).stdout
         assert got == want, scene
+
+
+def test_pick_vectors_on_device():
+    """avbd_pick (Solver::pick, solver.cpp:145-228) against the reference's answers on 400 rays, one launch."""
+    z = npz("pick_vectors.npz")
+    g = H.HipWorld()
+    g.scene("Pyramid")
+    g.step(60)
+    body, local = g.w.pick(z["origins"], z["directions"])
+    assert np.array_equal(body, z["body"])
+    assert H.same_bits(local, z["local"])

@@ -99,3 +99,16 @@ def test_collide_and_solve_kats():
         assert H.same_bits(c, z["collide_contacts"][k][:len(c)].view(H.CONTACT_DT))
     for k in range(len(z["solve6_A"])):
         assert H.same_bits(H.solve6("orc", z["solve6_A"][k], z["solve6_b"][k]), z["solve6_x"][k])
+
+
+def test_pick_vectors():
+    """Solver::pick (solver.cpp:145-228) of the restatement against the reference's answers on 400 rays."""
+    z = npz("pick_vectors.npz")
+    w = H.CpuWorld("orc")
+    w.scene("Pyramid")
+    w.step(60)
+    assert (z["body"] >= 0).sum() > 200 and (z["body"] < 0).sum() > 50
+    for k in range(len(z["body"])):
+        b, local = w.pick(z["origins"][k], z["directions"][k])
+        assert b == z["body"][k], k
+        assert H.same_bits(local, z["local"][k]), k

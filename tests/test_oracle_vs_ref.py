@@ -107,3 +107,39 @@ def test_solve_kats():
         Ia, Ja = H.world_inertia("orc", (1.0, 0.5, 2.0), 1.5, q)
         Ib, Jb = H.world_inertia("ref", (1.0, 0.5, 2.0), 1.5, q)
         assert H.same_bits(Ia, Ib) and H.same_bits(Ja, Jb)
+
+
+def test_pick_ties_inside_and_static_bodies():
+    """Solver::pick: equal hit distances go to the newer body, a ray that starts inside a box picks it at t = 0, static
+    bodies are never picked."""
+    a, b = H.CpuWorld("orc"), H.CpuWorld("ref")
+    for w in (a, b):
+        w.add_body((30, 1, 30), 0.0, 0.5, (0, -0.5, 0))
+        w.add_body((1, 1, 1), 1.0, 0.5, (0, 2.0, 0))
+        w.add_body((1, 1, 1), 1.0, 0.5, (0, 2.0, 0))          # same box again: every hit is a tie
+        w.add_body((1, 2, 1), 1.0, 0.5, (3, 2.0, 0), (0, 0, 0.3826834, 0.9238795))
+    rays = [((0, 10, 0), (0, -1, 0)), ((0, 2.1, 0.2), (1, 0, 0)), ((10, 2, 0), (-3, 0, 0)), ((0, 10, 5), (0, -1, 0)),
+            ((-10, 2, 0), (1, 0, 0)), ((3, 9, 0), (0, -2, 0)), ((0, 2, 0), (0, 0, 0)), ((0, 2, 0), (1e-4, 0, 0))]
+    seen = []
+    for o, d in rays:
+        ra, la = a.pick(o, d); rb, lb = b.pick(o, d)
+        assert ra == rb, (o, d)
+        assert H.same_bits(la, lb), (o, d)
+        seen.append(ra)
+    assert seen[0] == 2 and seen[1] == 2 and seen[2] == 3 and seen[3] == -1 and seen[4] == 2 and seen[6] == -1 and seen[7] == -1
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_pick_random_pile(seed):
+    a, b = H.CpuWorld("orc"), H.CpuWorld("ref")
+    rng = np.random.default_rng(seed)
+    for w in (a, b):
+        H.random_pile(w, np.random.default_rng(seed), 30)
+    a.step(40); b.step(40)
+    hits = 0
+    for k in range(300):
+        o = rng.uniform(-8, 8, 3) + np.array([0, 8, 0]); t = rng.uniform(-3, 3, 3) + np.array([0, 1, 0])
+        ra, la = a.pick(o, t - o); rb, lb = b.pick(o, t - o)
+        assert ra == rb and H.same_bits(la, lb), k
+        hits += ra >= 0
+    assert hits > 30
