@@ -159,6 +159,7 @@ struct AvbdContext {
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
     bool residentSpread = true;    /* AVBD_RESIDENT_SPREAD=0: slot = linear wave index */
+    bool residentOutOfOrder = false;/* AVBD_RESIDENT_OOO=0: a wave with several bodies sweeps them strictly in order */
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     int numStatic = 0;
@@ -724,6 +725,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.quietPermille = c->residentQuiet;
     X.prStride = kResStride;
     X.spread = c->residentSpread ? 1 : 0;
+    X.outOfOrder = c->residentOutOfOrder ? 1 : 0;
     const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
     const bool wholeLoop = itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded;
     const bool sharded = c->nranks > 1 || c->forceSharded;
@@ -991,6 +993,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_OOO")) c->residentOutOfOrder = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;
         if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;

@@ -131,11 +131,12 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     const float4* massPlane = B.plane(BP_MASS);
     {
         /* a plain pile of contacts: the resident schedule (avbd_resident.h).  veto bits set by the topology kernels —
-         * bit0: a swept body has > 64 contacts or a joint/spring, bit1: more swept bodies than resident waves,
-         * bit2: a swept body has > 33 contacts (too many for the short product lines of the two-workgroups-per-CU launch) */
+         * bit0: a swept body has > 64 contacts or a joint/spring, bit1: more swept bodies than resident waves
+         * (bit2, a swept body with > 33 contacts, is informational: the two-workgroups-per-CU launch multiplies the rows
+         * that do not fit its short product lines after the wait) */
         const int veto = cnt->residentBad;
         const bool lite = WPE == 2;
-        if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi) && (!lite || (veto & 4) == 0)) {
+        if (X.enabled && (veto & 1) == 0 && ((veto & 2) == 0 || X.multi)) {
             float* products = reinterpret_cast<float*>(sDynamic) + wv * 27 * X.prStride;
             const bool multi = lite || (veto & 2) || X.forceMulti;
             /* one body per wave: the four waves of a CU take slots a quarter of the sweep order apart, so that they are

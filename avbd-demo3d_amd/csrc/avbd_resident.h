@@ -61,6 +61,7 @@ struct ResidentExchange {
     int planesAlways;  /* sharded runs: other kernels of the step read the pose planes after every iteration */
     float4* send;      /* sharded runs: this rank's rows of the all-gather, filled by the wave that publishes the pose */
     const int* sendSlot; /* [bodyCap] row of a body this rank solves */
+    int outOfOrder;    /* MULTI: a wave runs whichever of its bodies has its inputs ready (oldest iteration first) instead of sweeping them in order */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -105,7 +106,7 @@ static_assert(kResJFloats + kResSFloats <= 66 * kEntryRec, "the J and S areas re
  * later rows (a body with more than 12 contacts) go through the lane's product line in LDS */
 constexpr int kResRegRows = 36;
 
-__device__ __forceinline__ void store_products(const AccLane& a, const float* J, float (&pr)[kResRegRows], float* prLine, int nRows)
+__device__ __forceinline__ void store_products(const AccLane& a, const float* J, float (&pr)[kResRegRows], float* prLine, int nRows, int lineRows)
 {
 #pragma unroll
     for (int r = 0; r < kResRegRows; ++r) pr[r] = 0.0f;
@@ -123,7 +124,8 @@ __device__ __forceinline__ void store_products(const AccLane& a, const float* J,
             }
         }
     }
-    for (int r = kResRegRows; r < nRows; ++r) {
+    const int lineEnd = nRows < kResRegRows + lineRows ? nRows : kResRegRows + lineRows;   /* rows past the line: multiplied after the wait */
+    for (int r = kResRegRows; r < lineEnd; ++r) {
         const float va = ja[r * 6], vb = jb[r * 6];
         prLine[r - kResRegRows] = rhs ? va : va * vb;
     }
@@ -132,7 +134,7 @@ __device__ __forceinline__ void store_products(const AccLane& a, const float* J,
 __device__ __forceinline__ float comp4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 template <bool ALLON, bool JOINTS>
-__device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr)[kResRegRows], const float* prLine, const float* S, int nRows)
+__device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr)[kResRegRows], const float* prLine, const float* S, int nRows, const float* J, int lineRows)
 {
     /* every lane runs the same instruction stream (idle lanes 27..63 compute a value nobody reads): no divergent branches,
      * only wave-uniform ones on the row count.  ALLON: every row is a Manifold row with a usable penalty (the normal case);
@@ -172,10 +174,25 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
             }
         }
     }
-    /* the rare tail: rows past the register window, four at a time from the LDS product line */
+    /* the rare tail: rows past the register window, four at a time from the LDS product line; rows past the end of a short
+     * line (two workgroups per CU, a body with more than 34 entries) are multiplied here, from J — same product, same bits */
     const float4* p4 = reinterpret_cast<const float4*>(prLine);
+    const float* ja = J + a.opA;
+    const float* jb = J + (rhs ? a.opA : a.opB);
     for (int r4 = kResRegRows; r4 < nRows; r4 += 4) {
-        const float4 pv = p4[(r4 - kResRegRows) >> 2], sw = s4[r4 >> 2], gw = g4[r4 >> 2];
+        float4 pv;
+        if (r4 - kResRegRows + 4 <= lineRows) pv = p4[(r4 - kResRegRows) >> 2];   /* wave-uniform */
+        else {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r4 + k < nRows ? r4 + k : r4;
+                const float va = ja[r * 6], vb = jb[r * 6];
+                t[k] = rhs ? va : va * vb;
+            }
+            pv = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        const float4 sw = s4[r4 >> 2], gw = g4[r4 >> 2];
         float4 ow = make_float4(1.f, 1.f, 1.f, 1.f), mw = ow;
         if (!ALLON) { ow = o4[r4 >> 2]; if (JOINTS) mw = m4[r4 >> 2]; }
 #pragma unroll
@@ -237,45 +254,54 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 
     /* everything a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
      * wrote (first iteration), or what this same wave parked after the body's previous task (MULTI, later iterations) */
-    auto load_task = [&](int slot, int it) {
-        body = __builtin_amdgcn_readfirstlane(order[slot]);           /* wave-uniform: scalar loads and scalar branches below */
-        eBeg = __builtin_amdgcn_readfirstlane(incStart[body]);
-        nEnt = __builtin_amdgcn_readfirstlane(incStart[body + 1]) - eBeg;
+    /* who the entries of a body are and whom they wait for: enough to tell whether a task can start */
+    auto load_header = [&](int body_, int eBeg_, int nEnt_) {
+        body = body_; eBeg = eBeg_; nEnt = nEnt_;
         has = lane < nEnt;
-        fixedN = false;
-        isJoint = false;
+        isJoint = false; moving = false; owned = false; other = 0; idx = 0; isA = false;
         if (has) {
             const int ent = inc[eBeg + lane];
             idx = inc_index(ent); isA = inc_isA(ent) != 0;
             isJoint = JOINTS && inc_kind(ent) == FK_JOINT;         /* JOINTS = false: contacts only, the joint code below is compiled out */
         }
         if (JOINTS && has && isJoint) {
-            /* one half of a Joint (joint.cpp:68-139): rows 3*part .. 3*part+2; lambda / penalty live in the GForce record, which
-             * only the owner writes during the launch (and where it parks them between its tasks) */
             const GForce& f = gf[idx >> 1];
             jPart = idx & 1;
             hasA = f.bodyA >= 0;
             other = isA ? f.bodyB : f.bodyA;
             moving = other >= 0 && B.solved[other] != 0;
             owned = !moving || other > body;
+            if (other < 0) other = 0;                                  /* world anchor: a fixed partner, never polled */
+        } else if (has) {
+            const int2 pr = M.pair[idx >> 2];
+            other = isA ? pr.y : pr.x;
+            moving = B.solved[other] != 0;
+            owned = !moving || other > body;
+        }
+        offP = other * 48; offV = idx * 16; offD = ((JOINTS && isJoint) ? X.jointRecBase + idx : idx) * 32;
+    };
+    /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this
+     * step wrote (first iteration), or what this same wave parked after the body's previous task (MULTI, later iterations) */
+    auto load_rest = [&](int it) {
+        fixedN = false;
+        if (JOINTS && has && isJoint) {
+            /* one half of a Joint (joint.cpp:68-139): rows 3*part .. 3*part+2; lambda / penalty live in the GForce record, which
+             * only the owner writes during the launch (and where it parks them between its tasks) */
+            const GForce& f = gf[idx >> 1];
             c.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); c.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
             jq0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
             for (int k = 0; k < 3; ++k) { c.lambda[k] = f.lambda[jPart * 3 + k]; c.penalty[k] = f.penalty[jPart * 3 + k]; c.C[k] = f.C[jPart * 3 + k]; }
             jStiff = mk3(f.stiffness[jPart * 3], f.stiffness[jPart * 3 + 1], f.stiffness[jPart * 3 + 2]);
             jMotor = mk3(f.motor[jPart * 3], f.motor[jPart * 3 + 1], f.motor[jPart * 3 + 2]);
             opos = zero3(); orot = identq();
-            if (other >= 0) {
+            if (isA || hasA) {
                 const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];
                 opos = mk3(op.x, op.y, op.z); orot = mkq(oq.x, oq.y, oq.z, oq.w);
-            } else other = 0;                                          /* world anchor: a fixed partner, never polled */
+            }
         } else if (has) {
             const int m = idx >> 2;
-            const int2 pr = M.pair[m];
-            other = isA ? pr.y : pr.x;
             oinv = massPlane[other].y;
             fric = M.fric[m];
-            moving = B.solved[other] != 0;
-            owned = !moving || other > body;
             load_contact<false>(M, idx, c);                           /* owned contacts: also what this wave's last dual left there */
             if (MULTI && it > 0 && !owned) {                          /* this visitor's own copy of the normal and its memo */
                 const float4 pn = X.privN[(size_t)(eBeg + lane) * 3], p1 = X.privN[(size_t)(eBeg + lane) * 3 + 1], p2 = X.privN[(size_t)(eBeg + lane) * 3 + 2];
@@ -299,7 +325,12 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         const float4 j0 = B.plane(BP_J0)[body], j1 = B.plane(BP_J1)[body], j2 = B.plane(BP_J2)[body];
         Ib = mkm(mk3(i0.x, i0.y, i0.z), mk3(i1.x, i1.y, i1.z), mk3(i2.x, i2.y, i2.z));
         Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
-        offP = other * 48; offV = idx * 16; offD = ((JOINTS && isJoint) ? X.jointRecBase + idx : idx) * 32;
+    };
+    auto load_task = [&](int slot, int it) {
+        const int b = __builtin_amdgcn_readfirstlane(order[slot]);    /* wave-uniform: scalar loads and scalar branches below */
+        const int e0 = __builtin_amdgcn_readfirstlane(incStart[b]);
+        load_header(b, e0, __builtin_amdgcn_readfirstlane(incStart[b + 1]) - e0);
+        load_rest(it);
     };
     /* MULTI: park the body's state until its next task; the last task leaves the step's final state (rows included) */
     auto save_task = [&](bool last) {
@@ -327,17 +358,21 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = t0;
 #define RS_STAMP(i) do { unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)
+#define RS_STAMP_DRAINED(i) do { __builtin_amdgcn_s_waitcnt(0); RS_STAMP(i); } while (0)   /* after the loads / stores issued so far have completed */
 #else
 #define RS_STAMP(i) do { } while (0)
+#define RS_STAMP_DRAINED(i) do { } while (0)
 #endif
 
     /* [itBegin, itEnd): the whole loop on one GPU; one iteration per launch when poses are exchanged between GPUs after every
      * iteration (MULTI only: the parked state and the stamped records carry over from launch to launch) */
-    for (int it = (MULTI ? itBegin : 0); it < (MULTI && itEnd < totalIt ? itEnd : totalIt); ++it) {
-      for (int slot = w; slot < nd; slot += W) {                       /* MULTI = false: exactly one slot (the caller checks w < nd) */
-        if (MULTI || it == 0) load_task(slot, it);
+    const int itFirst = MULTI ? itBegin : 0, itStop = (MULTI && itEnd < totalIt) ? itEnd : totalIt;
+
+    /* one task: the visit of `body` (already loaded) in iteration `it`; false = the launch is being abandoned */
+    auto run_task = [&](int it) __attribute__((always_inline)) -> bool {
 #ifdef AVBD_DF_STATS
-        unsigned* trec = reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)it * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8;
+        unsigned trecDummy[8];                                      /* per-task time stamps are kept for one body per wave only */
+        unsigned* trec = MULTI ? trecDummy : reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)it * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8;
         if (lane == 0) { trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[5] = (unsigned)body; }
 #endif
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
@@ -391,7 +426,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         }
         wave_sync();
         float pr[kResRegRows];
-        store_products(a, J, pr, prLine, nEnt * 3);
+        store_products(a, J, pr, prLine, nEnt * 3, X.prStride);
         RS_STAMP(7);
 #ifdef AVBD_DF_STATS
         if (lane == 0) trec[1] = (unsigned)tprev;
@@ -428,7 +463,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if ((++spins & 1023u) == 0) {
                     bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
                                 __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                    if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
                 }
             }
             RS_STAMP(0);
@@ -496,7 +531,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         const bool allOn = __all(rowsOn);
         wave_sync();
         RS_STAMP(1);
-        if (allOn) accumulate_products<true, JOINTS>(a, pr, prLine, S, nEnt * 3); else accumulate_products<false, JOINTS>(a, pr, prLine, S, nEnt * 3);
+        if (allOn) accumulate_products<true, JOINTS>(a, pr, prLine, S, nEnt * 3, J, X.prStride); else accumulate_products<false, JOINTS>(a, pr, prLine, S, nEnt * 3, J, X.prStride);
         if (lane < 27) accs[lane] = a.acc;
         wave_sync();
         RS_STAMP(2);
@@ -562,9 +597,94 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         if (lane == 0) trec[4] = (unsigned)tprev;
         stat[5] += 1;
 #endif
-        if (MULTI) save_task(it == totalIt - 1);
-        else break;
-      }
+        return true;
+    };
+
+    if constexpr (!MULTI) {
+        /* one body for the whole launch (the caller checks w < nd) */
+        load_task(w, 0);
+        for (int it = itFirst; it < itStop; ++it)
+            if (!run_task(it)) return;
+    } else {
+        /* Several bodies per wave.  In order: t = it * slots + slot, a linear extension of the dependency order.  Out of order
+         * (X.outOfOrder): the wave runs whichever of its bodies has its inputs published — the dependencies between tasks are
+         * carried by the stamped records alone, so any order that respects them gives the same bits — oldest iteration first,
+         * so the head of the in-order list (which is what the rest of the launch may be waiting for) is never passed over
+         * once it is ready.  Lane k keeps the bookkeeping of the wave's k-th body: its next iteration and ONE record to watch
+         * (the input that was missing when the body was last examined); a body is examined in full only when that record
+         * has arrived. */
+        const int K = w < nd ? (nd - w + W - 1) / W : 0;
+        if (!X.outOfOrder || K < 2) {
+            for (int it = itFirst; it < itStop; ++it)
+                for (int slot = w; slot < nd; slot += W) {
+                    load_task(slot, it);
+                    RS_STAMP_DRAINED(10);
+                    if (!run_task(it)) return;
+                    save_task(it == totalIt - 1);
+                    RS_STAMP_DRAINED(11);
+                }
+        } else {
+            int bodyK = 0, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
+            unsigned blkStamp = 0;
+            if (lane < K) {
+                bodyK = order[w + lane * W];
+                eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK;
+                itK = itFirst;
+            }
+            int itLow = itFirst;                                        /* no unfinished body of this wave is at an earlier iteration */
+            unsigned idle = 0;
+            for (;;) {
+                const bool active = itK < itStop;
+                if (__ballot(active) == 0) break;
+                while (__ballot(active && itK == itLow) == 0) ++itLow;
+                bool ok = active;
+                if (active && blkOff >= 0) { const v4u r = xld(rP, blkOff); ok = stamp_reached(r.w, blkStamp); }
+                int it = -1;
+                unsigned long long cand = __ballot(ok);
+                while (cand) {
+                    int t = itLow;
+                    unsigned long long m;
+                    while ((m = __ballot(ok && itK == t)) == 0) ++t;
+                    const int k = __ffsll((long long)m) - 1;
+                    load_header(__builtin_amdgcn_readlane(bodyK, k), __builtin_amdgcn_readlane(eBegK, k), __builtin_amdgcn_readlane(nEntK, k));
+                    /* every moving partner's pose of the iteration this visit reads: published?  (The visit / dual records of the
+                     * same producer task follow its pose within the task; run_task waits for those.) */
+                    unsigned need = 0; bool wants = false;
+                    if (has && moving) {
+                        if (owned) { wants = true; need = X.base + (unsigned)t + 1u; }
+                        else if (t > 0) { wants = true; need = X.base + (unsigned)t; }
+                    }
+                    bool got = true;
+                    if (wants) { const v4u r = xld(rP, offP + 32); got = stamp_reached(r.w, need); }
+                    const unsigned long long missing = __ballot(!got);
+                    if (missing == 0) {
+                        if (lane == k) { ++itK; ++blkStamp; }              /* the same partner is the likeliest to be late again */
+                        it = t;
+                        break;
+                    }
+                    const int f = __ffsll((long long)missing) - 1;
+                    const int bo = __builtin_amdgcn_readlane(offP + 32, f);
+                    const unsigned bs = (unsigned)__builtin_amdgcn_readlane((int)need, f);
+                    if (lane == k) { blkOff = bo; blkStamp = bs; ok = false; }
+                    cand = __ballot(ok);
+                }
+                if (it < 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((++idle & 1023u) == 0) {
+                        bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+                                    __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                    }
+                    continue;
+                }
+                RS_STAMP(9);
+                load_rest(it);
+                RS_STAMP_DRAINED(10);
+                if (!run_task(it)) return;
+                save_task(it == totalIt - 1);
+                RS_STAMP_DRAINED(11);
+            }
+        }
     }
 #ifdef AVBD_DF_STATS
     if (lane == 0) {

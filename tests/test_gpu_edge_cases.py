@@ -401,3 +401,31 @@ def test_cli_pick_through_the_host_mirror():
     miss = subprocess.run([exe, "--nogfx", "--scene", "Pyramid", "--steps", "1", "--quiet", "--pick", "0,50,0,0,1,0"],
                           capture_output=True, text=True, check=True).stdout
     assert "Pick: none" in miss
+
+
+@pytest.mark.parametrize("ooo", ["0", "1"])
+def test_two_workgroups_per_cu_with_a_body_of_more_than_34_entries(monkeypatch, ooo):
+    """The launch with two workgroups per CU keeps short product lines (rows 36..103); a body with more entries than that
+    (a dynamic plate carrying 3 x 4 cubes: ~52 contacts) multiplies its last rows after the wait.  Few resident waves
+    (AVBD_ITER_BLOCKS=2: 16 waves for 29 swept bodies) so that every wave owns several bodies, swept in order or out of order."""
+    monkeypatch.setenv("AVBD_RESIDENT_FORCE_LITE", "1")
+    monkeypatch.setenv("AVBD_ITER_BLOCKS", "2")
+    monkeypatch.setenv("AVBD_RESIDENT_OOO", ooo)
+    o, g = pair()
+    for w in (o, g):
+        w.add_body((40, 1, 40), 0.0, 0.5, (0, -0.5, 0))
+        w.add_body((6, 0.5, 8), 0.5, 0.6, (0, 0.27, 0))
+        for i in range(3):
+            for j in range(4):
+                w.add_body((1, 1, 1), 1.0, 0.5, ((i - 1) * 1.4, 1.04, (j - 1.5) * 1.4))
+        for i in range(4):
+            for j in range(4):
+                w.add_body((1, 1, 1), 1.0, 0.5, (8 + i * 1.1, 0.52 + 1.03 * j, 0))
+        w.set_params(iterations=7)
+    for s in range(30):
+        o.step(); g.step()
+        H.assert_same_world(o, g, f"plate under the short product lines, step {s + 1}")
+    assert int(g.w.stats()["schedule"]) == 3
+    f = o.forces()
+    plate = sum(int(r["numContacts"]) for r in f if 1 in (int(r["bodyA"]), int(r["bodyB"])))
+    assert 34 < plate <= 64, plate
