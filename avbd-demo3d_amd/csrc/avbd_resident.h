@@ -62,6 +62,7 @@ struct ResidentExchange {
     float4* send;      /* sharded runs: this rank's rows of the all-gather, filled by the wave that publishes the pose */
     const int* sendSlot; /* [bodyCap] row of a body this rank solves */
     int outOfOrder;    /* MULTI: a wave runs whichever of its bodies has its inputs ready (oldest iteration first) instead of sweeping them in order */
+    int* probe;        /* [incidence capacity] out of order: who an entry waits for (partner | moving << 24 | owned << 25 | hasA << 26), kept from a body's first examination */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -255,16 +256,21 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     /* everything a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
      * wrote (first iteration), or what this same wave parked after the body's previous task (MULTI, later iterations) */
     /* who the entries of a body are and whom they wait for: enough to tell whether a task can start */
-    auto load_header = [&](int body_, int eBeg_, int nEnt_) {
+    auto load_header = [&](int body_, int eBeg_, int nEnt_, bool parked) {
         body = body_; eBeg = eBeg_; nEnt = nEnt_;
         has = lane < nEnt;
         isJoint = false; moving = false; owned = false; other = 0; idx = 0; isA = false;
+        int pw = 0;
         if (has) {
             const int ent = inc[eBeg + lane];
+            if (MULTI && parked) pw = X.probe[eBeg + lane];
             idx = inc_index(ent); isA = inc_isA(ent) != 0;
             isJoint = JOINTS && inc_kind(ent) == FK_JOINT;         /* JOINTS = false: contacts only, the joint code below is compiled out */
         }
-        if (JOINTS && has && isJoint) {
+        if (MULTI && parked) {                                     /* wave-uniform: the body has been examined before */
+            other = pw & 0xffffff; moving = (pw >> 24) & 1; owned = (pw >> 25) & 1;
+            if (JOINTS) { hasA = (pw >> 26) & 1; jPart = idx & 1; }
+        } else if (JOINTS && has && isJoint) {
             const GForce& f = gf[idx >> 1];
             jPart = idx & 1;
             hasA = f.bodyA >= 0;
@@ -278,6 +284,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             moving = B.solved[other] != 0;
             owned = !moving || other > body;
         }
+        if (MULTI && !parked && X.outOfOrder && has) X.probe[eBeg + lane] = other | ((moving ? 1 : 0) << 24) | ((owned ? 1 : 0) << 25) | ((hasA ? 1 : 0) << 26);
         offP = other * 48; offV = idx * 16; offD = ((JOINTS && isJoint) ? X.jointRecBase + idx : idx) * 32;
     };
     /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this
@@ -329,7 +336,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     auto load_task = [&](int slot, int it) {
         const int b = __builtin_amdgcn_readfirstlane(order[slot]);    /* wave-uniform: scalar loads and scalar branches below */
         const int e0 = __builtin_amdgcn_readfirstlane(incStart[b]);
-        load_header(b, e0, __builtin_amdgcn_readfirstlane(incStart[b + 1]) - e0);
+        load_header(b, e0, __builtin_amdgcn_readfirstlane(incStart[b + 1]) - e0, false);
         load_rest(it);
     };
     /* MULTI: park the body's state until its next task; the last task leaves the step's final state (rows included) */
@@ -624,7 +631,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     RS_STAMP_DRAINED(11);
                 }
         } else {
-            int bodyK = 0, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
+            int bodyK = 0, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1, seenK = 0;
             unsigned blkStamp = 0;
             if (lane < K) {
                 bodyK = order[w + lane * W];
@@ -646,7 +653,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     unsigned long long m;
                     while ((m = __ballot(ok && itK == t)) == 0) ++t;
                     const int k = __ffsll((long long)m) - 1;
-                    load_header(__builtin_amdgcn_readlane(bodyK, k), __builtin_amdgcn_readlane(eBegK, k), __builtin_amdgcn_readlane(nEntK, k));
+                    load_header(__builtin_amdgcn_readlane(bodyK, k), __builtin_amdgcn_readlane(eBegK, k), __builtin_amdgcn_readlane(nEntK, k), __builtin_amdgcn_readlane(seenK, k) != 0);
+                    if (lane == k) seenK = 1;
                     /* every moving partner's pose of the iteration this visit reads: published?  (The visit / dual records of the
                      * same producer task follow its pose within the task; run_task waits for those.) */
                     unsigned need = 0; bool wants = false;
