@@ -1,15 +1,16 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one build (run ON the MI355X box, from the repo root):
-#   bash profiles/collect.sh <tag>          e.g. r1_dataflow_v2
+#   bash profiles/collect.sh <tag> [bench.py scene arguments]     e.g. r1_resident      or      r1_8k --scene StressN:20
 # Three separate passes (kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), each with the program directly
 # after "--" (no shell hop), then profiles/summarise.py reduces them to the small files that are committed.
 set -u
 TAG=${1:-r1}
+shift
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 100 --warmup 10 --no-cpu > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 20 --warmup 5 --no-cpu > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 bench.py --steps 20 --warmup 5 --no-cpu > "$OUT/bench_write.json" 2> "$OUT/write.err"
-python3 bench.py --steps 200 --warmup 20 > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 100 --warmup 10 --no-cpu "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 20 --warmup 5 --no-cpu "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 bench.py --steps 20 --warmup 5 --no-cpu "$@" > "$OUT/bench_write.json" 2> "$OUT/write.err"
+python3 bench.py --steps 200 --warmup 20 "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 profiles/summarise.py "$OUT" "$TAG"
