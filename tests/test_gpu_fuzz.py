@@ -92,3 +92,22 @@ def test_jointed_scene_with_several_bodies_per_wave():
             o.step(); g.step()
             H.assert_same_world_fast(o, g, f"seed {seed} step {s + 1}", check_rows=True)
         assert int(g.w.stats()["schedule"]) == 3
+
+
+@pytest.mark.parametrize("lite", ["0", "1"])
+def test_random_jointed_scenes_out_of_order_sweep(monkeypatch, lite):
+    """Few resident waves (AVBD_ITER_BLOCKS=1: 4 or 8 waves) so that a wave owns up to 40 bodies, swept out of order
+    (AVBD_RESIDENT_OOO=1: whichever body has its inputs published, oldest iteration first), with one or two workgroups per CU.
+    The order of execution changes, the data flow does not: every step bit for bit."""
+    monkeypatch.setenv("AVBD_ITER_BLOCKS", "1")
+    monkeypatch.setenv("AVBD_RESIDENT_OOO", "1")
+    monkeypatch.setenv("AVBD_RESIDENT_FORCE_LITE", lite)
+    monkeypatch.setenv("AVBD_RESIDENT_LITE_FROM", "0")
+    for seed in range(400, 412):
+        o, g = H.CpuWorld("orc"), H.HipWorld()
+        for w in (o, g):
+            build_jointed(w, seed)
+        for s in range(14):
+            o.step(); g.step()
+            H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
+        assert int(g.w.stats()["schedule"]) == 3
