@@ -4,7 +4,8 @@
  * code (iterate_resident<MULTI, JOINTS>):
  *   - up to 1024 swept bodies: every body gets ONE wavefront for the whole launch (all iterations), state in registers;
  *   - more bodies: every wave takes every W-th body of the sweep order and parks a body's state between its tasks
- *     (two workgroups per CU, 2048 waves, when every body has at most 33 contacts);
+ *     (two workgroups per CU, 2048 waves, from 1024 swept bodies; in order, or — from 16 bodies per wave — whichever body
+ *     has its inputs published, see X.outOfOrder);
  *   - sharded runs: one launch per iteration; state is parked between the launches the same way.
  * The description below is written for the first form.
  *
@@ -97,8 +98,8 @@ __device__ __forceinline__ void replay_normal(ContactRows& c, bool& fixedN)
 constexpr int kResRows = 192, kResStride = 160;      /* a product line holds rows 36..191 (the first 36 live in registers) */
 constexpr int kResJFloats = kResRows * 6, kResSFloats = 8 * kResRows;   /* slot 6: zeros (what off-diagonal entries add), slot 7: Manifold row? */
 constexpr int kResProductBytesPerWave = 27 * kResStride * 4;
-/* two workgroups per CU (k_iterate<2>): product lines only for rows 36..99, i.e. bodies with at most 33 contacts
- * (4 x 7 344 B + 45 KB of row staging = 75 KB per workgroup) */
+/* two workgroups per CU (k_iterate<2>): short product lines, rows 36..103 (4 x 7 344 B + 45 KB of row staging = 75 KB per
+ * workgroup); a body with more than kResLiteMaxEntries entries multiplies its last rows after the wait (accumulate_products) */
 constexpr int kResStrideLite = 68, kResLiteMaxEntries = 33;
 constexpr int kResProductBytesPerWaveLite = 27 * kResStrideLite * 4;
 static_assert(kResJFloats + kResSFloats <= 66 * kEntryRec, "the J and S areas reuse the row staging area of k_iterate");
