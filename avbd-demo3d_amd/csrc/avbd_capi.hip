@@ -159,6 +159,7 @@ struct AvbdContext {
     bool orderByIndex = true;      /* data-flow schedules sweep in descending creation index; AVBD_ORDER=levels: dependency levels (always in AVBD_MODE=levels) */
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
+    int frontPairsPerWave = 8;      /* AVBD_FRONT_PPW: persistent manifolds re-collided per wavefront of k_front_small */
     bool residentSpread = true;    /* AVBD_RESIDENT_SPREAD=0: slot = linear wave index */
     int residentOutOfOrder = -1;    /* AVBD_RESIDENT_OOO=0/1: a wave with several bodies sweeps them strictly in order / takes whichever is ready; default: by size */
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
@@ -643,10 +644,11 @@ int step_begin(AvbdContext* c)
         SpanGuard g(c, F_NARROW);
         ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
         const int slices = (n + 31) / 32;
-        const int persistBlocks = std::max(1, std::min(4096, (c->stats.numManifolds + c->stats.numCandidates + n + 31) / 32));
+        const int ppw = c->frontPairsPerWave;
+        const int persistBlocks = std::max(1, std::min(16384, (c->stats.numManifolds + c->stats.numCandidates + n + ppw - 1) / ppw));
         const int broadBlocks = (int)(((long long)n * slices + 31) / 32);
         hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(32), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
-                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices);
+                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices, ppw);
         c->cur ^= 1;
     } else {
     {
@@ -1000,6 +1002,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_FRONT_PPW")) c->frontPairsPerWave = std::min(32, std::max(1, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT_OOO")) c->residentOutOfOrder = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;

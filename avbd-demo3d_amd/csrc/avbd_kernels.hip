@@ -370,7 +370,7 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 constexpr int kFrontHits = 1024;   /* 32 threads x 32 pairs: a workgroup can never find more */
 __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
                                                       const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
-                                                      int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
+                                                      int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices, int ppw)
 {
     ManifoldInit miPriv;             /* statically indexed after unrolling: registers; the dynamically indexed state is in sOld */
     __shared__ ManifoldOld sOld[32];
@@ -382,7 +382,9 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
 #endif
         const int nOld = cnt->numManifolds;
-        for (int item = blockIdx.x * 32 + threadIdx.x; item < nOld; item += persistBlocks * 32)
+        /* ppw pairs per wavefront: the pairs of a wave take different paths through the SAT (face A / face B / edge, 1-4 contacts),
+         * and there are more SIMDs than pairs to give each wave few of them */
+        for (int item = blockIdx.x * ppw + threadIdx.x; (int)threadIdx.x < ppw && item < nOld; item += persistBlocks * ppw)
             narrow_pair(B, src, dst, item, 0, 0, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P
 #ifdef AVBD_DF_STATS
                         , dbg
