@@ -296,10 +296,11 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
 #ifdef AVBD_DF_STATS
     if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A.pos.x == 12345.0f);
 #endif
-    if (!manifold_initialize(mi, old, A, fa, Bp, fb)) return;
+    const bool alive = manifold_initialize(mi, old, A, fa, Bp, fb);
 #ifdef AVBD_DF_STATS
-    if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+    if (dbg) { dbg[2] = __builtin_amdgcn_s_memrealtime(); if (!alive) dbg[3] = dbg[2]; }
 #endif
+    if (!alive) return;
 
     /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
     const int rows = mi.numContacts * 3;
