@@ -64,7 +64,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick",
+    "avbd_group_step", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings",
 ]
 
 
@@ -233,6 +233,17 @@ class World:
 
     def remove_force(self, list_index):
         self._chk(self.L.avbd_remove_force(self.h, int(list_index)))
+
+    WARNING_LABELS = ("linear velocity", "angular velocity", "predicted position", "predicted orientation", "position", "orientation")
+
+    def warnings(self, capacity=128):
+        """Non-finite resets of the last step in the reference's print order -> (count, [(body, kind, (x, y, z)), ...])."""
+        dt = np.dtype([("body", "<i4"), ("kind", "<i4"), ("value", "<f4", 3)])
+        buf = np.zeros(capacity, dt)
+        n = self.L.avbd_get_warnings(self.h, buf.ctypes.data_as(C.c_void_p), capacity)
+        if n < 0:
+            self._chk(n)
+        return n, [(int(r["body"]), int(r["kind"]), tuple(float(x) for x in r["value"])) for r in buf[:min(n, capacity)]]
 
     def pick(self, origins, directions):
         """Solver::pick (solver.cpp:145-228) for a batch of rays → (body indices, -1 = miss; local hit points)."""

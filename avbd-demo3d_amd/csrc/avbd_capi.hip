@@ -817,7 +817,7 @@ int step_iterate_levels(AvbdContext* c)
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
             hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
-                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p);
+                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p, it);
             ++c->prof.launches_primal; ++c->prof.launches_total;
         }
         if (it < P.iterations) {
@@ -977,7 +977,9 @@ int avbd_create(int device, AvbdContext** out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_createError = "hipStreamCreate failed"; delete c; return AVBD_E_HIP; }
     if (hipHostMalloc((void**)&c->hRb, sizeof(Readback), hipHostMallocDefault) != hipSuccess) { delete c; return AVBD_E_HIP; }
     std::memset(c->hRb, 0, sizeof(Readback));
-    if (c->dCnt.alloc(1) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    /* the Counters word, then the warning log of the step (kWarnCap records of 32 B) */
+    static_assert(sizeof(WarnRec) == 32 && sizeof(Counters) == 64, "warning log layout");
+    if (c->dCnt.alloc(1 + kWarnCap * sizeof(WarnRec) / sizeof(Counters)) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
     (void)hipMemset(c->dCnt.p, 0, sizeof(Counters));
     (void)hipMemset(c->dDiag.p, 0, sizeof(DiagAccum));
     (void)hipMemset(c->dNext.p, 0, sizeof(int));
@@ -1363,6 +1365,23 @@ int avbd_get_diagnostics(AvbdContext* c, AvbdDiagnostics* out)
     out->maxLinearSpeed = f(d.maxLinearSpeed); out->maxAngularSpeed = f(d.maxAngularSpeed); out->maxNormalImpulse = f(d.maxNormalImpulse);
     out->activeContacts = d.activeContacts; out->activeManifolds = d.activeManifolds; out->dynamicBodies = d.dynamicBodies;
     return AVBD_OK;
+}
+
+int avbd_get_warnings(AvbdContext* c, AvbdWarning* out, int capacity)
+{
+    if (!c || capacity < 0 || (capacity && !out)) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Counters cnt;
+    HIPCHK(c, hipMemcpy(&cnt, c->dCnt.p, sizeof(Counters), hipMemcpyDeviceToHost));
+    const int have = std::min(cnt.warnings, kWarnCap);
+    if (have <= 0) return 0;
+    std::vector<WarnRec> log((size_t)have);
+    HIPCHK(c, hipMemcpy(log.data(), c->dCnt.p + 1, sizeof(WarnRec) * (size_t)have, hipMemcpyDeviceToHost));
+    std::sort(log.begin(), log.end(), [](const WarnRec& a, const WarnRec& b) { return a.key < b.key; });
+    const int n = std::min(have, capacity);
+    for (int i = 0; i < n; ++i) { out[i].body = log[(size_t)i].body; out[i].kind = log[(size_t)i].kind; out[i].value[0] = log[(size_t)i].x; out[i].value[1] = log[(size_t)i].y; out[i].value[2] = log[(size_t)i].z; }
+    return cnt.warnings;
 }
 
 int avbd_get_step_stats(AvbdContext* c, AvbdStepStats* out)

@@ -272,8 +272,8 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
             f3 p; q4 q;
             solve_pose(accs, accs + 32, lane, L, p, q);
             if (lane == 0) {
-                sanitize3(p, cntW);
-                sanitizeq(q, cntW);
+                sanitize3(p, cntW, warn_key(1, it, body, 0), body, WK_POS);
+                sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);
                 st4<true>(B.plane(BP_POSR) + body, pack3(p, smp.w));
                 st4<true>(B.plane(BP_QUAT) + body, packq(q));
                 if (X.send) { const int k = X.sendSlot[body]; X.send[2 * k] = pack3(p, smp.w); X.send[2 * k + 1] = packq(q); }   /* this rank's all-gather rows */
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
             f3 p; q4 q;
             solve_pose(accs, accs + 32, lane, L, p, q);
             if (lane == 0) {
-                sanitize3(p, cntW);
-                sanitizeq(q, cntW);
+                sanitize3(p, cntW, warn_key(1, it, body, 0), body, WK_POS);
+                sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);
                 st4<true>(B.plane(BP_POSR) + body, pack3(p, smp.w));
                 st4<true>(B.plane(BP_QUAT) + body, packq(q));
                 if (X.send) { const int k = X.sendSlot[body]; X.send[2 * k] = pack3(p, smp.w); X.send[2 * k + 1] = packq(q); }   /* this rank's all-gather rows */

@@ -679,8 +679,17 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
 /* ------------------------------------------------------------------------------------------
  * K4 predict — solver.cpp:299-337
  * ------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ void sanitize3(f3& v, Counters* cnt) { if (!finite3(v)) { atomicAdd(&cnt->warnings, 1); v = zero3(); } }
-__device__ __forceinline__ void sanitizeq(q4& q, Counters* cnt) { if (!finiteq(q)) { atomicAdd(&cnt->warnings, 1); q = identq(); } }
+__device__ __noinline__ void warn_log(Counters* cnt, unsigned key, int body, int kind, float x, float y, float z)
+{
+    const int i = atomicAdd(&cnt->warnings, 1);
+    if (i < kWarnCap) {
+        WarnRec r; r.key = key; r.body = body; r.x = x; r.y = y; r.z = z; r.kind = kind; r.pad0 = 0; r.pad1 = 0;
+        reinterpret_cast<WarnRec*>(cnt + 1)[i] = r;
+    }
+}
+/* solver.cpp:51-66: reset to zero / identity; the warning text is printed by the host from the log */
+__device__ __forceinline__ void sanitize3(f3& v, Counters* cnt, unsigned key, int body, int kind) { if (!finite3(v)) { warn_log(cnt, key, body, kind, v.x, v.y, v.z); v = zero3(); } }
+__device__ __forceinline__ void sanitizeq(q4& q, Counters* cnt, unsigned key, int body, int kind) { if (!finiteq(q)) { warn_log(cnt, key, body, kind, q.x, q.y, q.z); q = identq(); } }
 
 __device__ __forceinline__ void predict_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt)
 {
@@ -701,8 +710,8 @@ __device__ __forceinline__ void predict_body(const BodyTable& B, int i, const So
         atomicAdd(&cnt->dynamicBodies, 1);
         f3 v = ld3(B.plane(BP_LINV), i);
         f3 vprev = ld3(B.plane(BP_PLIN), i);
-        sanitize3(v, cnt);
-        sanitize3(w, cnt);
+        sanitize3(v, cnt, warn_key(0, 0, i, 0), i, WK_LINVEL);
+        sanitize3(w, cnt, warn_key(0, 0, i, 1), i, WK_ANGVEL);
         const float dt = P.dt;
         const f3 g = mk3(P.gx, P.gy, P.gz);
         npos = pos + v * dt + g * (dt * dt);
@@ -718,8 +727,8 @@ __device__ __forceinline__ void predict_body(const BodyTable& B, int i, const So
         }
         pos = pos + (v * dt + g * (aw * dt * dt));
         rot = nrot;
-        sanitize3(pos, cnt);
-        sanitizeq(rot, cnt);
+        sanitize3(pos, cnt, warn_key(0, 0, i, 2), i, WK_PRED_POS);
+        sanitizeq(rot, cnt, warn_key(0, 0, i, 3), i, WK_PRED_ROT);
         B.plane(BP_LINV)[i] = pack3(v, 0.f);
     }
     B.plane(BP_ANGV)[i] = pack3(w, 0.f);
@@ -1073,8 +1082,8 @@ __device__ __forceinline__ void velocity_body(const BodyTable& B, int i, const S
     w = av;
     v = v * linearDamping;
     w = w * angularDamping;
-    sanitize3(v, cnt);
-    sanitize3(w, cnt);
+    sanitize3(v, cnt, warn_key(2, 0, i, 0), i, WK_LINVEL);
+    sanitize3(w, cnt, warn_key(2, 0, i, 1), i, WK_ANGVEL);
     B.plane(BP_LINV)[i] = pack3(v, 0.f);
     B.plane(BP_ANGV)[i] = pack3(w, 0.f);
     speedLin = len3(v);                                              /* solver.cpp:472-497: maxima over the dynamic bodies */

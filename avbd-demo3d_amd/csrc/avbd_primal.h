@@ -600,7 +600,7 @@ constexpr int kWavesPerBlock = 4;
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                                  const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
-                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt)
+                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt, int it)
 {
     __shared__ float sRows[kWavesPerBlock][66 * kEntryRec];
     __shared__ float sAcc[kWavesPerBlock][64];
@@ -628,8 +628,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, Man
     f3 p; q4 q;
     solve_pose(accs, accs + 32, lane, L, p, q);
     if (lane == 0) {
-        sanitize3(p, cnt);                                            /* solver.cpp:407-408 */
-        sanitizeq(q, cnt);
+        sanitize3(p, cnt, warn_key(1, it, body, 0), body, WK_POS);     /* solver.cpp:407-408 */
+        sanitizeq(q, cnt, warn_key(1, it, body, 1), body, WK_ROT);
         float4 pr = B.plane(BP_POSR)[body];
         B.plane(BP_POSR)[body] = pack3(p, pr.w);
         B.plane(BP_QUAT)[body] = packq(q);

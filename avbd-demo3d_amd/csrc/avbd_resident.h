@@ -546,8 +546,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         f3 p; q4 q;
         solve_pose(accs, accs + 32, lane, L, p, q);
         if (lane == 0) {
-            sanitize3(p, cntW);
-            sanitizeq(q, cntW);
+            sanitize3(p, cntW, warn_key(1, it, body, 0), body, WK_POS);
+            sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);
             const int o = body * 48;
             v4u r0 = {fbits(p.x), fbits(p.y), fbits(p.z), stampNow}, r1 = {fbits(q.x), fbits(q.y), fbits(q.z), stampNow}, r2 = {fbits(q.w), 0u, 0u, stampNow};
 #ifdef AVBD_DF_STATS

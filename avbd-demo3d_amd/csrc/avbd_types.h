@@ -88,6 +88,18 @@ struct Counters {
     int pad[6];
 };
 
+/* What the reference prints when it resets a non-finite quantity (solver.cpp:51-66), kept for the host to print after the
+ * step: the first kWarnCap hits of a step, right behind the Counters word they are counted in.  `key` orders them the way
+ * the reference's sequential loops would have printed them: phase (predict / iteration sweep / velocity update), iteration,
+ * position in the body list (newest first), statement. */
+struct WarnRec { unsigned key; int body; float x, y, z; int kind; int pad0, pad1; };
+constexpr int kWarnCap = 128;
+enum WarnKind : int { WK_LINVEL = 0, WK_ANGVEL, WK_PRED_POS, WK_PRED_ROT, WK_POS, WK_ROT };
+__host__ __device__ inline unsigned warn_key(int phase, int it, int body, int sub)
+{
+    return ((unsigned)phase << 28) | ((unsigned)(it & 63) << 22) | ((0xFFFFFu - (unsigned)body) << 2) | (unsigned)sub;
+}
+
 struct DiagAccum { /* uint views of non-negative floats so atomicMax orders them */
     unsigned maxPenetration, maxViolation, maxLinearSpeed, maxAngularSpeed, maxNormalImpulse;
     int activeContacts, activeManifolds, dynamicBodies;

@@ -420,6 +420,20 @@ void Solver::pull()
         if (rc < 0) fail("avbd_download_bodies", rc);
         for (size_t i = 0; i < n; ++i) unpackBody(impl->byIndex[i], impl->shadow[i]);
     }
+    {   /* what solver.cpp:51-66 prints while it steps: the kernels log it, the host prints it (same text, same order) */
+        AvbdWarning w[128];
+        int nw = avbd_get_warnings(ctx, w, 128);
+        if (nw < 0) fail("avbd_get_warnings", nw);
+        static const char* const label[6] = {"linear velocity", "angular velocity", "predicted position", "predicted orientation", "position", "orientation"};
+        for (int i = 0; i < nw && i < 128; ++i) {
+            const int id = (w[i].body >= 0 && (size_t)w[i].body < impl->byIndex.size()) ? impl->byIndex[(size_t)w[i].body]->id : w[i].body;
+            if (w[i].kind == 3 || w[i].kind == 5)
+                std::printf("[Physics] Warning: body %d produced non-finite %s; resetting to identity.\n", id, label[w[i].kind]);
+            else
+                std::printf("[Physics] Warning: body %d produced non-finite %s (%.3f, %.3f, %.3f); resetting to zero.\n", id, label[w[i].kind % 6],
+                            w[i].value[0], w[i].value[1], w[i].value[2]);
+        }
+    }
     AvbdDiagnostics d;
     int rc = avbd_get_diagnostics(ctx, &d);
     if (rc) fail("avbd_get_diagnostics", rc);

@@ -215,6 +215,16 @@ int  avbd_force_row_count(AvbdContext* ctx, int force_index, int* rows);
 int  avbd_force_compute_constraint(AvbdContext* ctx, int force_index, float alpha, float* C, float* fmin, float* fmax, float* lambda);
 int  avbd_force_compute_derivatives(AvbdContext* ctx, int force_index, int body, int row, float J_linear[3], float J_angular[3]);
 
+/* ---- the warnings of the last step (solver.cpp:51-66: "[Physics] Warning: body %d produced non-finite %s ...; resetting").
+ * The kernels reset the quantity exactly like the reference and log what it would have printed; this call returns the
+ * number of resets of the last step (>= 0) and fills up to `capacity` records (at most the first 128 are kept) in the order
+ * the reference's sequential loops print them.  `kind`: 0 linear velocity, 1 angular velocity, 2 predicted position,
+ * 3 predicted orientation, 4 position, 5 orientation; `value` is the offending vector (xyz of a quaternion).  Inputs that
+ * are NaN keep their sign; a NaN GENERATED by an operation is positive on gfx950 and negative on x86, so printf("%.3f")
+ * may show `nan` where the reference shows `-nan` — the only character of the text that can differ. ---- */
+typedef struct AvbdWarning { int body; int kind; float value[3]; } AvbdWarning;
+int  avbd_get_warnings(AvbdContext* ctx, AvbdWarning* out, int capacity);
+
 /* ---- Solver::pick (solver.cpp:145-228): for each of `nrays` rays (origin xyz, direction xyz — any non-zero length),
  * the creation index of the nearest DYNAMIC body whose box the ray enters (ties: the newer body, as the reference's
  * newest-first list walk resolves them) and the hit point in that body's local frame; -1 (and a zero point) for a miss
