@@ -209,3 +209,13 @@ def test_cli_headless_trace_md5_every_reference_scene():
     for scene, md5 in meta.items():
         out = subprocess.run([exe, "--nogfx", "--scene", scene, "--steps", "300"], capture_output=True, check=True).stdout
         assert hashlib.md5(out).hexdigest() == md5, scene
+
+
+def test_cli_flag_aliases_and_unknown_scene():
+    """main.cpp:195-219: `--headless`, `-s`, `-n` are aliases; an unknown scene name silently selects scene 0 ("Empty");
+    `--steps` goes through atoi (garbage -> 0 steps)."""
+    exe = os.path.join(H.ROOT, "avbd-demo3d_amd", "avbd_demo3d")
+    run = lambda *a: subprocess.run([exe, *a], capture_output=True, check=True).stdout
+    assert run("--headless", "-s", "Stack", "-n", "7") == run("--nogfx", "--scene", "Stack", "--steps", "7")
+    assert run("--nogfx", "--scene", "NoSuchScene", "--steps", "3") == run("--nogfx", "--scene", "Empty", "--steps", "3")
+    assert run("--nogfx", "--scene", "Ground", "--steps", "abc").splitlines() == [b"Running in headless mode: scene 'Ground', steps=0"]
