@@ -161,6 +161,7 @@ struct AvbdContext {
     bool topologyDidPredict = false;
     int frontPairsPerWave = 8;      /* AVBD_FRONT_PPW: persistent manifolds re-collided per wavefront of k_front_small */
     bool residentSpread = true;    /* AVBD_RESIDENT_SPREAD=0: slot = linear wave index */
+    int residentPatience = 300;     /* AVBD_RESIDENT_PATIENCE: ticks of 10 ns (see ResidentExchange.patience) */
     int residentOutOfOrder = -1;    /* AVBD_RESIDENT_OOO=0/1: a wave with several bodies sweeps them strictly in order / takes whichever is ready; default: by size */
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
@@ -764,13 +765,15 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     /* several bodies per wave and more than residentLiteFrom of them: two workgroups per CU (twice the waves, short product lines) */
     const bool lite = X.enabled && X.multi && (c->residentForceLite || (c->residentLiteFrom > 0 && dynBodies > c->residentLiteFrom * X.maxWaves));
     if (lite) { X.prStride = kResStrideLite; X.maxWaves *= 2; }
-    /* out-of-order sweep of a wave's bodies: pays once a wave owns many bodies (measured: 64 000 cubes, 31 per wave, -10 %;
-     * 8 000 cubes, 4 per wave, +11 % — examining a body after its inputs arrive is slower than waiting for it prepared) */
-    X.outOfOrder = (X.enabled && X.multi && (c->residentOutOfOrder == 1 || (c->residentOutOfOrder < 0 && dynBodies >= 16 * X.maxWaves))) ? 1 : 0;
+    /* out-of-order sweep of a wave's bodies: pays once a wave owns several bodies (measured ms/step in order / out of order:
+     * 4 096 cubes, 2 per wave, 1.31 / 1.89; 8 000 cubes, 4 per wave, 2.68 / 2.58; 22 000 cubes, 11 per wave, 5.67 / 4.80;
+     * 64 000 cubes, 31 per wave, 12.3 / 9.9) */
+    X.outOfOrder = (X.enabled && X.multi && (c->residentOutOfOrder == 1 || (c->residentOutOfOrder < 0 && dynBodies > 3 * X.maxWaves))) ? 1 : 0;
     if (X.outOfOrder && c->probeCap < (size_t)c->incCap) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap;
     }
     X.probe = c->xProbe.p;
+    X.patience = c->residentPatience;
     const bool throughput = lite || (!X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
     if (throughput) {
         int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
@@ -1005,6 +1008,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_FRONT_PPW")) c->frontPairsPerWave = std::min(32, std::max(1, std::atoi(e)));
+        if (const char* e = std::getenv("AVBD_RESIDENT_PATIENCE")) c->residentPatience = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_OOO")) c->residentOutOfOrder = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;

@@ -4,7 +4,7 @@
  * code (iterate_resident<MULTI, JOINTS>):
  *   - up to 1024 swept bodies: every body gets ONE wavefront for the whole launch (all iterations), state in registers;
  *   - more bodies: every wave takes every W-th body of the sweep order and parks a body's state between its tasks
- *     (two workgroups per CU, 2048 waves, from 1024 swept bodies; in order, or — from 16 bodies per wave — whichever body
+ *     (two workgroups per CU, 2048 waves, from 1024 swept bodies; in order, or — from 4 bodies per wave — whichever body
  *     has its inputs published, see X.outOfOrder);
  *   - sharded runs: one launch per iteration; state is parked between the launches the same way.
  * The description below is written for the first form.
@@ -63,6 +63,7 @@ struct ResidentExchange {
     float4* send;      /* sharded runs: this rank's rows of the all-gather, filled by the wave that publishes the pose */
     const int* sendSlot; /* [bodyCap] row of a body this rank solves */
     int outOfOrder;    /* MULTI: a wave runs whichever of its bodies has its inputs ready (oldest iteration first) instead of sweeping them in order */
+    int patience;      /* out of order, nothing ready: ticks (10 ns) a wave waits on its oldest task, prepared, before it looks at its other bodies again (0: never blocks) */
     int* probe;        /* [incidence capacity] out of order: who an entry waits for (partner | moving << 24 | owned << 25 | hasA << 26), kept from a body's first examination */
 };
 
@@ -376,27 +377,40 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
      * iteration (MULTI only: the parked state and the stamped records carry over from launch to launch) */
     const int itFirst = MULTI ? itBegin : 0, itStop = (MULTI && itEnd < totalIt) ? itEnd : totalIt;
 
-    /* one task: the visit of `body` (already loaded) in iteration `it`; false = the launch is being abandoned */
-    auto run_task = [&](int it) __attribute__((always_inline)) -> bool {
+    /* One task = prepare_task (everything that depends only on this wave's own state: may run long before the inputs arrive)
+     * + finish_task (wait for the partners' records, second half of the visit, accumulate, solve, publish, dual).
+     * finish_task returns 1 when the task is done, 0 when the launch is being abandoned, 2 when `patience` (ticks of 10 ns,
+     * 0 = unlimited) ran out before the inputs arrived: nothing has been written by then, the task is simply taken up again
+     * later.  What the first half leaves for the second: */
+    AccLane a = {};
+    f3 wOwn = zero3();
+    bool needP = false, needV = false, needD = false;
+    unsigned sP = 0, sV = 0, sD = 0;
+    ContactPre pre; f3 G[3];
+    float pr[kResRegRows];
+    float* const J = rows;
+    float* const S = rows + kResJFloats;
+    float* const prLine = products + (lane < 27 ? lane : 0) * X.prStride;
+    int tmoOff = -1; unsigned tmoStamp = 0;                         /* the record a timed-out task was still waiting for */
 #ifdef AVBD_DF_STATS
-        unsigned trecDummy[8];                                      /* per-task time stamps are kept for one body per wave only */
-        unsigned* trec = MULTI ? trecDummy : reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)it * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8;
+    unsigned trecDummy[8];                                          /* per-task time stamps are kept for one body per wave only */
+#define RS_TREC(it) (MULTI ? trecDummy : reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)(it) * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8)
+#endif
+
+    auto prepare_task = [&](int it) __attribute__((always_inline)) {
+#ifdef AVBD_DF_STATS
+        unsigned* trec = RS_TREC(it);
         if (lane == 0) { trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[5] = (unsigned)body; }
 #endif
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
-        const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;        /* what this task publishes */
 
         /* ---- before the wait: everything that depends only on this wave's own state ---- */
         world_inertia_parallel(lane, L.rot, Ib, Jb, accs + 32, L.Iw, L.invIw);   /* rigid.cpp:51-59 */
-        AccLane a = init_acc_lane(lane, L);
-        f3 wOwn = zero3();
-        bool needP = false, needV = false, needD = false;
-        unsigned sP = 0, sV = 0, sD = 0;
-        ContactPre pre; f3 G[3];
-        float* J = rows;
-        float* S = rows + kResJFloats;
-        float* prLine = products + (lane < 27 ? lane : 0) * X.prStride;
+        a = init_acc_lane(lane, L);
+        wOwn = zero3();
+        needP = false; needV = false; needD = false;
+        sP = 0; sV = 0; sD = 0;
         if (JOINTS && has && isJoint) {
             if (moving) {
                 needP = true;
@@ -433,12 +447,20 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             }
         }
         wave_sync();
-        float pr[kResRegRows];
         store_products(a, J, pr, prLine, nEnt * 3, X.prStride);
         RS_STAMP(7);
 #ifdef AVBD_DF_STATS
         if (lane == 0) trec[1] = (unsigned)tprev;
 #endif
+    };
+
+    auto finish_task = [&](int it, unsigned patience) __attribute__((always_inline)) -> int {
+#ifdef AVBD_DF_STATS
+        unsigned* trec = RS_TREC(it);
+#endif
+        const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const bool doDual = it < P.iterations;
+        const unsigned stampNow = X.base + (unsigned)it + 1u;
 
         /* ---- the wait IS the load: poll the records until every stamp is current ---- */
         {
@@ -471,7 +493,14 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if ((++spins & 1023u) == 0) {
                     bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
                                 __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+                    if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+                }
+                if (MULTI && patience && (unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0) > patience) {
+                    /* give the wave back to its other bodies; remember one record this task was still missing */
+                    const int f = __ffsll((long long)__ballot(!(okP & okV & okD))) - 1;
+                    tmoOff = __builtin_amdgcn_readlane(offP + 32, f);
+                    tmoStamp = (unsigned)__builtin_amdgcn_readlane((int)sP, f);
+                    return 2;
                 }
             }
             RS_STAMP(0);
@@ -605,8 +634,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         if (lane == 0) trec[4] = (unsigned)tprev;
         stat[5] += 1;
 #endif
-        return true;
+        return 1;
     };
+    auto run_task = [&](int it) __attribute__((always_inline)) -> bool { prepare_task(it); return finish_task(it, 0u) != 0; };
 
     if constexpr (!MULTI) {
         /* one body for the whole launch (the caller checks w < nd) */
@@ -676,6 +706,24 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     const unsigned bs = (unsigned)__builtin_amdgcn_readlane((int)need, f);
                     if (lane == k) { blkOff = bo; blkStamp = bs; ok = false; }
                     cand = __ballot(ok);
+                }
+                if (it < 0 && X.patience) {
+                    /* nothing can run: take the oldest task, do its first half and wait for its inputs — but only for a while.
+                     * If they arrive the hand-off is as short as in the in-order sweep; if not, the other bodies get their turn. */
+                    const int k = __ffsll((long long)__ballot(active && itK == itLow)) - 1;
+                    load_header(__builtin_amdgcn_readlane(bodyK, k), __builtin_amdgcn_readlane(eBegK, k), __builtin_amdgcn_readlane(nEntK, k),
+                                __builtin_amdgcn_readlane(seenK, k) != 0);
+                    if (lane == k) seenK = 1;
+                    load_rest(itLow);
+                    prepare_task(itLow);
+                    const int r = finish_task(itLow, (unsigned)X.patience);
+                    if (r == 0) return;
+                    if (r == 2) { if (lane == k) { blkOff = tmoOff; blkStamp = tmoStamp; } }
+                    else {
+                        if (lane == k) { ++itK; ++blkStamp; }
+                        save_task(itLow == totalIt - 1);
+                        continue;
+                    }
                 }
                 if (it < 0) {
                     __builtin_amdgcn_s_sleep(4);
