@@ -111,3 +111,24 @@ def test_random_jointed_scenes_out_of_order_sweep(monkeypatch, lite):
             o.step(); g.step()
             H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
         assert int(g.w.stats()["schedule"]) == 3
+
+
+def test_out_of_order_sweep_in_the_per_iteration_launches_of_a_sharded_run(monkeypatch):
+    """The one-launch-per-iteration schedule of sharded runs (here with one rank: RCCL communicator, all-gather after every
+    iteration) combined with several bodies per wave swept out of order: parked state, stamped records and watched records carry
+    over from launch to launch.  Bit for bit against the oracle."""
+    monkeypatch.setenv("AVBD_ITER_BLOCKS", "1")
+    monkeypatch.setenv("AVBD_RESIDENT_OOO", "1")
+    monkeypatch.setenv("AVBD_FORCE_SHARDED", "1")
+    pkg = H.load_product()
+    for seed in range(420, 428):
+        o, g = H.CpuWorld("orc"), H.HipWorld()
+        for w in (o, g):
+            build_jointed(w, seed)
+        b = g.bodies()
+        g.w.set_ownership(1, 0, np.where(b["invMass"] > 0, 0, -1).astype(np.int32))
+        g.w.comm_init(1, 0, pkg.comm_unique_id())
+        for s in range(10):
+            o.step(); g.step()
+            H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
+        assert int(g.w.stats()["schedule"]) == 3
