@@ -765,10 +765,10 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     /* several bodies per wave and more than residentLiteFrom of them: two workgroups per CU (twice the waves, short product lines) */
     const bool lite = X.enabled && X.multi && (c->residentForceLite || (c->residentLiteFrom > 0 && dynBodies > c->residentLiteFrom * X.maxWaves));
     if (lite) { X.prStride = kResStrideLite; X.maxWaves *= 2; }
-    /* out-of-order sweep of a wave's bodies: pays once a wave owns several bodies (measured ms/step in order / out of order:
-     * 4 096 cubes, 2 per wave, 1.31 / 1.89; 8 000 cubes, 4 per wave, 2.68 / 2.58; 22 000 cubes, 11 per wave, 5.67 / 4.80;
-     * 64 000 cubes, 31 per wave, 12.3 / 9.9) */
-    X.outOfOrder = (X.enabled && X.multi && (c->residentOutOfOrder == 1 || (c->residentOutOfOrder < 0 && dynBodies > 3 * X.maxWaves))) ? 1 : 0;
+    /* out-of-order sweep of a wave's bodies: pays once a wave owns many bodies (measured ms/step in order / out of order over
+     * bench.py's 200-step steady window: 4 096 cubes, 2 per wave, 1.31 / 1.89; 8 000 cubes, 4 per wave, 2.45 / 2.69;
+     * 22 000 cubes, 11 per wave, 5.58 / 4.94; 64 000 cubes, 31 per wave, 12.3 / 9.9) */
+    X.outOfOrder = (X.enabled && X.multi && (c->residentOutOfOrder == 1 || (c->residentOutOfOrder < 0 && dynBodies > 7 * X.maxWaves))) ? 1 : 0;
     if (X.outOfOrder && c->probeCap < (size_t)c->incCap) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap;
     }

@@ -4,7 +4,7 @@
  * code (iterate_resident<MULTI, JOINTS>):
  *   - up to 1024 swept bodies: every body gets ONE wavefront for the whole launch (all iterations), state in registers;
  *   - more bodies: every wave takes every W-th body of the sweep order and parks a body's state between its tasks
- *     (two workgroups per CU, 2048 waves, from 1024 swept bodies; in order, or — from 4 bodies per wave — whichever body
+ *     (two workgroups per CU, 2048 waves, from 1024 swept bodies; in order, or — from 8 bodies per wave — whichever body
  *     has its inputs published, see X.outOfOrder);
  *   - sharded runs: one launch per iteration; state is parked between the launches the same way.
  * The description below is written for the first form.
