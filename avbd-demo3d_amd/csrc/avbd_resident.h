@@ -136,7 +136,7 @@ __device__ __forceinline__ void store_products(const AccLane& a, const float* J,
 
 __device__ __forceinline__ float comp4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-template <bool ALLON, bool JOINTS>
+template <bool ALLON, bool JOINTS, bool SHORT>
 __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr)[kResRegRows], const float* prLine, const float* S, int nRows, const float* J, int lineRows)
 {
     /* every lane runs the same instruction stream (idle lanes 27..63 compute a value nobody reads): no divergent branches,
@@ -184,7 +184,7 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
     const float* jb = J + (rhs ? a.opA : a.opB);
     for (int r4 = kResRegRows; r4 < nRows; r4 += 4) {
         float4 pv;
-        if (r4 - kResRegRows + 4 <= lineRows) pv = p4[(r4 - kResRegRows) >> 2];   /* wave-uniform */
+        if (!SHORT || r4 - kResRegRows + 4 <= lineRows) pv = p4[(r4 - kResRegRows) >> 2];   /* wave-uniform; SHORT = false: the line holds every row */
         else {
             float t[4];
 #pragma unroll
@@ -382,12 +382,14 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
      * finish_task returns 1 when the task is done, 0 when the launch is being abandoned, 2 when `patience` (ticks of 10 ns,
      * 0 = unlimited) ran out before the inputs arrived: nothing has been written by then, the task is simply taken up again
      * later.  What the first half leaves for the second: */
-    AccLane a = {};
-    f3 wOwn = zero3();
-    bool needP = false, needV = false, needD = false;
-    unsigned sP = 0, sV = 0, sD = 0;
-    ContactPre pre; f3 G[3];
-    float pr[kResRegRows];
+    struct TaskPrep {
+        AccLane a;
+        f3 wOwn;
+        bool needP, needV, needD;
+        unsigned sP, sV, sD;
+        ContactPre pre; f3 G[3];
+        float pr[kResRegRows];
+    };
     float* const J = rows;
     float* const S = rows + kResJFloats;
     float* const prLine = products + (lane < 27 ? lane : 0) * X.prStride;
@@ -397,7 +399,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #define RS_TREC(it) (MULTI ? trecDummy : reinterpret_cast<unsigned*>(errWord + 16 + 1024 * 32) + ((size_t)(it) * 1024 + (blockIdx.x * kIterWaves + (threadIdx.x >> 6))) * 8)
 #endif
 
-    auto prepare_task = [&](int it) __attribute__((always_inline)) {
+    auto prepare_task = [&](int it, TaskPrep& T) __attribute__((always_inline)) {
+        AccLane& a = T.a; f3& wOwn = T.wOwn; bool& needP = T.needP; bool& needV = T.needV; bool& needD = T.needD;
+        unsigned& sP = T.sP; unsigned& sV = T.sV; unsigned& sD = T.sD; ContactPre& pre = T.pre; f3 (&G)[3] = T.G; float (&pr)[kResRegRows] = T.pr;
 #ifdef AVBD_DF_STATS
         unsigned* trec = RS_TREC(it);
         if (lane == 0) { trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[5] = (unsigned)body; }
@@ -447,14 +451,16 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             }
         }
         wave_sync();
-        store_products(a, J, pr, prLine, nEnt * 3, X.prStride);
+        store_products(a, J, pr, prLine, nEnt * 3, MULTI ? X.prStride : kResStride);
         RS_STAMP(7);
 #ifdef AVBD_DF_STATS
         if (lane == 0) trec[1] = (unsigned)tprev;
 #endif
     };
 
-    auto finish_task = [&](int it, unsigned patience) __attribute__((always_inline)) -> int {
+    auto finish_task = [&](int it, TaskPrep& T, unsigned patience) __attribute__((always_inline)) -> int {
+        AccLane& a = T.a; f3& wOwn = T.wOwn; bool& needP = T.needP; bool& needV = T.needV; bool& needD = T.needD;
+        unsigned& sP = T.sP; unsigned& sV = T.sV; unsigned& sD = T.sD; ContactPre& pre = T.pre; f3 (&G)[3] = T.G; float (&pr)[kResRegRows] = T.pr;
 #ifdef AVBD_DF_STATS
         unsigned* trec = RS_TREC(it);
 #endif
@@ -568,7 +574,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         const bool allOn = __all(rowsOn);
         wave_sync();
         RS_STAMP(1);
-        if (allOn) accumulate_products<true, JOINTS>(a, pr, prLine, S, nEnt * 3, J, X.prStride); else accumulate_products<false, JOINTS>(a, pr, prLine, S, nEnt * 3, J, X.prStride);
+        if (allOn) accumulate_products<true, JOINTS, MULTI>(a, pr, prLine, S, nEnt * 3, J, X.prStride); else accumulate_products<false, JOINTS, MULTI>(a, pr, prLine, S, nEnt * 3, J, X.prStride);
         if (lane < 27) accs[lane] = a.acc;
         wave_sync();
         RS_STAMP(2);
@@ -636,7 +642,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #endif
         return 1;
     };
-    auto run_task = [&](int it) __attribute__((always_inline)) -> bool { prepare_task(it); return finish_task(it, 0u) != 0; };
+    auto run_task = [&](int it) __attribute__((always_inline)) -> bool { TaskPrep T; prepare_task(it, T); return finish_task(it, T, 0u) != 0; };
 
     if constexpr (!MULTI) {
         /* one body for the whole launch (the caller checks w < nd) */
@@ -715,8 +721,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                                 __builtin_amdgcn_readlane(seenK, k) != 0);
                     if (lane == k) seenK = 1;
                     load_rest(itLow);
-                    prepare_task(itLow);
-                    const int r = finish_task(itLow, (unsigned)X.patience);
+                    TaskPrep T;
+                    prepare_task(itLow, T);
+                    const int r = finish_task(itLow, T, (unsigned)X.patience);
                     if (r == 0) return;
                     if (r == 2) { if (lane == k) { blkOff = tmoOff; blkStamp = tmoStamp; } }
                     else {
