@@ -219,3 +219,29 @@ def test_cli_flag_aliases_and_unknown_scene():
     assert run("--headless", "-s", "Stack", "-n", "7") == run("--nogfx", "--scene", "Stack", "--steps", "7")
     assert run("--nogfx", "--scene", "NoSuchScene", "--steps", "3") == run("--nogfx", "--scene", "Empty", "--steps", "3")
     assert run("--nogfx", "--scene", "Ground", "--steps", "abc").splitlines() == [b"Running in headless mode: scene 'Ground', steps=0"]
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's fields plus the roofline and cpu_baseline objects."""
+    import json
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-reference"],
+                         capture_output=True, text=True, check=True, cwd=H.ROOT).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["steps"] == 6 and b["warmup"] == 2 and b["higher_is_better"] is True and b["vs_baseline"] is None
+    assert b["unit"] == "steps/s" and b["dtype"] == "f32" and b["data"] == "synthetic" and b["scaling"] == "weak"
+    assert "workload" in b["config"] and "Stress1000" in b["config"]["workload"]
+    assert abs(b["value"] - 1000.0 / b["ms_per_step"]) / b["value"] < 1e-3
+    r = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    c = b["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["parity"] == "bit-exact" and c["value"] > 0
