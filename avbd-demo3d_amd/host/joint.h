@@ -1,26 +1,28 @@
-/* joint.h — 6-row weld joint of the drop-in host API (reference: source/joint.h:14-47, joint.cpp). */
+/* joint.h — host mirror of the reference's weld joint (source/joint.h:14-47, joint.cpp), MI355X build.
+ *
+ * The object is a handle: its six rows (three translational, three rotational) live in the device context as one GForce
+ * record (csrc/avbd_types.h) and are evaluated there (csrc/avbd_rows.h: joint_compute_constraint / joint_compute_derivatives;
+ * in the resident schedule one lane holds one half = three rows).  The members below exist so that scene code written
+ * against the reference compiles unchanged; they are copied into the device record when the solver first steps.
+ * Bug-compatible with the reference's row signs. */
 #pragma once
 #include "solver.h"
 
 struct Joint : Force {
-    vec3 rA, rB;
-    quat initialRelativeOrientation;
-    float angularStiffness;
-    float angularMotor;
-    float angularFracture;
-
-    /* body–body weld (joint.cpp:11-39) */
-    Joint(Solver* solver, Rigid* bodyA, Rigid* bodyB, const vec3& localAnchorA, const vec3& localAnchorB,
+    /* ---- construction, same two forms as the reference ---- */
+    Joint(Solver* owner, Rigid* a, Rigid* b, const vec3& anchorOnA, const vec3& anchorOnB,           /* two bodies (joint.cpp:11-39) */
           float linearStiffness = FLT_MAX, float angularStiffness = FLT_MAX, float motor = 0.0f, float fracture = FLT_MAX);
-    /* body–world weld at a world-space anchor (joint.cpp:42-61) */
-    Joint(Solver* solver, Rigid* bodyB, const vec3& worldAnchor, float linearStiffness = FLT_MAX,
-          float angularStiffness = FLT_MAX, float motor = 0.0f, float fracture = FLT_MAX);
+    Joint(Solver* owner, Rigid* b, const vec3& anchorInWorld,                                         /* body to world (joint.cpp:42-61) */
+          float linearStiffness = FLT_MAX, float angularStiffness = FLT_MAX, float motor = 0.0f, float fracture = FLT_MAX);
 
-    int getRowCount() const override { return 6; }
+    /* ---- Force interface: evaluated on the device ---- */
+    int  getRowCount() const override { return 6; }
     bool initialize() override { return true; }
     void computeConstraint(float alpha) override { deviceComputeConstraint(alpha); }
-    void computeDerivatives(vec3& J_linear, vec3& J_angular, const Rigid* body, int row) const override
-    {
-        deviceComputeDerivatives(J_linear, J_angular, body, row);
-    }
+    void computeDerivatives(vec3& Jlin, vec3& Jang, const Rigid* which, int row) const override { deviceComputeDerivatives(Jlin, Jang, which, row); }
+
+    /* ---- public state of the reference's struct (joint.h:16-24) ---- */
+    quat  initialRelativeOrientation;          /* conj(qA) * qB at creation */
+    vec3  rA, rB;                              /* anchors in the bodies' frames (rA in world space for a world joint) */
+    float angularStiffness, angularMotor, angularFracture;
 };

@@ -220,7 +220,7 @@ Joint::Joint(Solver* s, Rigid* b, const vec3& worldAnchor, float linearStiffness
 }
 
 Spring::Spring(Solver* s, Rigid* a, Rigid* b, const vec3& localAnchorA, const vec3& localAnchorB, float k, float rest)
-    : Force(s, a, b), rA(localAnchorA), rB(localAnchorB), restLength(rest), springStiffness(k)
+    : Force(s, a, b), springStiffness(k), restLength(rest), rA(localAnchorA), rB(localAnchorB)
 {
     deviceKind = AVBD_FORCE_SPRING;
     stiffness[0] = springStiffness;                                       /* spring.cpp:16-30 */

@@ -1,20 +1,19 @@
-/* spring.h — 1-row distance constraint of the drop-in host API (reference: source/spring.h:13-37, spring.cpp). */
+/* spring.h — host mirror of the reference's distance spring (source/spring.h:13-37, spring.cpp), MI355X build.
+ *
+ * One row of finite stiffness between two anchors; like every built-in force it is a handle on a GForce record of the device
+ * context and is evaluated there (csrc/avbd_rows.h: spring_compute_constraint / spring_compute_derivatives).  A negative rest
+ * length means "the distance at creation" (spring.cpp:17-22). */
 #pragma once
 #include "solver.h"
 
 struct Spring : Force {
-    vec3 rA, rB;
-    float restLength;
-    float springStiffness;
+    Spring(Solver* owner, Rigid* a, Rigid* b, const vec3& anchorOnA, const vec3& anchorOnB, float stiffness, float rest = -1.0f);
 
-    Spring(Solver* solver, Rigid* bodyA, Rigid* bodyB, const vec3& localAnchorA, const vec3& localAnchorB, float stiffness,
-           float rest = -1.0f);
-
-    int getRowCount() const override { return 1; }
+    int  getRowCount() const override { return 1; }
     bool initialize() override { return true; }
     void computeConstraint(float alpha) override { deviceComputeConstraint(alpha); }
-    void computeDerivatives(vec3& J_linear, vec3& J_angular, const Rigid* body, int row) const override
-    {
-        deviceComputeDerivatives(J_linear, J_angular, body, row);
-    }
+    void computeDerivatives(vec3& Jlin, vec3& Jang, const Rigid* which, int row) const override { deviceComputeDerivatives(Jlin, Jang, which, row); }
+
+    float springStiffness, restLength;         /* spring.h:17-18 */
+    vec3  rA, rB;                              /* anchors in the bodies' frames */
 };
