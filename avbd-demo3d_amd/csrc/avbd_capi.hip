@@ -32,6 +32,7 @@ constexpr int kReadbackLevels = 8192;
 
 struct Readback {
     Counters cnt;
+    GroupPlan plan;
     int lvlStart[kReadbackLevels + 1];
 };
 
@@ -165,6 +166,11 @@ struct AvbdContext {
     int residentOutOfOrder = -1;    /* AVBD_RESIDENT_OOO=0/1: a wave with several bodies sweeps them strictly in order / takes whichever is ready; default: by size */
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
+    /* group schedule (avbd_groups.h): several bodies in flight per wavefront, for scenes with more swept bodies than resident waves */
+    DevArr<GroupPlan> dPlan; DevArr<int> dUnit; int unitCap = 0;
+    int groupsMode = -1;           /* AVBD_GROUPS=0 never, 1 for every eligible scene (tests), default: more swept bodies than one-body-per-wave waves */
+    bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
+    bool groupsLaunched = false;   /* the last iteration loop was offered to k_iterate_groups (the device may still decline: GroupPlan.bad) */
     int numStatic = 0;
     bool statsFresh = true;
 
@@ -600,6 +606,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     HIPCHK(c, hipMemcpyAsync(&c->hRb->cnt, c->dCnt.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     if (withLevels)
         HIPCHK(c, hipMemcpyAsync(c->hRb->lvlStart, c->lvlStart.p, sizeof(int) * (std::min(kReadbackLevels, c->lvlCap) + 1), hipMemcpyDeviceToHost, c->stream));
+    if (c->groupsLaunched) HIPCHK(c, hipMemcpyAsync(&c->hRb->plan, c->dPlan.p, sizeof(GroupPlan), hipMemcpyDeviceToHost, c->stream));
     int iterError = 0;
     if (c->dFlags.p)
         HIPCHK(c, hipMemcpyAsync(&iterError, c->dFlags.p + 2 * (size_t)c->bodyCap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -609,6 +616,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.numIncidences = cnt.numIncidences; c->stats.numCandidates = cnt.numCandidates; c->stats.numLevels = cnt.numLevels;
     c->stats.numDynamic = cnt.dynamicBodies;
     c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && (cnt.residentBad & 1) == 0 && ((cnt.residentBad & 2) == 0 || c->residentMultiLaunched)) ? (((cnt.residentBad & 2) || c->residentMultiLaunched) ? 3 : 2) : 1);
+    if (c->groupsLaunched && c->hRb->plan.bad == 0) c->stats.schedule = 4;   /* group schedule (avbd_groups.h) */
     int nj = 0, ns = 0, ni = 0;
     for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
@@ -626,6 +634,18 @@ int refresh_stats(AvbdContext* c, bool withLevels)
 }
 
 /* ---- one Solver::step() split into phases so that several contexts (GPUs) can be driven in lock-step ---- */
+
+/* Can this step's iteration loop be offered to the group schedule?  Host-side prerequisites only (one GPU, contacts and
+ * ignore markers only, stamps fit); the device declines on its own if a body has too many entries (GroupPlan.bad). */
+bool groups_eligible(const AvbdContext* c)
+{
+    if (c->groupsMode == 0 || c->mode == 0 || !c->residentAllowed || c->nranks != 1 || c->forceSharded || !c->dPlan.p) return false;
+    const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
+    if (totalIt <= 0 || totalIt > 60) return false;
+    for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return false;
+    const int dyn = (int)c->hBodies.size() - c->numStatic;
+    return c->groupsMode == 1 || dyn > c->iterBlocks * kIterWaves;
+}
 
 /* phases 1-3 of solver.cpp:255-337 + the topology rebuild; leaves the stream ready for the iteration loop */
 int step_begin(AvbdContext* c)
@@ -690,6 +710,17 @@ int step_begin(AvbdContext* c)
         }
         if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
             HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, (size_t)2 * c->bodyCap * sizeof(int), c->stream));   /* the error word behind them is sticky */
+    }
+    c->groupsPlanned = false;
+    if (groups_eligible(c)) {
+        const int W = 2 * c->iterBlocks * kGrpWavesPerBlock;
+        const int needUnits = 4 * W;                                   /* one body per sub-group */
+        if (c->unitCap < needUnits) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, c->dUnit.alloc((size_t)needUnits)); c->unitCap = needUnits;
+        }
+        hipLaunchKernelGGL(k_group_plan, dim3(1), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->dPlan.p, c->dUnit.p, c->unitCap, W, 1);
+        c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
     return AVBD_OK;
@@ -775,17 +806,28 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     X.probe = c->xProbe.p;
     X.patience = c->residentPatience;
     const bool throughput = lite || (!X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
+    /* group schedule first; the launch below then runs only if the device declined (runIf) */
+    const int* runIf = nullptr;
+    c->groupsLaunched = false;
+    if (c->groupsPlanned && X.enabled && wholeLoop && !X.joints) {
+        const int W = 2 * c->iterBlocks * kGrpWavesPerBlock;
+        hipExtLaunchKernelGGL(k_iterate_groups, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
+                              X, c->dPlan.p, c->dUnit.p, W, c->iterSleep);
+        runIf = &c->dPlan.p->bad;
+        c->groupsLaunched = true;
+        e0 = nullptr;                                                  /* the profiling span covers both launches (the second one is empty unless the device declined) */
+    }
     if (throughput) {
         int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
         if (blocks2 < 1) blocks2 = 1;
         if (lite) blocks2 = 2 * c->iterBlocks;
         auto kern = X.joints ? k_iterate<2, true> : k_iterate<2, false>;
         hipExtLaunchKernelGGL(kern, dim3(blocks2), dim3(64 * kIterWaves), kIterWaves * kResProductBytesPerWaveLite, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X, runIf);
     } else {
         auto kern = X.joints ? k_iterate<1, true> : k_iterate<1, false>;
         hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X);
+                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X, runIf);
     }
     ++c->prof.launches_primal; ++c->prof.launches_total;
     HIPCHK(c, hipGetLastError());
@@ -982,7 +1024,9 @@ int avbd_create(int device, AvbdContext** out)
     std::memset(c->hRb, 0, sizeof(Readback));
     /* the Counters word, then the warning log of the step (kWarnCap records of 32 B) */
     static_assert(sizeof(WarnRec) == 32 && sizeof(Counters) == 64, "warning log layout");
-    if (c->dCnt.alloc(1 + kWarnCap * sizeof(WarnRec) / sizeof(Counters)) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    if (c->dCnt.alloc(1 + kWarnCap * sizeof(WarnRec) / sizeof(Counters)) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess ||
+        c->dPlan.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    (void)hipMemset(c->dPlan.p, 0, sizeof(GroupPlan));
     (void)hipMemset(c->dCnt.p, 0, sizeof(Counters));
     (void)hipMemset(c->dDiag.p, 0, sizeof(DiagAccum));
     (void)hipMemset(c->dNext.p, 0, sizeof(int));
@@ -1000,6 +1044,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_SHARDED")) c->residentSharded = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_FORCE_LITE")) c->residentForceLite = std::atoi(e) != 0;
@@ -1021,6 +1066,8 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_iterate<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate<2>, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
+        fe = hipFuncSetAttribute((const void*)k_iterate_groups, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
@@ -1043,6 +1090,7 @@ int avbd_destroy(AvbdContext* c)
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release();
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
+    c->dPlan.release(); c->dUnit.release();
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);

@@ -1,0 +1,514 @@
+/*
+ * avbd_groups.h — "group" schedule of the iteration loop (solver.cpp:340-431): several bodies in flight per wavefront.
+ *
+ * The resident schedule (avbd_resident.h) gives a body a whole wavefront: one lane per contact, 27 lanes for the ordered
+ * accumulation, the rest idle — fine while there are at most as many swept bodies as resident waves, a serial resource
+ * beyond (9.6 us of wave time per task once a wave has to park and reload bodies).  Here a wavefront is cut
+ * into sub-groups of 16 / 32 / 64 lanes by the body's number of incidence entries, each sub-group owns ONE body for the
+ * whole launch (state in registers, like the one-body-per-wave form) and the sub-groups of a wave advance independently:
+ * a pass of the wave's loop polls the records every waiting sub-group still misses and then runs the task of every
+ * sub-group whose inputs have arrived, under the lane mask of those sub-groups.  No sub-group ever waits for another one
+ * of its wave, so the only dependencies are the reference's own (avbd_iterate.h) and any placement is deadlock-free.
+ *
+ *   - same hand-off records, stamps and arithmetic as avbd_resident.h (pose / visit / dual, 16-byte `sc1` records);
+ *   - per-wave LDS is indexed by lane exactly as there (row = 3 * lane + k), so a sub-group simply uses the rows of its
+ *     own lanes; the 27 accumulator entries of a body live on the first 16 lanes of its sub-group (two per lane);
+ *   - a waiting lane polls ONE record (the last one its producer writes) until that arrives and only then fetches the
+ *     rest: waves that cannot run stay off the memory system (round 1: 3.35x the algorithmic traffic was poll traffic).
+ *
+ * Plan (k_group_plan, every step, on the device): swept bodies are classed by entry count (<= 16, <= 32, <= 64), each
+ * class gets its own waves (a wave's lane layout is static), consecutive bodies of a class go to different waves.
+ */
+#pragma once
+#include "avbd_iterate.h"
+
+#pragma clang fp contract(off)
+
+namespace avbd {
+
+struct GroupPlan {
+    int nClass[3];     /* swept bodies with <= 16 / <= 32 / <= 64 incidence entries */
+    int waves[3];      /* resident waves of each class; layout in the launch: class 2 (64 lanes) | class 1 | class 0 */
+    int rounds[3];     /* bodies per sub-group */
+    int bad;           /* != 0: this step cannot run in the group schedule (the launch queued behind it runs instead) */
+    int nd;            /* swept bodies */
+    int pad[5];
+};
+static_assert(sizeof(GroupPlan) == 64, "GroupPlan layout");
+
+constexpr int kGrpWavesPerBlock = 4;
+constexpr int kGrpLineRows = 20;          /* rows per 16 lanes whose pre-multiplied products wait in an LDS line (a 32-lane sub-group has 40, a wave 80) */
+constexpr int kGrpLineFloats = 27 * kGrpLineRows;   /* per 16 lanes */
+constexpr int kGrpSSlots = 6;             /* f | penalty | gyro.x | gyro.y | gyro.z | zeros */
+constexpr int kGrpAccFloats = 64;         /* per 16 lanes: 27 accumulator entries, 21 floats of solve / inertia exchange */
+constexpr int kGrpConstFloats = 32;       /* per 16 lanes: inertial pose, mass, body-frame inertia and inverse inertia */
+constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAccFloats + kGrpLineFloats + kGrpConstFloats);
+constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 77 568 B: two workgroups per CU */
+static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytes <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
+
+/* ---- plan: classes, waves per class, unit table ------------------------------------------------------------------------
+ * unit[(k * W + w) * 4 + j] = body of sub-group j of wave w in round k (-1: none).  Single workgroup, two passes over the
+ * sweep order (class counts, then ranks by tiles of 4096 slots with one shuffle-based scan per tile). */
+__global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __restrict__ order, const int* __restrict__ lvlStart, Counters* cnt,
+                                                     const int* __restrict__ incStart, GroupPlan* plan, int* __restrict__ unit, int unitCap, int W, int maxRounds)
+{
+    __shared__ unsigned long long sWaveTotals[16];
+    __shared__ unsigned long long sTile;
+    __shared__ int sPlan[16];
+    const int t = threadIdx.x;
+    const int nd = lvlStart[cnt->numLevels];
+    auto cls_of = [&](int slot) -> int {
+        const int b = order[slot];
+        const int ne = incStart[b + 1] - incStart[b];
+        return ne <= 16 ? 0 : (ne <= 32 ? 1 : 2);
+    };
+    /* pass 1: class counts, 21 bits each */
+    unsigned long long mine = 0;
+    for (int s = t; s < nd; s += 1024) mine += 1ull << (21 * cls_of(s));
+    const unsigned long long all = block_scan_inclusive_u64(mine, sWaveTotals);
+    if (t == 1023) {
+        int n[3] = {(int)(all & 0x1fffff), (int)((all >> 21) & 0x1fffff), (int)((all >> 42) & 0x1fffff)};
+        int wv[3], rounds[3] = {1, 1, 1};
+        const int need1 = (n[1] + 1) / 2, need0 = (n[0] + 3) / 4;
+        int bad = (cnt->residentBad & 1) || nd == 0 || nd >= (1 << 21);
+        if (n[2] + need1 + need0 <= W) {
+            /* every body keeps its sub-group for the whole launch; class 0 takes all the waves that are left */
+            wv[2] = n[2]; wv[1] = need1; wv[0] = n[0] ? W - wv[2] - wv[1] : 0;
+        } else {
+            /* several bodies per sub-group: waves in proportion to the lane-quarters a class needs */
+            const long long U = (long long)n[0] + 2ll * n[1] + 4ll * n[2];
+            wv[2] = n[2] ? (int)max(1ll, (4ll * n[2] * W) / U) : 0;
+            wv[1] = n[1] ? (int)max(1ll, (2ll * n[1] * W) / U) : 0;
+            wv[0] = W - wv[2] - wv[1];
+            if (wv[0] < (n[0] ? 1 : 0)) bad = 1;
+            for (int c = 0; c < 3; ++c) if (n[c]) { const int per = wv[c] * (4 >> c); rounds[c] = (n[c] + per - 1) / per; }
+        }
+        const int kmax = max(rounds[0], max(rounds[1], rounds[2]));
+        if (kmax > maxRounds || (long long)kmax * W * 4 > unitCap) bad = 1;
+        for (int c = 0; c < 3; ++c) { sPlan[c] = n[c]; sPlan[3 + c] = wv[c]; sPlan[6 + c] = rounds[c]; }
+        sPlan[9] = bad; sPlan[10] = kmax;
+        plan->nClass[0] = n[0]; plan->nClass[1] = n[1]; plan->nClass[2] = n[2];
+        plan->waves[0] = wv[0]; plan->waves[1] = wv[1]; plan->waves[2] = wv[2];
+        plan->rounds[0] = rounds[0]; plan->rounds[1] = rounds[1]; plan->rounds[2] = rounds[2];
+        plan->bad = bad; plan->nd = nd;
+    }
+    __syncthreads();
+    if (sPlan[9]) return;
+    const int kmax = sPlan[10];
+    for (int i = t; i < kmax * W * 4; i += 1024) unit[i] = -1;
+    __syncthreads();
+    const int base2 = 0, base1 = sPlan[5], base0 = sPlan[5] + sPlan[4];
+    unsigned long long running = 0;
+    for (int tile = 0; tile < nd; tile += 4096) {
+        const int s0 = tile + 4 * t;
+        int cl[4]; unsigned long long mine4 = 0;
+        for (int k = 0; k < 4; ++k) { cl[k] = s0 + k < nd ? cls_of(s0 + k) : -1; if (cl[k] >= 0) mine4 += 1ull << (21 * cl[k]); }
+        const unsigned long long incl = block_scan_inclusive_u64(mine4, sWaveTotals);
+        unsigned long long off = running + incl - mine4;
+        for (int k = 0; k < 4; ++k) {
+            if (cl[k] < 0) continue;
+            const int c = cl[k];
+            const int r = (int)((off >> (21 * c)) & 0x1fffff);
+            off += 1ull << (21 * c);
+            const int Wc = sPlan[3 + c], G = 4 >> c;
+            const int round = r / (Wc * G), rest = r - round * (Wc * G);
+            const int wave = (c == 2 ? base2 : (c == 1 ? base1 : base0)) + rest % Wc, j = rest / Wc;
+            unit[(round * W + wave) * 4 + j * (1 << c)] = order[s0 + k];
+        }
+        if (t == 1023) sTile = incl;
+        __syncthreads();
+        running += sTile;
+        __syncthreads();
+    }
+}
+
+/* World-space inertia and inverse inertia (rigid.cpp:51-59) by the first nine lanes of a sub-group, one entry (i, j) of both
+ * matrices per lane; same expression trees as world_inertia_parallel. */
+__device__ __forceinline__ void world_inertia_group(int gl, q4 rot, m33 Ib, m33 Jb, float* xch, m33& Iw, m33& invIw)
+{
+    const m33 R = quat_to_mat(rot);
+    const m33 Rt = mtranspose(R);
+    const int e = gl < 9 ? gl : 0;
+    const int i = e % 3, j = e / 3;
+    const f3 ri = i == 0 ? Rt.c0 : (i == 1 ? Rt.c1 : Rt.c2);
+    const f3 rj = j == 0 ? Rt.c0 : (j == 1 ? Rt.c1 : Rt.c2);
+    const f3 mi = mk3(dot3(ri, Ib.c0), dot3(ri, Ib.c1), dot3(ri, Ib.c2));
+    const f3 mj = mk3(dot3(ri, Jb.c0), dot3(ri, Jb.c1), dot3(ri, Jb.c2));
+    const float v = dot3(mi, rj), v2 = dot3(mj, rj);
+    if (gl < 9) { xch[gl] = v; xch[9 + gl] = v2; }
+    wave_sync();
+    Iw = mkm(mk3(xch[0], xch[1], xch[2]), mk3(xch[3], xch[4], xch[5]), mk3(xch[6], xch[7], xch[8]));
+    invIw = mkm(mk3(xch[9], xch[10], xch[11]), mk3(xch[12], xch[13], xch[14]), mk3(xch[15], xch[16], xch[17]));
+    wave_sync();
+}
+
+/* one accumulator entry: operand offsets into a J row, kind, gyro slot, running sum */
+struct GAcc { int opA, opB, mode, gy; float acc; };
+__device__ __forceinline__ GAcc make_gacc(int entry, const BodyLocal& L)
+{
+    const AccLane a = init_acc_lane(entry, L);
+    GAcc g; g.opA = a.opA; g.opB = a.opB; g.mode = a.mode; g.gy = a.gy; g.acc = a.acc;
+    return g;
+}
+
+/* products Ja*Jb (rhs entries: J alone) of the sub-group's first `lineRows` rows, before the wait, into the entry's LDS line */
+__device__ __forceinline__ void grp_store_line(const GAcc& a, const float* Jg, float* line, int nRows, int lineRows)
+{
+    const bool rhs = a.mode == 2;
+    const float* ja = Jg + a.opA;
+    const float* jb = Jg + (rhs ? a.opA : a.opB);
+    const int n = nRows < lineRows ? nRows : lineRows;
+    for (int r4 = 0; r4 < n; r4 += 4) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r4 + k < n ? r4 + k : r4;
+            const float va = ja[r * 6], vb = jb[r * 6];
+            t[k] = rhs ? va : va * vb;
+        }
+        *reinterpret_cast<float4*>(line + r4) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+
+/* ordered accumulation (solver.cpp:383-397): acc += (Ja*Jb)*penalty [+ gyro] / acc += J*f, row by row in list order, for the
+ * two entries of a lane at once (two independent chains of additions).  ALLON: every row has a usable penalty
+ * (solver.cpp:387), the normal case; otherwise a lhs entry skips the rows whose penalty is not positive and finite. */
+struct GAccView { const float4 *p4, *s4, *g4; const float *ja, *jb; bool isAA, rhs; };
+__device__ __forceinline__ GAccView grp_view(const GAcc& a, const float* line, const float* Sg, const float* Jg)
+{
+    GAccView v;
+    v.isAA = a.mode == 1; v.rhs = a.mode == 2;
+    v.p4 = reinterpret_cast<const float4*>(line);
+    v.s4 = reinterpret_cast<const float4*>(Sg + (v.rhs ? 0 : kResRows));
+    v.g4 = reinterpret_cast<const float4*>(Sg + kResRows * (a.gy >= 0 ? a.gy - 6 : 5));   /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
+    v.ja = Jg + a.opA; v.jb = Jg + (v.rhs ? a.opA : a.opB);
+    return v;
+}
+template <bool ALLON>
+__device__ __forceinline__ float grp_add_row(float acc, float pr, float sv, float gv, const GAccView& v)
+{
+    const float nv = acc + pr * sv;
+    const float nvg = nv + gv;
+    const float nv2 = v.isAA ? nvg : nv;
+    if (ALLON) return nv2;
+    const bool on = v.rhs || ((sv > 0.0f) & (fabsf(sv) <= FLT_MAX));   /* lhs entries scale by the penalty itself */
+    return on ? nv2 : acc;
+}
+template <bool ALLON, bool TWO>
+__device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* line0, const float* line1, const float* Sg, const float* Jg, int nRows, int lineRows)
+{
+    const GAccView v0 = grp_view(a0, line0, Sg, Jg), v1 = grp_view(a1, line1, Sg, Jg);
+    const int n = nRows < lineRows ? nRows : lineRows;
+    float acc0 = a0.acc, acc1 = a1.acc;
+    float4 p0 = v0.p4[0], s0 = v0.s4[0], g0 = v0.g4[0], p1, s1, g1;
+    if (TWO) { p1 = v1.p4[0]; s1 = v1.s4[0]; g1 = v1.g4[0]; }
+    for (int r4 = 0; r4 < n; r4 += 4) {
+        const float4 cp0 = p0, cs0 = s0, cg0 = g0, cp1 = p1, cs1 = s1, cg1 = g1;
+        if (r4 + 4 < n) {                                            /* the next block's operands are in flight while this one is added */
+            const int q = (r4 >> 2) + 1;
+            p0 = v0.p4[q]; s0 = v0.s4[q]; g0 = v0.g4[q];
+            if (TWO) { p1 = v1.p4[q]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r4 + k < n) {
+                acc0 = grp_add_row<ALLON>(acc0, comp4(cp0, k), comp4(cs0, k), comp4(cg0, k), v0);
+                if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(cp1, k), comp4(cs1, k), comp4(cg1, k), v1);
+            }
+        }
+    }
+    /* rows past the line: multiplied here, from the Jacobians in LDS — same product, same bits */
+    for (int r4 = lineRows; r4 < nRows; r4 += 4) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r4 + k < nRows ? r4 + k : r4;
+            const float va = v0.ja[r * 6], vb = v0.jb[r * 6];
+            t0[k] = v0.rhs ? va : va * vb;
+            if (TWO) { const float wa = v1.ja[r * 6], wb = v1.jb[r * 6]; t1[k] = v1.rhs ? wa : wa * wb; }
+        }
+        const float4 sw0 = v0.s4[r4 >> 2], gw0 = v0.g4[r4 >> 2];
+        float4 sw1 = sw0, gw1 = gw0;
+        if (TWO) { sw1 = v1.s4[r4 >> 2]; gw1 = v1.g4[r4 >> 2]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r4 + k < nRows) {
+                acc0 = grp_add_row<ALLON>(acc0, t0[k], comp4(sw0, k), comp4(gw0, k), v0);
+                if (TWO) acc1 = grp_add_row<ALLON>(acc1, t1[k], comp4(sw1, k), comp4(gw1, k), v1);
+            }
+        }
+    }
+    a0.acc = acc0; a1.acc = acc1;
+}
+
+__device__ __forceinline__ float grp_bcast(float v, int srcLane) { return __shfl(v, srcLane, 64); }
+
+/* The whole iteration loop, contacts only; every sub-group keeps one body for the launch (plan->rounds == 1). */
+__global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
+                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ unit, int W, int sleepSel)
+{
+    extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave J | S | accs | product lines | constants */
+    if (plan->bad) return;                                           /* the host queued the fallback launch behind this one */
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * kGrpWavesPerBlock + wv;
+    const int W2 = plan->waves[2], W1 = plan->waves[1], W0 = plan->waves[0];
+    if (w >= W2 + W1 + W0) return;
+    const int cls = w < W2 ? 2 : (w < W2 + W1 ? 1 : 0);              /* wave-uniform */
+    const int gw = 16 << cls, gl = lane & (gw - 1), gBase = lane & ~(gw - 1);
+    const unsigned long long gMask = (cls == 2 ? ~0ull : ((1ull << gw) - 1ull)) << gBase;
+    float* const J = reinterpret_cast<float*>(sGroups) + wv * kGrpWaveFloats;
+    float* const S = J + kResJFloats;
+    float* const Jg = J + gBase * 18;
+    float* const Sg = S + gBase * 3;
+    float* const accs = S + kGrpSSlots * kResRows + (gBase >> 4) * kGrpAccFloats;
+    float* const xch = accs + 32;
+    float* const lines = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gBase >> 4) * kGrpLineFloats;
+    float* const cst = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + 4 * kGrpLineFloats + (gBase >> 4) * kGrpConstFloats;
+    const int lineRows = kGrpLineRows << cls;
+
+    const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
+    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+    const float4* massPlane = B.plane(BP_MASS);
+    const float invDt2 = 1.0f / (P.dt * P.dt);
+
+    /* ---- the sub-group's body: everything that does not come from another wave of this launch ---- */
+    const int body = unit[w * 4 + (gBase >> 4)];
+    const bool valid = body >= 0;
+    int eBeg = 0, nEnt = 0;
+    if (valid) { eBeg = incStart[body]; nEnt = incStart[body + 1] - eBeg; }
+    const bool has = valid && gl < nEnt;
+    const int nRows = nEnt * 3;
+    int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
+    float oinv = 0.0f, fric = 0.0f;
+    ContactRows c;
+    c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
+    for (int k = 0; k < 3; ++k) { c.lambda[k] = 0.0f; c.penalty[k] = 0.0f; c.C[k] = 0.0f; c.fmin[k] = 0.0f; c.fmax[k] = 0.0f; }
+    f3 wOther = zero3(), pOther = zero3();
+    if (has) {
+        const int ent = inc[eBeg + gl];
+        idx = inc_index(ent); isA = inc_isA(ent) != 0;
+        const int2 pr = M.pair[idx >> 2];
+        other = isA ? pr.y : pr.x;
+        moving = B.solved[other] != 0;
+        owned = !moving || other > body;
+        oinv = massPlane[other].y;
+        fric = M.fric[idx >> 2];
+        load_contact<false>(M, idx, c);
+        const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose; constant for unswept partners */
+        wOther = qrotate(mkq(oq.x, oq.y, oq.z, oq.w), isA ? c.rB : c.rA);
+        pOther = mk3(op.x, op.y, op.z) + wOther;
+    }
+    const int offP = other * 48, offV = idx * 16, offD = idx * 32;
+    f3 pos = zero3(); q4 rot = identq(); float invMass = 0.0f, radius = 0.0f;
+    if (valid) {
+        const float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
+        pos = mk3(pp.x, pp.y, pp.z); rot = mkq(pq.x, pq.y, pq.z, pq.w); radius = pp.w;
+        invMass = massPlane[body].y;
+    }
+    if (valid && gl == 0) {                                          /* constants of the body that every task needs again */
+        const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
+        cst[0] = snp.x; cst[1] = snp.y; cst[2] = snp.z; cst[3] = smp.x;
+        cst[4] = snq.x; cst[5] = snq.y; cst[6] = snq.z; cst[7] = snq.w;
+        for (int k = 0; k < 3; ++k) {
+            const float4 ik = B.plane(BP_I0 + k)[body], jk = B.plane(BP_J0 + k)[body];
+            cst[8 + 3 * k] = ik.x; cst[9 + 3 * k] = ik.y; cst[10 + 3 * k] = ik.z;
+            cst[17 + 3 * k] = jk.x; cst[18 + 3 * k] = jk.y; cst[19 + 3 * k] = jk.z;
+        }
+    }
+    for (int r = lane; r < kResRows; r += 64) S[5 * kResRows + r] = 0.0f;
+    wave_sync();
+
+    /* ---- what the first half of a task leaves for the second ---- */
+    GAcc a0, a1;
+    f3 wOwn = zero3();
+    bool needP = false, needV = false, needD = false, okP = true, okV = true, okD = true;
+    unsigned sP = 0, sV = 0, sD = 0;
+    ContactPre pre; f3 G[3];
+    v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vv = p0, d0 = p0, d1 = p0;
+    pre.n = pre.t1 = pre.t2 = zero3(); pre.biasN = pre.biasT1 = pre.biasT2 = pre.cap = 0.0f;
+    G[0] = G[1] = G[2] = zero3();
+    a0.opA = a0.opB = 0; a0.mode = 3; a0.gy = -1; a0.acc = 0.0f; a1 = a0;
+
+#ifdef AVBD_DF_STATS
+    unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+#define GS_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)
+#else
+#define GS_STAMP(i) do { } while (0)
+#endif
+    int it = 0;                                                      /* the sub-group's next iteration (uniform over its lanes) */
+    const int itStop = totalIt;
+
+    auto prepare_task = [&]() __attribute__((always_inline)) {
+        const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const unsigned stampNow = X.base + (unsigned)it + 1u;
+        BodyLocal L;
+        L.pos = pos; L.rot = rot; L.invMass = invMass; L.invDt2 = invDt2;
+        {
+            L.npos = mk3(cst[0], cst[1], cst[2]); L.mass = cst[3]; L.nrot = mkq(cst[4], cst[5], cst[6], cst[7]);
+            const m33 Ib = mkm(mk3(cst[8], cst[9], cst[10]), mk3(cst[11], cst[12], cst[13]), mk3(cst[14], cst[15], cst[16]));
+            const m33 Jb = mkm(mk3(cst[17], cst[18], cst[19]), mk3(cst[20], cst[21], cst[22]), mk3(cst[23], cst[24], cst[25]));
+            world_inertia_group(gl, rot, Ib, Jb, xch, L.Iw, L.invIw);     /* rigid.cpp:51-59 */
+        }
+        GS_STAMP(10);
+        a0 = make_gacc(gl < 27 ? gl : 63, L);
+        a1 = make_gacc((cls == 0 && gl + 16 < 27) ? gl + 16 : 63, L);
+        wOwn = zero3();
+        needP = false; needV = false; needD = false; sP = 0; sV = 0; sD = 0;
+        if (has) {
+            wOwn = qrotate(rot, isA ? c.rA : c.rB);                    /* manifold.cpp:27 and :265 use the same product */
+            if (moving) {
+                if (owned) { replay_normal(c, fixedN); needV = true; sV = stampNow; needP = true; sP = stampNow; }
+                else if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
+            }
+            ContactBasis db;
+            contact_constraint_pre(c, alpha, isA ? invMass : oinv, isA ? oinv : invMass, pre, db);
+            f3 Jl[3], Ja[3];
+            contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
+            for (int k = 0; k < 3; ++k) {
+                G[k] = abs3(cross3(Ja[k], L.invIw * Ja[k]));          /* solver.cpp:393-397, to be scaled by |f| */
+                float* jr = J + (lane * 3 + k) * 6;
+                jr[0] = Jl[k].x; jr[1] = Jl[k].y; jr[2] = Jl[k].z; jr[3] = Ja[k].x; jr[4] = Ja[k].y; jr[5] = Ja[k].z;
+            }
+        }
+        okP = !needP; okV = !needV; okD = !needD;
+        wave_sync();
+        GS_STAMP(11);
+        grp_store_line(a0, Jg, lines + (gl < 27 ? gl : 0) * lineRows, nRows, lineRows);
+        if (cls == 0) grp_store_line(a1, Jg, lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows, nRows, lineRows);
+        wave_sync();
+    };
+
+    auto finish_task = [&]() __attribute__((always_inline)) {
+        const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const bool doDual = it < P.iterations;
+        const unsigned stampNow = X.base + (unsigned)it + 1u;
+        if (needP) {
+            const f3 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); const q4 orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
+            wOther = qrotate(orot, isA ? c.rB : c.rA);
+            pOther = opos + wOther;
+        }
+        if (needV) { c.lambda[1] = bitsf(vv.x); c.lambda[2] = bitsf(vv.y); c.stick = vv.z != 0; }
+        if (needD) {
+            c.lambda[0] = bitsf(d0.x); c.lambda[1] = bitsf(d0.y); c.lambda[2] = bitsf(d0.z);
+            c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
+            c.stick = (d1.w & 1u) != 0;
+        }
+        /* ---- primal visit (solver.cpp:344-409) ---- */
+        bool rowsOn = true;
+        if (has) {
+            const f3 pOwn = pos + wOwn;
+            contact_constraint_post(c, pre, isA ? pOwn : pOther, isA ? pOther : pOwn, fric);
+            if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xst(rV, offV, r); }
+            for (int k = 0; k < 3; ++k) {
+                const float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;     /* solver.cpp:379-381 with stiffness FLT_MAX, motor 0 */
+                const float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+                const f3 gyro = G[k] * fabsf(f);
+                const bool penOk = (c.penalty[k] > 0.0f) & (fabsf(c.penalty[k]) <= FLT_MAX);   /* solver.cpp:387 */
+                const int r = lane * 3 + k;
+                S[r] = f; S[kResRows + r] = c.penalty[k]; S[2 * kResRows + r] = gyro.x; S[3 * kResRows + r] = gyro.y; S[4 * kResRows + r] = gyro.z;
+                rowsOn &= penOk;
+            }
+        }
+        const bool allOn = (__ballot(rowsOn) & gMask) == gMask;
+        wave_sync();
+        GS_STAMP(7);
+        {
+            const float* l0 = lines + (gl < 27 ? gl : 0) * lineRows;
+            const float* l1 = lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows;
+            if (cls == 0) { if (allOn) grp_accumulate<true, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
+            else          { if (allOn) grp_accumulate<true, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
+        }
+        if (gl < 27) accs[gl] = a0.acc;
+        if (cls == 0 && gl + 16 < 27) accs[gl + 16] = a1.acc;
+        wave_sync();
+        GS_STAMP(8);
+        BodyLocal L; L.pos = pos; L.rot = rot;
+        f3 p; q4 q;
+        solve_pose(accs, xch, gl, L, p, q);
+        if (gl == 0) {
+            sanitize3(p, cntW, warn_key(1, it, body, 0), body, WK_POS);
+            sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);
+            const int o = body * 48;
+            v4u r0 = {fbits(p.x), fbits(p.y), fbits(p.z), stampNow}, r1 = {fbits(q.x), fbits(q.y), fbits(q.z), stampNow}, r2 = {fbits(q.w), 0u, 0u, stampNow};
+            xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
+        }
+        pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
+        rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
+        GS_STAMP(9);
+        /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
+        if (doDual && has && owned) {
+            const f3 wNew = qrotate(rot, isA ? c.rA : c.rB);
+            const f3 pNew = pos + wNew;
+            dual_contact_pts(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
+                             isA ? oinv : invMass, fric, P, alpha);
+            if (moving) {
+                v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
+                v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), (stampNow << 1) | (c.stick ? 1u : 0u)};
+                xst(rD, offD, r0); xst(rD, offD + 16, r1);
+            }
+        }
+        /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
+        if (it == itStop - 1) {
+            if (gl == 0) { B.plane(BP_POSR)[body] = pack3(pos, radius); B.plane(BP_QUAT)[body] = packq(rot); }
+            if (has && owned) store_contact_dual<false>(M, idx, c, true);
+        }
+    };
+
+    if (valid) prepare_task();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    GS_STAMP(3);
+    unsigned spins = 0;
+    for (;;) {
+        const bool active = valid && it < itStop;
+        if (__ballot(active) == 0) break;
+        /* ---- poll: the records ARE the payload (avbd_resident.h); only lanes that still miss something load ---- */
+        if (active) {
+            const bool lp = !okP, lv = !okV, ld = !okD;
+            if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
+            if (lv) vv = xld(rV, offV);
+            if (ld) { d0 = xld(rD, offD); d1 = xld(rD, offD + 16); }
+            asm volatile("" ::: "memory");
+            if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
+            if (lv) okV = stamp_reached(vv.w, sV);
+            if (ld) okD = stamp_reached(d0.w, sD) & stamp_reached(d1.w >> 1, sD);
+        }
+        const bool laneOk = !active || (okP & okV & okD);
+        const bool go = active && ((__ballot(laneOk) & gMask) == gMask);
+        GS_STAMP(0);
+#ifdef AVBD_DF_STATS
+        stat[14] += 1;
+        if (__ballot(go)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(go && gl == 0)); }
+#endif
+        if (go) {
+            finish_task();
+            ++it;
+        }
+        GS_STAMP(1);
+        if (go) {
+            if (it < itStop) prepare_task();
+            spins = 0;
+        }
+        GS_STAMP(2);
+        if (__ballot(go) == 0) {
+            if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
+            else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0) {
+                bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+                            __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+            }
+        }
+    }
+
+#ifdef AVBD_DF_STATS
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(errWord + 16) + (size_t)w * 16;
+        stat[6] = __builtin_amdgcn_s_memrealtime() - t0;
+        for (int i = 0; i < 16; ++i) o[i] = stat[i];
+    }
+#endif
+}
+
+} // namespace avbd

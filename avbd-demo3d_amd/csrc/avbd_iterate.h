@@ -113,8 +113,9 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
                                                               const int* __restrict__ adjStart, const int* __restrict__ adjRef,
                                                               const int* __restrict__ adjOther, const int* __restrict__ incStart,
                                                               const int* __restrict__ inc, SolverParams P, IterateState S, Counters* cntW, int sleepSel, int itBegin, int itEnd,
-                                                              ResidentExchange X)
+                                                              ResidentExchange X, const int* __restrict__ runIf)
 {
+    if (runIf && *runIf == 0) return;                              /* queued behind k_iterate_groups: runs only when that launch declined the step */
     __shared__ float sRows[kIterWaves][66 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
     extern __shared__ float4 sDynamic[];   /* latency mode: pins one workgroup per CU; the resident schedule keeps its product lines here */

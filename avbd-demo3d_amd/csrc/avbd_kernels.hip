@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
 } // namespace avbd
 #include "avbd_primal.h"
 #include "avbd_iterate.h"
+#include "avbd_groups.h"
 namespace avbd {
 static_assert(kResLiteMaxEntriesDecl == kResLiteMaxEntries, "the topology kernels and the resident schedule must agree on the short product lines");
 
