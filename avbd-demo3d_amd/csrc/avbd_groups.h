@@ -200,21 +200,27 @@ __device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* 
     const GAccView v0 = grp_view(a0, line0, Sg, Jg), v1 = grp_view(a1, line1, Sg, Jg);
     const int n = nRows < lineRows ? nRows : lineRows;
     float acc0 = a0.acc, acc1 = a1.acc;
+    /* whole blocks of four rows without predicates (the next block's operands are in flight while this one is added),
+     * then the last one to three rows */
+    const int nFull = n & ~3;
     float4 p0 = v0.p4[0], s0 = v0.s4[0], g0 = v0.g4[0], p1, s1, g1;
     if (TWO) { p1 = v1.p4[0]; s1 = v1.s4[0]; g1 = v1.g4[0]; }
-    for (int r4 = 0; r4 < n; r4 += 4) {
+    for (int r4 = 0; r4 < nFull; r4 += 4) {
         const float4 cp0 = p0, cs0 = s0, cg0 = g0, cp1 = p1, cs1 = s1, cg1 = g1;
-        if (r4 + 4 < n) {                                            /* the next block's operands are in flight while this one is added */
-            const int q = (r4 >> 2) + 1;
-            p0 = v0.p4[q]; s0 = v0.s4[q]; g0 = v0.g4[q];
-            if (TWO) { p1 = v1.p4[q]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
-        }
+        const int q = (r4 >> 2) + 1;                                 /* the block behind the last full one exists in the line and in S (never past the sub-group's rows + 3) */
+        p0 = v0.p4[q]; s0 = v0.s4[q]; g0 = v0.g4[q];
+        if (TWO) { p1 = v1.p4[q]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (r4 + k < n) {
-                acc0 = grp_add_row<ALLON>(acc0, comp4(cp0, k), comp4(cs0, k), comp4(cg0, k), v0);
-                if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(cp1, k), comp4(cs1, k), comp4(cg1, k), v1);
-            }
+            acc0 = grp_add_row<ALLON>(acc0, comp4(cp0, k), comp4(cs0, k), comp4(cg0, k), v0);
+            if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(cp1, k), comp4(cs1, k), comp4(cg1, k), v1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (nFull + k < n) {
+            acc0 = grp_add_row<ALLON>(acc0, comp4(p0, k), comp4(s0, k), comp4(g0, k), v0);
+            if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(p1, k), comp4(s1, k), comp4(g1, k), v1);
         }
     }
     /* rows past the line: multiplied here, from the Jacobians in LDS — same product, same bits */
@@ -376,8 +382,10 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         wave_sync();
         GS_STAMP(11);
         grp_store_line(a0, Jg, lines + (gl < 27 ? gl : 0) * lineRows, nRows, lineRows);
+        GS_STAMP(12);
         if (cls == 0) grp_store_line(a1, Jg, lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows, nRows, lineRows);
         wave_sync();
+        GS_STAMP(13);
     };
 
     auto finish_task = [&]() __attribute__((always_inline)) {
