@@ -248,19 +248,30 @@ __device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* 
 }
 
 __device__ __forceinline__ float grp_bcast(float v, int srcLane) { return __shfl(v, srcLane, 64); }
+/* the stamp word of a record alone (aux 16 = sc1, like xld) */
+__device__ __forceinline__ unsigned xldw(__amdgpu_buffer_rsrc_t r, int byteOff) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byteOff, 0, 16); }
 
-/* The whole iteration loop, contacts only; every sub-group keeps one body for the launch (plan->rounds == 1). */
+/* The whole iteration loop, contacts only.  A sub-group keeps ONE body for the launch when the plan has one round (state in
+ * registers from the first iteration to the last); with several rounds it runs whichever of its bodies has its inputs
+ * published (oldest iteration first) and parks a body's state between its tasks exactly like the resident schedule does
+ * (owned contacts in the Manifold tables, which only their owner writes; a first visitor's copy of normal + tangent memo
+ * and the pose in arrays private to the sub-group).  The sub-groups of a wave pick independently and the wave runs their
+ * picks together, so a wave that serves 4 x K bodies does several tasks per pass. */
+template <bool MULTI>
 __global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
                       Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ unit, int W, int sleepSel)
 {
     extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave J | S | accs | product lines | constants */
-    if (plan->bad) return;                                           /* the host queued the fallback launch behind this one */
+    /* the host queues k_iterate_groups<false>, <true> and the fallback launch one behind the other; the plan says which one runs */
+    if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * kGrpWavesPerBlock + wv;
     const int W2 = plan->waves[2], W1 = plan->waves[1], W0 = plan->waves[0];
     if (w >= W2 + W1 + W0) return;
     const int cls = w < W2 ? 2 : (w < W2 + W1 ? 1 : 0);              /* wave-uniform */
+    const int rounds = __builtin_amdgcn_readfirstlane(plan->rounds[cls]);
+    constexpr bool multi = MULTI;                                    /* (a class of a several-round plan may have one round: same code, state parked) */
     const int gw = 16 << cls, gl = lane & (gw - 1), gBase = lane & ~(gw - 1);
     const unsigned long long gMask = (cls == 2 ? ~0ull : ((1ull << gw) - 1ull)) << gBase;
     float* const J = reinterpret_cast<float*>(sGroups) + wv * kGrpWaveFloats;
@@ -274,56 +285,97 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     const int lineRows = kGrpLineRows << cls;
 
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
-    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+    const int itStop = P.iterations + (P.postStabilize ? 1 : 0);
     const float4* massPlane = B.plane(BP_MASS);
     const float invDt2 = 1.0f / (P.dt * P.dt);
 
-    /* ---- the sub-group's body: everything that does not come from another wave of this launch ---- */
-    const int body = unit[w * 4 + (gBase >> 4)];
-    const bool valid = body >= 0;
-    int eBeg = 0, nEnt = 0;
-    if (valid) { eBeg = incStart[body]; nEnt = incStart[body + 1] - eBeg; }
-    const bool has = valid && gl < nEnt;
-    const int nRows = nEnt * 3;
+    /* ---- the task in hand: body and iteration, uniform over the lanes of the sub-group ---- */
+    int it = 0;
+    int body = -1, eBeg = 0, nRows = 0;
+    bool valid = false, has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
     c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
     for (int k = 0; k < 3; ++k) { c.lambda[k] = 0.0f; c.penalty[k] = 0.0f; c.C[k] = 0.0f; c.fmin[k] = 0.0f; c.fmax[k] = 0.0f; }
     f3 wOther = zero3(), pOther = zero3();
-    if (has) {
-        const int ent = inc[eBeg + gl];
-        idx = inc_index(ent); isA = inc_isA(ent) != 0;
-        const int2 pr = M.pair[idx >> 2];
-        other = isA ? pr.y : pr.x;
-        moving = B.solved[other] != 0;
-        owned = !moving || other > body;
-        oinv = massPlane[other].y;
-        fric = M.fric[idx >> 2];
-        load_contact<false>(M, idx, c);
-        const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose; constant for unswept partners */
-        wOther = qrotate(mkq(oq.x, oq.y, oq.z, oq.w), isA ? c.rB : c.rA);
-        pOther = mk3(op.x, op.y, op.z) + wOther;
-    }
-    const int offP = other * 48, offV = idx * 16, offD = idx * 32;
+    int offP = 0, offV = 0, offD = 0;
     f3 pos = zero3(); q4 rot = identq(); float invMass = 0.0f, radius = 0.0f;
-    if (valid) {
-        const float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
-        pos = mk3(pp.x, pp.y, pp.z); rot = mkq(pq.x, pq.y, pq.z, pq.w); radius = pp.w;
-        invMass = massPlane[body].y;
-    }
-    if (valid && gl == 0) {                                          /* constants of the body that every task needs again */
-        const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
-        cst[0] = snp.x; cst[1] = snp.y; cst[2] = snp.z; cst[3] = smp.x;
-        cst[4] = snq.x; cst[5] = snq.y; cst[6] = snq.z; cst[7] = snq.w;
-        for (int k = 0; k < 3; ++k) {
-            const float4 ik = B.plane(BP_I0 + k)[body], jk = B.plane(BP_J0 + k)[body];
-            cst[8 + 3 * k] = ik.x; cst[9 + 3 * k] = ik.y; cst[10 + 3 * k] = ik.z;
-            cst[17 + 3 * k] = jk.x; cst[18 + 3 * k] = jk.y; cst[19 + 3 * k] = jk.z;
+
+    /* who the entries of a body are and whom they wait for: enough to tell whether a task can start.  `seen`: the body has been
+     * examined before in this launch, its partners are in X.probe (partner | moving << 24 | owned << 25). */
+    auto load_header = [&](int b, int e0, int ne, bool seen) __attribute__((always_inline)) {
+        body = b; valid = b >= 0; eBeg = e0;
+        has = valid && gl < ne;
+        nRows = ne * 3;
+        idx = 0; other = 0; isA = false; owned = false; moving = false;
+        if (has) {
+            const int ent = inc[e0 + gl];
+            idx = inc_index(ent); isA = inc_isA(ent) != 0;
+            if (seen) {
+                const int pw = X.probe[e0 + gl];
+                other = pw & 0xffffff; moving = (pw >> 24) & 1; owned = (pw >> 25) & 1;
+            } else {
+                const int2 pr = M.pair[idx >> 2];
+                other = isA ? pr.y : pr.x;
+                moving = B.solved[other] != 0;
+                owned = !moving || other > b;
+                if (multi) X.probe[e0 + gl] = other | ((moving ? 1 : 0) << 24) | ((owned ? 1 : 0) << 25);
+            }
         }
-    }
+        offP = other * 48; offV = idx * 16; offD = idx * 32;
+    };
+    /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
+     * wrote (first iteration), or what this sub-group parked after the body's previous task (several rounds, later iterations) */
+    auto load_rest = [&]() __attribute__((always_inline)) {
+        fixedN = false;
+        if (has) {
+            oinv = massPlane[other].y;
+            fric = M.fric[idx >> 2];
+            load_contact<false>(M, idx, c);                           /* owned contacts: also what this sub-group's last dual left there */
+            if (multi && it > 0 && !owned) {                          /* this visitor's own copy of the normal and its memo */
+                const float4 pn = X.privN[(size_t)(eBeg + gl) * 3], p1 = X.privN[(size_t)(eBeg + gl) * 3 + 1], p2 = X.privN[(size_t)(eBeg + gl) * 3 + 2];
+                c.normal = mk3(pn.x, pn.y, pn.z); c.u1 = mk3(p1.x, p1.y, p1.z); c.u2 = mk3(p2.x, p2.y, p2.z);
+            }
+            const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose; constant for unswept partners */
+            wOther = qrotate(mkq(oq.x, oq.y, oq.z, oq.w), isA ? c.rB : c.rA);
+            pOther = mk3(op.x, op.y, op.z) + wOther;
+        }
+        if (valid) {
+            float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
+            radius = pp.w;
+            if (multi && it > 0) { pp = X.privPose[(size_t)body * 2]; pq = X.privPose[(size_t)body * 2 + 1]; }
+            pos = mk3(pp.x, pp.y, pp.z); rot = mkq(pq.x, pq.y, pq.z, pq.w);
+            invMass = massPlane[body].y;
+        }
+        if (valid && gl == 0) {                                      /* constants of the body that every task needs again */
+            const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
+            cst[0] = snp.x; cst[1] = snp.y; cst[2] = snp.z; cst[3] = smp.x;
+            cst[4] = snq.x; cst[5] = snq.y; cst[6] = snq.z; cst[7] = snq.w;
+            for (int k = 0; k < 3; ++k) {
+                const float4 ik = B.plane(BP_I0 + k)[body], jk = B.plane(BP_J0 + k)[body];
+                cst[8 + 3 * k] = ik.x; cst[9 + 3 * k] = ik.y; cst[10 + 3 * k] = ik.z;
+                cst[17 + 3 * k] = jk.x; cst[18 + 3 * k] = jk.y; cst[19 + 3 * k] = jk.z;
+            }
+        }
+        wave_sync();
+    };
+    /* several rounds: park the body's state until its next task (its last task has written the step's final state already) */
+    auto park_body = [&]() __attribute__((always_inline)) {
+        if (has) {
+            int idxF = idx, slotF = eBeg + gl;
+            asm volatile("" : "+v"(idxF), "+v"(slotF));
+            if (owned) store_contact_dual<false>(M, idxF, c, false);
+            else {
+                X.privN[(size_t)slotF * 3] = make_float4(c.normal.x, c.normal.y, c.normal.z, 0.f);
+                X.privN[(size_t)slotF * 3 + 1] = make_float4(c.u1.x, c.u1.y, c.u1.z, 0.f);
+                X.privN[(size_t)slotF * 3 + 2] = make_float4(c.u2.x, c.u2.y, c.u2.z, 0.f);
+            }
+        }
+        if (gl == 0) { X.privPose[(size_t)body * 2] = pack3(pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(rot); }
+    };
+
     for (int r = lane; r < kResRows; r += 64) S[5 * kResRows + r] = 0.0f;
-    wave_sync();
 
     /* ---- what the first half of a task leaves for the second ---- */
     GAcc a0, a1;
@@ -331,7 +383,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     bool needP = false, needV = false, needD = false, okP = true, okV = true, okD = true;
     unsigned sP = 0, sV = 0, sD = 0;
     ContactPre pre; f3 G[3];
-    v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vv = p0, d0 = p0, d1 = p0;
+    v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vd = p0, d1 = p0;   /* vd: the visit record of an owned contact, or the first dual record of another one */
     pre.n = pre.t1 = pre.t2 = zero3(); pre.biasN = pre.biasT1 = pre.biasT2 = pre.cap = 0.0f;
     G[0] = G[1] = G[2] = zero3();
     a0.opA = a0.opB = 0; a0.mode = 3; a0.gy = -1; a0.acc = 0.0f; a1 = a0;
@@ -343,8 +395,6 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
 #else
 #define GS_STAMP(i) do { } while (0)
 #endif
-    int it = 0;                                                      /* the sub-group's next iteration (uniform over its lanes) */
-    const int itStop = totalIt;
 
     auto prepare_task = [&]() __attribute__((always_inline)) {
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
@@ -397,9 +447,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             wOther = qrotate(orot, isA ? c.rB : c.rA);
             pOther = opos + wOther;
         }
-        if (needV) { c.lambda[1] = bitsf(vv.x); c.lambda[2] = bitsf(vv.y); c.stick = vv.z != 0; }
+        if (needV) { c.lambda[1] = bitsf(vd.x); c.lambda[2] = bitsf(vd.y); c.stick = vd.z != 0; }
         if (needD) {
-            c.lambda[0] = bitsf(d0.x); c.lambda[1] = bitsf(d0.y); c.lambda[2] = bitsf(d0.z);
+            c.lambda[0] = bitsf(vd.x); c.lambda[1] = bitsf(vd.y); c.lambda[2] = bitsf(vd.z);
             c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
             c.stick = (d1.w & 1u) != 0;
         }
@@ -459,57 +509,150 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
         if (it == itStop - 1) {
-            if (gl == 0) { B.plane(BP_POSR)[body] = pack3(pos, radius); B.plane(BP_QUAT)[body] = packq(rot); }
-            if (has && owned) store_contact_dual<false>(M, idx, c, true);
+            /* (opaque copies of the indices: the nine table addresses of a contact are formed here, once, instead of living in
+             * registers through the whole loop) */
+            int bodyF = body, idxF = idx;
+            asm volatile("" : "+v"(bodyF), "+v"(idxF));
+            if (gl == 0) { B.plane(BP_POSR)[bodyF] = pack3(pos, radius); B.plane(BP_QUAT)[bodyF] = packq(rot); }
+            if (has && owned) store_contact_dual<false>(M, idxF, c, true);
         }
     };
 
-    if (valid) prepare_task();
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    GS_STAMP(3);
     unsigned spins = 0;
-    for (;;) {
-        const bool active = valid && it < itStop;
-        if (__ballot(active) == 0) break;
-        /* ---- poll: the records ARE the payload (avbd_resident.h); only lanes that still miss something load ---- */
-        if (active) {
-            const bool lp = !okP, lv = !okV, ld = !okD;
-            if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
-            if (lv) vv = xld(rV, offV);
-            if (ld) { d0 = xld(rD, offD); d1 = xld(rD, offD + 16); }
-            asm volatile("" ::: "memory");
-            if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
-            if (lv) okV = stamp_reached(vv.w, sV);
-            if (ld) okD = stamp_reached(d0.w, sD) & stamp_reached(d1.w >> 1, sD);
+    /* the poll of a prepared task: the records ARE the payload (avbd_resident.h); only lanes that still miss something load */
+    auto poll_records = [&]() __attribute__((always_inline)) {
+        const bool lp = !okP, lv = !okV, ld = !okD;
+        if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
+        if (lv) vd = xld(rV, offV);
+        if (ld) { vd = xld(rD, offD); d1 = xld(rD, offD + 16); }
+        asm volatile("" ::: "memory");
+        if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
+        if (lv) okV = stamp_reached(vd.w, sV);
+        if (ld) okD = stamp_reached(vd.w, sD) & stamp_reached(d1.w >> 1, sD);
+    };
+    auto back_off = [&]() __attribute__((always_inline)) -> bool {     /* false: the launch is being abandoned */
+        if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
+        else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 1023u) == 0) {
+            bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+                        __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }
-        const bool laneOk = !active || (okP & okV & okD);
-        const bool go = active && ((__ballot(laneOk) & gMask) == gMask);
-        GS_STAMP(0);
+        return true;
+    };
+
+    if constexpr (!MULTI) {
+        /* ---- one body per sub-group for the whole launch ---- */
+        {
+            const int b = unit[w * 4 + (gBase >> 4)];
+            int e0 = 0, ne = 0;
+            if (b >= 0) { e0 = incStart[b]; ne = incStart[b + 1] - e0; }
+            load_header(b, e0, ne, false);
+            load_rest();
+        }
+        if (valid) prepare_task();
+        GS_STAMP(3);
+        for (;;) {
+            const bool active = valid && it < itStop;
+            if (__ballot(active) == 0) break;
+            if (active) poll_records();
+            const bool laneOk = !active || (okP & okV & okD);
+            const bool go = active && ((__ballot(laneOk) & gMask) == gMask);
+            GS_STAMP(0);
 #ifdef AVBD_DF_STATS
-        stat[14] += 1;
-        if (__ballot(go)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(go && gl == 0)); }
+            stat[14] += 1;
+            if (__ballot(go)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(go && gl == 0)); }
 #endif
-        if (go) {
-            finish_task();
-            ++it;
-        }
-        GS_STAMP(1);
-        if (go) {
-            if (it < itStop) prepare_task();
-            spins = 0;
-        }
-        GS_STAMP(2);
-        if (__ballot(go) == 0) {
-            if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
-            else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
-            if ((++spins & 1023u) == 0) {
-                bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
-                            __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+            if (go) {
+                finish_task();
+                ++it;
             }
+            GS_STAMP(1);
+            if (go) {
+                if (it < itStop) prepare_task();
+                spins = 0;
+            }
+            GS_STAMP(2);
+            if (__ballot(go) == 0 && !back_off()) return;
+        }
+    } else {
+        /* ---- several bodies per sub-group, out of order: a sub-group runs whichever of its bodies has its inputs published —
+         * the dependencies between tasks are carried by the stamped records alone, so any order that respects them gives the
+         * same bits — oldest iteration first, so the head of the in-order list (which is what the rest of the launch may be
+         * waiting for) is never passed over once it is ready.  Lane k of a sub-group keeps the bookkeeping of its k-th body: the
+         * next iteration and ONE record to watch (the input that was missing when the body was last examined); a body is
+         * examined in full only when that record has arrived.  Every pass of the wave runs the picks of all its sub-groups
+         * together. ---- */
+        int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1, seenK = 0;
+        unsigned blkStamp = 0;
+        if (gl < rounds) {
+            bodyK = unit[(gl * W + w) * 4 + (gBase >> 4)];
+            if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
+        }
+        GS_STAMP(3);
+        for (;;) {
+            const bool activeK = itK < itStop;
+            if (__ballot(activeK) == 0) break;
+            bool candK = activeK;
+            if (activeK && blkOff >= 0) { const unsigned st = xldw(rP, blkOff); candK = stamp_reached(st, blkStamp); }
+            bool sel = false;
+            for (;;) {
+                int key = candK ? ((itK << 6) | gl) : 0x7fffffff;
+                for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
+                const bool examine = !sel && key != 0x7fffffff;        /* uniform over the sub-group */
+                if (__ballot(examine) == 0) break;
+                if (examine) {
+                    const int k = gBase + (key & 63), t = key >> 6;
+                    load_header(__shfl(bodyK, k, 64), __shfl(eBegK, k, 64), __shfl(nEntK, k, 64), __shfl(seenK, k, 64) != 0);
+                    if (lane == k) seenK = 1;
+                    /* every moving partner's pose of the iteration this visit reads: published?  (The visit / dual records of the
+                     * same producer task follow its pose within the task; the poll before finish_task waits for those.) */
+                    unsigned need = 0; bool wants = false;
+                    if (has && moving) {
+                        if (owned) { wants = true; need = X.base + (unsigned)t + 1u; }
+                        else if (t > 0) { wants = true; need = X.base + (unsigned)t; }
+                    }
+                    bool got = true;
+                    if (wants) got = stamp_reached(xldw(rP, offP + 44), need);
+                    const unsigned long long missing = __ballot(!got) & gMask;
+                    if (missing == 0) {
+                        sel = true; it = t;
+                        if (lane == k) { ++itK; ++blkStamp; }                /* the same partner is the likeliest to be late again */
+                    } else {
+                        const int f = __ffsll((long long)missing) - 1;
+                        const int bo = __shfl(offP + 44, f, 64);
+                        const unsigned bs = (unsigned)__shfl((int)need, f, 64);
+                        if (lane == k) { blkOff = bo; blkStamp = bs; candK = false; }
+                    }
+                }
+            }
+            GS_STAMP(0);
+#ifdef AVBD_DF_STATS
+            stat[14] += 1;
+            if (__ballot(sel)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(sel && gl == 0)); }
+#endif
+            if (sel) {
+                load_rest();
+                prepare_task();
+            }
+            GS_STAMP(2);
+            /* the records that follow the poses within their producers' tasks */
+            for (;;) {
+                if (sel) poll_records();
+                const bool laneOk = !sel || (okP & okV & okD);
+                if (__ballot(laneOk) == ~0ull) break;
+                if (!back_off()) return;
+            }
+            if (sel) {
+                finish_task();
+                if (it < itStop - 1) park_body();
+                spins = 0;
+            }
+            GS_STAMP(1);
+            if (__ballot(sel) == 0 && !back_off()) return;
         }
     }
-
 #ifdef AVBD_DF_STATS
     if (lane == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(errWord + 16) + (size_t)w * 16;

@@ -97,3 +97,45 @@ def test_declined_on_device_runs_the_launch_behind_it(monkeypatch):
     assert _sched(g) != 4
     assert _plate_entries(o) > 64
     H.assert_same_world(o, g, "plate with more than 64 entries (declined)")
+
+
+@pytest.mark.parametrize("scene,steps,waves", [("Pyramid", 40, 8), ("Pyramid", 40, 1), ("Wall", 30, 5), ("Stress1000", 170, 64), ("Stress1000", 160, 20)])
+def test_several_bodies_per_sub_group(monkeypatch, scene, steps, waves):
+    """Fewer sub-groups than bodies (AVBD_GROUPS_WAVES limits the waves the plan may use, AVBD_GROUPS_ROUNDS allows several
+    bodies per sub-group): a sub-group runs whichever of its bodies is ready and parks their state between tasks; the sub-groups
+    of a wave pick independently."""
+    monkeypatch.setenv("AVBD_GROUPS", "1")
+    monkeypatch.setenv("AVBD_GROUPS_ROUNDS", "16")
+    monkeypatch.setenv("AVBD_GROUPS_WAVES", str(waves))
+    o = H.CpuWorld("orc"); o.scene(scene); o.step(steps)
+    g = H.HipWorld(); g.scene(scene); g.step(steps)
+    assert _sched(g) == 4
+    H.assert_same_world(o, g, f"{scene} step {steps} with {waves} waves (groups, several rounds)")
+    o.step(5); g.step(5)
+    H.assert_same_world(o, g, f"{scene} step {steps + 5} with {waves} waves (groups, several rounds)")
+
+
+@pytest.mark.parametrize("post,iters", [(1, 4), (0, 1)])
+def test_several_rounds_post_stabilize(monkeypatch, post, iters):
+    monkeypatch.setenv("AVBD_GROUPS", "1")
+    monkeypatch.setenv("AVBD_GROUPS_ROUNDS", "16")
+    monkeypatch.setenv("AVBD_GROUPS_WAVES", "6")
+    o = H.CpuWorld("orc"); o.scene("Packed:6"); o.set_params(postStabilize=post, iterations=iters)
+    g = H.HipWorld(); g.scene("Packed:6"); g.set_params(postStabilize=post, iterations=iters)
+    o.step(12); g.step(12)
+    assert _sched(g) == 4
+    H.assert_same_world(o, g, f"Packed:6 postStabilize={post} iterations={iters} (groups, 6 waves)")
+
+
+def test_wide_bodies_with_several_rounds(monkeypatch):
+    """Three classes at once and more bodies than sub-groups: 2 waves for a plate (> 32 entries) and nine cubes."""
+    monkeypatch.setenv("AVBD_GROUPS", "1")
+    monkeypatch.setenv("AVBD_GROUPS_ROUNDS", "16")
+    monkeypatch.setenv("AVBD_GROUPS_WAVES", "2")
+    o = H.CpuWorld("orc"); g = H.HipWorld()
+    for w in (o, g):
+        _plate_scene(w, 3)
+    for s in range(25):
+        o.step(); g.step()
+        H.assert_same_world(o, g, f"plate with 3x3 cubes on 2 waves, step {s + 1} (groups)")
+    assert _sched(g) == 4
