@@ -1637,6 +1637,19 @@ int avbd_download_forces(AvbdContext* c, AvbdForce* out, int capacity)
     return n;
 }
 
+int avbd_download_force(AvbdContext* c, int list_index, AvbdForce* out)
+{
+    if (!c || !out || list_index < 0) return AVBD_E_INVALID;
+    const int n = avbd_num_forces(c);
+    if (n < 0) return n;
+    if (list_index >= n) return c->fail(AVBD_E_INVALID, "avbd_download_force: index out of range");
+    std::vector<AvbdForce> all((size_t)list_index + 1);
+    const int rc = avbd_download_forces(c, all.data(), list_index + 1);
+    if (rc < 0) return rc;
+    *out = all[(size_t)list_index];
+    return AVBD_OK;
+}
+
 int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
 {
     if (!c || (!in && n > 0) || n < 0) return AVBD_E_INVALID;

@@ -204,5 +204,6 @@ private:
     void releaseMirrors();
     void pushParams();
     void pushEditedBodies();
+    void refreshMirror(Force* f, const AvbdForce& record);
     void fail(const char* what, int rc) const;
 };

@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 int Rigid::next_id = 1; /* never reset, like rigid.cpp:10 */
@@ -125,14 +127,21 @@ static void unlinkForce(Force* f)
 Force::~Force()
 {
     Solver* s = solver;
+    /* (the stored kind, not isManifold(): inside a base-class destructor the virtual call resolves to Force::isManifold) */
+    const bool manifold = deviceKind == AVBD_FORCE_MANIFOLD;
     if (!s->impl->clearing && !s->impl->syncing && deviceKind != -2) {
         auto& v = s->impl->userForces;
         size_t k = v.size();
-        if (!isManifold()) for (size_t i = 0; i < v.size(); ++i) if (v[i] == this) { k = i; break; }
+        if (!manifold) for (size_t i = 0; i < v.size(); ++i) if (v[i] == this) { k = i; break; }
         const bool userOnDevice = k < s->impl->flushedForces;
-        if (userOnDevice || (isManifold() && listIndex >= 0)) {
+        if (manifold) {
+            /* whatever happens below, syncForces() must never see this pointer again */
+            auto& mm = s->impl->manifolds;
+            for (size_t i = 0; i < mm.size(); ++i) if ((Force*)mm[i] == this) { mm.erase(mm.begin() + (long)i); break; }
+        }
+        if (userOnDevice || (manifold && listIndex >= 0)) {
             /* `delete force` of a force that lives on the device (force.cpp:31-69): rebuilt without it */
-            if (listIndex < 0) s->syncForces();
+            if (listIndex < 0) s->syncForces();                         /* (a user force: positions of the device list) */
             int rc = avbd_remove_force(s->ctx, listIndex);
             if (rc) s->fail("avbd_remove_force", rc);
             if (userOnDevice) --s->impl->flushedForces;
@@ -140,21 +149,23 @@ Force::~Force()
             for (Manifold* m : s->impl->manifolds) m->listIndex = -1;
         }
         if (k < v.size()) v.erase(v.begin() + (long)k);
-        if (isManifold()) {
-            auto& mm = s->impl->manifolds;
-            for (size_t i = 0; i < mm.size(); ++i) if ((Force*)mm[i] == this) { mm.erase(mm.begin() + (long)i); break; }
-        }
     }
     unlinkForce(this);
 }
 
 void Force::deviceComputeConstraint(float alpha)
 {
-    solver->flush();
-    if (listIndex < 0) solver->syncForces();
-    int rc = avbd_force_compute_constraint(solver->ctx, listIndex, alpha, C, fmin, fmax, lambda);
-    if (rc) solver->fail("avbd_force_compute_constraint", rc);
-    solver->syncForces(); /* pick up the reference's in-place mutations (normal, stick, cone-clamped lambda) */
+    Solver* s = solver;
+    s->flush();
+    if (listIndex < 0) s->syncForces();           /* mirrors are matched and updated IN PLACE: `this` survives */
+    if (listIndex < 0) s->fail("computeConstraint on a force that no longer exists on the device", AVBD_E_INVALID);
+    int rc = avbd_force_compute_constraint(s->ctx, listIndex, alpha, C, fmin, fmax, lambda);
+    if (rc) s->fail("avbd_force_compute_constraint", rc);
+    /* the reference's in-place mutations (manifold.cpp:185-186, 224-231, 241, 243: normal, cone-clamped lambda, stick,
+     * penetration) come back through this one record; no mirror is created or destroyed here */
+    AvbdForce r;
+    if ((rc = avbd_download_force(s->ctx, listIndex, &r))) s->fail("avbd_download_force", rc);
+    s->refreshMirror(this, r);
 }
 
 void Force::deviceComputeDerivatives(vec3& Jl, vec3& Ja, const Rigid* body, int row) const
@@ -517,6 +528,25 @@ void Solver::step()                                                        /* so
     }
 }
 
+void Solver::refreshMirror(Force* f, const AvbdForce& r)
+{
+    if (r.kind == AVBD_FORCE_MANIFOLD) {
+        Manifold* m = static_cast<Manifold*>(f);
+        m->numContacts = r.numContacts; m->combinedFriction = r.combinedFriction;
+        for (int c = 0; c < r.numContacts; ++c) {
+            const AvbdContact& s = r.contacts[c];
+            Manifold::Contact& d = m->contacts[c];
+            d.feature.value = s.feature; d.rA = vec3(s.rA[0], s.rA[1], s.rA[2]); d.rB = vec3(s.rB[0], s.rB[1], s.rB[2]);
+            d.normal = vec3(s.normal[0], s.normal[1], s.normal[2]); d.penetration = s.penetration; d.C0_n = s.C0_n;
+            d.C0_t = vec3(s.C0_t[0], s.C0_t[1], s.C0_t[2]); d.stick = s.stick != 0;
+        }
+    }
+    for (int k = 0; k < MAX_CONSTRAINT_ROWS; ++k) {
+        f->C[k] = r.C[k]; f->fmin[k] = r.fmin[k]; f->fmax[k] = r.fmax[k]; f->lambda[k] = r.lambda[k];
+        f->penalty[k] = r.penalty[k]; f->motor[k] = r.motor[k]; f->stiffness[k] = r.stiffness[k];
+    }
+}
+
 void Solver::syncForces()
 {
     flush();
@@ -527,10 +557,11 @@ void Solver::syncForces()
         int rc = avbd_download_forces(ctx, rec.data(), n);
         if (rc < 0) fail("avbd_download_forces", rc);
     }
-    /* drop the old manifold mirrors and every list link, then rebuild oldest → newest with head insertion */
-    impl->syncing = true;
-    for (Manifold* m : impl->manifolds) delete m;
-    impl->syncing = false;
+    /* Manifold mirrors are matched by their pair of bodies and UPDATED IN PLACE (a pointer the caller holds stays valid as
+     * long as the manifold exists on the device, like in the reference, where step() deletes only separated manifolds);
+     * every list link is rebuilt oldest -> newest with head insertion; mirrors of manifolds that are gone are deleted. */
+    std::map<std::pair<const Rigid*, const Rigid*>, Manifold*> old;
+    for (Manifold* m : impl->manifolds) old[std::make_pair((const Rigid*)m->bodyA, (const Rigid*)m->bodyB)] = m;
     impl->manifolds.clear();
     forces = nullptr;
     for (Rigid* b : impl->byIndex) b->forces = nullptr;
@@ -539,14 +570,17 @@ void Solver::syncForces()
         const AvbdForce& r = rec[(size_t)i];
         Force* f = nullptr;
         if (r.kind == AVBD_FORCE_MANIFOLD) {
-            Manifold* m = new Manifold(this, bodyByIndex(r.bodyA), bodyByIndex(r.bodyB));
-            m->numContacts = r.numContacts; m->combinedFriction = r.combinedFriction;
-            for (int c = 0; c < r.numContacts; ++c) {
-                const AvbdContact& s = r.contacts[c];
-                Manifold::Contact& d = m->contacts[c];
-                d.feature.value = s.feature; d.rA = vec3(s.rA[0], s.rA[1], s.rA[2]); d.rB = vec3(s.rB[0], s.rB[1], s.rB[2]);
-                d.normal = vec3(s.normal[0], s.normal[1], s.normal[2]); d.penetration = s.penetration; d.C0_n = s.C0_n;
-                d.C0_t = vec3(s.C0_t[0], s.C0_t[1], s.C0_t[2]); d.stick = s.stick != 0;
+            Rigid* a = bodyByIndex(r.bodyA); Rigid* b = bodyByIndex(r.bodyB);
+            auto it = old.find(std::make_pair((const Rigid*)a, (const Rigid*)b));
+            Manifold* m;
+            if (it != old.end()) {
+                m = it->second; old.erase(it);
+                m->next = forces; forces = m;
+                m->nextA = nullptr; m->nextB = nullptr;
+                if (a) { m->nextA = a->forces; a->forces = m; }
+                if (b) { m->nextB = b->forces; b->forces = m; }
+            } else {
+                m = new Manifold(this, a, b);                             /* the constructor links it at the three list heads */
             }
             impl->manifolds.push_back(m);
             f = m;
@@ -557,15 +591,16 @@ void Solver::syncForces()
             f = impl->userForces[k];
             --userLeft;
             f->next = forces; forces = f;
+            f->nextA = nullptr; f->nextB = nullptr;
             if (f->bodyA) { f->nextA = f->bodyA->forces; f->bodyA->forces = f; }
             if (f->bodyB) { f->nextB = f->bodyB->forces; f->bodyB->forces = f; }
         }
         f->listIndex = i;
-        for (int k = 0; k < MAX_CONSTRAINT_ROWS; ++k) {
-            f->C[k] = r.C[k]; f->fmin[k] = r.fmin[k]; f->fmax[k] = r.fmax[k]; f->lambda[k] = r.lambda[k];
-            f->penalty[k] = r.penalty[k]; f->motor[k] = r.motor[k]; f->stiffness[k] = r.stiffness[k];
-        }
+        refreshMirror(f, r);
     }
+    impl->syncing = true;                                                  /* ~Force: no device call, nothing left to unlink */
+    for (auto& kv : old) delete kv.second;
+    impl->syncing = false;
 }
 
 /* ------------------------------------------------------------------ C ABI glue ------------ */

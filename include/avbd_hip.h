@@ -189,6 +189,8 @@ int  avbd_upload_bodies(AvbdContext* ctx, const AvbdBody* in, int n_bodies);
 /* ---- force list in the reference's solver-list order: newest first (force.cpp:16-18) ---- */
 int  avbd_num_forces(AvbdContext* ctx);
 int  avbd_download_forces(AvbdContext* ctx, AvbdForce* out, int capacity);
+/* one record of that list (what a host mirror of Force reads back after a row-API call: solver.h:85-109 members) */
+int  avbd_download_force(AvbdContext* ctx, int list_index, AvbdForce* out);
 /* replace every force by `n` records given newest first (snapshot restore / teacher forcing) */
 int  avbd_upload_forces(AvbdContext* ctx, const AvbdForce* in, int n);
 

@@ -151,6 +151,29 @@ void orc_set_forces(void* h, const HarnessForce* in, int n)
 
 void orc_set_step_index(void* h, int s) { ((World*)h)->stepIndex = s; }
 
+/* row API (solver.h:102-108) on the list_index-th force of the solver list, newest first — same entry points as ref_shim.cpp */
+int orc_force_compute_constraint(void* h, int list_index, float alpha)
+{
+    World* w = (World*)h;
+    const int n = (int)w->forceList.size();
+    if (list_index < 0 || list_index >= n) return -1;
+    Force& f = w->pool[w->forceList[(size_t)(n - 1 - list_index)]];
+    w->computeConstraint(f, alpha);
+    return w->rowCount(f);
+}
+
+int orc_force_compute_derivatives(void* h, int list_index, int body, int row, float* Jl, float* Ja)
+{
+    World* w = (World*)h;
+    const int n = (int)w->forceList.size();
+    if (list_index < 0 || list_index >= n) return -1;
+    const Force& f = w->pool[w->forceList[(size_t)(n - 1 - list_index)]];
+    V3 jl, ja;
+    w->computeDerivatives(f, jl, ja, body, row);
+    Jl[0] = jl.x; Jl[1] = jl.y; Jl[2] = jl.z; Ja[0] = ja.x; Ja[1] = ja.y; Ja[2] = ja.z;
+    return 0;
+}
+
 void orc_get_diag(void* h, HarnessDiag* d)
 {
     const Diag& s = ((World*)h)->last;

@@ -232,6 +232,32 @@ void ref_get_forces(void* h, HarnessForce* out)
     }
 }
 
+/* The row API of the reference called through its own virtuals (solver.h:102-108) on the list_index-th force of the
+ * solver list (newest first).  computeConstraint mutates the force in place exactly as inside Solver::step(); the caller
+ * reads the result back with ref_get_forces. */
+int ref_force_compute_constraint(void* h, int list_index, float alpha)
+{
+    RefWorld* w = (RefWorld*)h;
+    int k = 0;
+    for (Force* f = w->solver->forces; f; f = f->next, ++k)
+        if (k == list_index) { f->computeConstraint(alpha); return f->getRowCount(); }
+    return -1;
+}
+
+int ref_force_compute_derivatives(void* h, int list_index, int body, int row, float* Jl, float* Ja)
+{
+    RefWorld* w = (RefWorld*)h;
+    int k = 0;
+    for (Force* f = w->solver->forces; f; f = f->next, ++k)
+        if (k == list_index) {
+            vec3 jl, ja;
+            f->computeDerivatives(jl, ja, (body >= 0 && body < (int)w->bodies.size()) ? w->bodies[(size_t)body] : nullptr, row);
+            put3(Jl, jl); put3(Ja, ja);
+            return 0;
+        }
+    return -1;
+}
+
 void ref_get_diag(void* h, HarnessDiag* d)
 {
     const Solver::Diagnostics& s = ((RefWorld*)h)->solver->lastDiagnostics;

@@ -22,6 +22,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import harness as H  # noqa: E402
+from harness import build_row_api_scene  # noqa: E402
 
 REF_CLI = os.path.join(H.ORACLE_DIR, "_ref", "avbd_ref")
 
@@ -57,6 +58,25 @@ def main():
         if s + 1 == 140:
             np.savez_compressed(os.path.join(HERE, "stress1000_snapshot_step140.npz"), bodies=w.bodies(), forces=w.forces())
     np.savez_compressed(os.path.join(HERE, "stress1000_states.npz"), **states)
+    # 2b. row API through the reference's own virtuals (solver.h:102-108): Force::computeConstraint(alpha) on every force of a
+    #     snapshot (with its in-place mutations), then computeDerivatives for both endpoints and every row
+    rows = {}
+    for tag, scene, steps, alpha in (("pyramid", "Pyramid", 40, 0.95), ("jointed", "@jointed", 2, 0.3), ("stack", "Stack", 25, 1.0)):
+        r = H.CpuWorld("ref"); build_row_api_scene(r, scene); r.step(steps)
+        before_b, before_f = r.bodies(), r.forces()
+        nf = len(before_f)
+        derivs = np.zeros((nf, 2, 12, 6), np.float32)
+        for i in range(nf):
+            nrow = r.force_compute_constraint(i, alpha)
+            assert nrow == int(before_f["rows"][i])
+            for e, body in enumerate((int(before_f["bodyA"][i]), int(before_f["bodyB"][i]))):
+                for row in range(nrow):
+                    jl, ja = r.force_compute_derivatives(i, body, row)
+                    derivs[i, e, row, :3] = jl; derivs[i, e, row, 3:] = ja
+        rows[f"{tag}_bodies"] = before_b; rows[f"{tag}_forces"] = before_f; rows[f"{tag}_after"] = r.forces()
+        rows[f"{tag}_derivs"] = derivs; rows[f"{tag}_alpha"] = np.float32(alpha); rows[f"{tag}_steps"] = np.int32(steps)
+    np.savez_compressed(os.path.join(HERE, "row_api_vectors.npz"), **rows)
+
     np.save(os.path.join(HERE, "stress1000_diag_600.npy"), diags)
     meta["stress1000"] = {"first_contact_step": int(np.argmax(diags["activeContacts"] > 0)) + 1,
                           "step600": {k: (float(diags[599][k]) if diags[599][k].dtype.kind == "f" else int(diags[599][k])) for k in H.DIAG_DT.names}}

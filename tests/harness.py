@@ -85,7 +85,7 @@ def load(prefix):
               "set_diag_logging", "print_step", "solve3", "solve6", "world_inertia"):
         g(n).restype = None
     for n in ("scene", "add_body", "add_joint", "add_spring", "add_ignore", "num_bodies", "num_forces",
-              "step_index", "collide", "pick"):
+              "step_index", "collide", "pick", "force_compute_constraint", "force_compute_derivatives"):
         g(n).restype = C.c_int
     _libs[prefix] = lib
     return lib
@@ -136,6 +136,16 @@ class CpuWorld:
 
     def add_spring(self, a, b, rA, rB, stiffness, rest=-1.0):
         return self._c("add_spring")(self.h, a, b, _f(rA), _f(rB), C.c_float(stiffness), C.c_float(rest))
+
+    def force_compute_constraint(self, i, alpha):
+        """Force::computeConstraint(alpha) of the i-th force (newest first); mutates it in place, returns its row count."""
+        return self._c("force_compute_constraint")(self.h, int(i), C.c_float(alpha))
+
+    def force_compute_derivatives(self, i, body, row):
+        Jl, Ja = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        r = self._c("force_compute_derivatives")(self.h, int(i), int(body), int(row), _f(Jl), _f(Ja))
+        assert r == 0
+        return Jl, Ja
 
     def pick(self, origin, direction):
         """Solver::pick → (creation index or -1, local hit point)."""
@@ -247,6 +257,23 @@ def random_pile(world, rng, n, spread=2.0, height=6.0, ground=True, size_range=(
 # --------------------------------------------------------------------------------------------
 # product side: the HIP library through its C ABI (avbd-demo3d_amd/__init__.py is the ctypes binding)
 # --------------------------------------------------------------------------------------------
+def build_row_api_scene(w, scene):
+    """Scenes of the row-API golden vectors (tests/golden/row_api_vectors.npz): a reference scene by name, or "@jointed":
+    ground + four cubes with a body-body weld, a world-anchored joint with finite angular stiffness, a spring and two
+    touching cubes, so that every force kind has rows."""
+    if scene != "@jointed":
+        w.scene(scene)
+        return
+    w.scene("Ground")
+    a = w.add_body((1, 1, 1), 1.0, 0.5, (0.0, 0.5, 0.0), quat=(0.0, 0.1, 0.0, 0.99498744))
+    b = w.add_body((1, 0.5, 1), 2.0, 0.4, (1.1, 0.8, 0.1))
+    c = w.add_body((0.6, 0.6, 0.6), 1.0, 0.6, (-1.4, 2.0, 0.3), lin=(0.2, 0.0, -0.1))
+    d = w.add_body((0.8, 0.8, 0.8), 1.0, 0.5, (0.1, 1.4, 0.05))
+    w.add_joint(a, b, (0.5, 0.0, 0.0), (-0.6, 0.0, 0.0))
+    w.add_joint(-1, c, (-1.4, 2.4, 0.3), ang_stiff=500.0)
+    w.add_spring(c, d, (0.0, -0.3, 0.0), (0.0, 0.4, 0.0), 800.0)
+
+
 def load_product():
     import importlib.util
     import sys

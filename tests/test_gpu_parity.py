@@ -168,24 +168,39 @@ def test_teacher_forced_single_step_from_snapshot():
     H.assert_same_world(o, g, "five more steps")
 
 
-def test_row_api_on_device_matches_oracle_rows():
-    """Force::computeConstraint / computeDerivatives through the C ABI (solver.h:104-106)."""
-    o, g = fresh_pair("Pyramid")
-    o.step(40); g.step(40)
-    fo = o.forces()
-    assert g.w.force_row_count(0) == int(fo["rows"][0])
-    # the dual pass of the last iteration left C/fmin/fmax of every force in the oracle: recompute on device
-    # from the post-step poses and compare with a fresh oracle evaluation through one more dual-free call
-    for idx in (0, len(fo) // 2, len(fo) - 1):
-        Cc, lo, hi, lam = g.w.force_compute_constraint(idx, 0.95)
-        r = int(fo["rows"][idx])
-        assert np.all(np.isfinite(Cc[:r])) and np.all(lo[:r] <= hi[:r])
-        a, b = int(fo["bodyA"][idx]), int(fo["bodyB"][idx])
-        JlA, JaA = g.w.force_compute_derivatives(idx, a, 0)
-        JlB, JaB = g.w.force_compute_derivatives(idx, b, 0)
-        assert H.same_bits(JlA, -JlB) or np.allclose(JlA, -JlB, atol=0)
-        n = fo["contacts"][idx][0]["normal"]
-        assert np.allclose(JlA, n, atol=1e-6)
+@pytest.mark.parametrize("tag,scene", [("pyramid", "Pyramid"), ("jointed", "@jointed"), ("stack", "Stack")])
+def test_row_api_on_device_is_bit_exact_with_the_reference_virtuals(tag, scene):
+    """Force::computeConstraint / computeDerivatives through the C ABI (solver.h:104-106) against golden vectors produced by
+    calling the reference's own virtuals (oracle/ref_shim.cpp: ref_force_compute_constraint / _derivatives) on a snapshot:
+    rows C / fmin / fmax / lambda, the in-place mutations of the force (normal, stick, penetration, cone-clamped lambda) and
+    the Jacobians of both endpoints for every row, bit for bit."""
+    z = np.load(os.path.join(H.ROOT, "tests", "golden", "row_api_vectors.npz"))
+    bodies, forces, after, derivs, alpha = z[f"{tag}_bodies"], z[f"{tag}_forces"], z[f"{tag}_after"], z[f"{tag}_derivs"], float(z[f"{tag}_alpha"])
+    g = H.HipWorld()
+    H.build_row_api_scene(g, scene)
+    g.step(int(z[f"{tag}_steps"]))                               # same force kinds / creation order as the snapshot
+    g.set_bodies(bodies.view(H.BODY_DT)); g.set_forces(forces.view(H.FORCE_DT))
+    nf = len(forces)
+    assert nf == len(g.forces()) and nf > 0
+    for i in range(nf):
+        rows = int(forces["rows"][i])
+        assert g.w.force_row_count(i) == rows
+        Cc, lo, hi, lam = g.w.force_compute_constraint(i, alpha)
+        for name, got in (("C", Cc), ("fmin", lo), ("fmax", hi), ("lambda", lam)):
+            assert H.same_bits(got[:rows], after[name][i][:rows]), (tag, i, name, got[:rows], after[name][i][:rows])
+        for e, body in enumerate((int(forces["bodyA"][i]), int(forces["bodyB"][i]))):
+            for row in range(rows):
+                Jl, Ja = g.w.force_compute_derivatives(i, body, row)
+                assert H.same_bits(np.concatenate([Jl, Ja]), derivs[i, e, row]), (tag, i, e, row, Jl, Ja, derivs[i, e, row])
+    got = g.forces()
+    for name in ("C", "fmin", "fmax", "lambda", "penalty"):
+        for i in range(nf):
+            rows = int(forces["rows"][i])
+            assert H.same_bits(got[name][i][:rows], after[name][i][:rows]), (tag, i, name)
+    for i in range(nf):
+        for ci in range(int(forces["numContacts"][i])):
+            for name in ("normal", "penetration", "stick", "rA", "rB", "feature"):
+                assert H.same_bits(np.asarray(got["contacts"][i][ci][name]), np.asarray(after["contacts"][i][ci][name])), (tag, i, ci, name)
 
 
 def test_cli_headless_trace_md5():
