@@ -166,6 +166,7 @@ struct AvbdContext {
     int residentOutOfOrder = -1;    /* AVBD_RESIDENT_OOO=0/1: a wave with several bodies sweeps them strictly in order / takes whichever is ready; default: by size */
     int residentQuiet = 500;       /* AVBD_RESIDENT_QUIET: permille of the previous wait spent asleep before polling */
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
+    bool liteResident = true;    /* two workgroups of k_iterate<2> fit a CU (checked at create); otherwise every launch stays at one workgroup per CU */
     /* group schedule (avbd_groups.h): several bodies in flight per wavefront, for scenes with more swept bodies than resident waves */
     DevArr<GroupPlan> dPlan; DevArr<int> dUnit; int unitCap = 0;
     int groupsMode = -1;           /* AVBD_GROUPS=0 never, 1 for every eligible scene (tests), default: more swept bodies than one-body-per-wave waves */
@@ -820,7 +821,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     }
     X.probe = c->xProbe.p;
     X.patience = c->residentPatience;
-    const bool throughput = lite || (!X.enabled && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
+    const bool throughput = lite || (!X.enabled && c->liteResident && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
     /* group schedule first; the launch below then runs only if the device declined (runIf) */
     const int* runIf = nullptr;
     c->groupsLaunched = false;
@@ -1089,6 +1090,24 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_iterate_groups<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
+        {   /* Every persistent launch spins on records that other workgroups of the same launch produce: ALL its workgroups must be
+             * resident at once.  Ask the runtime how many workgroups of each kernel fit a CU with the exact dynamic LDS it is
+             * launched with, clamp the grid sizes (and any AVBD_ITER_BLOCKS override) to that, and switch a schedule off when
+             * its prerequisite does not hold on this device / this build (compiler register use, partitioned device). */
+            const int cus = std::max(1, prop.multiProcessorCount);
+            auto fits = [&](const void* fn, int dynLds) -> int {
+                int perCu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fn, 64 * kIterWaves, (size_t)dynLds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+                return perCu;
+            };
+            const int occ1 = std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad));
+            const int occ2 = std::min(fits((const void*)k_iterate<2, false>, kIterWaves * kResProductBytesPerWaveLite), fits((const void*)k_iterate<2, true>, kIterWaves * kResProductBytesPerWaveLite));
+            const int occG = std::min(fits((const void*)k_iterate_groups<false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true>, kGrpLdsBytes));
+            if (occ1 < 1) { c->mode = 0; c->residentAllowed = false; }      /* not even one workgroup per CU: one launch per level, nothing spins */
+            c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
+            if (occ2 * cus < 2 * c->iterBlocks) { c->residentLiteFrom = 0; c->residentForceLite = false; c->iterForceMode = c->iterForceMode == 2 ? 0 : c->iterForceMode; c->liteResident = false; }
+            if (occG * cus < 2 * c->iterBlocks) c->groupsMode = 0;
+        }
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
@@ -1287,9 +1306,42 @@ namespace {
 struct SnapshotHeader { char magic[8]; int bodyBytes, forceBytes, nBodies, nForces, stepIndex, reserved; AvbdParams params; };
 }
 
+/* Every record that reaches the device tables comes through here first (uploads, snapshots from a file, removals): a bad
+ * index or count must never become an out-of-bounds access in a kernel or in the host packing loops. */
+static int validate_forces(AvbdContext* c, const AvbdForce* in, int n, int nBodies)
+{
+    char why[160];
+    for (int i = 0; i < n; ++i) {
+        const AvbdForce& f = in[i];
+        const char* bad = nullptr;
+        if (f.kind != AVBD_FORCE_MANIFOLD && f.kind != AVBD_FORCE_JOINT && f.kind != AVBD_FORCE_SPRING && f.kind != AVBD_FORCE_IGNORE) bad = "unknown kind";
+        else if (f.bodyB < 0 || f.bodyB >= nBodies || f.bodyA < -1 || f.bodyA >= nBodies) bad = "body index out of range";
+        else if (f.kind != AVBD_FORCE_JOINT && f.bodyA < 0) bad = "only a Joint may be anchored to the world";
+        else if (f.rows < 0 || f.rows > 12) bad = "row count out of range";
+        else if (f.kind == AVBD_FORCE_MANIFOLD && (f.numContacts < 0 || f.numContacts > 4)) bad = "numContacts out of range";
+        else if (f.kind == AVBD_FORCE_MANIFOLD && f.bodyA == f.bodyB) bad = "manifold between a body and itself";
+        if (bad) {
+            std::snprintf(why, sizeof(why), "force record %d: %s (kind %d, bodies %d/%d, rows %d, contacts %d)", i, bad, f.kind, f.bodyA, f.bodyB, f.rows, f.numContacts);
+            return c->fail(AVBD_E_INVALID, why);
+        }
+    }
+    return AVBD_OK;
+}
+
 static int restore_state(AvbdContext* c, const AvbdParams& params, int stepIndex, const AvbdBody* bodies, int nBodies, const AvbdForce* forces, int nForces)
 {
     int rc;
+    /* validate BEFORE touching the context: a failed restore leaves the old scene in place */
+    if (nBodies < 0 || nForces < 0 || nBodies > (1 << 20) - 2 || stepIndex < 0) return c->fail(AVBD_E_INVALID, "restore: counts out of range");
+    if (!(params.iterations >= 0 && params.iterations <= 100000) || !(params.dt == params.dt)) return c->fail(AVBD_E_INVALID, "restore: parameters out of range");
+    if ((rc = validate_forces(c, forces, nForces, nBodies))) return rc;
+    {
+        int nm = 0;
+        for (int i = 0; i < nForces; ++i) nm += forces[i].kind == AVBD_FORCE_MANIFOLD;
+        int cap = std::max(1024, c->bodyCap);                         /* what ensure_capacity will size the manifold pool to */
+        while (cap < nBodies) cap *= 2;
+        if (nm > std::max(std::max(8192, cap * 16), c->mCap)) return c->fail(AVBD_E_CAPACITY, "restore: more manifolds than the pool of this many bodies can hold");
+    }
     if ((rc = avbd_clear(c))) return rc;
     if ((rc = avbd_set_params(c, &params))) return rc;
     for (int i = 0; i < nBodies; ++i) {
@@ -1353,7 +1405,16 @@ int avbd_load_snapshot(AvbdContext* c, const char* path)
               h.forceBytes == (int)sizeof(AvbdForce) && h.nBodies >= 0 && h.nForces >= 0 && h.nBodies <= (1 << 20) - 2;
     std::vector<AvbdBody> bodies; std::vector<AvbdForce> forces;
     if (ok) {
-        bodies.resize((size_t)std::max(h.nBodies, 1)); forces.resize((size_t)std::max(h.nForces, 1));
+        /* the counts must agree with the size of the file before anything is allocated from them */
+        long here = std::ftell(f), end = -1;
+        if (here >= 0 && std::fseek(f, 0, SEEK_END) == 0) { end = std::ftell(f); (void)std::fseek(f, here, SEEK_SET); }
+        const long long need = (long long)h.nBodies * (long long)sizeof(AvbdBody) + (long long)h.nForces * (long long)sizeof(AvbdForce);
+        ok = here >= 0 && end >= here && (long long)(end - here) == need;
+    }
+    if (ok) {
+        try {
+            bodies.resize((size_t)std::max(h.nBodies, 1)); forces.resize((size_t)std::max(h.nForces, 1));
+        } catch (...) { std::fclose(f); return c->fail(AVBD_E_CAPACITY, "avbd_load_snapshot: out of host memory"); }
         if (h.nBodies) ok = std::fread(bodies.data(), sizeof(AvbdBody), (size_t)h.nBodies, f) == (size_t)h.nBodies;
         if (ok && h.nForces) ok = std::fread(forces.data(), sizeof(AvbdForce), (size_t)h.nForces, f) == (size_t)h.nForces;
     }
@@ -1655,6 +1716,7 @@ int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
     if (!c || (!in && n > 0) || n < 0) return AVBD_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc;
+    if ((rc = validate_forces(c, in, n, (int)c->hBodies.size()))) return rc;
     if ((rc = upload_bodies_if_stale(c))) return rc;
     int nm = 0;
     for (int i = 0; i < n; ++i) nm += in[i].kind == AVBD_FORCE_MANIFOLD;

@@ -519,6 +519,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     };
 
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tIdle = t0;                                   /* when this wave last made progress (bounds the spin, not the launch) */
     unsigned spins = 0;
     /* the poll of a prepared task: the records ARE the payload (avbd_resident.h); only lanes that still miss something load */
     auto poll_records = [&]() __attribute__((always_inline)) {
@@ -535,7 +536,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
         else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
         if ((++spins & 1023u) == 0) {
-            bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (spins == 1024u) tIdle = now - 1024ull * 30ull;        /* first check since the last task: the wait began about here */
+            bool dead = (now - tIdle > kSpinTimeoutTicks) ||
                         __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }

@@ -497,7 +497,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
                 else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
                 if ((++spins & 1023u) == 0) {
-                    bool dead = (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) ||
+                    bool dead = (__builtin_amdgcn_s_memrealtime() - tWait0 > kSpinTimeoutTicks) ||   /* measured from the start of THIS wait */
                                 __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                     if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
                 }

@@ -90,18 +90,43 @@ def dependency_chain_hops(forces, bodies, total_iterations):
     return longest
 
 
+PMC_SUMMARIES = {"Stress1000": "r2_resident_window_summary.json", "StressN:20": "r2_8k_window_summary.json", "StressN:40": "r2_64k_window_summary.json"}
+
+
 def pmc_traffic(scene, fused):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r1_resident_window_summary.json; (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md §HBM).  PMC counters
-    cannot be read from inside the process, so this is null for any other workload or mode."""
-    path = os.path.join(ROOT, "profiles", "r1_resident_window_summary.json")
-    if scene != "Stress1000" or not fused or not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so this is NOT a
+    measurement of this run: it is the figure of the committed rocprofv3 --pmc passes of the same command on the same build
+    (profiles/collect.sh; (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md §HBM), labelled as such by `traffic_source`;
+    null for any workload or mode without a committed profile."""
+    name = PMC_SUMMARIES.get(scene)
+    if name is None or not fused:
+        return None, None
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
     try:
         d = json.load(open(path))
-        return round((2.0 * d["FETCH_SIZE_KB_last40"] + d["WRITE_SIZE_KB_last40"]) * 1024.0, 1)
+        return round((2.0 * d["FETCH_SIZE_KB_last40"] + d["WRITE_SIZE_KB_last40"]) * 1024.0, 1), "committed profile profiles/" + name + " (not this run)"
     except Exception:
-        return None
+        return None, None
+
+
+STRONG_SCENE, STRONG_PRESIM = "StressN:40", 460     # BASELINE.json configs[3]: 64 000 cubes, steady window after the pile has landed
+
+
+def spawn_ranks(args):
+    """`--gpus N` without torchrun's environment: start the N ranks as CHILD processes (python -m torch.distributed.run) before this
+    process has touched the GPU, relay their output, exit with their code.  Nothing that has initialised HIP is ever re-exec'ed."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("AVBD_BENCH_SPAWN_ECHO"):                      # tests: show the launch instead of doing it
+        print(json.dumps({"spawn": cmd}))
+        sys.exit(0)
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def cpu_baseline(pkg, world, scene, snapshot_bodies, snapshot_forces, step_index, cpu_steps):
@@ -148,9 +173,14 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (torch.distributed + RCCL + sharded schedule) even with one rank")
     ap.add_argument("--no-reference", action="store_true", help="cpu_baseline from the port only (skip the run of oracle/_ref)")
+    ap.add_argument("--no-strong-n1", action="store_true", help="N=1: skip the extra 64 000-cube line (the N=1 point of the strong-scaling experiment)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus and not (args.gpus == 1 and world_size == 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -166,15 +196,16 @@ def main():
         pkg.build()
     w = pkg.World(local_rank)
 
-    # N > 1: N Stress1000 piles side by side along z, one z-slab per GPU; value counts 1000-cube-equivalent steps
-    scene = args.scene or ("Stress1000" if not sharded else f"StressGrid:10,10,{10 * world_size}")
-    presim = args.presim if args.presim is not None else (0 if scene.startswith("Packed") else 400)
+    # N = 1: BASELINE configs[1] (Stress1000).  N > 1: north_star's strong-scaling experiment, the SAME 64 000-cube scene sharded over
+    # the N GPUs by slabs along x (configs[3]); value = steps/s of that one scene, never multiplied by N
+    scene = args.scene or ("Stress1000" if not sharded else STRONG_SCENE)
+    presim = args.presim if args.presim is not None else (0 if scene.startswith("Packed") else (STRONG_PRESIM if scene == STRONG_SCENE else 400))
     w.scene(scene)
     iterations = int(w.params()["iterations"])
     if sharded:
         import torch
         b0 = w.bodies()
-        owner = pkg.partition_by_axis(b0["position"], b0["invMass"], world_size, axis=2)
+        owner = pkg.partition_by_axis(b0["position"], b0["invMass"], world_size, axis=0)
         w.set_ownership(world_size, rank, owner)
         uid = [pkg.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -226,8 +257,10 @@ def main():
         bytes_per_launch = p["algorithmic_bytes_primal"] / p["launches_primal"]
         achieved = bytes_per_launch / per_launch_s / 1e9
         fused = p["launches_primal"] <= 1.5 * max(1, p["steps"]) * max(1, world_size if world_size > 1 else 1) or os.environ.get("AVBD_MODE") != "levels"
-        roof = {"bound": "hbm", "kernel": "k_iterate" if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": pmc_traffic(scene, fused),
+        traffic, traffic_source = pmc_traffic(scene, fused and not sharded)
+        sched = int(stats["schedule"])
+        roof = {"bound": "hbm", "kernel": ("k_iterate_groups" if sched == 4 else "k_iterate") if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": round(bytes_per_launch, 1), "us_per_launch": round(per_launch_s * 1e6, 3),
                 "launches_per_step": round(p["launches_primal"] / max(1, p["steps"]), 2),
                 "step_algorithmic_GBps": round(ab["B_step"] * args.steps / elapsed / 1e9, 3),
@@ -285,18 +318,39 @@ def main():
         whole = {"steps": 600, "steps_per_s": round(600 / tw, 3), "ms_per_step": round(tw / 600 * 1e3, 5)}
         w2.close()
 
+    # N = 1 point of the strong-scaling experiment: the 64 000-cube scene on this one GPU, same window as the N > 1 runs
+    strong_n1 = None
+    if rank == 0 and not sharded and args.scene is None and not args.no_strong_n1:
+        try:
+            w3 = pkg.World(local_rank)
+            w3.scene(STRONG_SCENE)
+            w3.step(STRONG_PRESIM + 10)
+            w3.synchronize()
+            k3 = 50
+            t0 = time.perf_counter()
+            w3.step(k3)
+            w3.synchronize()
+            t3 = time.perf_counter() - t0
+            st3 = w3.stats()
+            strong_n1 = {"workload": f"{STRONG_SCENE} (iterations={int(w3.params()['iterations'])}) steady window: steps {STRONG_PRESIM + 10}..{STRONG_PRESIM + 10 + k3}",
+                         "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
+                         "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"])}
+            w3.close()
+        except Exception as e:
+            strong_n1 = {"error": repr(e)}
+
     if rank == 0:
-        # sharded runs step ONE scene of N x 1000 cubes: count it as N Stress1000-equivalent steps per step
-        total_steps = args.steps * world_size
+        total_steps = args.steps                                 # steps of the one scene every rank works on
         line = {
             "metric": "solver steps/sec + ms/step, Stress1000 @ iters=20, 1/2/4/8 MI355X",
             "value": round(total_steps / elapsed, 3), "unit": "steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene} (iterations={iterations}) steady window: steps {snap_step}..{snap_step + args.steps}",
                        "mode": "exact (bit-identical to the reference CPU solver)" if world_size == 1 else
                                "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)",
-                       "parallelism": "1 GPU" if not sharded else f"{world_size} z-slabs, RCCL all-gather of 32 B/body after every iteration; value = {world_size} x scene steps/s (1000-cube equivalents)",
+                       "parallelism": "1 GPU" if not sharded else f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene",
+                       "strong_scaling_n1": strong_n1,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
                        "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
                        "whole_run_from_scratch": whole},

@@ -86,3 +86,19 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
     assert "liboracle" not in out and "avbd_ref" not in out
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu_before_touching_the_gpu():
+    """`bench.py --gpus N` without torchrun's environment starts N child ranks (python -m torch.distributed.run ... bench.py) and
+    relays them; with an environment that contradicts --gpus it refuses instead of silently running one GPU."""
+    import json
+    import sys
+    bench = os.path.join(H.ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "7", "--warmup", "3"], capture_output=True, text=True,
+                         env=dict(env, AVBD_BENCH_SPAWN_ECHO="1"), check=True).stdout
+    cmd = json.loads(out.strip().splitlines()[-1])["spawn"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "3"] and cmd[-7].endswith("bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="4", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr

@@ -240,7 +240,7 @@ def test_bench_line_contract():
     """bench.py prints ONE JSON line with the driver's fields plus the roofline and cpu_baseline objects."""
     import json
     import sys
-    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-reference"],
+    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-reference", "--no-strong-n1"],
                          capture_output=True, text=True, check=True, cwd=H.ROOT).stdout
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -256,7 +256,24 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    # PMC counters cannot be read in-process: a traffic figure is either absent or labelled with the committed profile it comes from
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
     c = b["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["parity"] == "bit-exact" and c["value"] > 0
+
+
+def test_bench_sharded_path_reports_strong_scaling_of_one_scene():
+    """The N > 1 code path (torch.distributed + RCCL + sharded schedule) with one rank on a small scene: `value` is the
+    steps/s of the ONE scene all ranks work on (never multiplied by the rank count) and the line says "strong"."""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--force-dist", "--scene", "Packed:6", "--steps", "5", "--warmup", "2"],
+                         capture_output=True, text=True, check=True, cwd=H.ROOT, env=env).stdout
+    b = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert b["scaling"] == "strong" and b["n_gpus"] == 1 and b["steps"] == 5
+    assert abs(b["value"] - 1000.0 / b["ms_per_step"]) / b["value"] < 1e-3
+    assert "Packed:6" in b["config"]["workload"] and "all-gather" in b["config"]["parallelism"]
