@@ -173,7 +173,17 @@ struct AvbdContext {
     int groupsMaxRounds = 1;       /* AVBD_GROUPS_ROUNDS: most bodies one sub-group may serve, at most 16.  Default 1: only scenes whose bodies all fit a sub-group of their own;
                                     * with several bodies per sub-group the resident schedule's parked sweep is faster (22 000 cubes: 4.1 ms against 5.0 ms per step) */
     int groupsWaves = 0;           /* AVBD_GROUPS_WAVES: resident waves the plan may use (tests: few waves, many rounds); 0 = all */
+    /* sharded runs as one persistent launch per step with the exchange on a second stream (ShardExchange, avbd_groups.h) */
+    int shardPersistent = -1;      /* AVBD_SHARD_PERSISTENT=0 never, 1 whenever the prerequisites hold (default) */
+    bool canWaitValue = false;     /* hipStreamWaitValue32 / WriteValue32 work on this device */
+    hipStream_t stream2 = nullptr; /* exchange stream: wait for an iteration -> all-gather -> release its readers */
+    hipEvent_t evBegin = nullptr, evGathered = nullptr;
+    unsigned* sigDone = nullptr; unsigned* sigGather = nullptr;   /* hipMallocSignalMemory words */
+    DevArr<unsigned> dDone; DevArr<float4> dGather[2]; DevArr<int> dRow; size_t gatherRows = 0;
+    int shardWaves = 0;            /* waves the plan of a sharded step may use (contexts that share a device split them; room for the collective's kernel) */
+    bool shardRanPersistent = false;
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
+    bool rowsStale = true;         /* ownership changed: the gather rows of the bodies must be uploaded again */
     bool groupsLaunched = false;   /* the last iteration loop was offered to k_iterate_groups (the device may still decline: GroupPlan.bad) */
     int numStatic = 0;
     bool statsFresh = true;
@@ -397,6 +407,7 @@ int upload_bodies_if_stale(AvbdContext* c)
         }
         c->maxCount = 0;
         for (int r = 0; r < c->nranks; ++r) { c->maxCount = std::max(c->maxCount, c->hRankStart[(size_t)r + 1]); c->hRankStart[(size_t)r + 1] += c->hRankStart[(size_t)r]; }
+        c->rowsStale = true;
         c->hPerm.assign((size_t)std::max(n, 1), 0);
         std::vector<int> cur(c->hRankStart.begin(), c->hRankStart.end() - 1);
         for (int i = 0; i < n; ++i) if (c->hOwner[(size_t)i] >= 0) c->hPerm[(size_t)cur[(size_t)c->hOwner[(size_t)i]]++] = i;
@@ -641,7 +652,13 @@ int refresh_stats(AvbdContext* c, bool withLevels)
 
 int groups_waves(const AvbdContext* c)
 {
-    const int all = 2 * c->iterBlocks * kGrpWavesPerBlock;             /* two workgroups of four waves per CU */
+    int all = 2 * c->iterBlocks * kGrpWavesPerBlock;                   /* two workgroups of four waves per CU */
+    if (c->nranks > 1 || c->forceSharded) {
+        /* a sharded step: contexts that share this device split the waves (avbd_group_step sets shardWaves); with a real
+         * collective its kernel needs room beside the persistent launch: four workgroup slots stay free */
+        if (c->shardWaves > 0) all = std::min(all, c->shardWaves);
+        else if (c->comm) all -= 4 * kGrpWavesPerBlock;
+    }
     return c->groupsWaves > 0 ? std::min(c->groupsWaves, all) : all;
 }
 
@@ -649,10 +666,12 @@ int groups_waves(const AvbdContext* c)
  * ignore markers only, stamps fit); the device declines on its own if a body has too many entries (GroupPlan.bad). */
 bool groups_eligible(const AvbdContext* c)
 {
-    if (c->groupsMode == 0 || c->mode == 0 || !c->residentAllowed || c->nranks != 1 || c->forceSharded || !c->dPlan.p) return false;
+    if (c->groupsMode == 0 || c->mode == 0 || !c->residentAllowed || !c->dPlan.p) return false;
     const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
     if (totalIt <= 0 || totalIt > 60) return false;
     for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return false;
+    if (c->nranks > 1 || c->forceSharded)                              /* sharded: the persistent launch IS the group schedule */
+        return c->shardPersistent != 0 && c->canWaitValue && c->sigDone && c->sigGather && c->stream2;
     const int dyn = (int)c->hBodies.size() - c->numStatic;
     return c->groupsMode == 1 || dyn > c->iterBlocks * kIterWaves;
 }
@@ -735,7 +754,7 @@ int step_begin(AvbdContext* c)
             if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
             if (c->probeCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap; }
         }
-        hipLaunchKernelGGL(k_group_plan, dim3(1), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->dPlan.p, c->dUnit.p, c->unitCap, W, std::min(16, c->groupsMaxRounds));
+        hipLaunchKernelGGL(k_group_plan, dim3(1), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->dPlan.p, c->dUnit.p, c->unitCap, W, (c->nranks > 1 || c->forceSharded) ? 1 : std::min(16, c->groupsMaxRounds));
         c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -825,13 +844,13 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     /* group schedule first; the launch below then runs only if the device declined (runIf) */
     const int* runIf = nullptr;
     c->groupsLaunched = false;
-    if (c->groupsPlanned && X.enabled && wholeLoop && !X.joints) {
+    if (c->groupsPlanned && X.enabled && wholeLoop && !X.joints && !sharded) {
         const int W = groups_waves(c);
-        hipExtLaunchKernelGGL(k_iterate_groups<false>, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
-                              X, c->dPlan.p, c->dUnit.p, W, c->iterSleep);
+        hipExtLaunchKernelGGL((k_iterate_groups<false, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
+                              X, c->dPlan.p, c->dUnit.p, W, c->iterSleep, ShardExchange{});
         if (c->groupsMaxRounds > 1)
-            hipLaunchKernelGGL(k_iterate_groups<true>, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
-                               X, c->dPlan.p, c->dUnit.p, W, c->iterSleep);
+            hipLaunchKernelGGL((k_iterate_groups<true, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
+                               X, c->dPlan.p, c->dUnit.p, W, c->iterSleep, ShardExchange{});
         runIf = &c->dPlan.p->bad;
         c->groupsLaunched = true;
         e0 = nullptr;                                                  /* the profiling span covers both launches (the second one is empty unless the device declined) */
@@ -957,6 +976,105 @@ int step_end(AvbdContext* c, bool haveCounts)
 }
 
 int rccl_allgather(AvbdContext* c); /* below, next to the communicator set-up */
+int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream);
+
+/* Sharded step, persistent form: has the device accepted the plan (every owned body in a sub-group of its own)?  One small
+ * readback; the per-iteration schedule is the fallback. */
+int shard_plan_accepted(AvbdContext* c, bool& ok)
+{
+    ok = false;
+    if (!c->groupsPlanned) return AVBD_OK;
+    HIPCHK(c, hipMemcpyAsync(&c->hRb->plan, c->dPlan.p, sizeof(GroupPlan), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const GroupPlan& p = c->hRb->plan;
+    ok = p.bad == 0 && p.rounds[0] <= 1 && p.rounds[1] <= 1 && p.rounds[2] <= 1;
+    return AVBD_OK;
+}
+
+/* (re)size the exchange buffers of the persistent sharded step and upload the row of every body */
+int shard_prepare_buffers(AvbdContext* c)
+{
+    const size_t rows = (size_t)std::max(1, c->maxCount) * (size_t)c->nranks;
+    if (c->gatherRows < rows || !c->dDone.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->dGather[0].alloc(2 * rows)); HIPCHK(c, c->dGather[1].alloc(2 * rows));
+        HIPCHK(c, hipMemset(c->dGather[0].p, 0, 2 * rows * sizeof(float4))); HIPCHK(c, hipMemset(c->dGather[1].p, 0, 2 * rows * sizeof(float4)));
+        HIPCHK(c, c->dDone.alloc(64));
+        c->gatherRows = rows;
+    }
+    if (c->dRow.n < (size_t)c->bodyCap || c->rowsStale) {
+        if (c->dRow.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRow.alloc((size_t)c->bodyCap)); }
+        const int n = (int)c->hBodies.size();
+        std::vector<int> row((size_t)std::max(n, 1), -1);
+        for (int r = 0; r < c->nranks; ++r)
+            for (int k = c->hRankStart[(size_t)r]; k < c->hRankStart[(size_t)r + 1]; ++k)
+                row[(size_t)c->hPerm[(size_t)k]] = r * std::max(1, c->maxCount) + (k - c->hRankStart[(size_t)r]);
+        HIPCHK(c, hipMemcpy(c->dRow.p, row.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        c->rowsStale = false;
+    }
+    return AVBD_OK;
+}
+
+/* Queue the persistent launch of a sharded step on the solver stream.  The caller queues the exchange (one wait -> gather ->
+ * release per iteration) on c->stream2 and the final unpack. */
+int shard_launch_persistent(AvbdContext* c)
+{
+    int rc;
+    if ((rc = shard_prepare_buffers(c))) return rc;
+    BodyTable B = body_table(c);
+    SolverParams P = solver_params(c);
+    ManifoldTable M = c->mbuf[c->cur].view();
+    IterateState S;
+    S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
+    ResidentExchange X{};
+    X.pose = c->xPose.p; X.visit = c->xVisit.p; X.dual = c->xDual.p;
+    const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes + (size_t)4 * c->gCap * sizeof(float4), poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
+    if (c->xDual.n * sizeof(float4) < dualBytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->xDual.alloc(dualBytes / sizeof(float4)));
+        HIPCHK(c, hipMemset(c->xDual.p, 0, dualBytes));
+        X.dual = c->xDual.p;
+    }
+    X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
+    X.enabled = 1;
+    if (c->xSerial >= (1u << 24) - 2u) {
+        HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, visitBytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
+        c->xSerial = 0;
+    }
+    ++c->xSerial;
+    X.base = c->xSerial * 64u;
+    ShardExchange Z{};
+    Z.gather[0] = c->dGather[0].p; Z.gather[1] = c->dGather[1].p;
+    Z.gatherBytes = (unsigned)(2 * c->gatherRows * sizeof(float4));
+    Z.row = c->dRow.p; Z.done = c->dDone.p; Z.doneSignal = c->sigDone; Z.gatherWord = c->sigGather;
+    Z.nOwned = c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank];
+    HIPCHK(c, hipMemsetAsync(c->dDone.p, 0, 64 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipEventRecord(c->evBegin, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evBegin, 0));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+    hipExtLaunchKernelGGL((k_iterate_groups<false, true>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
+                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, groups_waves(c), c->iterSleep, Z);
+    ++c->prof.launches_primal; ++c->prof.launches_total;
+    HIPCHK(c, hipGetLastError());
+    c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false;
+    c->shardRanPersistent = true;
+    return AVBD_OK;
+}
+
+/* after the last all-gather: the other ranks' final poses into the body table, on the solver stream */
+int shard_finish_persistent(AvbdContext* c, int totalIt)
+{
+    HIPCHK(c, hipEventRecord(c->evGathered, c->stream2));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evGathered, 0));
+    if (c->maxCount > 0)
+        hipLaunchKernelGGL(k_unpack_poses, dim3(grid_for(c->maxCount, 128, 1 << 20), c->nranks), dim3(128), 0, c->stream, body_table(c), c->dPerm.p,
+                           c->dRankStart.p, c->nranks, c->rank, c->maxCount, c->dGather[(totalIt - 1) & 1].p);
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
 
 int step_once(AvbdContext* c)
 {
@@ -973,6 +1091,22 @@ int step_once(AvbdContext* c)
     if (c->nranks > 1 || c->forceSharded) {
         if (c->mode == 0) return c->fail(AVBD_E_INVALID, "sharded runs need the data-flow mode");
         if (!c->comm) return c->fail(AVBD_E_COMM, "context is sharded (avbd_set_ownership) but has no communicator: call avbd_comm_init or drive it through avbd_group_step");
+        bool persistent = false;
+        c->shardRanPersistent = false;
+        if ((rc = shard_plan_accepted(c, persistent))) return rc;
+        if (persistent) {
+            /* ONE launch for the whole loop; the exchange runs beside it on the second stream: wait until this rank has finished
+             * iteration it (every rank does the same), all-gather the rows in place, release the tasks that read them */
+            if ((rc = shard_launch_persistent(c))) return rc;
+            const unsigned base = c->xSerial * 64u;
+            for (int it = 0; it < totalIt; ++it) {
+                HIPCHK(c, hipStreamWaitValue32(c->stream2, c->sigDone, base + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                if ((rc = rccl_allgather_inplace(c, c->dGather[it & 1].p, c->stream2))) return rc;
+                HIPCHK(c, hipStreamWriteValue32(c->stream2, c->sigGather, base + (unsigned)it + 1u, 0));
+            }
+            if ((rc = shard_finish_persistent(c, totalIt))) return rc;
+            return step_end(c, needReadback);
+        }
         for (int it = 0; it < totalIt; ++it) {
             if ((rc = step_iterate(c, it, it + 1))) return rc;
             if ((rc = step_pack(c))) return rc;
@@ -1040,6 +1174,17 @@ int avbd_create(int device, AvbdContext** out)
     if (const char* f = std::getenv("AVBD_FORCE_SHARDED")) c->forceSharded = std::atoi(f) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_createError = "hipStreamCreate failed"; delete c; return AVBD_E_HIP; }
     if (hipHostMalloc((void**)&c->hRb, sizeof(Readback), hipHostMallocDefault) != hipSuccess) { delete c; return AVBD_E_HIP; }
+    {   /* second stream + signal words of the persistent sharded step; without them sharded runs launch once per iteration */
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&c->evBegin, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGathered, hipEventDisableTiming) == hipSuccess &&
+            hipExtMallocWithFlags((void**)&c->sigDone, 8, hipMallocSignalMemory) == hipSuccess && hipExtMallocWithFlags((void**)&c->sigGather, 8, hipMallocSignalMemory) == hipSuccess) {
+            (void)hipMemset(c->sigDone, 0, 8); (void)hipMemset(c->sigGather, 0, 8);
+            c->canWaitValue = true;
+        } else (void)hipGetLastError();
+        if (const char* e = std::getenv("AVBD_SHARD_PERSISTENT")) c->shardPersistent = std::atoi(e) != 0 ? 1 : 0;
+    }
     std::memset(c->hRb, 0, sizeof(Readback));
     /* the Counters word, then the warning log of the step (kWarnCap records of 32 B) */
     static_assert(sizeof(WarnRec) == 32 && sizeof(Counters) == 64, "warning log layout");
@@ -1087,8 +1232,9 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_iterate<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate<2>, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
-        fe = hipFuncSetAttribute((const void*)k_iterate_groups<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         {   /* Every persistent launch spins on records that other workgroups of the same launch produce: ALL its workgroups must be
              * resident at once.  Ask the runtime how many workgroups of each kernel fit a CU with the exact dynamic LDS it is
@@ -1102,7 +1248,8 @@ int avbd_create(int device, AvbdContext** out)
             };
             const int occ1 = std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad));
             const int occ2 = std::min(fits((const void*)k_iterate<2, false>, kIterWaves * kResProductBytesPerWaveLite), fits((const void*)k_iterate<2, true>, kIterWaves * kResProductBytesPerWaveLite));
-            const int occG = std::min(fits((const void*)k_iterate_groups<false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true>, kGrpLdsBytes));
+            const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, false>, kGrpLdsBytes)),
+                                      fits((const void*)k_iterate_groups<false, true>, kGrpLdsBytes));
             if (occ1 < 1) { c->mode = 0; c->residentAllowed = false; }      /* not even one workgroup per CU: one launch per level, nothing spins */
             c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
             if (occ2 * cus < 2 * c->iterBlocks) { c->residentLiteFrom = 0; c->residentForceLite = false; c->iterForceMode = c->iterForceMode == 2 ? 0 : c->iterForceMode; c->liteResident = false; }
@@ -1131,6 +1278,10 @@ int avbd_destroy(AvbdContext* c)
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->dPlan.release(); c->dUnit.release();
+    c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release();
+    if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather);
+    if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);
@@ -2037,6 +2188,15 @@ int rccl_allgather(AvbdContext* c)
     if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclAllGather failed");
     return AVBD_OK;
 }
+
+int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream)
+{
+    /* in place: this rank's block of `buffer` is its contribution (sendbuff = recvbuff + rank * count) */
+    const size_t count = (size_t)8 * std::max(1, c->maxCount);
+    int r = g_rccl.AllGather(buffer + (size_t)2 * std::max(1, c->maxCount) * c->rank, buffer, count, /* ncclFloat32 */ 7, c->comm, stream);
+    if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclAllGather failed");
+    return AVBD_OK;
+}
 } // namespace
 
 static void destroy_comm(void* comm) { if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }
@@ -2103,10 +2263,49 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
             AvbdContext* c = ctxs[r];
             if (!c || c->nranks != n || c->rank != r || c->mode == 0) return AVBD_E_INVALID;
             (void)hipSetDevice(c->device);
+            {   /* this context's share of its device's resident waves */
+                int sharing = 0;
+                for (int q = 0; q < n; ++q) sharing += ctxs[q] && ctxs[q]->device == c->device;
+                c->shardWaves = std::max(kGrpWavesPerBlock, (2 * c->iterBlocks * kGrpWavesPerBlock / std::max(1, sharing)) / kGrpWavesPerBlock * kGrpWavesPerBlock);
+            }
             if ((rc = step_begin(c))) return rc;
             c->statsFresh = false;
         }
         const int totalIt = ctxs[0]->params.iterations + (ctxs[0]->params.postStabilize ? 1 : 0);
+        {   /* persistent form (one launch per rank and step, exchange on the second streams) when every rank's plan fits its share
+             * of the device: the launches of contexts that share a device must ALL be resident at the same time */
+            bool all = true;
+            for (int r = 0; r < n && all; ++r) {
+                bool ok = false;
+                (void)hipSetDevice(ctxs[r]->device);
+                if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
+                all = ok;
+            }
+            for (int r = 0; r < n; ++r) ctxs[r]->shardRanPersistent = false;
+            if (all) {
+                for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = shard_launch_persistent(ctxs[r]))) return rc; }
+                for (int dst = 0; dst < n; ++dst) {
+                    AvbdContext* d = ctxs[dst];
+                    (void)hipSetDevice(d->device);
+                    const size_t rows = (size_t)2 * std::max(1, d->maxCount);
+                    for (int it = 0; it < totalIt; ++it) {
+                        for (int src = 0; src < n; ++src) {
+                            if (src == dst) continue;
+                            AvbdContext* q = ctxs[src];
+                            HIPCHK(d, hipStreamWaitValue32(d->stream2, q->sigDone, q->xSerial * 64u + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                            HIPCHK(d, hipMemcpyAsync(d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream2));
+                        }
+                        HIPCHK(d, hipStreamWriteValue32(d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u, 0));
+                    }
+                }
+                for (int r = 0; r < n; ++r) {
+                    (void)hipSetDevice(ctxs[r]->device);
+                    if ((rc = shard_finish_persistent(ctxs[r], totalIt))) return rc;
+                    if ((rc = step_end(ctxs[r], false))) return rc;
+                }
+                continue;
+            }
+        }
         for (int it = 0; it < totalIt; ++it) {
             for (int r = 0; r < n; ++r) {
                 AvbdContext* c = ctxs[r];

@@ -36,6 +36,27 @@ struct GroupPlan {
 };
 static_assert(sizeof(GroupPlan) == 64, "GroupPlan layout");
 
+/* Sharded runs in ONE persistent launch per step: this rank sweeps the bodies it owns; a body owned by another
+ * rank ("remote") is a fixed pose during an iteration and changes between iterations through the all-gather.
+ *   - the wave that publishes a pose also writes the body's row (position+radius, orientation) into this rank's block of
+ *     gather[it & 1] and counts the task in done[it]; the task that completes an iteration raises `doneSignal` to
+ *     base + it + 1, which is what a second stream waits for (hipStreamWaitValue32) before it all-gathers gather[it & 1] in
+ *     place and writes base + it + 1 into `gatherWord` (hipStreamWriteValue32);
+ *   - a task of iteration it >= 1 with a remote partner polls `gatherWord` until it reaches base + it (the all-gather behind
+ *     iteration it - 1) and then reads the partner's row from gather[(it - 1) & 1].  Tasks without a remote partner never
+ *     wait for the exchange: the interior of a slab runs ahead of it.
+ * Two gather buffers are enough: gather(it + 1) needs every task of iteration it + 1, and those come after the last reader
+ * of gather(it - 1). */
+struct ShardExchange {
+    float4* gather[2];        /* [nranks * maxCount * 2]: rank-major blocks of (position+radius, orientation) rows */
+    unsigned gatherBytes;
+    const int* row;           /* [bodies]: row of a body inside a gather buffer (its owner's block), -1 for replicated (static) bodies */
+    unsigned* done;           /* [64]: tasks of iteration it this rank has finished (zeroed before the launch) */
+    unsigned* doneSignal;     /* hipMallocSignalMemory: base + (iterations completed by this rank) */
+    unsigned* gatherWord;     /* hipMallocSignalMemory: base + (all-gathers that have landed) */
+    int nOwned;               /* swept bodies of this rank */
+};
+
 constexpr int kGrpWavesPerBlock = 4;
 constexpr int kGrpLineRows = 20;          /* rows per 16 lanes whose pre-multiplied products wait in an LDS line (a 32-lane sub-group has 40, a wave 80) */
 constexpr int kGrpLineFloats = 27 * kGrpLineRows;   /* per 16 lanes */
@@ -257,14 +278,15 @@ __device__ __forceinline__ unsigned xldw(__amdgpu_buffer_rsrc_t r, int byteOff) 
  * (owned contacts in the Manifold tables, which only their owner writes; a first visitor's copy of normal + tangent memo
  * and the pose in arrays private to the sub-group).  The sub-groups of a wave pick independently and the wave runs their
  * picks together, so a wave that serves 4 x K bodies does several tasks per pass. */
-template <bool MULTI>
+template <bool MULTI, bool SHARD>
 __global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
-                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ unit, int W, int sleepSel)
+                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ unit, int W, int sleepSel, ShardExchange Z)
 {
+    static_assert(!(MULTI && SHARD), "the sharded launch keeps every body in a sub-group of its own");
     extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave J | S | accs | product lines | constants */
     /* the host queues k_iterate_groups<false>, <true> and the fallback launch one behind the other; the plan says which one runs */
-    if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;
+    if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;   /* (SHARD: the host has read the plan) */
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * kGrpWavesPerBlock + wv;
     const int W2 = plan->waves[2], W1 = plan->waves[1], W0 = plan->waves[0];
@@ -285,6 +307,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     const int lineRows = kGrpLineRows << cls;
 
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
+    const __amdgpu_buffer_rsrc_t rG0 = xrsrc(SHARD ? (void*)Z.gather[0] : (void*)X.pose, SHARD ? Z.gatherBytes : 16u),
+                                 rG1 = xrsrc(SHARD ? (void*)Z.gather[1] : (void*)X.pose, SHARD ? Z.gatherBytes : 16u),
+                                 rGW = xrsrc(SHARD ? (void*)Z.gatherWord : (void*)X.pose, 4u);
     const int itStop = P.iterations + (P.postStabilize ? 1 : 0);
     const float4* massPlane = B.plane(BP_MASS);
     const float invDt2 = 1.0f / (P.dt * P.dt);
@@ -294,6 +319,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     int body = -1, eBeg = 0, nRows = 0;
     bool valid = false, has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
+    bool remote = false; int offR = 0; int ownRow = 0;                /* SHARD: the partner is swept by another rank; its row / this body's row in a gather buffer */
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
     c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
@@ -340,7 +366,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose; constant for unswept partners */
             wOther = qrotate(mkq(oq.x, oq.y, oq.z, oq.w), isA ? c.rB : c.rA);
             pOther = mk3(op.x, op.y, op.z) + wOther;
+            if (SHARD) { remote = !moving && oinv > 0.0f; offR = remote ? Z.row[other] * 32 : 0; }
         }
+        if (SHARD && valid) ownRow = Z.row[body] * 32;
         if (valid) {
             float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
             radius = pp.w;
@@ -381,6 +409,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     GAcc a0, a1;
     f3 wOwn = zero3();
     bool needP = false, needV = false, needD = false, okP = true, okV = true, okD = true;
+    bool needR = false, okR = true; unsigned sR = 0;                 /* SHARD: the all-gather behind the previous iteration */
     unsigned sP = 0, sV = 0, sD = 0;
     ContactPre pre; f3 G[3];
     v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vd = p0, d1 = p0;   /* vd: the visit record of an owned contact, or the first dual record of another one */
@@ -429,6 +458,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             }
         }
         okP = !needP; okV = !needV; okD = !needD;
+        if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }
         wave_sync();
         GS_STAMP(11);
         grp_store_line(a0, Jg, lines + (gl < 27 ? gl : 0) * lineRows, nRows, lineRows);
@@ -444,6 +474,13 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         const unsigned stampNow = X.base + (unsigned)it + 1u;
         if (needP) {
             const f3 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); const q4 orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
+            wOther = qrotate(orot, isA ? c.rB : c.rA);
+            pOther = opos + wOther;
+        }
+        if (SHARD && needR) {
+            /* the partner's pose after iteration it - 1, as every rank received it (Jacobi across the cut) */
+            const v4u g0 = (it & 1) ? xld(rG0, offR) : xld(rG1, offR), g1 = (it & 1) ? xld(rG0, offR + 16) : xld(rG1, offR + 16);
+            const f3 opos = mk3(bitsf(g0.x), bitsf(g0.y), bitsf(g0.z)); const q4 orot = mkq(bitsf(g1.x), bitsf(g1.y), bitsf(g1.z), bitsf(g1.w));
             wOther = qrotate(orot, isA ? c.rB : c.rA);
             pOther = opos + wOther;
         }
@@ -491,6 +528,10 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             const int o = body * 48;
             v4u r0 = {fbits(p.x), fbits(p.y), fbits(p.z), stampNow}, r1 = {fbits(q.x), fbits(q.y), fbits(q.z), stampNow}, r2 = {fbits(q.w), 0u, 0u, stampNow};
             xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
+            if (SHARD) {                                              /* this rank's row of the all-gather behind iteration `it` */
+                v4u s0 = {fbits(p.x), fbits(p.y), fbits(p.z), fbits(radius)}, s1 = {fbits(q.x), fbits(q.y), fbits(q.z), fbits(q.w)};
+                if (it & 1) { xst(rG1, ownRow, s0); xst(rG1, ownRow + 16, s1); } else { xst(rG0, ownRow, s0); xst(rG0, ownRow + 16, s1); }
+            }
         }
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
@@ -505,6 +546,14 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
                 v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), (stampNow << 1) | (c.stick ? 1u : 0u)};
                 xst(rD, offD, r0); xst(rD, offD + 16, r1);
+            }
+        }
+        if (SHARD) {
+            /* count the task once its row has reached memory; the task that completes the iteration tells the exchange stream */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (gl == 0) {
+                const unsigned before = __hip_atomic_fetch_add(Z.done + it, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1u == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, stampNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
@@ -531,6 +580,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
         if (lv) okV = stamp_reached(vd.w, sV);
         if (ld) okD = stamp_reached(vd.w, sD) & stamp_reached(d1.w >> 1, sD);
+        if (SHARD && !okR) okR = stamp_reached(xldw(rGW, 0), sR);
     };
     auto back_off = [&]() __attribute__((always_inline)) -> bool {     /* false: the launch is being abandoned */
         if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
@@ -540,7 +590,14 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             if (spins == 1024u) tIdle = now - 1024ull * 30ull;        /* first check since the last task: the wait began about here */
             bool dead = (now - tIdle > kSpinTimeoutTicks) ||
                         __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+            if (__any(dead)) {
+                if (lane == 0) {
+                    __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    /* the exchange stream must not wait for iterations that will never complete */
+                    if (SHARD) __hip_atomic_fetch_max(Z.doneSignal, X.base + 63u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return false;
+            }
         }
         return true;
     };
@@ -560,7 +617,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             const bool active = valid && it < itStop;
             if (__ballot(active) == 0) break;
             if (active) poll_records();
-            const bool laneOk = !active || (okP & okV & okD);
+            const bool laneOk = !active || (okP & okV & okD & okR);
             const bool go = active && ((__ballot(laneOk) & gMask) == gMask);
             GS_STAMP(0);
 #ifdef AVBD_DF_STATS

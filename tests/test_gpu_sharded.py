@@ -1,5 +1,11 @@
 """Sharded (multi-context) path on ONE GPU: two contexts of one process driven in lock-step by avbd_group_step, which
-runs exactly the per-iteration schedule of the one-process-per-GPU RCCL path (exchange by device copies instead)."""
+runs exactly the schedule of the one-process-per-GPU RCCL path (exchange by device copies instead of the collective).
+
+Two forms of that schedule give the same bits (both are Jacobi across the cut, one exchange per iteration):
+  persistent  (default)  ONE launch per rank and step (k_iterate_groups<false, true>); the exchange runs beside it on a second
+              stream: hipStreamWaitValue32 on the rank's iteration counter -> gather -> hipStreamWriteValue32 releases the
+              tasks that read remote rows; tasks without a remote partner never wait for it.  stats.schedule == 4.
+  per-iteration (AVBD_SHARD_PERSISTENT=0, or when a rank's bodies do not fit a sub-group each) one launch per iteration."""
 import numpy as np
 import pytest
 
@@ -30,7 +36,19 @@ def sharded_pair(build):
     return pkg, worlds, owner
 
 
-def test_independent_shards_are_bit_exact():
+@pytest.fixture(params=["1", "0"], ids=["persistent", "per-iteration"])
+def shard_mode(request, monkeypatch):
+    monkeypatch.setenv("AVBD_SHARD_PERSISTENT", request.param)
+    return request.param
+
+
+def expect_schedule(worlds, mode):
+    for w in worlds:
+        sched = int(w.w.stats()["schedule"])
+        assert (sched == 4) == (mode == "1"), (sched, mode)
+
+
+def test_independent_shards_are_bit_exact(shard_mode):
     """Two piles that never touch each other: sharding must not change a single bit."""
     pkg, worlds, owner = sharded_pair(lambda w: two_piles(w, 20.0))
     assert set(owner[1:]) == {0, 1} and owner[0] == -1
@@ -46,9 +64,58 @@ def test_independent_shards_are_bit_exact():
     # every manifold lives on exactly the rank(s) that solve one of its bodies
     total = sum(int(w.w.stats()["numManifolds"]) for w in worlds)
     assert total == len(o.forces())
+    expect_schedule(worlds, shard_mode)
 
 
-def test_coupled_shards_stay_close_to_the_single_gpu_sweep():
+def test_persistent_and_per_iteration_schedules_of_a_cut_pile_give_the_same_bits(monkeypatch):
+    """One pile cut in two, 30 steps: the persistent launch (interior tasks run ahead of the exchange) and the one-launch-per-
+    iteration schedule are the same iteration, bit for bit — on both ranks."""
+    scene = "PackedGrid:4,3,8"
+    finals = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AVBD_SHARD_PERSISTENT", mode)
+        pkg = H.load_product()
+        worlds = [H.HipWorld(), H.HipWorld()]
+        for w in worlds:
+            w.scene(scene)
+        b = worlds[0].bodies()
+        owner = pkg.partition_by_axis(b["pos"], b["invMass"], 2, axis=2)
+        for r, w in enumerate(worlds):
+            w.w.set_ownership(2, r, owner)
+        for s in range(6):
+            pkg.group_step([w.w for w in worlds], 5)
+        expect_schedule(worlds, mode)
+        finals[mode] = [w.bodies() for w in worlds]
+        fo = [w.forces() for w in worlds]
+        finals[mode + "f"] = fo
+    for r in range(2):
+        assert finals["1"][r].tobytes() == finals["0"][r].tobytes(), f"rank {r}: body state differs between the two schedules"
+        assert finals["1f"][r].tobytes() == finals["0f"][r].tobytes(), f"rank {r}: force state differs between the two schedules"
+
+
+def test_four_ranks_share_one_device_in_the_persistent_form():
+    """Four contexts, a quarter of the device's resident waves each, all four persistent launches in flight together."""
+    scene = "PackedGrid:4,4,8"
+    pkg = H.load_product()
+    worlds = [H.HipWorld() for _ in range(4)]
+    for w in worlds:
+        w.scene(scene)
+    b = worlds[0].bodies()
+    owner = pkg.partition_by_axis(b["pos"], b["invMass"], 4, axis=2)
+    for r, w in enumerate(worlds):
+        w.w.set_ownership(4, r, owner)
+    single = H.HipWorld(); single.scene(scene)
+    pkg.group_step([w.w for w in worlds], 20)
+    single.step(20)
+    ref = worlds[0].bodies()
+    for r in range(1, 4):
+        br = worlds[r].bodies()
+        assert H.same_bits(ref["pos"], br["pos"]) and H.same_bits(ref["quat"], br["quat"]) and H.same_bits(ref["linVel"], br["linVel"])
+    expect_schedule(worlds, "1")
+    assert np.abs(ref["pos"] - single.bodies()["pos"]).max() < 5e-2
+
+
+def test_coupled_shards_stay_close_to_the_single_gpu_sweep(shard_mode):
     """One pile cut in two: Jacobi coupling across the cut (one pose exchange per iteration) — close, not identical."""
     scene = "PackedGrid:4,3,8"
     pkg = H.load_product()
@@ -70,10 +137,12 @@ def test_coupled_shards_stay_close_to_the_single_gpu_sweep():
     assert err < 5e-2, f"max position deviation from the single-GPU sweep after 25 steps: {err}"
     cut = sum(int(w.w.stats()["numManifolds"]) for w in worlds)
     assert cut >= int(single.w.stats()["numManifolds"])  # cut manifolds are replicated on both sides
+    expect_schedule(worlds, shard_mode)
 
 
-def test_rccl_single_rank_schedule_is_bit_exact(monkeypatch):
-    """The RCCL code path (communicator, all-gather every iteration) with one rank: same bits as the fused launch."""
+def test_rccl_single_rank_schedule_is_bit_exact(monkeypatch, shard_mode):
+    """The RCCL code path (communicator, all-gather every iteration — on the second stream beside the persistent launch, or
+    between the per-iteration launches) with one rank: same bits as the fused launch."""
     monkeypatch.setenv("AVBD_FORCE_SHARDED", "1")
     pkg = H.load_product()
     g = H.HipWorld(); g.scene("Pyramid")
@@ -85,6 +154,7 @@ def test_rccl_single_rank_schedule_is_bit_exact(monkeypatch):
     for s in range(4):
         g.step(10); o.step(10)
         H.assert_same_world(o, g, f"rccl 1-rank after {10 * (s + 1)} steps")
+    expect_schedule([g], shard_mode)
 
 
 def _two_big_piles(w, n=13, gap=25.0):
@@ -97,7 +167,7 @@ def _two_big_piles(w, n=13, gap=25.0):
     w.set_params(iterations=10)
 
 
-def test_independent_shards_of_a_large_scene_are_bit_exact():
+def test_independent_shards_of_a_large_scene_are_bit_exact(shard_mode):
     """4 394 cubes in two piles that never touch, one pile per rank: beyond 4096 bodies every rank runs the grid broadphase and
     the multi-launch topology, and its 2 197 swept bodies take the resident schedule with several bodies per wave, one launch per
     iteration — the combination an 8-GPU run of a large scene uses.  Independent shards must not change a single bit."""
@@ -112,5 +182,5 @@ def test_independent_shards_of_a_large_scene_are_bit_exact():
             bg = w.bodies()
             for f in ("pos", "quat", "linVel", "angVel"):
                 assert H.same_bits(bo[f], bg[f]), f"rank {r} field {f} after step {s + 1}"
-    assert all(int(w.w.stats()["schedule"]) == 3 for w in worlds)
+    assert all(int(w.w.stats()["schedule"]) == (4 if shard_mode == "1" else 3) for w in worlds)
     assert sum(int(w.w.stats()["numManifolds"]) for w in worlds) == len(o.forces())
