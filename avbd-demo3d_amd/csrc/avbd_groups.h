@@ -39,8 +39,8 @@ static_assert(sizeof(GroupPlan) == 64, "GroupPlan layout");
 /* Sharded runs in ONE persistent launch per step: this rank sweeps the bodies it owns; a body owned by another
  * rank ("remote") is a fixed pose during an iteration and changes between iterations through the all-gather.
  *   - the wave that publishes a pose also writes the body's row (position+radius, orientation) into this rank's block of
- *     gather[it & 1] and counts the task in done[it]; the task that completes an iteration raises `doneSignal` to
- *     base + it + 1, which is what a second stream waits for (hipStreamWaitValue32) before it all-gathers gather[it & 1] in
+ *     gather[it & 1]; a wave counts its bodies in done[it] once all of them are past iteration it, and the wave that completes
+ *     the rank's iteration raises `doneSignal` to base + it + 1, which is what a second stream waits for (hipStreamWaitValue32) before it all-gathers gather[it & 1] in
  *     place and writes base + it + 1 into `gatherWord` (hipStreamWriteValue32);
  *   - a task of iteration it >= 1 with a remote partner polls `gatherWord` until it reaches base + it (the all-gather behind
  *     iteration it - 1) and then reads the partner's row from gather[(it - 1) & 1].  Tasks without a remote partner never
@@ -548,14 +548,6 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 xst(rD, offD, r0); xst(rD, offD + 16, r1);
             }
         }
-        if (SHARD) {
-            /* count the task once its row has reached memory; the task that completes the iteration tells the exchange stream */
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (gl == 0) {
-                const unsigned before = __hip_atomic_fetch_add(Z.done + it, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + 1u == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, stampNow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
         /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
         if (it == itStop - 1) {
             /* (opaque copies of the indices: the nine table addresses of a contact are formed here, once, instead of living in
@@ -613,6 +605,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         if (valid) prepare_task();
         GS_STAMP(3);
+        int reported = 0;                                             /* SHARD: iterations this wave has counted in Z.done */
         for (;;) {
             const bool active = valid && it < itStop;
             if (__ballot(active) == 0) break;
@@ -632,6 +625,25 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             if (go) {
                 if (it < itStop) prepare_task();
                 spins = 0;
+            }
+            if (SHARD && __ballot(go)) {
+                /* Count finished iterations per WAVE: iteration k of this wave is complete when all its sub-groups are past it; one
+                 * atomic per wave and iteration (not per task: 8 000 returning atomics on one word per iteration cost 20 % of the
+                 * launch), issued once the rows have reached memory.  The wave that completes the rank's iteration raises the
+                 * signal the exchange stream waits for. */
+                int low = valid ? it : itStop;
+                low = min(low, __shfl_xor(low, 16, 64)); low = min(low, __shfl_xor(low, 32, 64));
+                low = __builtin_amdgcn_readfirstlane(low);
+                if (reported < low) {
+                    const unsigned mine = (unsigned)__popcll(__ballot(valid && gl == 0));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        for (int k = reported; k < low; ++k) {
+                            const unsigned before = __hip_atomic_fetch_add(Z.done + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (before + mine == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    reported = low;
+                }
             }
             GS_STAMP(2);
             if (__ballot(go) == 0 && !back_off()) return;

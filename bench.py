@@ -194,6 +194,8 @@ def main():
     pkg = load_pkg()
     if not os.path.exists(pkg.LIB_PATH):
         pkg.build()
+    if args.force_dist and world_size == 1:
+        os.environ["AVBD_FORCE_SHARDED"] = "1"                   # one rank, but the sharded schedule (exchange every iteration)
     w = pkg.World(local_rank)
 
     # N = 1: BASELINE configs[1] (Stress1000).  N > 1: north_star's strong-scaling experiment, the SAME 64 000-cube scene sharded over
