@@ -64,7 +64,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_download_force", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings",
+    "avbd_group_step", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings",
 ]
 
 
@@ -125,6 +125,19 @@ def partition_by_axis(position, inv_mass, nranks, axis=0):
     if rc:
         raise AvbdError(f"avbd_partition_by_axis failed: {rc}")
     return owner
+
+
+def exchange_layout(owner, nranks):
+    """Layout of the per-iteration pose exchange (pure host code of the library, no GPU needed): (rankStart, perm, row, maxCount)."""
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    n = len(owner)
+    rank_start = np.zeros(nranks + 1, np.int32); perm = np.zeros(max(n, 1), np.int32); row = np.zeros(max(n, 1), np.int32)
+    most = C.c_int(0)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = lib().avbd_exchange_layout(n, ip(owner), int(nranks), ip(rank_start), ip(perm), ip(row), C.byref(most))
+    if rc:
+        raise AvbdError(f"avbd_exchange_layout failed: {rc}")
+    return rank_start, perm[:int(rank_start[-1])], row[:n], most.value
 
 
 def comm_unique_id():

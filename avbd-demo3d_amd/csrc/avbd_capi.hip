@@ -193,6 +193,7 @@ struct AvbdContext {
     std::vector<int> hOwner;            /* per body: owning rank, -1 = replicated (static) */
     DevArr<int> dSolved;                /* per body: 1 = dynamic and owned by this rank */
     std::vector<int> hPerm, hRankStart; /* solved bodies grouped by rank */
+    std::vector<int> hRow;              /* row of every body in an all-gather buffer (avbd_exchange_layout) */
     DevArr<int> dPerm, dRankStart, dSendSlot;
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
@@ -403,14 +404,13 @@ int upload_bodies_if_stale(AvbdContext* c)
             if (!dyn) c->hOwner[(size_t)i] = -1;
             else if (c->hOwner[(size_t)i] < 0 || c->hOwner[(size_t)i] >= c->nranks) c->hOwner[(size_t)i] = 0;
             solved[(size_t)i] = dyn && c->hOwner[(size_t)i] == c->rank;
-            if (dyn) ++c->hRankStart[(size_t)c->hOwner[(size_t)i] + 1];
         }
-        c->maxCount = 0;
-        for (int r = 0; r < c->nranks; ++r) { c->maxCount = std::max(c->maxCount, c->hRankStart[(size_t)r + 1]); c->hRankStart[(size_t)r + 1] += c->hRankStart[(size_t)r]; }
-        c->rowsStale = true;
+        /* the exchange layout (who sits where in the all-gather) comes from the one host function the C ABI exports */
         c->hPerm.assign((size_t)std::max(n, 1), 0);
-        std::vector<int> cur(c->hRankStart.begin(), c->hRankStart.end() - 1);
-        for (int i = 0; i < n; ++i) if (c->hOwner[(size_t)i] >= 0) c->hPerm[(size_t)cur[(size_t)c->hOwner[(size_t)i]]++] = i;
+        c->hRow.assign((size_t)std::max(n, 1), -1);
+        c->rowsStale = true;
+        if (avbd_exchange_layout(n, c->hOwner.data(), c->nranks, c->hRankStart.data(), c->hPerm.data(), c->hRow.data(), &c->maxCount) != AVBD_OK)
+            return c->fail(AVBD_E_INVALID, "exchange layout: owner index out of range");
         if (n) {
             HIPCHK(c, hipMemcpyAsync(c->dSolved.p, solved.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->dPerm.p, c->hPerm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1005,11 +1005,7 @@ int shard_prepare_buffers(AvbdContext* c)
     if (c->dRow.n < (size_t)c->bodyCap || c->rowsStale) {
         if (c->dRow.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRow.alloc((size_t)c->bodyCap)); }
         const int n = (int)c->hBodies.size();
-        std::vector<int> row((size_t)std::max(n, 1), -1);
-        for (int r = 0; r < c->nranks; ++r)
-            for (int k = c->hRankStart[(size_t)r]; k < c->hRankStart[(size_t)r + 1]; ++k)
-                row[(size_t)c->hPerm[(size_t)k]] = r * std::max(1, c->maxCount) + (k - c->hRankStart[(size_t)r]);
-        HIPCHK(c, hipMemcpy(c->dRow.p, row.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        if (n) HIPCHK(c, hipMemcpy(c->dRow.p, c->hRow.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         c->rowsStale = false;
     }
     return AVBD_OK;
@@ -2212,6 +2208,33 @@ int avbd_partition_by_axis(int n, const float* position, const float* invMass, i
     std::stable_sort(dyn.begin(), dyn.end(), [&](int a, int b) { return position[3 * (size_t)a + axis] < position[3 * (size_t)b + axis]; });
     const size_t m = dyn.size();
     for (size_t k = 0; k < m; ++k) owner[dyn[k]] = (int)std::min<size_t>((size_t)nranks - 1, k * (size_t)nranks / std::max<size_t>(m, 1));
+    return AVBD_OK;
+}
+
+int avbd_exchange_layout(int n, const int* owner, int nranks, int* rankStart, int* perm, int* row, int* maxCount)
+{
+    /* Host-only (no device needed): the layout of the per-iteration pose exchange.  Bodies with owner r (0 <= r < nranks) are
+     * rank r's; negative owners are replicated (static) bodies.  rankStart[nranks + 1]: prefix counts; perm[n]: swept bodies
+     * grouped by rank, creation order inside a rank; row[n]: r * max(1, maxCount) + position inside rank r's block — the row of
+     * a body in every all-gather buffer (equal-sized blocks, one per rank) — or -1; maxCount: largest block. */
+    if (n < 0 || nranks < 1 || (n && !owner) || !rankStart || (n && (!perm || !row)) || !maxCount) return AVBD_E_INVALID;
+    for (int r = 0; r <= nranks; ++r) rankStart[r] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (owner[i] >= nranks) return AVBD_E_INVALID;
+        if (owner[i] >= 0) ++rankStart[owner[i] + 1];
+    }
+    int most = 0;
+    for (int r = 0; r < nranks; ++r) { most = std::max(most, rankStart[r + 1]); rankStart[r + 1] += rankStart[r]; }
+    *maxCount = most;
+    std::vector<int> cur(rankStart, rankStart + nranks);
+    const int block = std::max(1, most);
+    for (int i = 0; i < n; ++i) {
+        row[i] = -1;
+        if (owner[i] < 0) continue;
+        const int k = cur[(size_t)owner[i]]++;
+        perm[k] = i;
+        row[i] = owner[i] * block + (k - rankStart[owner[i]]);
+    }
     return AVBD_OK;
 }
 

@@ -249,6 +249,13 @@ int  avbd_kat_arith(AvbdContext* ctx, int n, const float* a, const float* b, flo
  * the single-GPU sweep.  There is no such mode in the reference. */
 int  avbd_partition_by_axis(int n, const float* position /* 3n */, const float* invMass /* n */, int nranks, int axis, int* owner /* n out */);
 int  avbd_set_ownership(AvbdContext* ctx, int nranks, int rank, const int* owner, int n);
+/* Layout of the per-iteration exchange for an ownership vector; host-only, needs no device (the contract of the
+ * exchange is 13 floats per body — position, orientation, velocities; this library exchanges the 8 floats that change inside
+ * the iteration loop, {position + radius, orientation}, and re-derives the velocities from the gathered poses exactly as
+ * solver.cpp:434-469 does, so both forms carry the same information).  rankStart[nranks + 1] prefix counts, perm[n] swept
+ * bodies grouped by rank, row[n] the row of a body in every all-gather buffer (equal blocks of max(1, maxCount) rows per rank;
+ * -1 for replicated bodies), maxCount the largest block. */
+int  avbd_exchange_layout(int n, const int* owner, int nranks, int* rankStart, int* perm, int* row, int* maxCount);
 int  avbd_comm_unique_id(char id[128]);                                   /* ncclGetUniqueId on one rank, broadcast by the caller */
 int  avbd_comm_init(AvbdContext* ctx, int nranks, int rank, const char id[128]);  /* ncclCommInitRank; avbd_step then exchanges per iteration */
 /* the same sharded schedule for `n` contexts living in ONE process (exchange by device-to-device copies) */

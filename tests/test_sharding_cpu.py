@@ -1,9 +1,12 @@
-"""Host-side logic of the sharded path without a GPU: the partitioner, and the per-iteration pose exchange protocol
-(pack own rows → all-gather of equal-sized blocks → unpack the other ranks' rows) run by two processes over gloo."""
+"""Host-side logic of the sharded path without a GPU: the partitioner and the exchange layout are the LIBRARY's own host
+functions (avbd_partition_by_axis, avbd_exchange_layout — the code the device path sizes its buffers and rows with); the
+per-iteration exchange protocol built on them (every rank writes its rows into its block of the gather buffer, in-place
+all-gather of equal blocks, everybody reads the other ranks' rows) is run by two processes over gloo."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -29,6 +32,24 @@ def test_partition_by_axis_equal_slabs():
             assert pos[owner == r, 0].max() <= pos[owner == r + 1, 0].min()
 
 
+def test_exchange_layout_rows_are_a_bijection_onto_the_blocks():
+    rng = np.random.default_rng(9)
+    for nranks in (1, 2, 3, 8):
+        n = 500
+        owner = rng.integers(-1, nranks, n).astype(np.int32)
+        starts, perm, row, most = pkg.exchange_layout(owner, nranks)
+        counts = np.bincount(owner[owner >= 0], minlength=nranks)
+        assert most == counts.max() and list(np.diff(starts)) == list(counts)
+        assert (row[owner < 0] == -1).all()
+        block = max(1, most)
+        for r in range(nranks):
+            mine = np.nonzero(owner == r)[0]
+            assert list(perm[starts[r]:starts[r + 1]]) == list(mine)                 # creation order inside a rank
+            assert list(row[mine]) == list(r * block + np.arange(len(mine)))
+    with pytest.raises(Exception):
+        pkg.exchange_layout(np.array([0, 5], np.int32), 2)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -40,23 +61,23 @@ def _exchange_worker(rank, world, port, n, seed, out_dir):
     pos = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
     inv = np.ones(n, np.float32); inv[0] = 0.0
     owner = pkg.partition_by_axis(pos, inv, world, axis=2)
-    # the same grouping the library builds on the device: solved bodies rank by rank
-    perm = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)])
-    starts = np.concatenate([[0], np.cumsum([np.sum(owner == r) for r in range(world)])])
-    max_count = int(np.diff(starts).max())
+    # the library's own layout: rows of the gather buffers, blocks of max_count rows per rank
+    starts, perm, row, max_count = pkg.exchange_layout(owner, world)
+    block = max(1, max_count)
     # every rank starts from the same global table, then "solves" (perturbs) only its own bodies
     table = np.zeros((n, 8), np.float32); table[:, :3] = pos; table[:, 7] = 1.0
+    gather = [np.zeros((world * block, 8), np.float32) for _ in range(2)]           # two buffers, alternating like the device path
     for it in range(3):
         mine = perm[starts[rank]:starts[rank + 1]]
         table[mine, :3] += np.float32(0.01 * (it + 1) * (rank + 1))
-        send = np.zeros((max_count, 8), np.float32); send[:len(mine)] = table[mine]
-        recv = [torch.zeros(max_count, 8) for _ in range(world)]
-        dist.all_gather(recv, torch.from_numpy(send))
+        g = gather[it & 1]
+        g[row[mine]] = table[mine]                                                  # publish: each body's row of this rank's block
+        blocks = [torch.zeros(block, 8) for _ in range(world)]
+        dist.all_gather(blocks, torch.from_numpy(g[rank * block:(rank + 1) * block].copy()))   # in place: block r comes from rank r
         for r in range(world):
-            if r == rank:
-                continue
-            theirs = perm[starts[r]:starts[r + 1]]
-            table[theirs] = recv[r].numpy()[:len(theirs)]
+            g[r * block:(r + 1) * block] = blocks[r].numpy()
+        theirs = np.nonzero((owner >= 0) & (owner != rank))[0]
+        table[theirs] = g[row[theirs]]                                              # what a boundary task reads
     np.save(os.path.join(out_dir, f"table{rank}.npy"), table)
     dist.destroy_process_group()
 
