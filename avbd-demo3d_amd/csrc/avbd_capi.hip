@@ -2396,6 +2396,18 @@ int avbd_debug_task_times(AvbdContext* c, unsigned* out, int iterations)
     return AVBD_OK;
 }
 
+int avbd_debug_group_task_times(AvbdContext* c, unsigned* out, int iterations)
+{
+    /* -DAVBD_DF_STATS builds: per task (iteration-major, body index) {inputs seen, pose published, task end, wave} in 10 ns ticks */
+    if (!c || !out || iterations < 1) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t words = (size_t)iterations * c->hBodies.size() * 4;
+    if (!c->xPrivN.p || c->privNCap * sizeof(float4) < words * sizeof(unsigned)) return c->fail(AVBD_E_INVALID, "no task time buffer");
+    HIPCHK(c, hipMemcpy(out, c->xPrivN.p, words * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
 int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)
 {
     if (!c || !out) return AVBD_E_INVALID;

@@ -535,6 +535,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
+#ifdef AVBD_DF_STATS
+        if (!MULTI && gl == 0) (reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)body) * 4)[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
         GS_STAMP(9);
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
         if (doDual && has && owned) {
@@ -617,10 +620,17 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             stat[14] += 1;
             if (__ballot(go)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(go && gl == 0)); }
 #endif
+#ifdef AVBD_DF_STATS
+            unsigned* trec = reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)(body < 0 ? 0 : body)) * 4;   /* tools/debug_groups_critical.py */
+            if (go && gl == 0) trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
             if (go) {
                 finish_task();
                 ++it;
             }
+#ifdef AVBD_DF_STATS
+            if (go && gl == 0) { trec[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[3] = (unsigned)w; }
+#endif
             GS_STAMP(1);
             if (go) {
                 if (it < itStop) prepare_task();

@@ -268,6 +268,7 @@ int  avbd_profile_get(AvbdContext* ctx, AvbdProfile* out);
 /* the raw hipStream_t of the context (as void*), so a caller can record its own events on it */
 void* avbd_stream(AvbdContext* ctx);
 /* debug builds (-DAVBD_DF_STATS): per-wave time breakdown of the last k_iterate launch, 16 counters per wave */
+int  avbd_debug_group_task_times(AvbdContext* ctx, unsigned* out /* iterations * bodies * 4 */, int iterations);
 int  avbd_debug_iterate_stats(AvbdContext* ctx, unsigned long long* out, int waves);
 /* Per-task time stamps of the resident schedule (builds with -DAVBD_DF_STATS only; zeros otherwise): out[it][1024][8] u32. */
 int  avbd_debug_task_times(AvbdContext* ctx, unsigned* out, int iterations);

@@ -9,8 +9,8 @@ shift
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 100 --warmup 10 --no-cpu "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 20 --warmup 5 --no-cpu "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 bench.py --steps 20 --warmup 5 --no-cpu "$@" > "$OUT/bench_write.json" 2> "$OUT/write.err"
-python3 bench.py --steps 200 --warmup 20 "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 100 --warmup 10 --no-cpu --no-strong-n1 "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-strong-n1 "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-strong-n1 "$@" > "$OUT/bench_write.json" 2> "$OUT/write.err"
+python3 bench.py --steps 200 --warmup 20 --no-strong-n1 "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 profiles/summarise.py "$OUT" "$TAG"
