@@ -182,6 +182,8 @@ struct AvbdContext {
     DevArr<unsigned> dDone; DevArr<float4> dGather[2]; DevArr<int> dRow; size_t gatherRows = 0;
     int shardWaves = 0;            /* waves the plan of a sharded step may use (contexts that share a device split them; room for the collective's kernel) */
     bool shardRanPersistent = false;
+    bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
+    DevArr<int> dSlotOf;
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
     bool rowsStale = true;         /* ownership changed: the gather rows of the bodies must be uploaded again */
     bool groupsLaunched = false;   /* the last iteration loop was offered to k_iterate_groups (the device may still decline: GroupPlan.bad) */
@@ -636,6 +638,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
     c->statsFresh = true;
+    if (cnt.overflow & 32) return c->fail(AVBD_E_HIP, "race checker: the schedule of this step is not race-free (two bodies of one launch share a force, or the sweep order is not a linear extension of the dependencies)");
     if (cnt.overflow) {
         char buf[160];
         std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
@@ -739,6 +742,14 @@ int step_begin(AvbdContext* c)
         }
         if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
             HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, (size_t)2 * c->bodyCap * sizeof(int), c->stream));   /* the error word behind them is sticky */
+    }
+    if (c->raceCheck && n > 0) {
+        if (c->dSlotOf.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dSlotOf.alloc((size_t)c->bodyCap)); }
+        HIPCHK(c, hipMemsetAsync(c->dSlotOf.p, 0xff, (size_t)c->bodyCap * sizeof(int), c->stream));
+        const bool byLevel = c->mode == 0 || !c->orderByIndex;
+        for (int pass = 0; pass < 2; ++pass)
+            hipLaunchKernelGGL(k_race_check, dim3(grid_for(n, 256, 1024)), dim3(256), 0, c->stream, B, c->mbuf[c->cur].view(), c->dG.p, c->dCnt.p, c->dCnt.p, c->adjStart.p, c->adjRef.p,
+                               c->adjOther.p, c->incStart.p, c->inc.p, c->level.p, c->order.p, c->lvlStart.p, c->dSlotOf.p, byLevel ? 1 : 0, pass);
     }
     c->groupsPlanned = false;
     if (groups_eligible(c)) {
@@ -1204,6 +1215,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_RACE_CHECK")) c->raceCheck = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_GROUPS_WAVES")) c->groupsWaves = std::max(0, std::atoi(e));
@@ -1273,7 +1285,7 @@ int avbd_destroy(AvbdContext* c)
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release();
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
-    c->dPlan.release(); c->dUnit.release();
+    c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release();
     c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release();
     if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather);
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);

@@ -472,6 +472,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;
+#ifdef AVBD_DF_STATS
+        if (gl == 0) race_note_consumed(errWord - 2 * B.cap, body, it);
+#endif
         if (needP) {
             const f3 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); const q4 orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
             wOther = qrotate(orot, isA ? c.rB : c.rA);
@@ -522,6 +525,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         BodyLocal L; L.pos = pos; L.rot = rot;
         f3 p; q4 q;
         solve_pose(accs, xch, gl, L, p, q);
+#ifdef AVBD_DF_STATS
+        race_check_publish(errWord - 2 * B.cap, cntW, body, other, has && moving, it);
+#endif
         if (gl == 0) {
             sanitize3(p, cntW, warn_key(1, it, body, 0), body, WK_POS);
             sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);
@@ -536,7 +542,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
 #ifdef AVBD_DF_STATS
-        if (!MULTI && gl == 0) (reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)body) * 4)[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+        if (!MULTI && gl == 0 && X.privN) (reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)body) * 4)[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
         GS_STAMP(9);
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
@@ -621,7 +627,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             if (__ballot(go)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(go && gl == 0)); }
 #endif
 #ifdef AVBD_DF_STATS
-            unsigned* trec = reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)(body < 0 ? 0 : body)) * 4;   /* tools/debug_groups_critical.py */
+            unsigned trecNone[4];
+            unsigned* trec = X.privN ? reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)(body < 0 ? 0 : body)) * 4 : trecNone;   /* tools/debug_groups_critical.py */
             if (go && gl == 0) trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
             if (go) {

@@ -1196,6 +1196,43 @@ __global__ void k_unpack_poses(BodyTable B, const int* perm, const int* rankStar
     B.plane(BP_QUAT)[b] = recv[2 * ((size_t)r * maxCount + k) + 1];
 }
 
+/* ---- debug race checker (AVBD_RACE_CHECK=1) --------------------------------------------------------
+ * The schedules are race-free by construction; this kernel checks the construction, every step, from the topology the step
+ * will run on:
+ *   level schedule (one launch per level): no two bodies of one launch share a force that has rows — a launch would read a
+ *     pose / write a manifold that another wavefront of the same launch writes;
+ *   data-flow schedules: the sweep order is a linear extension of "later-created swept neighbours first" (what makes the
+ *     smallest unfinished task runnable, hence the persistent launches deadlock-free), lists a swept body exactly once, and
+ *     every incidence entry of a body refers to a force that body is an endpoint of.
+ * A violation sets bit 5 of Counters.overflow; the host turns it into an error at the next synchronising call. */
+__global__ void k_race_check(BodyTable B, ManifoldTable M, const GForce* gf, const Counters* cnt, Counters* cntW, const int* __restrict__ adjStart,
+                             const int* __restrict__ adjRef, const int* __restrict__ adjOther, const int* __restrict__ incStart, const int* __restrict__ inc,
+                             const int* __restrict__ level, const int* __restrict__ order, const int* __restrict__ lvlStart, int* __restrict__ slotOf, int byLevel, int pass)
+{
+    const int nd = lvlStart[cnt->numLevels];
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nd; s += gridDim.x * blockDim.x) {
+        const int b = order[s];
+        bool bad = b < 0 || b >= B.n || !B.solved[b];
+        if (pass == 0) { if (!bad) slotOf[b] = s; else atomicOr(&cntW->overflow, 32); continue; }
+        if (bad || slotOf[b] != s) { atomicOr(&cntW->overflow, 32); continue; }            /* listed twice: the later slot won */
+        for (int k = adjStart[b]; k < adjStart[b + 1]; ++k) {
+            const int o = adjOther[k];
+            if (o < 0 || inc_kind(adjRef[k]) == FK_IGNORE || !B.solved[o]) continue;
+            if (byLevel) { if (level[o] == level[b]) bad = true; }
+            else if (o > b && !(slotOf[o] < s)) bad = true;
+        }
+        for (int e = incStart[b]; e < incStart[b + 1]; ++e) {
+            const int ent = inc[e], kind = inc_kind(ent), idx = inc_index(ent);
+            int a = -2, c2 = -2;
+            if (kind == FK_MANIFOLD) { const int2 pr = M.pair[idx >> 2]; a = pr.x; c2 = pr.y; if ((idx & 3) >= M.nc[idx >> 2]) bad = true; }
+            else if (kind == FK_JOINT) { a = gf[idx >> 1].bodyA; c2 = gf[idx >> 1].bodyB; }
+            else { a = gf[idx].bodyA; c2 = gf[idx].bodyB; }
+            if ((inc_isA(ent) ? a : c2) != b) bad = true;
+        }
+        if (bad) atomicOr(&cntW->overflow, 32);
+    }
+}
+
 /* ---- known-answer kernels --------------------------------------------------------------- */
 struct KatContact { int feature; float rA[3], rB[3], normal[3]; float penetration, C0_n, C0_t[3]; int stick; };
 

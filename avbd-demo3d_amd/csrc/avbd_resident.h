@@ -76,6 +76,25 @@ __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); 
 __device__ __forceinline__ float bitsf(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ float bcast0(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
 
+#ifdef AVBD_DF_STATS
+/* Debug race checker for the stamped records (stats builds only): "a record is never overwritten before its
+ * reader has consumed it".  Every task notes `consumed[body] = it + 1` once its inputs are in registers; a task that is about
+ * to overwrite its pose record with iteration `it` checks the readers of the value it destroys (iteration it - 1): an
+ * earlier-created partner read it in ITS task it - 1, a later-created partner reads it in its task `it`.  The Gauss-Seidel
+ * dependencies imply both; a violation sets bit 5 of Counters.overflow. */
+__device__ __forceinline__ void race_note_consumed(int* consumed, int body, int it)
+{
+    __hip_atomic_store(consumed + body, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void race_check_publish(const int* consumed, Counters* cnt, int body, int other, bool hasMovingPartner, int it)
+{
+    if (!hasMovingPartner || it < 1) return;
+    const int seen = __hip_atomic_load(consumed + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int need = other > body ? it + 1 : it;
+    if (seen < need) atomicOr(&cnt->overflow, 32);
+}
+#endif
+
 /* What one computeConstraint call does to the stored normal and its tangent memo (manifold.cpp:185-186 through
  * contact_basis_memo): used to replay the calls the OTHER visitor / the dual made since this wave last touched the
  * contact.  Once the normal is a fixed point of the normalisation every later call leaves it alone. */
@@ -520,6 +539,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             }
 #endif
             prevWait = (unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0);
+#ifdef AVBD_DF_STATS
+            if (lane == 0) race_note_consumed(errWord - 2 * B.cap, body, it);
+#endif
             if (needP) {
                 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
                 if (!(JOINTS && isJoint)) {
@@ -580,6 +602,9 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         RS_STAMP(2);
         f3 p; q4 q;
         solve_pose(accs, accs + 32, lane, L, p, q);
+#ifdef AVBD_DF_STATS
+        race_check_publish(errWord - 2 * B.cap, cntW, body, other, has && moving && !(JOINTS && isJoint), it);
+#endif
         if (lane == 0) {
             sanitize3(p, cntW, warn_key(1, it, body, 0), body, WK_POS);
             sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);

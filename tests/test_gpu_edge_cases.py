@@ -507,3 +507,22 @@ def test_non_finite_warnings_are_the_reference_lines_in_the_reference_order(capf
     first_warning = next(i for i, l in enumerate(out) if l.startswith("[Physics] Warning"))
     first_diag = next(i for i, l in enumerate(out) if l.startswith("[Physics] step"))
     assert first_warning < first_diag
+
+
+def test_debug_race_checker_accepts_every_schedule(monkeypatch):
+    """AVBD_RACE_CHECK=1: after every topology rebuild a kernel checks that the schedule about to run is race-free —
+    no two bodies of one level launch share a force; the sweep order of the data-flow schedules is a linear extension of the
+    dependencies and lists every swept body once; every incidence entry belongs to its body.  It must stay silent on all
+    schedules (and the results stay bit-exact)."""
+    monkeypatch.setenv("AVBD_RACE_CHECK", "1")
+    for env in ({}, {"AVBD_MODE": "levels"}, {"AVBD_ORDER": "levels"}, {"AVBD_GROUPS": "1"}, {"AVBD_FUSED_TOPOLOGY": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        o = H.CpuWorld("orc"); o.scene("Pyramid"); o.step(25)
+        g = H.HipWorld(); g.scene("Pyramid"); g.step(25)
+        g.w.synchronize()                                    # a violation would surface here as AVBD_E_HIP
+        H.assert_same_world(o, g, f"Pyramid under the race checker with {env}")
+        for k in env:
+            monkeypatch.delenv(k)
+    g = H.HipWorld(); g.scene("Packed:12"); g.set_params(iterations=4); g.step(6); g.w.synchronize()
+    assert int(g.w.stats()["schedule"]) == 4
