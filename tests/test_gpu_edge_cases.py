@@ -220,6 +220,7 @@ def test_resident_schedule_with_several_bodies_per_wave(monkeypatch):
     """More swept bodies than resident wavefronts (1728 > 1024): every wave takes every W-th body of the level order and
     parks a body's state between its tasks (stats.schedule == 3).  AVBD_RESIDENT_MULTI=0 sends the scene to the task
     schedule instead (1).  Post-stabilisation changes which task is a body's last."""
+    monkeypatch.setenv("AVBD_GROUPS", "0")                       # (by default a scene of this size takes the group schedule, test_gpu_groups.py)
     for post in (0, 1):
         o = H.CpuWorld("orc"); o.scene("Packed:12"); o.set_params(postStabilize=post, iterations=6); o.step(14)
         for multi, sched in (("1", 3), ("0", 1)):
@@ -411,6 +412,7 @@ def test_two_workgroups_per_cu_with_a_body_of_more_than_34_entries(monkeypatch, 
     monkeypatch.setenv("AVBD_RESIDENT_FORCE_LITE", "1")
     monkeypatch.setenv("AVBD_ITER_BLOCKS", "2")
     monkeypatch.setenv("AVBD_RESIDENT_OOO", ooo)
+    monkeypatch.setenv("AVBD_GROUPS", "0")                       # the resident schedule's parked sweep is what this test is about
     o, g = pair()
     for w in (o, g):
         w.add_body((40, 1, 40), 0.0, 0.5, (0, -0.5, 0))

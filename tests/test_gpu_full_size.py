@@ -26,7 +26,33 @@ def test_config3_8000_cubes_bit_exact_vs_oracle():
         o.step(); g.step()
         H.assert_same_world_fast(o, g, f"Packed:20 step {s + 1}")
     st = g.w.stats()
-    assert int(st["numManifolds"]) > 5000 and int(st["schedule"]) == 3     # resident, several bodies per wavefront
+    assert int(st["numManifolds"]) > 5000 and int(st["schedule"]) == 4     # group schedule: every body resident in a sub-group of a wavefront
+
+
+def test_config3_8000_cubes_resident_schedule_with_parked_bodies_bit_exact_vs_oracle(monkeypatch):
+    """The same scene through the schedule that scenes beyond 8 192 bodies (and scenes with joints) take: several bodies per
+    wavefront, state parked between tasks."""
+    monkeypatch.setenv("AVBD_GROUPS", "0")
+    o, g = H.CpuWorld("orc"), H.HipWorld()
+    for w in (o, g):
+        w.scene("Packed:20")
+    for s in range(6):
+        o.step(); g.step()
+        H.assert_same_world_fast(o, g, f"Packed:20 step {s + 1} (parked sweep)")
+    assert int(g.w.stats()["schedule"]) == 3
+
+
+def test_config2_falling_8000_cubes_bit_exact_vs_oracle_on_landing():
+    """configs[2] itself (StressN:20, the falling scene, not the packed variant): the reference cannot load a snapshot and its
+    O(n^2) broadphase makes 130 steps of free fall expensive on the CPU, so the restatement is started from the device's own
+    state shortly before the first contact and both go through the landing of the first layers, bit for bit."""
+    g = H.HipWorld(); g.scene("StressN:20"); g.step(131)                 # first contacts appear in step 132
+    o = H.CpuWorld("orc"); o.scene("StressN:20")
+    o.set_bodies(g.bodies()); o.set_forces(g.forces()); o.set_step_index(g.step_index())
+    for s in range(8):
+        o.step(); g.step()
+        H.assert_same_world_fast(o, g, f"StressN:20 step {132 + s}")
+    assert int(g.diag()["activeContacts"]) > 1000
 
 
 def test_config3_8000_cubes_long_run_is_deterministic_and_finite():
