@@ -182,6 +182,10 @@ struct AvbdContext {
     DevArr<unsigned> dDone; DevArr<float4> dGather[2]; DevArr<int> dRow; size_t gatherRows = 0;
     int shardWaves = 0;            /* waves the plan of a sharded step may use (contexts that share a device split them; room for the collective's kernel) */
     bool shardRanPersistent = false;
+    /* user-defined Force subclasses: rows evaluated by the caller between launches (avbd_add_host_force) */
+    std::vector<int> hostForceG;           /* ordinal -> index in hG */
+    std::vector<HostRowsDev> hHostRows; DevArr<HostRowsDev> dHostRows;
+    AvbdHostForceFn hostFn = nullptr; void* hostUser = nullptr;
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
@@ -602,7 +606,7 @@ int launch_topology(AvbdContext* c, bool fromStep)
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, n, c->degForce.p, c->degInc.p, c->adjStart.p, c->incStart.p, c->dCnt.p, c->dNext.p);
     hipLaunchKernelGGL(k_fill_adj, dim3(grid_for((long long)c->stats.numManifolds + c->stats.numCandidates + ng + 4096, 256, 2048)), dim3(256), 0, c->stream,
                        M, c->dCnt.p, c->dG.p, ng, c->adjStart.p, c->degForce.p, c->adjRef.p, c->adjOther.p, c->adjKey.p);
-    hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->adjStart.p, c->adjRef.p, c->adjOther.p,
+    hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dG.p, c->adjStart.p, c->adjRef.p, c->adjOther.p,
                        c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p, c->dCnt.p);
     if (fromStep) {
         if (c->mode != 0 && c->orderByIndex)
@@ -635,7 +639,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && (cnt.residentBad & 1) == 0 && ((cnt.residentBad & 2) == 0 || c->residentMultiLaunched)) ? (((cnt.residentBad & 2) || c->residentMultiLaunched) ? 3 : 2) : 1);
     if (c->groupsLaunched && c->hRb->plan.bad == 0) c->stats.schedule = 4;   /* group schedule (avbd_groups.h) */
     int nj = 0, ns = 0, ni = 0;
-    for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }
+    for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }   /* (host forces: stats.numBodies etc. only) */
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
     c->statsFresh = true;
     if (cnt.overflow & 32) return c->fail(AVBD_E_HIP, "race checker: the schedule of this step is not race-free (two bodies of one launch share a force, or the sweep order is not a linear extension of the dependencies)");
@@ -911,7 +915,7 @@ int step_iterate_levels(AvbdContext* c)
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
             hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
-                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p, it);
+                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p, it, c->dHostRows.p);
             ++c->prof.launches_primal; ++c->prof.launches_total;
         }
         if (it < P.iterations) {
@@ -1083,9 +1087,175 @@ int shard_finish_persistent(AvbdContext* c, int totalIt)
     return AVBD_OK;
 }
 
+/* ---- steps of a scene that contains user-defined Force subclasses (avbd_add_host_force) --------------------------------------
+ * Their virtuals are the caller's code, so the rows of every visit are fetched from the host right before the launch that reads
+ * them: one k_primal launch per Gauss-Seidel level (the level schedule is exact: bodies of a level share no force), host in
+ * the loop for the levels that visit an endpoint of such a force and for the dual pass.  Slow by construction, exact by
+ * construction: the subclass sees the same sequence of initialize / computeConstraint / computeDerivatives calls, with the same
+ * body poses, as inside the reference's Solver::step (solver.cpp:273-296, 371-399, 411-430). */
+int host_current_pose(AvbdContext* c, int body, float out[7])
+{
+    float4 pq[2];
+    HIPCHK(c, hipMemcpyAsync(&pq[0], c->dPlanes.p + (size_t)BP_POSR * c->bodyCap + body, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&pq[1], c->dPlanes.p + (size_t)BP_QUAT * c->bodyCap + body, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out[0] = pq[0].x; out[1] = pq[0].y; out[2] = pq[0].z; out[3] = pq[1].x; out[4] = pq[1].y; out[5] = pq[1].z; out[6] = pq[1].w;
+    return AVBD_OK;
+}
+
+int host_force_call(AvbdContext* c, int ord, int phase, float alpha, int body, bool fromDevice, AvbdHostRows& R)
+{
+    const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)ord]];
+    float pa[7], pb[7];
+    int rc;
+    for (int e = 0; e < 2; ++e) {
+        const int b = e == 0 ? g.bodyA : g.bodyB;
+        float* o = e == 0 ? pa : pb;
+        if (b < 0) continue;
+        if (fromDevice) { if ((rc = host_current_pose(c, b, o))) return rc; }
+        else { const AvbdBody& hb = c->hBodies[(size_t)b]; for (int k = 0; k < 3; ++k) o[k] = hb.position[k]; for (int k = 0; k < 4; ++k) o[3 + k] = hb.orientation[k]; }
+    }
+    if (c->hostFn(c->hostUser, ord, phase, alpha, body, g.bodyA >= 0 ? pa : nullptr, pb, &R) != 0)
+        return c->fail(AVBD_E_INVALID, "the host force callback reported an error");
+    if (R.rows < 0 || R.rows > 12) return c->fail(AVBD_E_INVALID, "host force: row count out of range (0..12)");
+    return AVBD_OK;
+}
+
+void host_rows_to_record(const AvbdHostRows& R, HostRowsDev& h, bool sideA, bool sideB)
+{
+    h.rows = R.rows;
+    for (int r = 0; r < 12; ++r) {
+        h.C[r] = R.C[r]; h.fmin[r] = R.fmin[r]; h.fmax[r] = R.fmax[r]; h.lambda[r] = R.lambda[r]; h.penalty[r] = R.penalty[r];
+        h.stiffness[r] = R.stiffness[r]; h.motor[r] = R.motor[r];
+        for (int k = 0; k < 3; ++k) {
+            if (sideA) { h.JlA[r][k] = R.JlA[r][k]; h.JaA[r][k] = R.JaA[r][k]; }
+            if (sideB) { h.JlB[r][k] = R.JlB[r][k]; h.JaB[r][k] = R.JaB[r][k]; }
+        }
+    }
+}
+
+int step_with_host_rows(AvbdContext* c)
+{
+    if (!c->hostFn) return c->fail(AVBD_E_INVALID, "a user-defined Force is registered (avbd_add_host_force) but no callback (avbd_set_host_force_callback)");
+    if (c->nranks > 1 || c->forceSharded) return c->fail(AVBD_E_INVALID, "user-defined Force subclasses are not supported in sharded runs");
+    const int nh = (int)c->hostForceG.size();
+    const SolverParams P = solver_params(c);
+    int rc;
+    struct ModeGuard { AvbdContext* c; int saved; ~ModeGuard() { c->mode = saved; } } guard{c, c->mode};
+    c->mode = 0;                                                       /* level launches + level readback for this step */
+
+    /* ---- 2. initialize + warm start (solver.cpp:273-296) ---- */
+    if ((rc = download_bodies_to_host(c))) return rc;
+    if ((rc = gforces_to_host(c))) return rc;
+    std::vector<AvbdHostRows> R((size_t)nh);
+    for (int ord = 0; ord < nh; ++ord) {
+        std::memset(&R[(size_t)ord], 0, sizeof(AvbdHostRows));
+        if ((rc = host_force_call(c, ord, AVBD_HOST_INITIALIZE, P.alpha, -1, false, R[(size_t)ord]))) return rc;
+        AvbdHostRows& h = R[(size_t)ord];
+        for (int i = 0; i < h.rows; ++i) {
+            if (!P.postStabilize) h.lambda[i] *= P.alpha * P.gamma;
+            h.penalty[i] = rclamp(h.penalty[i] * P.gamma, kPenaltyMin, kPenaltyMax);
+            if (h.stiffness[i] > 0.0f && h.stiffness[i] < FLT_MAX) h.penalty[i] = rmin(h.penalty[i], h.stiffness[i]);
+        }
+        if ((rc = host_force_call(c, ord, AVBD_HOST_STORE, P.alpha, -1, false, h))) return rc;
+        GForce& g = c->hG[(size_t)c->hostForceG[(size_t)ord]];
+        if (g.pad != (ord | (h.rows << 24))) { g.pad = ord | (h.rows << 24); c->gStale = true; }
+        host_rows_to_record(h, c->hHostRows[(size_t)ord], false, false);
+    }
+    if (c->dHostRows.n < (size_t)nh) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dHostRows.alloc((size_t)std::max(nh, 16))); }
+
+    if ((rc = step_begin(c))) return rc;
+    if ((rc = refresh_stats(c, true))) return rc;                      /* the level schedule of this step */
+    const Counters& cnt = c->hRb->cnt;
+    const int L = cnt.numLevels;
+    std::vector<int> lvl;
+    const int* lvlStart = c->hRb->lvlStart;
+    if (L > kReadbackLevels) {
+        lvl.resize((size_t)L + 1);
+        HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * ((size_t)L + 1), hipMemcpyDeviceToHost));
+        lvlStart = lvl.data();
+    }
+    /* which level visits which endpoint: the level of a swept body */
+    std::vector<std::vector<std::pair<int, int>>> visits((size_t)std::max(L, 1));   /* per level: (body, host force), newest body first, newest force first */
+    {
+        std::vector<int> level((size_t)c->hBodies.size());
+        if (!level.empty()) HIPCHK(c, hipMemcpy(level.data(), c->level.p, level.size() * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint64_t, int>> byKey;
+        for (int ord = 0; ord < nh; ++ord) byKey.push_back({c->hG[(size_t)c->hostForceG[(size_t)ord]].key, ord});
+        std::sort(byKey.begin(), byKey.end(), [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return a.first > b.first; });
+        for (const auto& kv : byKey) {
+            const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)kv.second]];
+            if (host_force_rows(g) == 0) continue;
+            for (int e = 0; e < 2; ++e) {
+                const int b = e == 0 ? g.bodyA : g.bodyB;
+                if (b < 0 || !(c->hBodies[(size_t)b].invMass > 0.0f)) continue;
+                const int lv = level[(size_t)b] - 1;                 /* k_levels numbers the levels from 1; launch l sweeps level l + 1 */
+                if (lv >= 0 && lv < L) visits[(size_t)lv].push_back({b, kv.second});
+            }
+        }
+        for (auto& v : visits) std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    }
+
+    BodyTable B = body_table(c);
+    ManifoldTable M = c->mbuf[c->cur].view();
+    const int ng = (int)c->hG.size();
+    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+    const long long contactSlots = (long long)cnt.numManifolds * 4;
+    for (int it = 0; it < totalIt; ++it) {
+        const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const int writeRows = it >= P.iterations ? 1 : 0;
+        for (int l = 0; l < L; ++l) {
+            const int count = lvlStart[l + 1] - lvlStart[l];
+            if (count <= 0) continue;
+            for (const auto& v : visits[(size_t)l]) {
+                /* the visit of body v.first calls computeConstraint + computeDerivatives of host force v.second (solver.cpp:371-376) */
+                AvbdHostRows& h = R[(size_t)v.second];
+                if ((rc = host_force_call(c, v.second, AVBD_HOST_PRIMAL, alphaCur, v.first, true, h))) return rc;
+                const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)v.second]];
+                h.rows = std::min(h.rows, host_force_rows(g));          /* the entries of this step were laid out for that many rows */
+                host_rows_to_record(h, c->hHostRows[(size_t)v.second], v.first == g.bodyA, v.first == g.bodyB);
+                HIPCHK(c, hipMemcpyAsync(c->dHostRows.p + v.second, &c->hHostRows[(size_t)v.second], sizeof(HostRowsDev), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));            /* (the source is reused by the next visit) */
+            }
+            hipLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, B, M, c->dG.p, c->order.p,
+                               c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p, it, c->dHostRows.p);
+            ++c->prof.launches_primal; ++c->prof.launches_total;
+        }
+        if (it < P.iterations) {
+            if (contactSlots > 0) hipLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dCnt.p, P, alphaCur);
+            if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
+            for (int ord = 0; ord < nh; ++ord) {
+                /* solver.cpp:411-430 for a host force: computeConstraint, then the row update with rowPenaltyGain (solver.cpp:94-125) */
+                AvbdHostRows& h = R[(size_t)ord];
+                const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)ord]];
+                if (host_force_rows(g) == 0) continue;
+                if ((rc = host_force_call(c, ord, AVBD_HOST_DUAL, alphaCur, -1, true, h))) return rc;
+                h.rows = std::min(h.rows, host_force_rows(g));
+                for (int row = 0; row < h.rows; ++row) {
+                    if (h.stiffness[row] != FLT_MAX) continue;
+                    const float lu = rclamp(h.penalty[row] * h.C[row] + h.lambda[row], h.fmin[row], h.fmax[row]);
+                    const bool active = lu > h.fmin[row] && lu < h.fmax[row];
+                    h.lambda[row] = lu;
+                    if (active) {
+                        float lw = 0.0f, aw = 0.0f;
+                        if (g.bodyA >= 0) { lw += lensq3(mk3(h.JlA[row][0], h.JlA[row][1], h.JlA[row][2])); aw += lensq3(mk3(h.JaA[row][0], h.JaA[row][1], h.JaA[row][2])); }
+                        lw += lensq3(mk3(h.JlB[row][0], h.JlB[row][1], h.JlB[row][2])); aw += lensq3(mk3(h.JaB[row][0], h.JaB[row][1], h.JaB[row][2]));
+                        const float betaRow = row_penalty_gain(lw, aw, P.beta);
+                        h.penalty[row] = rmin(h.penalty[row] + betaRow * fabsf(h.C[row]), kPenaltyMax);
+                    }
+                }
+                if ((rc = host_force_call(c, ord, AVBD_HOST_STORE, alphaCur, -1, true, h))) return rc;
+            }
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return step_end(c, true);
+}
+
 int step_once(AvbdContext* c)
 {
     int rc;
+    if (!c->hostForceG.empty()) return step_with_host_rows(c);
     if ((rc = step_begin(c))) return rc;
     const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
     const bool needReadback = (c->mode == 0) || c->profiling;
@@ -1211,8 +1381,6 @@ int avbd_create(int device, AvbdContext** out)
         c->iterBlocks = std::max(1, prop.multiProcessorCount);
         c->iterLdsPad = kIterWaves * kResProductBytesPerWave;   /* 84 672 B: > half a CU's LDS, and the resident schedule's product lines */
         if (const char* e = std::getenv("AVBD_ITER_BLOCKS")) c->iterBlocks = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("AVBD_ITER_LDSPAD")) c->iterLdsPad = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("AVBD_ITER_SLEEP")) c->iterSleep = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RACE_CHECK")) c->raceCheck = std::atoi(e) != 0;
@@ -1220,14 +1388,9 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_GROUPS_WAVES")) c->groupsWaves = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
-        if (const char* e = std::getenv("AVBD_RESIDENT_SHARDED")) c->residentSharded = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_FORCE_LITE")) c->residentForceLite = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_LITE_FROM")) c->residentLiteFrom = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("AVBD_RESIDENT_MULTI_MAX")) c->residentMultiMax = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
-        if (const char* e = std::getenv("AVBD_RESIDENT_SPREAD")) c->residentSpread = std::atoi(e) != 0;
-        if (const char* e = std::getenv("AVBD_FRONT_PPW")) c->frontPairsPerWave = std::min(32, std::max(1, std::atoi(e)));
-        if (const char* e = std::getenv("AVBD_RESIDENT_PATIENCE")) c->residentPatience = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_OOO")) c->residentOutOfOrder = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;
@@ -1285,7 +1448,7 @@ int avbd_destroy(AvbdContext* c)
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release();
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
-    c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release();
+    c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release(); c->dHostRows.release();
     c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release();
     if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather);
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
@@ -1319,7 +1482,7 @@ int avbd_clear(AvbdContext* c)
     if (!c) return AVBD_E_INVALID;
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->hBodies.clear(); c->hI.clear(); c->hJ.clear(); c->hG.clear();
+    c->hBodies.clear(); c->hI.clear(); c->hJ.clear(); c->hG.clear(); c->hostForceG.clear(); c->hHostRows.clear();
     c->bodiesStale = true; c->deviceAhead = false; c->gStale = true; c->gDeviceAhead = false; c->adjDirty = true;
     c->stepIndex = 0; c->hostKeyCounter = 1; c->numStatic = 0;
     c->stats = AvbdStepStats{};
@@ -1438,6 +1601,31 @@ int avbd_add_ignore(AvbdContext* c, int bodyA, int bodyB)
     return add_gforce(c, g);
 }
 
+int avbd_add_host_force(AvbdContext* c, int bodyA, int bodyB, int* host_force)
+{
+    if (!c || !host_force) return AVBD_E_INVALID;
+    const int n = (int)c->hBodies.size();
+    if (bodyB < 0 || bodyB >= n || bodyA >= n || bodyA < -1) return c->fail(AVBD_E_INVALID, "host force body index out of range");
+    (void)hipSetDevice(c->device);
+    GForce g; init_gforce(g, FK_HOST, bodyA, bodyB);
+    const int ordinal = (int)c->hostForceG.size();
+    g.pad = ordinal;                                                   /* rows << 24 is filled in at every step begin */
+    int rc = add_gforce(c, g);
+    if (rc) return rc;
+    c->hostForceG.push_back((int)c->hG.size() - 1);
+    HostRowsDev h; std::memset(&h, 0, sizeof(h));
+    c->hHostRows.push_back(h);
+    *host_force = ordinal;
+    return AVBD_OK;
+}
+
+int avbd_set_host_force_callback(AvbdContext* c, AvbdHostForceFn fn, void* user)
+{
+    if (!c) return AVBD_E_INVALID;
+    c->hostFn = fn; c->hostUser = user;
+    return AVBD_OK;
+}
+
 int avbd_add_force(AvbdContext* c, const AvbdForce* r)
 {
     if (!c || !r) return AVBD_E_INVALID;
@@ -1473,7 +1661,7 @@ static int validate_forces(AvbdContext* c, const AvbdForce* in, int n, int nBodi
     for (int i = 0; i < n; ++i) {
         const AvbdForce& f = in[i];
         const char* bad = nullptr;
-        if (f.kind != AVBD_FORCE_MANIFOLD && f.kind != AVBD_FORCE_JOINT && f.kind != AVBD_FORCE_SPRING && f.kind != AVBD_FORCE_IGNORE) bad = "unknown kind";
+        if (f.kind != AVBD_FORCE_MANIFOLD && f.kind != AVBD_FORCE_JOINT && f.kind != AVBD_FORCE_SPRING && f.kind != AVBD_FORCE_IGNORE) bad = f.kind == AVBD_FORCE_HOST ? "a user-defined Force cannot be restored from a record (its state lives in the caller's object)" : "unknown kind";
         else if (f.bodyB < 0 || f.bodyB >= nBodies || f.bodyA < -1 || f.bodyA >= nBodies) bad = "body index out of range";
         else if (f.kind != AVBD_FORCE_JOINT && f.bodyA < 0) bad = "only a Joint may be anchored to the world";
         else if (f.rows < 0 || f.rows > 12) bad = "row count out of range";
@@ -1844,7 +2032,7 @@ int avbd_download_forces(AvbdContext* c, AvbdForce* out, int capacity)
             }
         } else {
             const GForce& g = c->hG[refs[i].index];
-            o.bodyA = g.bodyA; o.bodyB = g.bodyB; o.rows = force_row_count(g.kind, 0);
+            o.bodyA = g.bodyA; o.bodyB = g.bodyB; o.rows = g.kind == FK_HOST ? host_force_rows(g) : force_row_count(g.kind, 0);
             for (int r = 0; r < 6; ++r) {
                 o.C[r] = g.C[r]; o.fmin[r] = g.fmin[r]; o.fmax[r] = g.fmax[r]; o.lambda[r] = g.lambda[r];
                 o.penalty[r] = g.penalty[r]; o.stiffness[r] = g.stiffness[r]; o.motor[r] = g.motor[r];

@@ -55,7 +55,7 @@ __device__ __forceinline__ bool entry_owned(int ent, int body, const BodyTable& 
     const bool isA = inc_isA(ent) != 0;
     if (kind == FK_MANIFOLD) { const int2 pr = M.pair[idx >> 2]; other = isA ? pr.y : pr.x; }
     else if (kind == FK_JOINT) { const GForce& f = gf[idx >> 1]; other = isA ? f.bodyB : f.bodyA; }
-    else { const GForce& f = gf[idx]; other = isA ? f.bodyB : f.bodyA; }
+    else { const GForce& f = gf[idx & 0xFFFFFF]; other = isA ? f.bodyB : f.bodyA; }
     if (other < 0) return true;                                   /* world */
     if (!B.solved[other]) return true;                            /* static partner, or a body another GPU solves */
     return other > body;                                           /* partner is visited earlier in the sweep */

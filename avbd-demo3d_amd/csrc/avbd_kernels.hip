@@ -439,7 +439,7 @@ __global__ void k_gforce_prepare(BodyTable B, GForce* gf, int ng, int* degForce,
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ng) return;
     GForce& f = gf[g];
-    int rows = force_row_count(f.kind, 0);
+    int rows = f.kind == FK_HOST ? 0 : force_row_count(f.kind, 0);   /* (a host force's rows are decayed on the host, solver.cpp:281-293) */
     if (decay) {
         for (int r = 0; r < rows; ++r) {
             if (!P.postStabilize) f.lambda[r] *= P.alpha * P.gamma;
@@ -447,7 +447,7 @@ __global__ void k_gforce_prepare(BodyTable B, GForce* gf, int ng, int* degForce,
             if (f.stiffness[r] > 0.0f && f.stiffness[r] < FLT_MAX) f.penalty[r] = rmin(f.penalty[r], f.stiffness[r]);
         }
     }
-    int entries = f.kind == FK_JOINT ? 2 : (f.kind == FK_SPRING ? 1 : 0);
+    int entries = gforce_entries(f);
     if (f.bodyA >= 0) { atomicAdd(&degForce[f.bodyA], 1); if (B.solved[f.bodyA]) atomicAdd(&degInc[f.bodyA], entries); }
     if (f.bodyB >= 0) { atomicAdd(&degForce[f.bodyB], 1); if (B.solved[f.bodyB]) atomicAdd(&degInc[f.bodyB], entries); }
 }
@@ -510,7 +510,7 @@ __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* g
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         int a, b, kind, index; uint64_t key;
         if (item < nm) { int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; }
-        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = f.kind; index = item - nm; key = f.key; }
+        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = gforce_ref_kind(f.kind); index = item - nm; key = f.key; }
         if (a >= 0) {
             int pos = adjStart[a] + atomicAdd(&cursor[a], 1);
             adjRef[pos] = make_inc(1, kind, index); adjOther[pos] = b; adjKey[pos] = key;
@@ -524,7 +524,7 @@ __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* g
 
 /* Per dynamic body: order its adjacency newest-first (= the reference's body->forces walk,
  * force.cpp:21-29) and expand it into the row-incidence list consumed by k_primal. */
-__global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart, int* adjRef, int* adjOther, uint64_t* adjKey,
+__global__ void k_sort_expand(BodyTable B, ManifoldTable M, const GForce* gf, const int* adjStart, int* adjRef, int* adjOther, uint64_t* adjKey,
                               const int* incStart, int* inc, int* level, int* cursor, Counters* cnt)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,7 +551,8 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const int* adjStart,
             inc[o++] = make_inc(isA, FK_JOINT, idx * 2);
             inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1);
         } else if (kind == FK_SPRING) {
-            inc[o++] = make_inc(isA, FK_SPRING, idx);
+            const int parts = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1;    /* a host force: three rows per entry */
+            for (int q = 0; q < parts; ++q) inc[o++] = make_inc(isA, FK_SPRING, idx | (q << 24));
         }
         if (kind == FK_SPRING) nonManifold = true;                     /* joints are fine for the resident schedule, springs are not */
     }
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     for (int item = t; item < nm + ng; item += 1024) {
         int a, b, kind, index, rows; uint64_t key;
         if (item < nm) { const int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; rows = M.nc[item]; }
-        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = f.kind; index = item - nm; key = f.key; rows = kind == FK_JOINT ? 2 : (kind == FK_SPRING ? 1 : 0); }
+        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = f.kind; index = item - nm; key = f.key; rows = gforce_entries(f); kind = gforce_ref_kind(kind); }
         if (a >= 0) {
             const int pos = sAdj[a] + atomicAdd(&sCur[a], 1);
             adjTmp[pos] = make_int2(make_inc(1, kind, index), b);
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                 int* out = inc + sInc[b] + off;
                 if (kind == FK_MANIFOLD) { const int nc = sEntRows[pos]; for (int c = 0; c < nc; ++c) out[c] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
                 else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); }
-                else if (kind == FK_SPRING) { out[0] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
+                else if (kind == FK_SPRING) { const int parts = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1; for (int q = 0; q < parts; ++q) out[q] = make_inc(isA, FK_SPRING, idx | (q << 24)); sBad = 1; }
                 /* the key area is dead now (nothing below reads it): compact the neighbour lists into it, any order */
                 if (ro.y > b && kind != FK_IGNORE && sSwept[ro.y]) sNbr[s0 + atomicAdd(&sCur[b], 1)] = (unsigned short)ro.y;
             }
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                 const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
                 if (kind == FK_MANIFOLD) { const int nc = M.nc[idx]; for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
                 else if (kind == FK_JOINT) { inc[o++] = make_inc(isA, FK_JOINT, idx * 2); inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1); }
-                else if (kind == FK_SPRING) { inc[o++] = make_inc(isA, FK_SPRING, idx); sBad = 1; }
+                else if (kind == FK_SPRING) { const int parts = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1; for (int q = 0; q < parts; ++q) inc[o++] = make_inc(isA, FK_SPRING, idx | (q << 24)); sBad = 1; }
             }
             sCur[b] = s1 - s0;                                          /* the sweeps below filter the whole segment */
         }
@@ -1226,7 +1227,7 @@ __global__ void k_race_check(BodyTable B, ManifoldTable M, const GForce* gf, con
             int a = -2, c2 = -2;
             if (kind == FK_MANIFOLD) { const int2 pr = M.pair[idx >> 2]; a = pr.x; c2 = pr.y; if ((idx & 3) >= M.nc[idx >> 2]) bad = true; }
             else if (kind == FK_JOINT) { a = gf[idx >> 1].bodyA; c2 = gf[idx >> 1].bodyB; }
-            else { a = gf[idx].bodyA; c2 = gf[idx].bodyB; }
+            else { a = gf[idx & 0xFFFFFF].bodyA; c2 = gf[idx & 0xFFFFFF].bodyB; }
             if ((inc_isA(ent) ? a : c2) != b) bad = true;
         }
         if (bad) atomicOr(&cntW->overflow, 32);

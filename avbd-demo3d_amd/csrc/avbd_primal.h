@@ -376,7 +376,7 @@ __device__ __forceinline__ void dual_contact_pts(ContactRows& c, f3 pA, f3 wA, f
 /* ---- phase 1: evaluate one incidence entry (<= 3 rows) for `body` ---------------------------- */
 template <bool COH>
 __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const ManifoldTable& M, GForce* gf, const BodyLocal& L, float alpha,
-                                           bool writeRows, float* rec)
+                                           bool writeRows, float* rec, const HostRowsDev* hostRows = nullptr)
 {
     const int kind = inc_kind(ent), idx = inc_index(ent);
     const bool isA = inc_isA(ent) != 0;
@@ -416,6 +416,23 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
             /* API visibility of Force::C after a post-stabilisation visit (the last computeConstraint of the step, joint.cpp:68-106);
              * both endpoints store, the later visitor's value stays — its stores are ordered behind the earlier visitor's publish */
             if (writeRows) stf<COH>(&f.C[row], j.C[row]);
+        }
+    } else if (gf[idx & 0xFFFFFF].kind == FK_HOST) {
+        /* three rows of a user-defined Force: C / fmin / fmax / lambda and the Jacobians of THIS endpoint are what the subclass's
+         * computeConstraint / computeDerivatives produced on the host for this very visit; the row force is solver.cpp:379-381 */
+        const GForce& f = gf[idx & 0xFFFFFF];
+        const HostRowsDev& h = hostRows[host_force_ordinal(f)];
+        const int part = idx >> 24;
+        for (int k = 0; k < 3; ++k) {
+            const int row = part * 3 + k;
+            if (row >= h.rows) { rec[k * kRowRec + 11] = __int_as_float(0); continue; }
+            const float* jl = isA ? h.JlA[row] : h.JlB[row];
+            const float* ja = isA ? h.JaA[row] : h.JaB[row];
+            const float pen = h.penalty[row];
+            const float lw = (h.stiffness[row] == FLT_MAX) ? h.lambda[row] : 0.0f;
+            const float desired = pen * h.C[row] + lw + h.motor[row];
+            const float fr = rclamp(desired, h.fmin[row], h.fmax[row]);
+            put_row(rec + k * kRowRec, mk3(jl[0], jl[1], jl[2]), mk3(ja[0], ja[1], ja[2]), fr, pen, zero3(), kRowFlagValid);
         }
     } else { /* FK_SPRING */
         GForce& f = gf[idx];
@@ -546,7 +563,7 @@ __device__ __forceinline__ void dual_contact(const BodyTable& B, const ManifoldT
 template <bool COH>
 __device__ __forceinline__ void dual_gforce(const BodyTable& B, GForce& f, const SolverParams& P, bool writeRows)
 {
-    if (f.kind == FK_IGNORE) return;
+    if (f.kind == FK_IGNORE || f.kind == FK_HOST) return;            /* (a host force's dual runs on the host: its computeConstraint is a virtual) */
     const bool hasA = f.bodyA >= 0;
     f3 posA = zero3(), posB; q4 rotA = identq(), rotB;
     if (hasA) load_pose<COH>(B, f.bodyA, posA, rotA);
@@ -600,7 +617,8 @@ constexpr int kWavesPerBlock = 4;
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                                  const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
-                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt, int it)
+                                                                 const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt, int it,
+                                                                 const HostRowsDev* hostRows)
 {
     __shared__ float sRows[kWavesPerBlock][66 * kEntryRec];
     __shared__ float sAcc[kWavesPerBlock][64];
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, Man
     const int eBeg = incStart[body], eEnd = incStart[body + 1];
     for (int base = eBeg; base < eEnd; base += 64) {
         const int nHere = min(64, eEnd - base);
-        if (lane < nHere) eval_entry<false>(inc[base + lane], B, M, gf, L, alpha, writeRows != 0, rows + lane * kEntryRec);
+        if (lane < nHere) eval_entry<false>(inc[base + lane], B, M, gf, L, alpha, writeRows != 0, rows + lane * kEntryRec, hostRows);
         else if (lane < nHere + 2) clear_row_flags(rows + lane * kEntryRec);
         wave_sync();
         accumulate_rows(a, rows, nHere);

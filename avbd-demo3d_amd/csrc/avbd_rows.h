@@ -34,7 +34,9 @@ constexpr float kWarmMaxDrift       = 0.08f;        /* manifold.cpp:20 */
 constexpr float kWarmMinDot         = 0.9f;         /* manifold.cpp:21 */
 constexpr float kNormalForceCap     = 5000.0f;      /* manifold.cpp:22 */
 
-enum ForceKind : int { FK_MANIFOLD = 0, FK_JOINT = 1, FK_SPRING = 2, FK_IGNORE = 3 };
+enum ForceKind : int { FK_MANIFOLD = 0, FK_JOINT = 1, FK_SPRING = 2, FK_IGNORE = 3,
+                       FK_HOST = 4 /* a user-defined Force subclass (solver.h:85-109): its virtuals run on the host, the device gets rows.
+                                    * Exists as GForce.kind only; incidence / adjacency references use FK_SPRING with the part in bits 24+ */ };
 
 /* getRowCount(): manifold.cpp:66-69, joint.h:42, spring.h:33, ignorecollision.h:19 */
 AVBD_HD int force_row_count(int kind, int numContacts)

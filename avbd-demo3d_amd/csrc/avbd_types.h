@@ -74,6 +74,23 @@ struct GForce {
     float C[6], fmin[6], fmax[6], lambda[6], penalty[6], stiffness[6], motor[6];
 };
 
+/* Rows of a user-defined Force as its virtuals (getRowCount / computeConstraint / computeDerivatives, solver.h:102-108) left
+ * them on the host right before the visit that reads them; GForce.pad = ordinal | rows << 24. */
+struct HostRowsDev {
+    int rows, pad[3];
+    float C[12], fmin[12], fmax[12], lambda[12], penalty[12], stiffness[12], motor[12];
+    float JlA[12][3], JaA[12][3], JlB[12][3], JaB[12][3];
+};
+__host__ __device__ inline int host_force_ordinal(const GForce& f) { return f.pad & 0xFFFFFF; }
+__host__ __device__ inline int host_force_rows(const GForce& f) { return (f.pad >> 24) & 0xFF; }
+/* incidence entries (3 rows each) a Joint / Spring / IgnoreCollision / host force contributes to each of its swept endpoints */
+__host__ __device__ inline int gforce_entries(const GForce& f)
+{
+    return f.kind == 1 ? 2 : (f.kind == 2 ? 1 : (f.kind == 4 ? (host_force_rows(f) + 2) / 3 : 0));
+}
+/* kind of a GForce inside an adjacency / incidence reference (two bits): a host force looks like a spring there */
+__host__ __device__ inline int gforce_ref_kind(int kind) { return kind == 4 ? 2 : kind; }
+
 struct Counters {
     int numManifolds;   /* manifolds alive in the current buffer */
     int numCandidates;  /* broadphase output this step */

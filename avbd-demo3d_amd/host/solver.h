@@ -13,8 +13,9 @@
  *   force->computeConstraint  → evaluated on the device through avbd_force_compute_constraint
  *
  * Differences from the reference that a caller can observe are listed in INTEGRATION.md
- * (manifold mirrors are materialised on demand by Solver::syncForces(); user-defined Force
- * subclasses are rejected loudly because their virtuals cannot run on the device).
+ * (manifold mirrors are materialised on demand by Solver::syncForces(); a user-defined Force
+ * subclass keeps its virtuals on the host: the device fetches its rows before every visit —
+ * exact, slow — see INTEGRATION.md).
  */
 #pragma once
 
@@ -87,8 +88,9 @@ struct Force {
     float stiffness[MAX_CONSTRAINT_ROWS];
     float fracture[MAX_CONSTRAINT_ROWS];
 
-    int deviceKind;  /* AVBD_FORCE_* or -1 for a user subclass (build-only field) */
+    int deviceKind;  /* AVBD_FORCE_* of a built-in kind; -1: a user subclass not yet registered; AVBD_FORCE_HOST once it is (build-only field) */
     int listIndex;   /* position in the device's newest-first force list after syncForces(), else -1 */
+    int serial;      /* creation serial inside the solver (build-only field: orders built-in and user-defined forces alike) */
 
     Force(Solver* solver, Rigid* bodyA, Rigid* bodyB);
     virtual ~Force();
@@ -205,5 +207,6 @@ private:
     void pushParams();
     void pushEditedBodies();
     void refreshMirror(Force* f, const AvbdForce& record);
+    static int hostForceCallback(void* user, int hostForce, int phase, float alpha, int body, const float* poseA, const float* poseB, AvbdHostRows* rows);
     void fail(const char* what, int rc) const;
 };

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <utility>
 #include <vector>
@@ -26,6 +27,8 @@ struct Solver::Impl {
     size_t flushedForces = 0;
     std::vector<AvbdBody> shadow;       /* body state as last seen by the device */
     std::vector<Manifold*> manifolds;   /* mirrors created by syncForces() */
+    std::vector<Force*> hostForces;     /* user-defined subclasses by device ordinal (avbd_add_host_force) */
+    int nextSerial = 0;
     bool clearing = false;
     bool syncing = false;               /* syncForces() is replacing the manifold mirrors */
 };
@@ -97,8 +100,9 @@ Rigid::~Rigid()
 }
 
 /* ------------------------------------------------------------------ Force ----------------- */
-Force::Force(Solver* s, Rigid* a, Rigid* b) : solver(s), bodyA(a), bodyB(b), nextA(nullptr), nextB(nullptr), next(nullptr), deviceKind(-1), listIndex(-1)
+Force::Force(Solver* s, Rigid* a, Rigid* b) : solver(s), bodyA(a), bodyB(b), nextA(nullptr), nextB(nullptr), next(nullptr), deviceKind(-1), listIndex(-1), serial(0)
 {
+    serial = s->impl->nextSerial++;
     next = s->forces; s->forces = this;
     if (a) { nextA = a->forces; a->forces = this; }
     if (b) { nextB = b->forces; b->forces = this; }
@@ -129,6 +133,10 @@ Force::~Force()
     Solver* s = solver;
     /* (the stored kind, not isManifold(): inside a base-class destructor the virtual call resolves to Force::isManifold) */
     const bool manifold = deviceKind == AVBD_FORCE_MANIFOLD;
+    if (!s->impl->clearing && deviceKind == AVBD_FORCE_HOST) {
+        for (Force*& h : s->impl->hostForces)
+            if (h == this) s->fail("deleting a user-defined Force that is registered with the device is not supported (clear() the solver instead)", AVBD_E_INVALID);
+    }
     if (!s->impl->clearing && !s->impl->syncing && deviceKind != -2) {
         auto& v = s->impl->userForces;
         size_t k = v.size();
@@ -284,7 +292,7 @@ void Solver::releaseMirrors()
     while (forces) delete forces;
     while (bodies) delete bodies;
     impl->clearing = false;
-    impl->byIndex.clear(); impl->userForces.clear(); impl->flushedForces = 0; impl->shadow.clear(); impl->manifolds.clear();
+    impl->byIndex.clear(); impl->userForces.clear(); impl->hostForces.clear(); impl->flushedForces = 0; impl->shadow.clear(); impl->manifolds.clear();
     bodies = nullptr; forces = nullptr; numBodies = 0; flushedBodies = 0;
 }
 
@@ -371,9 +379,29 @@ void Solver::flush()
         for (int i = flushedBodies; i < n; ++i) packBody(impl->byIndex[(size_t)i], impl->shadow[(size_t)i]);
         flushedBodies = n;
     }
+    {   /* A Force that registered only with the base constructor is a user subclass: it joins the device's force list in creation
+         * order like the built-in kinds (the order decides the per-body accumulation order), but its virtuals stay here — the
+         * library asks for its rows before every visit (hostForceCallback below). */
+        std::vector<Force*> fresh;
+        for (Force* f = forces; f; f = f->next) if (f->deviceKind == -1) fresh.push_back(f);
+        for (Force* f : fresh) { f->deviceKind = AVBD_FORCE_HOST; impl->userForces.push_back(f); }
+        if (!fresh.empty()) {
+            std::stable_sort(impl->userForces.begin() + (long)impl->flushedForces, impl->userForces.end(), [](const Force* a, const Force* b) { return a->serial < b->serial; });
+            int rc = avbd_set_host_force_callback(ctx, &Solver::hostForceCallback, this);
+            if (rc) fail("avbd_set_host_force_callback", rc);
+        }
+    }
     for (; impl->flushedForces < impl->userForces.size(); ++impl->flushedForces) {
         Force* f = impl->userForces[impl->flushedForces];
-        if (f->deviceKind < 0) fail("user-defined Force subclasses cannot run on the device (no CPU solve path exists)", AVBD_E_INVALID);
+        if (f->deviceKind == AVBD_FORCE_HOST) {
+            if (!f->bodyB) fail("a user-defined Force needs bodyB", AVBD_E_INVALID);
+            int ord = -1;
+            int rc = avbd_add_host_force(ctx, f->bodyA ? f->bodyA->index : -1, f->bodyB->index, &ord);
+            if (rc) fail("avbd_add_host_force", rc);
+            if ((size_t)ord != impl->hostForces.size()) fail("host force ordinal out of step", AVBD_E_INVALID);
+            impl->hostForces.push_back(f);
+            continue;
+        }
         AvbdForce r;
         std::memset(&r, 0, sizeof(r));
         r.kind = f->deviceKind; r.bodyA = f->bodyA ? f->bodyA->index : -1; r.bodyB = f->bodyB ? f->bodyB->index : -1;
@@ -393,9 +421,62 @@ void Solver::flush()
         int rc = avbd_add_force(ctx, &r);
         if (rc) fail("avbd_add_force", rc);
     }
-    /* a Force that registered only with the base constructor is a user subclass */
-    for (Force* f = forces; f; f = f->next)
-        if (f->deviceKind < 0) fail("user-defined Force subclasses cannot run on the device (no CPU solve path exists)", AVBD_E_INVALID);
+}
+
+/* The library's window into a user-defined Force (include/avbd_hip.h: AvbdHostForceFn): it hands over the CURRENT poses of the
+ * two endpoints, the mirror objects take them, and the subclass's own virtuals run exactly where Solver::step would call them. */
+int Solver::hostForceCallback(void* user, int hostForce, int phase, float alphaNow, int body, const float* poseA, const float* poseB, AvbdHostRows* rows)
+{
+    Solver* s = static_cast<Solver*>(user);
+    if (hostForce < 0 || (size_t)hostForce >= s->impl->hostForces.size()) return 1;
+    Force* f = s->impl->hostForces[(size_t)hostForce];
+    if (!f) return 1;
+    auto take = [](Rigid* b, const float* p) {
+        if (!b || !p) return;
+        b->position = vec3(p[0], p[1], p[2]); b->orientation = quat(p[3], p[4], p[5], p[6]);
+    };
+    take(f->bodyA, poseA); take(f->bodyB, poseB);
+    auto copyOut = [&]() {
+        for (int i = 0; i < MAX_CONSTRAINT_ROWS; ++i) {
+            rows->C[i] = f->C[i]; rows->fmin[i] = f->fmin[i]; rows->fmax[i] = f->fmax[i]; rows->lambda[i] = f->lambda[i];
+            rows->penalty[i] = f->penalty[i]; rows->stiffness[i] = f->stiffness[i]; rows->motor[i] = f->motor[i];
+        }
+    };
+    auto derivatives = [&](const Rigid* b, float (*Jl)[3], float (*Ja)[3]) {
+        for (int row = 0; row < rows->rows; ++row) {
+            vec3 jl, ja;
+            f->computeDerivatives(jl, ja, b, row);
+            Jl[row][0] = jl.x; Jl[row][1] = jl.y; Jl[row][2] = jl.z; Ja[row][0] = ja.x; Ja[row][1] = ja.y; Ja[row][2] = ja.z;
+        }
+    };
+    switch (phase) {
+    case AVBD_HOST_INITIALIZE:
+        rows->rows = f->initialize() ? f->getRowCount() : 0;          /* (a force whose initialize() fails sits this step out) */
+        if (rows->rows > MAX_CONSTRAINT_ROWS) return 1;
+        copyOut();
+        return 0;
+    case AVBD_HOST_STORE:
+        for (int i = 0; i < MAX_CONSTRAINT_ROWS; ++i) { f->lambda[i] = rows->lambda[i]; f->penalty[i] = rows->penalty[i]; }
+        return 0;
+    case AVBD_HOST_PRIMAL: {
+        f->computeConstraint(alphaNow);
+        rows->rows = f->getRowCount();
+        if (rows->rows > MAX_CONSTRAINT_ROWS) return 1;
+        Rigid* b = s->bodyByIndex(body);
+        if (b == f->bodyA) derivatives(b, rows->JlA, rows->JaA); else derivatives(b, rows->JlB, rows->JaB);
+        copyOut();
+        return 0;
+    }
+    case AVBD_HOST_DUAL:
+        f->computeConstraint(alphaNow);
+        rows->rows = f->getRowCount();
+        if (rows->rows > MAX_CONSTRAINT_ROWS) return 1;
+        if (f->bodyA) derivatives(f->bodyA, rows->JlA, rows->JaA);
+        derivatives(f->bodyB, rows->JlB, rows->JaB);
+        copyOut();
+        return 0;
+    }
+    return 1;
 }
 
 void Solver::pushParams()
@@ -530,6 +611,7 @@ void Solver::step()                                                        /* so
 
 void Solver::refreshMirror(Force* f, const AvbdForce& r)
 {
+    if (r.kind == AVBD_FORCE_HOST) return;                                /* a user-defined Force: the object IS the state */
     if (r.kind == AVBD_FORCE_MANIFOLD) {
         Manifold* m = static_cast<Manifold*>(f);
         m->numContacts = r.numContacts; m->combinedFriction = r.combinedFriction;

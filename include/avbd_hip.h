@@ -81,7 +81,8 @@ typedef struct AvbdContact {
     int   stick;
 } AvbdContact;
 
-enum { AVBD_FORCE_MANIFOLD = 0, AVBD_FORCE_JOINT = 1, AVBD_FORCE_SPRING = 2, AVBD_FORCE_IGNORE = 3 };
+enum { AVBD_FORCE_MANIFOLD = 0, AVBD_FORCE_JOINT = 1, AVBD_FORCE_SPRING = 2, AVBD_FORCE_IGNORE = 3,
+       AVBD_FORCE_HOST = 4 /* user-defined subclass: rows evaluated by the caller, see avbd_add_host_force */ };
 
 /* One Force with its row arrays — struct Force solver.h:85-97 plus the Manifold / Joint / Spring
  * payloads (solver.h:112-143, joint.h:16-24, spring.h:15-25).  bodyA = -1 means the world. */
@@ -185,6 +186,31 @@ int  avbd_download_state13(AvbdContext* ctx, float* out, int capacity_bodies);
 int  avbd_upload_state13(AvbdContext* ctx, const float* in, int n_bodies);
 /* full dynamic state incl. prev velocities (teacher forcing / snapshots) */
 int  avbd_upload_bodies(AvbdContext* ctx, const AvbdBody* in, int n_bodies);
+
+/* ---- user-defined Force subclasses (solver.h:85-109): rows evaluated by the caller, between launches -----------------------------
+ * A Force whose getRowCount / initialize / computeConstraint / computeDerivatives are the caller's own code cannot run on the
+ * device.  It is registered with avbd_add_host_force; while such a force exists a step runs one launch per Gauss-Seidel level
+ * with the host in the loop (exact, slow): before a level that visits one of its endpoints, and in every dual pass, the library
+ * calls `fn` with the current poses of the two endpoints and the phase, and the callee fills / reads `rows`:
+ *   AVBD_HOST_INITIALIZE  step begin (solver.cpp:273-296): call initialize(); return rows (rows = 0: the force sits this step out) and the row
+ *                         state; the library applies the warm-start decay of solver.cpp:281-293 and hands lambda / penalty back with
+ *   AVBD_HOST_STORE       copy rows->lambda / rows->penalty into the object
+ *   AVBD_HOST_PRIMAL      visit of `body` (solver.cpp:371-399): call computeConstraint(alpha), then computeDerivatives(Jl, Ja, body, row)
+ *                         for every row into rows->JlA / JaA (body is endpoint A) or JlB / JaB; return C, fmin, fmax, lambda, penalty,
+ *                         stiffness, motor as the call left them
+ *   AVBD_HOST_DUAL        dual pass (solver.cpp:411-430): call computeConstraint(alpha) and computeDerivatives for BOTH endpoints; the library
+ *                         does the lambda / penalty update (rowPenaltyGain, solver.cpp:94-125) and hands the result back with AVBD_HOST_STORE
+ * A non-zero return value aborts the step with AVBD_E_INVALID. */
+enum { AVBD_HOST_INITIALIZE = 0, AVBD_HOST_STORE = 1, AVBD_HOST_PRIMAL = 2, AVBD_HOST_DUAL = 3 };
+typedef struct AvbdHostRows {
+    int   rows;
+    float C[12], fmin[12], fmax[12], lambda[12], penalty[12], stiffness[12], motor[12];
+    float JlA[12][3], JaA[12][3], JlB[12][3], JaB[12][3];
+} AvbdHostRows;
+typedef int (*AvbdHostForceFn)(void* user, int host_force, int phase, float alpha, int body,
+                               const float poseA[7] /* position, orientation; NULL for the world */, const float poseB[7], AvbdHostRows* rows);
+int  avbd_add_host_force(AvbdContext* ctx, int bodyA /* -1 = world */, int bodyB, int* host_force /* out: ordinal passed to the callback */);
+int  avbd_set_host_force_callback(AvbdContext* ctx, AvbdHostForceFn fn, void* user);
 
 /* ---- force list in the reference's solver-list order: newest first (force.cpp:16-18) ---- */
 int  avbd_num_forces(AvbdContext* ctx);
