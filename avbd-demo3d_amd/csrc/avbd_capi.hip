@@ -160,7 +160,6 @@ struct AvbdContext {
     bool orderByIndex = true;      /* data-flow schedules sweep in descending creation index; AVBD_ORDER=levels: dependency levels (always in AVBD_MODE=levels) */
     bool fusedTopology = true;     /* AVBD_FUSED_TOPOLOGY=0: always the multi-launch topology chain */
     bool topologyDidPredict = false;
-    int frontPairsPerWave = 8;      /* AVBD_FRONT_PPW: persistent manifolds re-collided per wavefront of k_front_small */
     bool residentSpread = true;    /* AVBD_RESIDENT_SPREAD=0: slot = linear wave index */
     int residentPatience = 300;     /* AVBD_RESIDENT_PATIENCE: ticks of 10 ns (see ResidentExchange.patience) */
     int residentOutOfOrder = -1;    /* AVBD_RESIDENT_OOO=0/1: a wave with several bodies sweeps them strictly in order / takes whichever is ready; default: by size */
@@ -700,12 +699,12 @@ int step_begin(AvbdContext* c)
         /* small scene: persistent manifolds and the broadphase (+ its own candidates) side by side in one launch */
         SpanGuard g(c, F_NARROW);
         ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
-        const int slices = (n + 31) / 32;
-        const int ppw = c->frontPairsPerWave;
+        const int slices = (n + kFrontSlice - 1) / kFrontSlice;
+        const int ppw = kPairsPerWave;                                /* sixteen lanes per pair */
         const int persistBlocks = std::max(1, std::min(16384, (c->stats.numManifolds + c->stats.numCandidates + n + ppw - 1) / ppw));
-        const int broadBlocks = (int)(((long long)n * slices + 31) / 32);
-        hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(32), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
-                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices, ppw);
+        const int broadBlocks = (int)(((long long)n * slices + 63) / 64);
+        hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(64), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
+                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices);
         c->cur ^= 1;
     } else {
     {
@@ -2305,7 +2304,7 @@ int avbd_kat_collide(AvbdContext* c, int n, const float* posA, const float* quat
     HIPCHK(c, hipMemcpy(dsA.p, sizeA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dpB.p, posB, 12 * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dqB.p, quatB, 16 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dsB.p, sizeB, 12 * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemset(dout.p, 0, sizeof(KatContact) * 4 * n));
-    hipLaunchKernelGGL(k_kat_collide, dim3(grid_for(n, 64, 1 << 20)), dim3(64), 0, c->stream, n, dpA.p, dqA.p, dsA.p, dpB.p, dqB.p, dsB.p, dout.p, dcnt.p);
+    hipLaunchKernelGGL(k_kat_collide, dim3(grid_for(n, kPairsPerWave, 1 << 20)), dim3(64), 0, c->stream, n, dpA.p, dqA.p, dsA.p, dpB.p, dqB.p, dsB.p, dout.p, dcnt.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     static_assert(sizeof(KatContact) == sizeof(AvbdContact), "contact record layout");

@@ -30,7 +30,13 @@ struct RawContact {      /* what addContact (collision.cpp:176-206) fills in */
 
 struct Obb { f3 center, half, ax0, ax1, ax2; };                  /* collision.cpp:31-35 */
 
-AVBD_HD f3 obb_axis(const Obb& b, int i) { return i == 0 ? b.ax0 : (i == 1 ? b.ax1 : b.ax2); }
+/* (component-wise selects of VALUES: `i == 0 ? b.ax0 : ...` on the structs becomes a select of addresses followed by a load, which
+ * forces both boxes of a pair into scratch memory on the device) */
+AVBD_HD f3 obb_axis(const Obb& b, int i)
+{
+    const float x0 = b.ax0.x, y0 = b.ax0.y, z0 = b.ax0.z, x1 = b.ax1.x, y1 = b.ax1.y, z1 = b.ax1.z, x2 = b.ax2.x, y2 = b.ax2.y, z2 = b.ax2.z;
+    return mk3(i == 0 ? x0 : (i == 1 ? x1 : x2), i == 0 ? y0 : (i == 1 ? y1 : y2), i == 0 ? z0 : (i == 1 ? z1 : z2));
+}
 
 AVBD_HD Obb make_obb(const BoxPose& p)                           /* collision.cpp:56-66 */
 {
@@ -44,11 +50,14 @@ AVBD_HD Obb make_obb(const BoxPose& p)                           /* collision.cp
 
 AVBD_HD float abs_dot(f3 a, f3 b) { return fabsf(dot3(a, b)); }  /* collision.cpp:68-71 */
 
+AVBD_HD float half_extent(const Obb& b, int i) { const float hx = b.half.x, hy = b.half.y, hz = b.half.z; return i == 0 ? hx : (i == 1 ? hy : hz); }
+
 AVBD_HD void face_axes(const Obb& b, int ai, f3& u, f3& v, float& eU, float& eV) /* collision.cpp:73-91 */
 {
-    if (ai == 0)      { u = b.ax1; v = b.ax2; eU = b.half.y; eV = b.half.z; }
-    else if (ai == 1) { u = b.ax0; v = b.ax2; eU = b.half.x; eV = b.half.z; }
-    else              { u = b.ax0; v = b.ax1; eU = b.half.x; eV = b.half.y; }
+    /* face ai spans the two other axes, lower index first: (1,2) (0,2) (0,1) */
+    const int iu = ai == 0 ? 1 : 0, iv = ai == 2 ? 1 : 2;
+    u = obb_axis(b, iu); v = obb_axis(b, iv);
+    eU = half_extent(b, iu); eV = half_extent(b, iv);
 }
 
 struct SatBest { int type, iA, iB; float sep; f3 nAB; bool valid; }; /* collision.cpp:37-44 */
@@ -131,7 +140,7 @@ AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& b
     f3 rax = obb_axis(refBox, refAxis);
     float fsign = dot3(outward, rax) >= 0.0f ? 1.0f : -1.0f;
     f3 fN = rax * fsign;
-    f3 fC = refBox.center + fN * comp3(refBox.half, refAxis);
+    f3 fC = refBox.center + fN * half_extent(refBox, refAxis);
     f3 fU, fV; float eU, eV;
     face_axes(refBox, refAxis, fU, fV, eU, eV);
 
@@ -150,7 +159,7 @@ AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& b
         f3 iax = obb_axis(incBox, incAxis);
         float s = dot3(iax, fN) > 0.0f ? -1.0f : 1.0f;
         f3 n = iax * s;
-        f3 c = incBox.center + n * comp3(incBox.half, incAxis);
+        f3 c = incBox.center + n * half_extent(incBox, incAxis);
         f3 u, v; float xu, xv;
         face_axes(incBox, incAxis, u, v, xu, xv);
         clip0[0] = c + u * xu + v * xv;
@@ -199,9 +208,9 @@ AVBD_HD void support_edge(const Obb& b, int ai, f3 dir, f3& e0, f3& e1)
     f3 x1 = obb_axis(b, a1), x2 = obb_axis(b, a2), x0 = obb_axis(b, ai);
     float s1 = dot3(dir, x1) >= 0.0f ? 1.0f : -1.0f;
     float s2 = dot3(dir, x2) >= 0.0f ? 1.0f : -1.0f;
-    f3 ec = b.center + x1 * (comp3(b.half, a1) * s1) + x2 * (comp3(b.half, a2) * s2);
-    e0 = ec - x0 * comp3(b.half, ai);
-    e1 = ec + x0 * comp3(b.half, ai);
+    f3 ec = b.center + x1 * (half_extent(b, a1) * s1) + x2 * (half_extent(b, a2) * s2);
+    e0 = ec - x0 * half_extent(b, ai);
+    e1 = ec + x0 * half_extent(b, ai);
 }
 
 /* collision.cpp:265-311 */

@@ -19,6 +19,7 @@
  */
 #include "avbd_types.h"
 #include "avbd_rows.h"
+#include "avbd_collide_coop.h"
 
 #pragma clang fp contract(off)
 
@@ -265,8 +266,93 @@ __device__ __forceinline__ BoxPose load_box(const BodyTable& B, int i, float& fr
     return p;
 }
 
-/* one pair: last step's manifold `item` of `src` (item >= 0) or a fresh candidate (a, b); survivors are appended to dst */
+/* One pair by the sixteen lanes of a group (avbd_collide_coop.h): last step's manifold `item` of `src` (item >= 0) or a fresh
+ * candidate (a, b); survivors are appended to dst, one lane per contact.  item / a / b are uniform over the group. */
 __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTable& src, const ManifoldTable& dst, int item, int a, int b, int step,
+                                            CoopScratch& ws, Counters* cnt, int* nextCount, int* degForce, int* degInc, const SolverParams& P, int gl, int gBase,
+                                            unsigned long long* dbg = nullptr)
+{
+    uint64_t key;
+    int oldN = 0;
+    if (item >= 0) {
+        const int2 pr = src.pair[item]; a = pr.x; b = pr.y; key = src.key[item];
+        oldN = src.nc[item];
+        if (gl < oldN) {                                              /* one lane per old contact */
+            const int s = item * 4 + gl;
+            const float4 ra = src.cRA[s], rb = src.cRB[s], nn = src.cN[s], lam = src.cLam[s], pen = src.cPen[s];
+            const int2 fs = src.cFS[s];
+            ws.oldFeature[gl] = fs.x; ws.oldStick[gl] = fs.y != 0 ? 1 : 0;
+            ws.oldRA[gl] = mk3(ra.x, ra.y, ra.z); ws.oldRB[gl] = mk3(rb.x, rb.y, rb.z); ws.oldNormal[gl] = mk3(nn.x, nn.y, nn.z);
+            ws.oldLambda[gl * 3 + 0] = lam.x; ws.oldLambda[gl * 3 + 1] = lam.y; ws.oldLambda[gl * 3 + 2] = lam.z;
+            ws.oldPenalty[gl * 3 + 0] = pen.x; ws.oldPenalty[gl * 3 + 1] = pen.y; ws.oldPenalty[gl * 3 + 2] = pen.z;
+        }
+    } else {
+        key = make_manifold_key(step, a, b);
+    }
+    gsync();
+    float fa, fb, ima, imb;
+    const BoxPose A = load_box(B, a, fa, ima);
+    const BoxPose Bp = load_box(B, b, fb, imb);
+#ifdef AVBD_DF_STATS
+    if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A.pos.x == 12345.0f);
+#endif
+    CoopContact cc;
+    const int nc = manifold_initialize_coop(oldN, ws, A, Bp, cc, gl, gBase);
+#ifdef AVBD_DF_STATS
+    if (dbg) { dbg[2] = __builtin_amdgcn_s_memrealtime(); if (!nc) dbg[3] = dbg[2]; }
+#endif
+    if (nc == 0) return;
+    const float combinedFriction = sqrtf(fa * fb);                     /* manifold.cpp:73 */
+
+    /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
+    if (gl < nc) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!P.postStabilize) cc.lambda[k] *= P.alpha * P.gamma;
+            cc.penalty[k] = rclamp(cc.penalty[k] * P.gamma, kPenaltyMin, kPenaltyMax);
+        }
+    }
+    int slot = 0;
+    if (gl == 0) slot = atomicAdd(nextCount, 1);
+    slot = gshfl(slot, gBase);
+    if (slot >= dst.cap) { if (gl == 0) atomicOr(&cnt->overflow, 2); return; }
+    if (gl == 0) {
+        dst.pair[slot] = make_int2(a, b);
+        dst.key[slot] = key;
+        dst.nc[slot] = nc;
+        dst.fric[slot] = combinedFriction;
+        atomicAdd(&degForce[a], 1);
+        atomicAdd(&degForce[b], 1);
+        int inc = 0;
+        if (B.solved[a]) { atomicAdd(&degInc[a], nc); inc += nc; }
+        if (B.solved[b]) { atomicAdd(&degInc[b], nc); inc += nc; }
+        atomicAdd(&cnt->numContacts, nc);
+        atomicAdd(&cnt->numIncidences, inc);
+    }
+    if (gl < nc) {
+        const int s = slot * 4 + gl;
+        dst.cRA[s] = pack3(cc.rA, cc.C0n);
+        dst.cRB[s] = pack3(cc.rB, cc.C0t1);
+        dst.cN[s] = pack3(cc.normal, cc.C0t2);
+        dst.cU1[s] = pack3(cc.u1, 0.f);
+        dst.cU2[s] = pack3(cc.u2, 0.f);
+        dst.cLam[s] = make_float4(cc.lambda[0], cc.lambda[1], cc.lambda[2], cc.penetration);
+        dst.cPen[s] = make_float4(cc.penalty[0], cc.penalty[1], cc.penalty[2], 0.0f);
+        dst.cFS[s] = make_int2(cc.feature, cc.stick ? 1 : 0);
+        dst.cC[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst.cFmin[s] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+        dst.cFmax[s] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+    }
+#ifdef AVBD_DF_STATS
+    if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+constexpr int kPairsPerWave = 4;       /* sixteen lanes per pair */
+
+/* One pair per LANE (the throughput form, for scenes beyond 4096 bodies: tens of thousands of pairs fill the machine, and a pair
+ * costs a third of the wave time it costs when sixteen lanes share it): last step's manifold `item` of `src` (item >= 0) or a fresh candidate (a, b); survivors are appended to dst */
+__device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const ManifoldTable& src, const ManifoldTable& dst, int item, int a, int b, int step,
                                             ManifoldInit& mi, ManifoldOld& old, Counters* cnt, int* nextCount, int* degForce, int* degInc, const SolverParams& P,
                                             unsigned long long* dbg = nullptr)
 {
@@ -360,7 +446,7 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         int a = 0, b = 0;
         if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
-        narrow_pair(B, src, dst, item < nOld ? item : -1, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+        narrow_pair_lane(B, src, dst, item < nOld ? item : -1, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
     }
 }
 
@@ -368,25 +454,25 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
  * manifolds (they do not depend on the broadphase); every other workgroup enumerates 32 (body, 32-body slice) pair sets,
  * keeps its sphere-overlapping, unconstrained pairs in LDS and then collides them itself, one pair per lane.  Creation
  * keys make the order in which manifolds are appended irrelevant (avbd_types.h: make_manifold_key). */
-constexpr int kFrontHits = 1024;   /* 32 threads x 32 pairs: a workgroup can never find more */
-__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
-                                                      const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
-                                                      int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices, int ppw)
+constexpr int kFrontSlice = 8;      /* bodies one thread of the fused broadphase tests: short slices = few candidates per workgroup, and a workgroup collides its own */
+constexpr int kFrontHits = 64 * kFrontSlice;   /* a workgroup can never find more */
+__global__ __launch_bounds__(64) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
+                                                    const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
+                                                    int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
 {
-    ManifoldInit miPriv;             /* statically indexed after unrolling: registers; the dynamically indexed state is in sOld */
-    __shared__ ManifoldOld sOld[32];
+    __shared__ CoopScratch sWs[kPairsPerWave];
     __shared__ int2 sHits[kFrontHits];
     __shared__ int sNumHits;
+    const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;
     if ((int)blockIdx.x < persistBlocks) {
 #ifdef AVBD_DF_STATS
         unsigned long long* dbg = (blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<unsigned long long*>(dst.cC + (size_t)dst.cap * 4 - 8) : nullptr;
         if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
 #endif
         const int nOld = cnt->numManifolds;
-        /* ppw pairs per wavefront: the pairs of a wave take different paths through the SAT (face A / face B / edge, 1-4 contacts),
-         * and there are more SIMDs than pairs to give each wave few of them */
-        for (int item = blockIdx.x * ppw + threadIdx.x; (int)threadIdx.x < ppw && item < nOld; item += persistBlocks * ppw)
-            narrow_pair(B, src, dst, item, 0, 0, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P
+        /* four pairs per wavefront, sixteen lanes each (avbd_collide_coop.h) */
+        for (int item = blockIdx.x * kPairsPerWave + gj; item < nOld; item += persistBlocks * kPairsPerWave)
+            narrow_pair(B, src, dst, item, 0, 0, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase
 #ifdef AVBD_DF_STATS
                         , dbg
 #endif
@@ -397,10 +483,10 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __syncthreads();
     const float4* posr = B.plane(BP_POSR);
     const int n = B.n;
-    const int t = ((int)blockIdx.x - persistBlocks) * 32 + threadIdx.x;
+    const int t = ((int)blockIdx.x - persistBlocks) * 64 + threadIdx.x;
     const int i = t / slices, sl = t - i * slices;
-    const int jBeg = sl * 32;
-    int jEnd = jBeg + 32; if (jEnd > i) jEnd = i;
+    const int jBeg = sl * kFrontSlice;
+    int jEnd = jBeg + kFrontSlice; if (jEnd > i) jEnd = i;
     if (i < n && jBeg < jEnd) {
         const float4 a = posr[i];
         const f3 pa = mk3(a.x, a.y, a.z);
@@ -426,9 +512,9 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __syncthreads();
     const int nHits = sNumHits;
     if (threadIdx.x == 0 && nHits) atomicAdd(&cnt->numCandidates, nHits);
-    for (int h = threadIdx.x; h < nHits; h += 32) {
+    for (int h = gj; h < nHits; h += kPairsPerWave) {
         const int2 pr = sHits[h];
-        narrow_pair(B, src, dst, -1, pr.x, pr.y, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+        narrow_pair(B, src, dst, -1, pr.x, pr.y, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase);
     }
 }
 
@@ -1237,28 +1323,30 @@ __global__ void k_race_check(BodyTable B, ManifoldTable M, const GForce* gf, con
 /* ---- known-answer kernels --------------------------------------------------------------- */
 struct KatContact { int feature; float rA[3], rB[3], normal[3]; float penetration, C0_n, C0_t[3]; int stick; };
 
-__global__ void k_kat_collide(int n, const float* pA, const float* qA, const float* sA, const float* pB, const float* qB, const float* sB,
-                              KatContact* out, int* counts)
+__global__ __launch_bounds__(64) void k_kat_collide(int n, const float* pA, const float* qA, const float* sA, const float* pB, const float* qB, const float* sB,
+                                                    KatContact* out, int* counts)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    /* the cooperative narrow phase the solver runs (avbd_collide_coop.h): four pairs per wavefront, sixteen lanes per pair */
+    __shared__ CoopScratch sWs[kPairsPerWave];
+    const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;
+    const int i = blockIdx.x * kPairsPerWave + gj;
+    if (i >= n) return;                                               /* uniform over the group */
     BoxPose A, Bx;
     A.pos = mk3(pA[3 * i], pA[3 * i + 1], pA[3 * i + 2]); A.rot = mkq(qA[4 * i], qA[4 * i + 1], qA[4 * i + 2], qA[4 * i + 3]);
     A.size = mk3(sA[3 * i], sA[3 * i + 1], sA[3 * i + 2]);
     Bx.pos = mk3(pB[3 * i], pB[3 * i + 1], pB[3 * i + 2]); Bx.rot = mkq(qB[4 * i], qB[4 * i + 1], qB[4 * i + 2], qB[4 * i + 3]);
     Bx.size = mk3(sB[3 * i], sB[3 * i + 1], sB[3 * i + 2]);
-    RawContact raw[4];
-    int nc = collide_boxes(A, Bx, raw);
-    counts[i] = nc;
-    for (int c = 0; c < 4; ++c) {
-        KatContact& o = out[4 * i + c];
-        if (c < nc) {
-            o.feature = raw[c].feature;
-            o.rA[0] = raw[c].rA.x; o.rA[1] = raw[c].rA.y; o.rA[2] = raw[c].rA.z;
-            o.rB[0] = raw[c].rB.x; o.rB[1] = raw[c].rB.y; o.rB[2] = raw[c].rB.z;
-            o.normal[0] = raw[c].normal.x; o.normal[1] = raw[c].normal.y; o.normal[2] = raw[c].normal.z;
-            o.penetration = raw[c].penetration; o.C0_n = 0.f; o.C0_t[0] = o.C0_t[1] = o.C0_t[2] = 0.f; o.stick = 0;
-        }
+    CoopScratch& ws = sWs[gj];
+    const int nc = collide_boxes_coop(A, Bx, ws, gl, gBase);
+    if (gl == 0) counts[i] = nc;
+    if (gl < nc) {
+        const RawContact& r = ws.raw[gl];
+        KatContact& o = out[4 * i + gl];
+        o.feature = r.feature;
+        o.rA[0] = r.rA.x; o.rA[1] = r.rA.y; o.rA[2] = r.rA.z;
+        o.rB[0] = r.rB.x; o.rB[1] = r.rB.y; o.rB[2] = r.rB.z;
+        o.normal[0] = r.normal.x; o.normal[1] = r.normal.y; o.normal[2] = r.normal.z;
+        o.penetration = r.penetration; o.C0_n = 0.f; o.C0_t[0] = o.C0_t[1] = o.C0_t[2] = 0.f; o.stick = 0;
     }
 }
 
