@@ -172,6 +172,21 @@ __device__ __forceinline__ GAcc make_gacc(int entry, const BodyLocal& L)
     return g;
 }
 
+/* operands and kind of accumulator entry `entry` (0-5 ll lower, 6-14 la, 15-20 aa lower, 21-26 rhs): the part of init_acc_lane
+ * that does not depend on the body */
+__device__ __forceinline__ void grp_entry_ops(int entry, GAcc& a)
+{
+    a.opA = 0; a.opB = 0; a.mode = 3; a.gy = -1; a.acc = 0.0f;
+    const int k6 = entry < 6 ? entry : (entry >= 15 && entry < 21 ? entry - 15 : 0);
+    const int ti = k6 < 3 ? k6 : (k6 < 5 ? k6 - 2 : 2);
+    const int tj = k6 < 3 ? 0 : (k6 < 5 ? 1 : 2);
+    if (entry < 6) { a.mode = 0; a.opA = ti; a.opB = tj; }
+    else if (entry < 15) { const int k = entry - 6; a.mode = 0; a.opA = k % 3; a.opB = 3 + k / 3; }
+    else if (entry < 21) { a.mode = 1; a.opA = 3 + ti; a.opB = 3 + tj; a.gy = (ti == tj) ? (8 + ti) : -1; }
+    else if (entry < 24) { a.mode = 2; a.opA = entry - 21; a.opB = 6; }
+    else if (entry < 27) { a.mode = 2; a.opA = 3 + (entry - 24); a.opB = 6; }
+}
+
 /* products Ja*Jb (rhs entries: J alone) of the sub-group's first `lineRows` rows, before the wait, into the entry's LDS line */
 __device__ __forceinline__ void grp_store_line(const GAcc& a, const float* Jg, float* line, int nRows, int lineRows)
 {
@@ -459,6 +474,10 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         okP = !needP; okV = !needV; okD = !needD;
         if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }
+        if (!MULTI && cls == 0) {                                     /* the seeds of the 27 sums, for the wave-wide accumulation */
+            if (gl < 27) accs[gl] = a0.acc;
+            if (gl + 16 < 27) accs[gl + 16] = a1.acc;
+        }
         wave_sync();
         GS_STAMP(11);
         grp_store_line(a0, Jg, lines + (gl < 27 ? gl : 0) * lineRows, nRows, lineRows);
@@ -468,7 +487,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         GS_STAMP(13);
     };
 
-    auto finish_task = [&]() __attribute__((always_inline)) {
+    bool allOnG = true;                                              /* what finish_visit leaves for the accumulation */
+    auto finish_visit = [&]() __attribute__((always_inline)) {
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;
@@ -509,18 +529,25 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 rowsOn &= penOk;
             }
         }
-        const bool allOn = (__ballot(rowsOn) & gMask) == gMask;
+        allOnG = (__ballot(rowsOn) & gMask) == gMask;
         wave_sync();
         GS_STAMP(7);
-        {
-            const float* l0 = lines + (gl < 27 ? gl : 0) * lineRows;
-            const float* l1 = lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows;
-            if (cls == 0) { if (allOn) grp_accumulate<true, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
-            else          { if (allOn) grp_accumulate<true, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
-        }
+        (void)alpha; (void)doDual;
+    };
+    /* the ordered sums by the lanes of the sub-group itself: two entries per lane in a 16-lane sub-group */
+    auto finish_accumulate = [&]() __attribute__((always_inline)) {
+        const float* l0 = lines + (gl < 27 ? gl : 0) * lineRows;
+        const float* l1 = lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows;
+        if (cls == 0) { if (allOnG) grp_accumulate<true, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
+        else          { if (allOnG) grp_accumulate<true, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
         if (gl < 27) accs[gl] = a0.acc;
         if (cls == 0 && gl + 16 < 27) accs[gl + 16] = a1.acc;
         wave_sync();
+    };
+    auto finish_solve = [&]() __attribute__((always_inline)) {
+        const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
+        const bool doDual = it < P.iterations;
+        const unsigned stampNow = X.base + (unsigned)it + 1u;
         GS_STAMP(8);
         BodyLocal L; L.pos = pos; L.rot = rot;
         f3 p; q4 q;
@@ -631,8 +658,32 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             unsigned* trec = X.privN ? reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)(body < 0 ? 0 : body)) * 4 : trecNone;   /* tools/debug_groups_critical.py */
             if (go && gl == 0) trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
+            /* When ONE sub-group of the wave runs (the usual case: 1.1 tasks per pass) its 27 ordered sums go to 27 lanes of the WHOLE
+             * wave, one chain of additions per lane instead of two per lane of the sub-group: everything an entry needs is in LDS
+             * (seed, product line, S slots). */
+            const unsigned long long goMask = __ballot(go);
+            if (go) finish_visit();
+            const unsigned long long leaders = goMask & 0x0001000100010001ull;
+            if (cls == 0 && leaders != 0 && (leaders & (leaders - 1)) == 0) {
+                const int gb = __builtin_amdgcn_readfirstlane(__ffsll((long long)leaders) - 1);        /* first lane of the running sub-group */
+                const int nRowsG = __builtin_amdgcn_readlane(nRows, gb);
+                const bool allOnW = __builtin_amdgcn_readlane(allOnG ? 1 : 0, gb) != 0;
+                float* const accsW = S + kGrpSSlots * kResRows + (gb >> 4) * kGrpAccFloats;
+                const float* const linesW = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gb >> 4) * kGrpLineFloats;
+                const float* const SgW = S + gb * 3;
+                const float* const JgW = J + gb * 18;
+                GAcc aw, none;
+                grp_entry_ops(lane < 27 ? lane : 63, aw);
+                aw.acc = accsW[lane < 27 ? lane : 0];
+                none = aw;
+                const float* lw = linesW + (lane < 27 ? lane : 0) * lineRows;
+                if (allOnW) grp_accumulate<true, false>(aw, none, lw, lw, SgW, JgW, nRowsG, lineRows);
+                else grp_accumulate<false, false>(aw, none, lw, lw, SgW, JgW, nRowsG, lineRows);
+                if (lane < 27) accsW[lane] = aw.acc;
+                wave_sync();
+            } else if (go) finish_accumulate();
             if (go) {
-                finish_task();
+                finish_solve();
                 ++it;
             }
 #ifdef AVBD_DF_STATS
@@ -734,7 +785,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 if (!back_off()) return;
             }
             if (sel) {
-                finish_task();
+                finish_visit();
+                finish_accumulate();
+                finish_solve();
                 if (it < itStop - 1) park_body();
                 spins = 0;
             }
