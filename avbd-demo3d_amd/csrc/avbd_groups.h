@@ -58,12 +58,10 @@ struct ShardExchange {
 };
 
 constexpr int kGrpWavesPerBlock = 4;
-constexpr int kGrpLineRows = 20;          /* rows per 16 lanes whose pre-multiplied products wait in an LDS line (a 32-lane sub-group has 40, a wave 80) */
-constexpr int kGrpLineFloats = 27 * kGrpLineRows;   /* per 16 lanes */
 constexpr int kGrpSSlots = 6;             /* f | penalty | gyro.x | gyro.y | gyro.z | zeros */
 constexpr int kGrpAccFloats = 64;         /* per 16 lanes: 27 accumulator entries, 21 floats of solve / inertia exchange */
 constexpr int kGrpConstFloats = 32;       /* per 16 lanes: inertial pose, mass, body-frame inertia and inverse inertia */
-constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAccFloats + kGrpLineFloats + kGrpConstFloats);
+constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAccFloats + kGrpConstFloats);
 constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 77 568 B: two workgroups per CU */
 static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytes <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
 
@@ -187,42 +185,27 @@ __device__ __forceinline__ void grp_entry_ops(int entry, GAcc& a)
     else if (entry < 27) { a.mode = 2; a.opA = 3 + (entry - 24); a.opB = 6; }
 }
 
-/* products Ja*Jb (rhs entries: J alone) of the sub-group's first `lineRows` rows, before the wait, into the entry's LDS line */
-__device__ __forceinline__ void grp_store_line(const GAcc& a, const float* Jg, float* line, int nRows, int lineRows)
-{
-    const bool rhs = a.mode == 2;
-    const float* ja = Jg + a.opA;
-    const float* jb = Jg + (rhs ? a.opA : a.opB);
-    const int n = nRows < lineRows ? nRows : lineRows;
-    for (int r4 = 0; r4 < n; r4 += 4) {
-        float t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = r4 + k < n ? r4 + k : r4;
-            const float va = ja[r * 6], vb = jb[r * 6];
-            t[k] = rhs ? va : va * vb;
-        }
-        *reinterpret_cast<float4*>(line + r4) = make_float4(t[0], t[1], t[2], t[3]);
-    }
-}
-
-/* ordered accumulation (solver.cpp:383-397): acc += (Ja*Jb)*penalty [+ gyro] / acc += J*f, row by row in list order, for the
- * two entries of a lane at once (two independent chains of additions).  ALLON: every row has a usable penalty
- * (solver.cpp:387), the normal case; otherwise a lhs entry skips the rows whose penalty is not positive and finite. */
-struct GAccView { const float4 *p4, *s4, *g4; const float *ja, *jb; bool isAA, rhs; };
-__device__ __forceinline__ GAccView grp_view(const GAcc& a, const float* line, const float* Sg, const float* Jg)
+/* ordered accumulation (solver.cpp:383-397): acc += (Ja*Jb)*penalty [+ gyro] / acc += J*f, row by row in list order.  The
+ * Jacobians lie TRANSPOSED in LDS (Jt[column][row]), so one 16-byte read brings an operand of four consecutive rows; the
+ * products are formed here, next to the additions they feed (the multiplications are off the chain of additions).  TWO: the
+ * two entries of a lane at once (two independent chains).  ALLON: every row has a usable penalty (solver.cpp:387), the normal
+ * case; otherwise a lhs entry skips the rows whose penalty is not positive and finite.  `rowBase`: first row of the sub-group
+ * (a multiple of 48). */
+struct GAccView { const float4 *a4, *b4, *s4, *g4; bool isAA, rhs; };
+__device__ __forceinline__ GAccView grp_view(const GAcc& a, const float* Jt, const float* S, int rowBase)
 {
     GAccView v;
     v.isAA = a.mode == 1; v.rhs = a.mode == 2;
-    v.p4 = reinterpret_cast<const float4*>(line);
-    v.s4 = reinterpret_cast<const float4*>(Sg + (v.rhs ? 0 : kResRows));
-    v.g4 = reinterpret_cast<const float4*>(Sg + kResRows * (a.gy >= 0 ? a.gy - 6 : 5));   /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
-    v.ja = Jg + a.opA; v.jb = Jg + (v.rhs ? a.opA : a.opB);
+    v.a4 = reinterpret_cast<const float4*>(Jt + a.opA * kResRows + rowBase);
+    v.b4 = reinterpret_cast<const float4*>(Jt + (v.rhs ? a.opA : a.opB) * kResRows + rowBase);
+    v.s4 = reinterpret_cast<const float4*>(S + (v.rhs ? 0 : kResRows) + rowBase);
+    v.g4 = reinterpret_cast<const float4*>(S + kResRows * (a.gy >= 0 ? a.gy - 6 : 5) + rowBase);   /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
     return v;
 }
 template <bool ALLON>
-__device__ __forceinline__ float grp_add_row(float acc, float pr, float sv, float gv, const GAccView& v)
+__device__ __forceinline__ float grp_add_row(float acc, float va, float vb, float sv, float gv, const GAccView& v)
 {
+    const float pr = v.rhs ? va : va * vb;
     const float nv = acc + pr * sv;
     const float nvg = nv + gv;
     const float nv2 = v.isAA ? nvg : nv;
@@ -231,53 +214,31 @@ __device__ __forceinline__ float grp_add_row(float acc, float pr, float sv, floa
     return on ? nv2 : acc;
 }
 template <bool ALLON, bool TWO>
-__device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* line0, const float* line1, const float* Sg, const float* Jg, int nRows, int lineRows)
+__device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* Jt, const float* S, int rowBase, int nRows)
 {
-    const GAccView v0 = grp_view(a0, line0, Sg, Jg), v1 = grp_view(a1, line1, Sg, Jg);
-    const int n = nRows < lineRows ? nRows : lineRows;
+    const GAccView v0 = grp_view(a0, Jt, S, rowBase), v1 = grp_view(a1, Jt, S, rowBase);
     float acc0 = a0.acc, acc1 = a1.acc;
-    /* whole blocks of four rows without predicates (the next block's operands are in flight while this one is added),
-     * then the last one to three rows */
-    const int nFull = n & ~3;
-    float4 p0 = v0.p4[0], s0 = v0.s4[0], g0 = v0.g4[0], p1, s1, g1;
-    if (TWO) { p1 = v1.p4[0]; s1 = v1.s4[0]; g1 = v1.g4[0]; }
+    /* whole blocks of four rows without predicates (the next block's operands are in flight while this one is added; the block
+     * behind the last full one exists in LDS, whatever it holds), then the last one to three rows */
+    const int nFull = nRows & ~3;
+    float4 ja0 = v0.a4[0], jb0 = v0.b4[0], s0 = v0.s4[0], g0 = v0.g4[0], ja1, jb1, s1, g1;
+    if (TWO) { ja1 = v1.a4[0]; jb1 = v1.b4[0]; s1 = v1.s4[0]; g1 = v1.g4[0]; }
     for (int r4 = 0; r4 < nFull; r4 += 4) {
-        const float4 cp0 = p0, cs0 = s0, cg0 = g0, cp1 = p1, cs1 = s1, cg1 = g1;
-        const int q = (r4 >> 2) + 1;                                 /* the block behind the last full one exists in the line and in S (never past the sub-group's rows + 3) */
-        p0 = v0.p4[q]; s0 = v0.s4[q]; g0 = v0.g4[q];
-        if (TWO) { p1 = v1.p4[q]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
+        const float4 ca0 = ja0, cb0 = jb0, cs0 = s0, cg0 = g0, ca1 = ja1, cb1 = jb1, cs1 = s1, cg1 = g1;
+        const int q = (r4 >> 2) + 1;
+        ja0 = v0.a4[q]; jb0 = v0.b4[q]; s0 = v0.s4[q]; g0 = v0.g4[q];
+        if (TWO) { ja1 = v1.a4[q]; jb1 = v1.b4[q]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            acc0 = grp_add_row<ALLON>(acc0, comp4(cp0, k), comp4(cs0, k), comp4(cg0, k), v0);
-            if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(cp1, k), comp4(cs1, k), comp4(cg1, k), v1);
+            acc0 = grp_add_row<ALLON>(acc0, comp4(ca0, k), comp4(cb0, k), comp4(cs0, k), comp4(cg0, k), v0);
+            if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(ca1, k), comp4(cb1, k), comp4(cs1, k), comp4(cg1, k), v1);
         }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (nFull + k < n) {
-            acc0 = grp_add_row<ALLON>(acc0, comp4(p0, k), comp4(s0, k), comp4(g0, k), v0);
-            if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(p1, k), comp4(s1, k), comp4(g1, k), v1);
-        }
-    }
-    /* rows past the line: multiplied here, from the Jacobians in LDS — same product, same bits */
-    for (int r4 = lineRows; r4 < nRows; r4 += 4) {
-        float t0[4], t1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = r4 + k < nRows ? r4 + k : r4;
-            const float va = v0.ja[r * 6], vb = v0.jb[r * 6];
-            t0[k] = v0.rhs ? va : va * vb;
-            if (TWO) { const float wa = v1.ja[r * 6], wb = v1.jb[r * 6]; t1[k] = v1.rhs ? wa : wa * wb; }
-        }
-        const float4 sw0 = v0.s4[r4 >> 2], gw0 = v0.g4[r4 >> 2];
-        float4 sw1 = sw0, gw1 = gw0;
-        if (TWO) { sw1 = v1.s4[r4 >> 2]; gw1 = v1.g4[r4 >> 2]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (r4 + k < nRows) {
-                acc0 = grp_add_row<ALLON>(acc0, t0[k], comp4(sw0, k), comp4(gw0, k), v0);
-                if (TWO) acc1 = grp_add_row<ALLON>(acc1, t1[k], comp4(sw1, k), comp4(gw1, k), v1);
-            }
+        if (nFull + k < nRows) {
+            acc0 = grp_add_row<ALLON>(acc0, comp4(ja0, k), comp4(jb0, k), comp4(s0, k), comp4(g0, k), v0);
+            if (TWO) acc1 = grp_add_row<ALLON>(acc1, comp4(ja1, k), comp4(jb1, k), comp4(s1, k), comp4(g1, k), v1);
         }
     }
     a0.acc = acc0; a1.acc = acc1;
@@ -299,7 +260,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                       Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ unit, int W, int sleepSel, ShardExchange Z)
 {
     static_assert(!(MULTI && SHARD), "the sharded launch keeps every body in a sub-group of its own");
-    extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave J | S | accs | product lines | constants */
+    extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave Jt | S | accs | constants */
     /* the host queues k_iterate_groups<false>, <true> and the fallback launch one behind the other; the plan says which one runs */
     if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;   /* (SHARD: the host has read the plan) */
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -313,13 +274,10 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     const unsigned long long gMask = (cls == 2 ? ~0ull : ((1ull << gw) - 1ull)) << gBase;
     float* const J = reinterpret_cast<float*>(sGroups) + wv * kGrpWaveFloats;
     float* const S = J + kResJFloats;
-    float* const Jg = J + gBase * 18;
-    float* const Sg = S + gBase * 3;
+    const int rowBase = gBase * 3;                                   /* the sub-group's first row in Jt and S */
     float* const accs = S + kGrpSSlots * kResRows + (gBase >> 4) * kGrpAccFloats;
     float* const xch = accs + 32;
-    float* const lines = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gBase >> 4) * kGrpLineFloats;
-    float* const cst = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + 4 * kGrpLineFloats + (gBase >> 4) * kGrpConstFloats;
-    const int lineRows = kGrpLineRows << cls;
+    float* const cst = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gBase >> 4) * kGrpConstFloats;
 
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
     const __amdgpu_buffer_rsrc_t rG0 = xrsrc(SHARD ? (void*)Z.gather[0] : (void*)X.pose, SHARD ? Z.gatherBytes : 16u),
@@ -468,8 +426,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
             for (int k = 0; k < 3; ++k) {
                 G[k] = abs3(cross3(Ja[k], L.invIw * Ja[k]));          /* solver.cpp:393-397, to be scaled by |f| */
-                float* jr = J + (lane * 3 + k) * 6;
-                jr[0] = Jl[k].x; jr[1] = Jl[k].y; jr[2] = Jl[k].z; jr[3] = Ja[k].x; jr[4] = Ja[k].y; jr[5] = Ja[k].z;
+                float* jr = J + lane * 3 + k;                          /* Jt[column][row] */
+                jr[0] = Jl[k].x; jr[kResRows] = Jl[k].y; jr[2 * kResRows] = Jl[k].z; jr[3 * kResRows] = Ja[k].x; jr[4 * kResRows] = Ja[k].y; jr[5 * kResRows] = Ja[k].z;
             }
         }
         okP = !needP; okV = !needV; okD = !needD;
@@ -480,11 +438,6 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         wave_sync();
         GS_STAMP(11);
-        grp_store_line(a0, Jg, lines + (gl < 27 ? gl : 0) * lineRows, nRows, lineRows);
-        GS_STAMP(12);
-        if (cls == 0) grp_store_line(a1, Jg, lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows, nRows, lineRows);
-        wave_sync();
-        GS_STAMP(13);
     };
 
     bool allOnG = true;                                              /* what finish_visit leaves for the accumulation */
@@ -536,10 +489,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     };
     /* the ordered sums by the lanes of the sub-group itself: two entries per lane in a 16-lane sub-group */
     auto finish_accumulate = [&]() __attribute__((always_inline)) {
-        const float* l0 = lines + (gl < 27 ? gl : 0) * lineRows;
-        const float* l1 = lines + (gl + 16 < 27 ? gl + 16 : 0) * lineRows;
-        if (cls == 0) { if (allOnG) grp_accumulate<true, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, true>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
-        else          { if (allOnG) grp_accumulate<true, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); else grp_accumulate<false, false>(a0, a1, l0, l1, Sg, Jg, nRows, lineRows); }
+        if (cls == 0) { if (allOnG) grp_accumulate<true, true>(a0, a1, J, S, rowBase, nRows); else grp_accumulate<false, true>(a0, a1, J, S, rowBase, nRows); }
+        else          { if (allOnG) grp_accumulate<true, false>(a0, a1, J, S, rowBase, nRows); else grp_accumulate<false, false>(a0, a1, J, S, rowBase, nRows); }
         if (gl < 27) accs[gl] = a0.acc;
         if (cls == 0 && gl + 16 < 27) accs[gl + 16] = a1.acc;
         wave_sync();
@@ -669,16 +620,12 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 const int nRowsG = __builtin_amdgcn_readlane(nRows, gb);
                 const bool allOnW = __builtin_amdgcn_readlane(allOnG ? 1 : 0, gb) != 0;
                 float* const accsW = S + kGrpSSlots * kResRows + (gb >> 4) * kGrpAccFloats;
-                const float* const linesW = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gb >> 4) * kGrpLineFloats;
-                const float* const SgW = S + gb * 3;
-                const float* const JgW = J + gb * 18;
                 GAcc aw, none;
                 grp_entry_ops(lane < 27 ? lane : 63, aw);
                 aw.acc = accsW[lane < 27 ? lane : 0];
                 none = aw;
-                const float* lw = linesW + (lane < 27 ? lane : 0) * lineRows;
-                if (allOnW) grp_accumulate<true, false>(aw, none, lw, lw, SgW, JgW, nRowsG, lineRows);
-                else grp_accumulate<false, false>(aw, none, lw, lw, SgW, JgW, nRowsG, lineRows);
+                if (allOnW) grp_accumulate<true, false>(aw, none, J, S, gb * 3, nRowsG);
+                else grp_accumulate<false, false>(aw, none, J, S, gb * 3, nRowsG);
                 if (lane < 27) accsW[lane] = aw.acc;
                 wave_sync();
             } else if (go) finish_accumulate();
