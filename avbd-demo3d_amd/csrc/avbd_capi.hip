@@ -169,8 +169,8 @@ struct AvbdContext {
     /* group schedule (avbd_groups.h): several bodies in flight per wavefront, for scenes with more swept bodies than resident waves */
     DevArr<GroupPlan> dPlan; DevArr<int> dUnit; int unitCap = 0;
     int groupsMode = -1;           /* AVBD_GROUPS=0 never, 1 for every eligible scene (tests), default: more swept bodies than one-body-per-wave waves */
-    int groupsMaxRounds = 1;       /* AVBD_GROUPS_ROUNDS: most bodies one sub-group may serve, at most 16.  Default 1: only scenes whose bodies all fit a sub-group of their own;
-                                    * with several bodies per sub-group the resident schedule's parked sweep is faster (22 000 cubes: 4.1 ms against 5.0 ms per step) */
+    int groupsMaxRounds = 16;      /* AVBD_GROUPS_ROUNDS: most bodies one sub-group may serve, at most 16 (1: only scenes whose bodies all fit a sub-group of their own;
+                                    * larger ones then take the resident schedule's parked sweep: 64 000 cubes 8.4 ms per iteration loop against 7.0 ms) */
     int groupsWaves = 0;           /* AVBD_GROUPS_WAVES: resident waves the plan may use (tests: few waves, many rounds); 0 = all */
     /* sharded runs as one persistent launch per step with the exchange on a second stream (ShardExchange, avbd_groups.h) */
     int shardPersistent = -1;      /* AVBD_SHARD_PERSISTENT=0 never, 1 whenever the prerequisites hold (default) */
@@ -591,7 +591,9 @@ int launch_topology(AvbdContext* c, bool fromStep)
         hipLaunchKernelGGL(k_count_deg, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, B, M, c->dCnt.p, c->degForce.p, c->degInc.p);
     }
     if (ng) hipLaunchKernelGGL(k_gforce_prepare, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, c->degForce.p, c->degInc.p, P, fromStep ? 1 : 0);
-    if (fromStep && c->fusedTopology && n <= kTopoBodies && c->mode != 0) {
+    /* (beyond kTopoEntries adjacency entries the one-workgroup kernel sorts in global memory: 2 744 cubes with 5 200 manifolds take
+     * 0.22 ms there against 0.05 ms for the launches below — the last known manifold count decides) */
+    if (fromStep && c->fusedTopology && n <= kTopoBodies && c->mode != 0 && 2ll * ((long long)c->stats.numManifolds + ng) <= kTopoEntries) {
         /* small scene: scans, scatter, per-body order, levels, predictor and flag reset as one workgroup in LDS */
         hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
