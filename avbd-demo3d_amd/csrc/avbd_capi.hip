@@ -167,7 +167,11 @@ struct AvbdContext {
     bool residentAllowed = true; /* AVBD_RESIDENT=0 disables the resident schedule */
     bool liteResident = true;    /* two workgroups of k_iterate<2> fit a CU (checked at create); otherwise every launch stays at one workgroup per CU */
     /* group schedule (avbd_groups.h): several bodies in flight per wavefront, for scenes with more swept bodies than resident waves */
-    DevArr<GroupPlan> dPlan; DevArr<int> dUnit; int unitCap = 0;
+    DevArr<GroupPlan> dPlan; DevArr<int> dUnit; int unitCap = 0;   /* dUnit: the bodies of each class in sweep order, [3 * bodyCap] */
+    /* scans over tiles of 4096 bodies (k_scan, k_group_plan): one stamped sum per tile; every launch takes a new stamp */
+    DevArr<tile_v4u> dTileAgg; unsigned tileStamp = 0;
+    int numSolved = 0;             /* bodies this rank sweeps (known at upload) */
+    bool orderValid = false;       /* c->order / level / lvlStart hold the sweep by creation index of the bodies on the device */
     int groupsMode = -1;           /* AVBD_GROUPS=0 never, 1 for every eligible scene (tests), default: more swept bodies than one-body-per-wave waves */
     int groupsMaxRounds = 16;      /* AVBD_GROUPS_ROUNDS: most bodies one sub-group may serve, at most 16 (1: only scenes whose bodies all fit a sub-group of their own;
                                     * larger ones then take the resident schedule's parked sweep: 64 000 cubes 8.4 ms per iteration loop against 7.0 ms) */
@@ -316,6 +320,10 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, c->degInc.alloc(newCap));
     HIPCHK(c, c->level.alloc(newCap));
     HIPCHK(c, c->order.alloc(newCap));
+    c->orderValid = false;
+    HIPCHK(c, c->dTileAgg.alloc((size_t)newCap / kTileBodies + 2));
+    HIPCHK(c, hipMemset(c->dTileAgg.p, 0, ((size_t)newCap / kTileBodies + 2) * sizeof(tile_v4u)));
+    c->tileStamp = 0;
     HIPCHK(c, c->lvlStart.alloc(c->lvlCap + 1));
     HIPCHK(c, c->lvlCount.alloc(c->lvlCap + 1));
     HIPCHK(c, hipMemset(c->adjStart.p, 0, (newCap + 1) * sizeof(int)));
@@ -404,12 +412,15 @@ int upload_bodies_if_stale(AvbdContext* c)
         c->hOwner.resize((size_t)n, 0);
         std::vector<int> solved((size_t)std::max(n, 1), 0);
         c->hRankStart.assign((size_t)c->nranks + 1, 0);
+        c->numSolved = 0;
         for (int i = 0; i < n; ++i) {
             const bool dyn = c->hBodies[(size_t)i].invMass > 0.0f;
             if (!dyn) c->hOwner[(size_t)i] = -1;
             else if (c->hOwner[(size_t)i] < 0 || c->hOwner[(size_t)i] >= c->nranks) c->hOwner[(size_t)i] = 0;
             solved[(size_t)i] = dyn && c->hOwner[(size_t)i] == c->rank;
+            c->numSolved += solved[(size_t)i];
         }
+        c->orderValid = false;
         /* the exchange layout (who sits where in the all-gather) comes from the one host function the C ABI exports */
         c->hPerm.assign((size_t)std::max(n, 1), 0);
         c->hRow.assign((size_t)std::max(n, 1), -1);
@@ -599,22 +610,31 @@ int launch_topology(AvbdContext* c, bool fromStep)
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
                            c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap /* not the error word behind them: a failure stays visible until the next synchronising call */, c->orderByIndex ? 1 : 0);
         c->topologyDidPredict = true;
+        c->orderValid = false;
         HIPCHK(c, hipGetLastError());
         c->adjDirty = false;
         return AVBD_OK;
     }
     c->topologyDidPredict = false;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, n, c->degForce.p, c->degInc.p, c->adjStart.p, c->incStart.p, c->dCnt.p, c->dNext.p);
+    /* the sweep by creation index only changes with the bodies: computed once, its per-step counters then come from k_scan */
+    const bool byIndex = fromStep && c->mode != 0 && c->orderByIndex;
+    const bool orderCached = byIndex && c->orderValid;
+    hipLaunchKernelGGL(k_scan, dim3(std::max(1, (n + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, n, c->degForce.p, c->degInc.p, c->adjStart.p, c->incStart.p, c->dCnt.p, c->dNext.p,
+                       c->dTileAgg.p, ++c->tileStamp, orderCached ? c->numSolved : -1, c->iterBlocks * kIterWaves);
     hipLaunchKernelGGL(k_fill_adj, dim3(grid_for((long long)c->stats.numManifolds + c->stats.numCandidates + ng + 4096, 256, 2048)), dim3(256), 0, c->stream,
                        M, c->dCnt.p, c->dG.p, ng, c->adjStart.p, c->degForce.p, c->adjRef.p, c->adjOther.p, c->adjKey.p);
     hipLaunchKernelGGL(k_sort_expand, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dG.p, c->adjStart.p, c->adjRef.p, c->adjOther.p,
-                       c->adjKey.p, c->incStart.p, c->inc.p, c->level.p, c->degForce.p, c->dCnt.p);
+                       c->adjKey.p, c->incStart.p, c->inc.p, byIndex ? nullptr : c->level.p, c->degForce.p, c->dCnt.p);
     if (fromStep) {
-        if (c->mode != 0 && c->orderByIndex)
-            hipLaunchKernelGGL(k_order_by_index, dim3(1), dim3(1024), 0, c->stream, B, c->level.p, c->lvlStart.p, c->order.p, c->dCnt.p, c->iterBlocks * kIterWaves);
-        else
+        if (byIndex) {
+            if (!orderCached)
+                hipLaunchKernelGGL(k_order_by_index, dim3(1), dim3(1024), 0, c->stream, B, c->level.p, c->lvlStart.p, c->order.p, c->dCnt.p, c->iterBlocks * kIterWaves);
+            c->orderValid = true;
+        } else {
+            c->orderValid = false;
             hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), kLevelsLdsBytes, c->stream, B, c->adjStart.p, c->adjRef.p, c->adjOther.p, c->level.p, c->lvlCount.p,
                                c->lvlStart.p, c->order.p, c->dCnt.p, c->lvlCap, c->iterBlocks * kIterWaves);
+        }
     }
     HIPCHK(c, hipGetLastError());
     c->adjDirty = false;
@@ -759,7 +779,7 @@ int step_begin(AvbdContext* c)
     c->groupsPlanned = false;
     if (groups_eligible(c)) {
         const int W = groups_waves(c);
-        const int needUnits = 2 * c->bodyCap + 16 * W;                 /* rounds x W x 4 sub-group slots, with room for the classes' round-up */
+        const int needUnits = 3 * c->bodyCap;                          /* the bodies of each of the three classes in sweep order */
         if (c->unitCap < needUnits) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, c->dUnit.alloc((size_t)needUnits)); c->unitCap = needUnits;
@@ -770,7 +790,8 @@ int step_begin(AvbdContext* c)
             if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
             if (c->probeCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap; }
         }
-        hipLaunchKernelGGL(k_group_plan, dim3(1), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->dPlan.p, c->dUnit.p, c->unitCap, W, (c->nranks > 1 || c->forceSharded) ? 1 : std::min(16, c->groupsMaxRounds));
+        hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
+                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, (c->nranks > 1 || c->forceSharded) ? 1 : std::min(16, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
         c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -861,12 +882,11 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     const int* runIf = nullptr;
     c->groupsLaunched = false;
     if (c->groupsPlanned && X.enabled && wholeLoop && !X.joints && !sharded) {
-        const int W = groups_waves(c);
         hipExtLaunchKernelGGL((k_iterate_groups<false, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
-                              X, c->dPlan.p, c->dUnit.p, W, c->iterSleep, ShardExchange{});
+                              X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
         if (c->groupsMaxRounds > 1)
             hipLaunchKernelGGL((k_iterate_groups<true, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
-                               X, c->dPlan.p, c->dUnit.p, W, c->iterSleep, ShardExchange{});
+                               X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
         runIf = &c->dPlan.p->bad;
         c->groupsLaunched = true;
         e0 = nullptr;                                                  /* the profiling span covers both launches (the second one is empty unless the device declined) */
@@ -968,9 +988,9 @@ int step_end(AvbdContext* c, bool haveCounts)
         hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
     {
         SpanGuard g(c, F_VELOCITY);
-        const int velBlocks = grid_for(n, 128, 1 << 20);
-        const int diagBlocks = contactSlots > 0 ? grid_for(contactSlots, 128, 1 << 20) : 1;
-        hipLaunchKernelGGL(k_tail, dim3(velBlocks + diagBlocks), dim3(128), 0, c->stream, B, M, P, c->dCnt.p, c->dDiag.p, velBlocks);
+        const int velBlocks = grid_for(n, 256, 1 << 20);
+        const int diagBlocks = contactSlots > 0 ? grid_for(contactSlots, 256, 1024) : 1;   /* (grid-stride; every workgroup ends with five atomics on one line) */
+        hipLaunchKernelGGL(k_tail, dim3(velBlocks + diagBlocks), dim3(256), 0, c->stream, B, M, P, c->dCnt.p, c->dDiag.p, velBlocks);
     }
     HIPCHK(c, hipGetLastError());
     c->deviceAhead = true;
@@ -1068,7 +1088,7 @@ int shard_launch_persistent(AvbdContext* c)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
     hipExtLaunchKernelGGL((k_iterate_groups<false, true>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
-                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, groups_waves(c), c->iterSleep, Z);
+                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
     ++c->prof.launches_primal; ++c->prof.launches_total;
     HIPCHK(c, hipGetLastError());
     c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false;

@@ -65,31 +65,53 @@ constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAc
 constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 77 568 B: two workgroups per CU */
 static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytes <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
 
-/* ---- plan: classes, waves per class, unit table ------------------------------------------------------------------------
- * unit[(k * W + w) * 4 + j] = body of sub-group j of wave w in round k (-1: none).  Single workgroup, two passes over the
- * sweep order (class counts, then ranks by tiles of 4096 slots with one shuffle-based scan per tile). */
+/* ---- plan: classes, waves per class, the bodies of each class in sweep order -----------------------------------------------
+ * byClass[c * cap + r] = r-th body of class c in sweep order.  Sub-group j of wave w (the wl-th wave of its class, which has Wc
+ * waves of G = 4 >> c sub-groups) serves, in round k, rank r = (k * G + j) * Wc + wl — bodies that follow each other in the
+ * sweep go to different waves.  One tile of 4096 slots of the sweep order per workgroup (tile_exclusive_prefix); the last
+ * tile, which learns the totals from its look-back, writes the plan header. */
+__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round)
+{
+    const int Wc = plan->waves[cls], G = 4 >> cls;
+    const int r = (round * G + j) * Wc + wl;
+    return r < plan->nClass[cls] ? byClass[cls * cap + r] : -1;
+}
+
 __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __restrict__ order, const int* __restrict__ lvlStart, Counters* cnt,
-                                                     const int* __restrict__ incStart, GroupPlan* plan, int* __restrict__ unit, int unitCap, int W, int maxRounds)
+                                                     const int* __restrict__ incStart, GroupPlan* plan, int* __restrict__ byClass, int cap, int W, int maxRounds,
+                                                     tile_v4u* agg, unsigned stamp)
 {
     __shared__ unsigned long long sWaveTotals[16];
-    __shared__ unsigned long long sTile;
-    __shared__ int sPlan[16];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long sBcast, sTileSum;
+    const int t = threadIdx.x, tile = blockIdx.x;
     const int nd = lvlStart[cnt->numLevels];
-    auto cls_of = [&](int slot) -> int {
-        const int b = order[slot];
-        const int ne = incStart[b + 1] - incStart[b];
-        return ne <= 16 ? 0 : (ne <= 32 ? 1 : 2);
-    };
-    /* pass 1: class counts, 21 bits each */
-    unsigned long long mine = 0;
-    for (int s = t; s < nd; s += 1024) mine += 1ull << (21 * cls_of(s));
-    const unsigned long long all = block_scan_inclusive_u64(mine, sWaveTotals);
-    if (t == 1023) {
+    const int s0 = tile * kTileBodies + 4 * t;
+    int cl[4], body[4]; unsigned long long mine4 = 0;                 /* class counts, 21 bits each */
+    for (int k = 0; k < 4; ++k) { body[k] = s0 + k < nd ? order[s0 + k] : -1; cl[k] = -1; }
+    for (int k = 0; k < 4; ++k)
+        if (body[k] >= 0) {
+            const int ne = incStart[body[k] + 1] - incStart[body[k]];
+            cl[k] = ne <= 16 ? 0 : (ne <= 32 ? 1 : 2);
+            mine4 += 1ull << (21 * cl[k]);
+        }
+    const unsigned long long incl = block_scan_inclusive_u64(mine4, sWaveTotals);
+    if (t == 1023) sTileSum = incl;
+    __syncthreads();
+    const unsigned long long before = tile_exclusive_prefix(agg, tile, sTileSum, stamp, &sBcast);
+    unsigned long long off = before + incl - mine4;
+    for (int k = 0; k < 4; ++k) {
+        if (cl[k] < 0) continue;
+        const int c = cl[k];
+        const int r = (int)((off >> (21 * c)) & 0x1fffff);
+        off += 1ull << (21 * c);
+        byClass[c * cap + r] = body[k];
+    }
+    if (t == 1023 && tile == (int)gridDim.x - 1) {
+        const unsigned long long all = before + incl;
         int n[3] = {(int)(all & 0x1fffff), (int)((all >> 21) & 0x1fffff), (int)((all >> 42) & 0x1fffff)};
         int wv[3], rounds[3] = {1, 1, 1};
         const int need1 = (n[1] + 1) / 2, need0 = (n[0] + 3) / 4;
-        int bad = (cnt->residentBad & 1) || nd == 0 || nd >= (1 << 21);
+        int bad = (cnt->residentBad & 1) || nd == 0 || nd >= (1 << 21) || nd > (int)gridDim.x * kTileBodies;
         if (n[2] + need1 + need0 <= W) {
             /* every body keeps its sub-group for the whole launch; class 0 takes all the waves that are left */
             wv[2] = n[2]; wv[1] = need1; wv[0] = n[0] ? W - wv[2] - wv[1] : 0;
@@ -103,41 +125,11 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
             for (int c = 0; c < 3; ++c) if (n[c]) { const int per = wv[c] * (4 >> c); rounds[c] = (n[c] + per - 1) / per; }
         }
         const int kmax = max(rounds[0], max(rounds[1], rounds[2]));
-        if (kmax > maxRounds || (long long)kmax * W * 4 > unitCap) bad = 1;
-        for (int c = 0; c < 3; ++c) { sPlan[c] = n[c]; sPlan[3 + c] = wv[c]; sPlan[6 + c] = rounds[c]; }
-        sPlan[9] = bad; sPlan[10] = kmax;
+        if (kmax > maxRounds) bad = 1;
         plan->nClass[0] = n[0]; plan->nClass[1] = n[1]; plan->nClass[2] = n[2];
         plan->waves[0] = wv[0]; plan->waves[1] = wv[1]; plan->waves[2] = wv[2];
         plan->rounds[0] = rounds[0]; plan->rounds[1] = rounds[1]; plan->rounds[2] = rounds[2];
         plan->bad = bad; plan->nd = nd;
-    }
-    __syncthreads();
-    if (sPlan[9]) return;
-    const int kmax = sPlan[10];
-    for (int i = t; i < kmax * W * 4; i += 1024) unit[i] = -1;
-    __syncthreads();
-    const int base2 = 0, base1 = sPlan[5], base0 = sPlan[5] + sPlan[4];
-    unsigned long long running = 0;
-    for (int tile = 0; tile < nd; tile += 4096) {
-        const int s0 = tile + 4 * t;
-        int cl[4]; unsigned long long mine4 = 0;
-        for (int k = 0; k < 4; ++k) { cl[k] = s0 + k < nd ? cls_of(s0 + k) : -1; if (cl[k] >= 0) mine4 += 1ull << (21 * cl[k]); }
-        const unsigned long long incl = block_scan_inclusive_u64(mine4, sWaveTotals);
-        unsigned long long off = running + incl - mine4;
-        for (int k = 0; k < 4; ++k) {
-            if (cl[k] < 0) continue;
-            const int c = cl[k];
-            const int r = (int)((off >> (21 * c)) & 0x1fffff);
-            off += 1ull << (21 * c);
-            const int Wc = sPlan[3 + c], G = 4 >> c;
-            const int round = r / (Wc * G), rest = r - round * (Wc * G);
-            const int wave = (c == 2 ? base2 : (c == 1 ? base1 : base0)) + rest % Wc, j = rest / Wc;
-            unit[(round * W + wave) * 4 + j * (1 << c)] = order[s0 + k];
-        }
-        if (t == 1023) sTile = incl;
-        __syncthreads();
-        running += sTile;
-        __syncthreads();
     }
 }
 
@@ -257,7 +249,7 @@ __device__ __forceinline__ unsigned xldw(__amdgpu_buffer_rsrc_t r, int byteOff) 
 template <bool MULTI, bool SHARD>
 __global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
-                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ unit, int W, int sleepSel, ShardExchange Z)
+                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z)
 {
     static_assert(!(MULTI && SHARD), "the sharded launch keeps every body in a sub-group of its own");
     extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave Jt | S | accs | constants */
@@ -268,6 +260,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     const int W2 = plan->waves[2], W1 = plan->waves[1], W0 = plan->waves[0];
     if (w >= W2 + W1 + W0) return;
     const int cls = w < W2 ? 2 : (w < W2 + W1 ? 1 : 0);              /* wave-uniform */
+    const int wl = w - (cls == 2 ? 0 : (cls == 1 ? W2 : W2 + W1));    /* which wave of its class */
     const int rounds = __builtin_amdgcn_readfirstlane(plan->rounds[cls]);
     constexpr bool multi = MULTI;                                    /* (a class of a several-round plan may have one round: same code, state parked) */
     const int gw = 16 << cls, gl = lane & (gw - 1), gBase = lane & ~(gw - 1);
@@ -584,7 +577,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     if constexpr (!MULTI) {
         /* ---- one body per sub-group for the whole launch ---- */
         {
-            const int b = unit[w * 4 + (gBase >> 4)];
+            const int b = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), 0);
             int e0 = 0, ne = 0;
             if (b >= 0) { e0 = incStart[b]; ne = incStart[b + 1] - e0; }
             load_header(b, e0, ne, false);
@@ -674,7 +667,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1, seenK = 0;
         unsigned blkStamp = 0;
         if (gl < rounds) {
-            bodyK = unit[(gl * W + w) * 4 + (gBase >> 4)];
+            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl);
             if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
         }
         GS_STAMP(3);

@@ -555,37 +555,86 @@ __device__ __forceinline__ unsigned long long block_scan_inclusive_u64(unsigned 
     return v + base;
 }
 
-/* Exclusive scans of the two degree arrays (single workgroup; n+1 outputs each), and cursor reset.  Tiles of 4096 bodies:
- * every thread takes four consecutive bodies (coalesced), one shuffle-based workgroup scan per tile, running offsets carried
- * from tile to tile (the chunk-per-thread form of this kernel took 250 us at 64 000 bodies: uncoalesced). */
-__global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc, int* adjStart, int* incStart, Counters* cnt, const int* nextCount)
+/* ---- scans over more bodies than one workgroup holds: one tile of 4096 per workgroup, decoupled look-back ----------------
+ * Every workgroup publishes the sum of its tile as ONE 16-byte record {low, high, stamp, 0} (sc1 store: written through to the
+ * level all XCDs share, observed untorn) and adds up the records of the tiles before it (sc1 loads, polled until they carry
+ * this launch's stamp).  Workgroups are dispatched in index order, so a workgroup only ever waits for ones that already run.
+ * `stamp` is unique per launch (the context counts them), so the records are never reset.  (The single-workgroup forms of
+ * these scans took 98 + 125 us per step at 64 000 bodies: sixteen tiles one after the other, each a memory round trip and
+ * two workgroup barriers.) */
+typedef unsigned tile_v4u __attribute__((ext_vector_type(4)));
+constexpr int kTileBodies = 4096;
+__device__ __forceinline__ unsigned long long tile_exclusive_prefix(tile_v4u* agg, int tile, unsigned long long mine, unsigned stamp, unsigned long long* sBcast)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)agg, 0, (tile + 1) * 16, 0x00020000);
+    if (threadIdx.x == 0) {
+        const tile_v4u rec = {(unsigned)mine, (unsigned)(mine >> 32), stamp, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(rec, r, tile * 16, 0, 16);
+    }
+    if (threadIdx.x < 64) {
+        unsigned long long prefix = 0;
+        for (int base = 0; base < tile; base += 64) {
+            const int p = base + (int)threadIdx.x;
+            unsigned long long v = 0;
+            bool have = p >= tile;
+            while (!__all(have)) {
+                if (!have) {
+                    const tile_v4u rec = __builtin_amdgcn_raw_buffer_load_b128(r, p * 16, 0, 16);
+                    if (rec.z == stamp) { v = ((unsigned long long)rec.y << 32) | rec.x; have = true; }
+                }
+                if (!__all(have)) __builtin_amdgcn_s_sleep(2);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+                v += ((unsigned long long)hi << 32) | lo;
+            }
+            prefix += v;
+        }
+        if (threadIdx.x == 0) *sBcast = prefix;
+    }
+    __syncthreads();
+    const unsigned long long prefix = *sBcast;
+    __syncthreads();
+    return prefix;
+}
+
+/* Exclusive scans of the two degree arrays (n+1 outputs each), and cursor reset: every thread takes four consecutive bodies
+ * (coalesced), one shuffle-based workgroup scan per tile, the offset of the tile by look-back.  `ndCached` >= 0: the sweep
+ * order of this scene is already on the device (it only changes with the bodies) — the step's counters that go with it are
+ * set here instead of by k_order_by_index. */
+__global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc, int* adjStart, int* incStart, Counters* cnt, const int* nextCount,
+                                               tile_v4u* agg, unsigned stamp, int ndCached, int residentWaves)
 {
     __shared__ unsigned long long sWaveTotals[16];
-    __shared__ unsigned long long sTile;
-    const int t = threadIdx.x;
-    unsigned long long running = 0;                                   /* high word: incidence entries, low word: forces */
-    for (int base = 0; base < n; base += 4096) {
-        const int i0 = base + 4 * t;
-        unsigned long long v[4];
-        unsigned long long mine = 0;
-        for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k;
-            v[k] = i < n ? (((unsigned long long)(unsigned)degInc[i] << 32) | (unsigned)degForce[i]) : 0ull;
-            mine += v[k];
-        }
-        const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
-        unsigned long long off = running + incl - mine;
-        for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k;
-            if (i < n) { adjStart[i] = (int)(unsigned)off; incStart[i] = (int)(off >> 32); degForce[i] = 0; degInc[i] = 0; /* become fill cursors */ }
-            off += v[k];
-        }
-        if (t == 1023) sTile = incl;
-        __syncthreads();
-        running += sTile;
-        __syncthreads();
+    __shared__ unsigned long long sBcast;
+    const int t = threadIdx.x, tile = blockIdx.x;
+    const int i0 = tile * kTileBodies + 4 * t;
+    unsigned long long v[4];                                          /* high word: incidence entries, low word: forces */
+    unsigned long long mine = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k;
+        v[k] = i < n ? (((unsigned long long)(unsigned)degInc[i] << 32) | (unsigned)degForce[i]) : 0ull;
+        mine += v[k];
     }
-    if (t == 0) { adjStart[n] = (int)(unsigned)running; incStart[n] = (int)(running >> 32); cnt->numManifolds = *nextCount; }
+    const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
+    __shared__ unsigned long long sTileSum;
+    if (t == 1023) sTileSum = incl;
+    __syncthreads();
+    const unsigned long long before = tile_exclusive_prefix(agg, tile, sTileSum, stamp, &sBcast);
+    unsigned long long off = before + incl - mine;
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k;
+        if (i < n) { adjStart[i] = (int)(unsigned)off; incStart[i] = (int)(off >> 32); degForce[i] = 0; degInc[i] = 0; /* become fill cursors */ }
+        off += v[k];
+    }
+    if (t == 1023 && tile == (int)gridDim.x - 1) {
+        const unsigned long long total = before + incl;
+        adjStart[n] = (int)(unsigned)total; incStart[n] = (int)(total >> 32); cnt->numManifolds = *nextCount;
+        if (ndCached >= 0) {
+            atomicExch(&cnt->numLevels, ndCached > 0 ? 1 : 0);
+            if (ndCached > residentWaves) atomicOr(&cnt->residentBad, 2);
+        }
+    }
 }
 
 __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* gf, int ng, const int* adjStart, int* cursor,
@@ -616,7 +665,7 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const GForce* gf, co
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B.n) return;
     cursor[b] = 0;
-    level[b] = 0;
+    if (level) level[b] = 0;                                          /* (sweep by creation index: k_order_by_index is the only writer) */
     if (!B.solved[b]) return;
     const int s = adjStart[b], e = adjStart[b + 1];
     for (int i = s + 1; i < e; ++i) {
@@ -1216,7 +1265,19 @@ __device__ __forceinline__ void diag_contacts(const BodyTable& B, const Manifold
         maxPen = p2 > maxPen ? p2 : maxPen; maxViol = v2 > maxViol ? v2 : maxViol; maxImp = i2 > maxImp ? i2 : maxImp;
         manifolds += __shfl_xor(manifolds, o); contacts += __shfl_xor(contacts, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    /* one set of atomics per workgroup: the five words share a cache line, and an atomic on one line costs about 13 ns whoever
+     * issues it (one set per wave was 45 000 atomics = 0.33 ms at 64 000 cubes) */
+    __shared__ float sMax[3][4];
+    __shared__ int sCount[2][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sMax[0][wv] = maxPen; sMax[1][wv] = maxViol; sMax[2][wv] = maxImp; sCount[0][wv] = manifolds; sCount[1][wv] = contacts; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (int)(blockDim.x >> 6);
+        for (int k = 1; k < nw; ++k) {
+            maxPen = sMax[0][k] > maxPen ? sMax[0][k] : maxPen; maxViol = sMax[1][k] > maxViol ? sMax[1][k] : maxViol; maxImp = sMax[2][k] > maxImp ? sMax[2][k] : maxImp;
+            manifolds += sCount[0][k]; contacts += sCount[1][k];
+        }
         if (manifolds) { atomicAdd(&diag->activeManifolds, manifolds); atomicAdd(&diag->activeContacts, contacts); }
         if (maxPen > 0.0f) atomic_max_nonneg(&diag->maxPenetration, maxPen);
         if (maxViol > 0.0f) atomic_max_nonneg(&diag->maxViolation, maxViol);
@@ -1240,7 +1301,12 @@ __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* c
             const float l2 = __shfl_xor(sl, o), a2 = __shfl_xor(sa, o);
             sl = l2 > sl ? l2 : sl; sa = a2 > sa ? a2 : sa;
         }
-        if ((threadIdx.x & 63) == 0) {
+        __shared__ float sSpeed[2][4];
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sSpeed[0][wv] = sl; sSpeed[1][wv] = sa; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < (int)(blockDim.x >> 6); ++k) { sl = sSpeed[0][k] > sl ? sSpeed[0][k] : sl; sa = sSpeed[1][k] > sa ? sSpeed[1][k] : sa; }
             if (sl > 0.0f) atomic_max_nonneg(&diag->maxLinearSpeed, sl);
             if (sa > 0.0f) atomic_max_nonneg(&diag->maxAngularSpeed, sa);
         }
