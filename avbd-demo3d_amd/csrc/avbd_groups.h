@@ -391,9 +391,18 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
 #define GS_STAMP(i) do { } while (0)
 #endif
 
+    /* which records of other tasks this task reads, and the stamps they must carry (from the header and `it` alone) */
+    auto set_needs = [&]() __attribute__((always_inline)) {
+        const unsigned stampNow = X.base + (unsigned)it + 1u;
+        needP = false; needV = false; needD = false; sP = 0; sV = 0; sD = 0;
+        if (has && moving) {
+            if (owned) { needV = true; sV = stampNow; needP = true; sP = stampNow; }
+            else if (it > 0) { needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
+        }
+        okP = !needP; okV = !needV; okD = !needD;
+    };
     auto prepare_task = [&]() __attribute__((always_inline)) {
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
-        const unsigned stampNow = X.base + (unsigned)it + 1u;
         BodyLocal L;
         L.pos = pos; L.rot = rot; L.invMass = invMass; L.invDt2 = invDt2;
         {
@@ -406,12 +415,12 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         a0 = make_gacc(gl < 27 ? gl : 63, L);
         a1 = make_gacc((cls == 0 && gl + 16 < 27) ? gl + 16 : 63, L);
         wOwn = zero3();
-        needP = false; needV = false; needD = false; sP = 0; sV = 0; sD = 0;
+        if (!MULTI) set_needs();                                      /* (several bodies per sub-group: set, and polled, when the body was examined) */
         if (has) {
             wOwn = qrotate(rot, isA ? c.rA : c.rB);                    /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
-                if (owned) { replay_normal(c, fixedN); needV = true; sV = stampNow; needP = true; sP = stampNow; }
-                else if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
+                if (owned) replay_normal(c, fixedN);
+                else if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); }
             }
             ContactBasis db;
             contact_constraint_pre(c, alpha, isA ? invMass : oinv, isA ? oinv : invMass, pre, db);
@@ -423,7 +432,6 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 jr[0] = Jl[k].x; jr[kResRows] = Jl[k].y; jr[2 * kResRows] = Jl[k].z; jr[3 * kResRows] = Ja[k].x; jr[4 * kResRows] = Ja[k].y; jr[5 * kResRows] = Ja[k].z;
             }
         }
-        okP = !needP; okV = !needV; okD = !needD;
         if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }
         if (!MULTI && cls == 0) {                                     /* the seeds of the 27 sums, for the wave-wide accumulation */
             if (gl < 27) accs[gl] = a0.acc;
@@ -543,17 +551,21 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     unsigned long long tIdle = t0;                                   /* when this wave last made progress (bounds the spin, not the launch) */
     unsigned spins = 0;
     /* the poll of a prepared task: the records ARE the payload (avbd_resident.h); only lanes that still miss something load */
-    auto poll_records = [&]() __attribute__((always_inline)) {
+    auto poll_issue = [&]() __attribute__((always_inline)) {
         const bool lp = !okP, lv = !okV, ld = !okD;
         if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
         if (lv) vd = xld(rV, offV);
         if (ld) { vd = xld(rD, offD); d1 = xld(rD, offD + 16); }
+    };
+    auto poll_check = [&]() __attribute__((always_inline)) {
+        const bool lp = !okP, lv = !okV, ld = !okD;
         asm volatile("" ::: "memory");
         if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
         if (lv) okV = stamp_reached(vd.w, sV);
         if (ld) okD = stamp_reached(vd.w, sD) & stamp_reached(d1.w >> 1, sD);
         if (SHARD && !okR) okR = stamp_reached(xldw(rGW, 0), sR);
     };
+    auto poll_records = [&]() __attribute__((always_inline)) { poll_issue(); poll_check(); };
     auto back_off = [&]() __attribute__((always_inline)) -> bool {     /* false: the launch is being abandoned */
         if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
         else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
@@ -676,9 +688,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             if (__ballot(activeK) == 0) break;
             bool candK = activeK;
             if (activeK && blkOff >= 0) { const unsigned st = xldw(rP, blkOff); candK = stamp_reached(st, blkStamp); }
-            bool sel = false;
+            bool sel = false, triedK = false;
             for (;;) {
-                int key = candK ? ((itK << 6) | gl) : 0x7fffffff;
+                int key = (candK && !triedK) ? ((itK << 6) | gl) : 0x7fffffff;
                 for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
                 const bool examine = !sel && key != 0x7fffffff;        /* uniform over the sub-group */
                 if (__ballot(examine) == 0) break;
@@ -686,25 +698,24 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                     const int k = gBase + (key & 63), t = key >> 6;
                     load_header(__shfl(bodyK, k, 64), __shfl(eBegK, k, 64), __shfl(nEntK, k, 64), __shfl(seenK, k, 64) != 0);
                     if (lane == k) seenK = 1;
-                    /* every moving partner's pose of the iteration this visit reads: published?  (The visit / dual records of the
-                     * same producer task follow its pose within the task; the poll before finish_task waits for those.) */
-                    unsigned need = 0; bool wants = false;
-                    if (has && moving) {
-                        if (owned) { wants = true; need = X.base + (unsigned)t + 1u; }
-                        else if (t > 0) { wants = true; need = X.base + (unsigned)t; }
-                    }
-                    bool got = true;
-                    if (wants) got = stamp_reached(xldw(rP, offP + 44), need);
-                    const unsigned long long missing = __ballot(!got) & gMask;
-                    if (missing == 0) {
-                        sel = true; it = t;
+                    /* the records this task reads and the state the body parked after its last task travel together: one memory
+                     * round trip tells whether the task can run and, if it can, has brought what it needs */
+                    it = t;
+                    set_needs();
+                    poll_issue();
+                    load_rest();
+                    poll_check();
+                    const unsigned long long noPose = __ballot(!okP) & gMask, noRest = __ballot(!(okV & okD)) & gMask;
+                    if ((noPose | noRest) == 0) {
+                        sel = true;
                         if (lane == k) { ++itK; ++blkStamp; }                /* the same partner is the likeliest to be late again */
-                    } else {
-                        const int f = __ffsll((long long)missing) - 1;
+                    } else if (noPose) {
+                        /* watch the pose of the first partner that is late (its last record's stamp word) */
+                        const int f = __ffsll((long long)noPose) - 1;
                         const int bo = __shfl(offP + 44, f, 64);
-                        const unsigned bs = (unsigned)__shfl((int)need, f, 64);
+                        const unsigned bs = (unsigned)__shfl((int)sP, f, 64);
                         if (lane == k) { blkOff = bo; blkStamp = bs; candK = false; }
-                    }
+                    } else if (lane == k) triedK = true;                     /* visit / dual records follow their producer's pose within its task: next pass */
                 }
             }
             GS_STAMP(0);
@@ -712,18 +723,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             stat[14] += 1;
             if (__ballot(sel)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(sel && gl == 0)); }
 #endif
-            if (sel) {
-                load_rest();
-                prepare_task();
-            }
+            if (sel) prepare_task();
             GS_STAMP(2);
-            /* the records that follow the poses within their producers' tasks */
-            for (;;) {
-                if (sel) poll_records();
-                const bool laneOk = !sel || (okP & okV & okD);
-                if (__ballot(laneOk) == ~0ull) break;
-                if (!back_off()) return;
-            }
             if (sel) {
                 finish_visit();
                 finish_accumulate();
