@@ -189,6 +189,7 @@ struct AvbdContext {
     std::vector<int> hostForceG;           /* ordinal -> index in hG */
     std::vector<HostRowsDev> hHostRows; DevArr<HostRowsDev> dHostRows;
     AvbdHostForceFn hostFn = nullptr; void* hostUser = nullptr;
+    bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
@@ -899,6 +900,15 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         hipExtLaunchKernelGGL(kern, dim3(blocks2), dim3(64 * kIterWaves), kIterWaves * kResProductBytesPerWaveLite, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
                               c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X, runIf);
     } else {
+        if (c->singleKernel && X.enabled && !X.multi && !X.forceMulti && wholeLoop && !runIf) {
+            /* every swept body has a resident wave: the kernel that holds nothing but that schedule; the launch below runs if the
+             * device vetoed it */
+            auto single = X.joints ? k_iterate_single<true> : k_iterate_single<false>;
+            hipExtLaunchKernelGGL(single, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, nullptr, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
+                                  c->incStart.p, c->inc.p, P, S.error, c->dCnt.p, c->iterSleep, itEnd, X);
+            runIf = &c->dCnt.p->residentBad;
+            e0 = nullptr;
+        }
         auto kern = X.joints ? k_iterate<1, true> : k_iterate<1, false>;
         hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
                               c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X, runIf);
@@ -1405,6 +1415,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_ITER_MODE")) c->iterForceMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RACE_CHECK")) c->raceCheck = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_SINGLE_KERNEL")) c->singleKernel = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_GROUPS_WAVES")) c->groupsWaves = std::max(0, std::atoi(e));
@@ -1420,6 +1431,8 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_FUSED_FRONT")) c->fusedFront = std::atoi(e) != 0;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_single<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_single<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); (void)hipGetLastError(); c->iterLdsPad = 0; }
         fe = hipFuncSetAttribute((const void*)k_iterate<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);

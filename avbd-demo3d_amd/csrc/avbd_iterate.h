@@ -105,6 +105,29 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
     return true;
 }
 
+/* One wavefront per body for the whole loop and nothing else in the kernel: the launch of scenes whose swept bodies all find a
+ * resident wave (Stress1000).  Same code as the resident branch of k_iterate<1> below, compiled on its own so that the register
+ * allocation of the loop that bounds the headline workload does not carry the other schedules' state.  Declines (returns at once)
+ * when the topology kernels raised any veto bit; the k_iterate launch queued behind it with runIf = &cnt->residentBad then does
+ * the step. */
+template <bool JOINTS>
+__global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_iterate_single(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
+                                                              const int* __restrict__ lvlStart, const Counters* __restrict__ cnt, const int* __restrict__ incStart,
+                                                              const int* __restrict__ inc, SolverParams P, int* errWord, Counters* cntW, int sleepSel, int itEnd, ResidentExchange X)
+{
+    if (cnt->residentBad != 0) return;
+    __shared__ float sRows[kIterWaves][66 * kEntryRec];
+    __shared__ float sAcc[kIterWaves][64];
+    extern __shared__ float4 sDynamic[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = gridDim.x * kIterWaves;
+    const int w = blockIdx.x * kIterWaves + wv;
+    const int nd = lvlStart[cnt->numLevels];
+    float* products = reinterpret_cast<float*>(sDynamic) + wv * 27 * X.prStride;
+    const int slot = X.spread ? wv * (int)gridDim.x + (int)blockIdx.x : w;
+    if (slot < nd) iterate_resident<false, JOINTS>(B, M, gf, order, nd, slot, W, incStart, inc, P, errWord, cntW, X, sleepSel, lane, sRows[wv], sAcc[wv], products, 0, itEnd);
+}
+
 /* WPE = wavefronts per SIMD the launch is sized for: 1 (latency mode, one workgroup per CU: the critical wave never shares
  * its SIMD with a spinning one) or 2 (throughput mode for scenes with thousands of tasks per wave). */
 template <int WPE, bool JOINTS>
