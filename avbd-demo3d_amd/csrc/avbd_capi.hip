@@ -189,6 +189,7 @@ struct AvbdContext {
     std::vector<int> hostForceG;           /* ordinal -> index in hG */
     std::vector<HostRowsDev> hHostRows; DevArr<HostRowsDev> dHostRows;
     AvbdHostForceFn hostFn = nullptr; void* hostUser = nullptr;
+    bool shardMulti = false;       /* the plan of the current sharded step has several rounds */
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
@@ -792,7 +793,7 @@ int step_begin(AvbdContext* c)
             if (c->probeCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap; }
         }
         hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
-                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, (c->nranks > 1 || c->forceSharded) ? 1 : std::min(16, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
+                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min(16, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
         c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -1033,7 +1034,8 @@ int shard_plan_accepted(AvbdContext* c, bool& ok)
     HIPCHK(c, hipMemcpyAsync(&c->hRb->plan, c->dPlan.p, sizeof(GroupPlan), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const GroupPlan& p = c->hRb->plan;
-    ok = p.bad == 0 && p.rounds[0] <= 1 && p.rounds[1] <= 1 && p.rounds[2] <= 1;
+    ok = p.bad == 0;
+    c->shardMulti = p.rounds[0] > 1 || p.rounds[1] > 1 || p.rounds[2] > 1;     /* several bodies per sub-group: k_iterate_groups<true, true> */
     return AVBD_OK;
 }
 
@@ -1097,7 +1099,9 @@ int shard_launch_persistent(AvbdContext* c)
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evBegin, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    hipExtLaunchKernelGGL((k_iterate_groups<false, true>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
+    X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
+    auto kern = c->shardMulti ? k_iterate_groups<true, true> : k_iterate_groups<false, true>;
+    hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
                           S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
     ++c->prof.launches_primal; ++c->prof.launches_total;
     HIPCHK(c, hipGetLastError());
@@ -1440,6 +1444,7 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         {   /* Every persistent launch spins on records that other workgroups of the same launch produce: ALL its workgroups must be
              * resident at once.  Ask the runtime how many workgroups of each kernel fit a CU with the exact dynamic LDS it is
@@ -1451,10 +1456,11 @@ int avbd_create(int device, AvbdContext** out)
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fn, 64 * kIterWaves, (size_t)dynLds) != hipSuccess) { (void)hipGetLastError(); return 0; }
                 return perCu;
             };
-            const int occ1 = std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad));
+            const int occ1 = std::min(std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad)),
+                                      std::min(fits((const void*)k_iterate_single<false>, c->iterLdsPad), fits((const void*)k_iterate_single<true>, c->iterLdsPad)));
             const int occ2 = std::min(fits((const void*)k_iterate<2, false>, kIterWaves * kResProductBytesPerWaveLite), fits((const void*)k_iterate<2, true>, kIterWaves * kResProductBytesPerWaveLite));
             const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, false>, kGrpLdsBytes)),
-                                      fits((const void*)k_iterate_groups<false, true>, kGrpLdsBytes));
+                                      std::min(fits((const void*)k_iterate_groups<false, true>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, true>, kGrpLdsBytes)));
             if (occ1 < 1) { c->mode = 0; c->residentAllowed = false; }      /* not even one workgroup per CU: one launch per level, nothing spins */
             c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
             if (occ2 * cus < 2 * c->iterBlocks) { c->residentLiteFrom = 0; c->residentForceLite = false; c->iterForceMode = c->iterForceMode == 2 ? 0 : c->iterForceMode; c->liteResident = false; }
@@ -2532,6 +2538,15 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
         {   /* persistent form (one launch per rank and step, exchange on the second streams) when every rank's plan fits its share
              * of the device: the launches of contexts that share a device must ALL be resident at the same time */
             bool all = true;
+            {   /* more than four contexts on one device: their 2 x n streams share the device's few hardware queues, and a queue
+                 * that waits for a signal word holds up whatever else is mapped to it — another context's launch, for one.  One
+                 * context per device (the real layout) has two streams. */
+                for (int r = 0; r < n; ++r) {
+                    int sharing = 0;
+                    for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
+                    if (sharing > 4) all = false;
+                }
+            }
             for (int r = 0; r < n && all; ++r) {
                 bool ok = false;
                 (void)hipSetDevice(ctxs[r]->device);

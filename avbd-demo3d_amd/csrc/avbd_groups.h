@@ -251,7 +251,6 @@ __global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves
 void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
                       Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z)
 {
-    static_assert(!(MULTI && SHARD), "the sharded launch keeps every body in a sub-group of its own");
     extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave Jt | S | accs | constants */
     /* the host queues k_iterate_groups<false>, <true> and the fallback launch one behind the other; the plan says which one runs */
     if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;   /* (SHARD: the host has read the plan) */
@@ -432,7 +431,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 jr[0] = Jl[k].x; jr[kResRows] = Jl[k].y; jr[2 * kResRows] = Jl[k].z; jr[3 * kResRows] = Ja[k].x; jr[4 * kResRows] = Ja[k].y; jr[5 * kResRows] = Ja[k].z;
             }
         }
-        if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }
+        if (SHARD && !MULTI) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }
         if (!MULTI && cls == 0) {                                     /* the seeds of the 27 sums, for the wave-wide accumulation */
             if (gl < 27) accs[gl] = a0.acc;
             if (gl + 16 < 27) accs[gl + 16] = a1.acc;
@@ -677,6 +676,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
          * examined in full only when that record has arrived.  Every pass of the wave runs the picks of all its sub-groups
          * together. ---- */
         int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1, seenK = 0;
+        int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
             bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl);
@@ -688,6 +688,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             if (__ballot(activeK) == 0) break;
             bool candK = activeK;
             if (activeK && blkOff >= 0) { const unsigned st = xldw(rP, blkOff); candK = stamp_reached(st, blkStamp); }
+            if (SHARD && activeK && blkOff == -2) candK = stamp_reached(xldw(rGW, 0), blkStamp);   /* waiting for an all-gather */
             bool sel = false, triedK = false;
             for (;;) {
                 int key = (candK && !triedK) ? ((itK << 6) | gl) : 0x7fffffff;
@@ -704,9 +705,11 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                     set_needs();
                     poll_issue();
                     load_rest();
+                    if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }   /* the all-gather behind the previous iteration */
                     poll_check();
                     const unsigned long long noPose = __ballot(!okP) & gMask, noRest = __ballot(!(okV & okD)) & gMask;
-                    if ((noPose | noRest) == 0) {
+                    const unsigned long long noGather = SHARD ? (__ballot(!okR) & gMask) : 0ull;
+                    if ((noPose | noRest | noGather) == 0) {
                         sel = true;
                         if (lane == k) { ++itK; ++blkStamp; }                /* the same partner is the likeliest to be late again */
                     } else if (noPose) {
@@ -715,6 +718,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                         const int bo = __shfl(offP + 44, f, 64);
                         const unsigned bs = (unsigned)__shfl((int)sP, f, 64);
                         if (lane == k) { blkOff = bo; blkStamp = bs; candK = false; }
+                    } else if (noGather) {
+                        if (lane == k) { blkOff = -2; blkStamp = X.base + (unsigned)t; candK = false; }
                     } else if (lane == k) triedK = true;                     /* visit / dual records follow their producer's pose within its task: next pass */
                 }
             }
@@ -731,6 +736,22 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 finish_solve();
                 if (it < itStop - 1) park_body();
                 spins = 0;
+            }
+            if (SHARD && __ballot(sel)) {
+                /* iteration k of this wave is complete when every body it serves is past it (see the one-body form above) */
+                int low = bodyK >= 0 ? itK : itStop;
+                for (int o = 1; o < 64; o <<= 1) low = min(low, __shfl_xor(low, o, 64));
+                low = __builtin_amdgcn_readfirstlane(low);
+                if (reportedM < low) {
+                    const unsigned mine = (unsigned)__popcll(__ballot(bodyK >= 0));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        for (int k = reportedM; k < low; ++k) {
+                            const unsigned before = __hip_atomic_fetch_add(Z.done + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (before + mine == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    reportedM = low;
+                }
             }
             GS_STAMP(1);
             if (__ballot(sel) == 0 && !back_off()) return;

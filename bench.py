@@ -261,7 +261,7 @@ def main():
         fused = p["launches_primal"] <= 1.5 * max(1, p["steps"]) * max(1, world_size if world_size > 1 else 1) or os.environ.get("AVBD_MODE") != "levels"
         traffic, traffic_source = pmc_traffic(scene, fused and not sharded)
         sched = int(stats["schedule"])
-        roof = {"bound": "hbm", "kernel": ("k_iterate_groups" if sched == 4 else "k_iterate") if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": ("k_iterate_groups" if sched == 4 else ("k_iterate_single" if sched == 2 and os.environ.get("AVBD_SINGLE_KERNEL", "1") != "0" else "k_iterate")) if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": round(bytes_per_launch, 1), "us_per_launch": round(per_launch_s * 1e6, 3),
                 "launches_per_step": round(p["launches_primal"] / max(1, p["steps"]), 2),

@@ -93,6 +93,35 @@ def test_persistent_and_per_iteration_schedules_of_a_cut_pile_give_the_same_bits
         assert finals["1f"][r].tobytes() == finals["0f"][r].tobytes(), f"rank {r}: force state differs between the two schedules"
 
 
+def test_persistent_form_with_several_bodies_per_sub_group_gives_the_same_bits(monkeypatch):
+    """Few resident waves (AVBD_GROUPS_WAVES): every sub-group of the persistent launch serves several bodies, out of order
+    (k_iterate_groups<true, true>) — tasks with a remote partner wait for the all-gather of the previous iteration, the wave
+    counts an iteration once all its bodies are past it.  Same bits as one launch per iteration, on both ranks."""
+    scene = "PackedGrid:4,3,8"
+    finals = {}
+    for mode in ("multi", "per-iteration"):
+        monkeypatch.setenv("AVBD_SHARD_PERSISTENT", "1" if mode == "multi" else "0")
+        if mode == "multi":
+            monkeypatch.setenv("AVBD_GROUPS_WAVES", "8")              # 8 waves per context = 32 sub-groups for 48 bodies each: two rounds
+        else:
+            monkeypatch.delenv("AVBD_GROUPS_WAVES", raising=False)
+        pkg = H.load_product()
+        worlds = [H.HipWorld(), H.HipWorld()]
+        for w in worlds:
+            w.scene(scene)
+        b = worlds[0].bodies()
+        owner = pkg.partition_by_axis(b["pos"], b["invMass"], 2, axis=2)
+        for r, w in enumerate(worlds):
+            w.w.set_ownership(2, r, owner)
+        for s in range(6):
+            pkg.group_step([w.w for w in worlds], 5)
+        expect_schedule(worlds, "1" if mode == "multi" else "0")
+        finals[mode] = ([w.bodies() for w in worlds], [w.forces() for w in worlds])
+    for r in range(2):
+        assert finals["multi"][0][r].tobytes() == finals["per-iteration"][0][r].tobytes(), f"rank {r}: body state differs"
+        assert finals["multi"][1][r].tobytes() == finals["per-iteration"][1][r].tobytes(), f"rank {r}: force state differs"
+
+
 def test_four_ranks_share_one_device_in_the_persistent_form():
     """Four contexts, a quarter of the device's resident waves each, all four persistent launches in flight together."""
     scene = "PackedGrid:4,4,8"
