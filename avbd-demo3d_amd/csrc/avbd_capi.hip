@@ -274,7 +274,7 @@ int ensure_capacity(AvbdContext* c, int nBodies)
 
     HIPCHK(c, c->dPlanes.alloc((size_t)BP_COUNT * newCap));
     HIPCHK(c, c->dSolved.alloc(newCap));
-    HIPCHK(c, hipMemset(c->dSolved.p, 0, newCap * sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(c->dSolved.p, 0, newCap * sizeof(int), c->stream));
     HIPCHK(c, c->dPerm.alloc(newCap));
     c->bodyCap = newCap;
 
@@ -311,9 +311,9 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, c->xPose.alloc((size_t)3 * newCap));
     HIPCHK(c, c->xVisit.alloc((size_t)4 * c->mCap));
     HIPCHK(c, c->xDual.alloc((size_t)8 * c->mCap));
-    HIPCHK(c, hipMemset(c->xPose.p, 0, (size_t)3 * newCap * sizeof(float4)));
-    HIPCHK(c, hipMemset(c->xVisit.p, 0, (size_t)4 * c->mCap * sizeof(float4)));
-    HIPCHK(c, hipMemset(c->xDual.p, 0, (size_t)8 * c->mCap * sizeof(float4)));
+    HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, (size_t)3 * newCap * sizeof(float4), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, (size_t)4 * c->mCap * sizeof(float4), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, (size_t)8 * c->mCap * sizeof(float4), c->stream));
     c->xSerial = 0;
     c->lvlCap = newCap + 2;
     HIPCHK(c, c->adjStart.alloc(newCap + 1));
@@ -324,16 +324,16 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, c->order.alloc(newCap));
     c->orderValid = false;
     HIPCHK(c, c->dTileAgg.alloc((size_t)newCap / kTileBodies + 2));
-    HIPCHK(c, hipMemset(c->dTileAgg.p, 0, ((size_t)newCap / kTileBodies + 2) * sizeof(tile_v4u)));
+    HIPCHK(c, hipMemsetAsync(c->dTileAgg.p, 0, ((size_t)newCap / kTileBodies + 2) * sizeof(tile_v4u), c->stream));
     c->tileStamp = 0;
     HIPCHK(c, c->lvlStart.alloc(c->lvlCap + 1));
     HIPCHK(c, c->lvlCount.alloc(c->lvlCap + 1));
-    HIPCHK(c, hipMemset(c->adjStart.p, 0, (newCap + 1) * sizeof(int)));
-    HIPCHK(c, hipMemset(c->incStart.p, 0, (newCap + 1) * sizeof(int)));
-    HIPCHK(c, hipMemset(c->degForce.p, 0, newCap * sizeof(int)));
-    HIPCHK(c, hipMemset(c->degInc.p, 0, newCap * sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(c->adjStart.p, 0, (newCap + 1) * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->incStart.p, 0, (newCap + 1) * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->degForce.p, 0, newCap * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->degInc.p, 0, newCap * sizeof(int), c->stream));
     HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 32 + 8192 * 32));
-    HIPCHK(c, hipMemset(c->dFlags.p, 0, ((size_t)2 * newCap + 32 + 8192 * 32) * sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * newCap + 32 + 8192 * 32) * sizeof(int), c->stream));
     c->adjDirty = true;
     c->bodiesStale = true;
     return AVBD_OK;
@@ -822,7 +822,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     if (c->xDual.n * sizeof(float4) < dualBytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, c->xDual.alloc(dualBytes / sizeof(float4)));
-        HIPCHK(c, hipMemset(c->xDual.p, 0, dualBytes));
+        HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
         X.dual = c->xDual.p;
     }
     X.jointRecBase = 4 * c->mCap;
@@ -1046,7 +1046,7 @@ int shard_prepare_buffers(AvbdContext* c)
     if (c->gatherRows < rows || !c->dDone.p) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, c->dGather[0].alloc(2 * rows)); HIPCHK(c, c->dGather[1].alloc(2 * rows));
-        HIPCHK(c, hipMemset(c->dGather[0].p, 0, 2 * rows * sizeof(float4))); HIPCHK(c, hipMemset(c->dGather[1].p, 0, 2 * rows * sizeof(float4)));
+        HIPCHK(c, hipMemsetAsync(c->dGather[0].p, 0, 2 * rows * sizeof(float4), c->stream)); HIPCHK(c, hipMemsetAsync(c->dGather[1].p, 0, 2 * rows * sizeof(float4), c->stream));
         HIPCHK(c, c->dDone.alloc(64));
         c->gatherRows = rows;
     }
@@ -1076,7 +1076,7 @@ int shard_launch_persistent(AvbdContext* c)
     if (c->xDual.n * sizeof(float4) < dualBytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, c->xDual.alloc(dualBytes / sizeof(float4)));
-        HIPCHK(c, hipMemset(c->xDual.p, 0, dualBytes));
+        HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
         X.dual = c->xDual.p;
     }
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
@@ -1392,7 +1392,7 @@ int avbd_create(int device, AvbdContext** out)
         if (can && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->evBegin, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGathered, hipEventDisableTiming) == hipSuccess &&
             hipExtMallocWithFlags((void**)&c->sigDone, 8, hipMallocSignalMemory) == hipSuccess && hipExtMallocWithFlags((void**)&c->sigGather, 8, hipMallocSignalMemory) == hipSuccess) {
-            (void)hipMemset(c->sigDone, 0, 8); (void)hipMemset(c->sigGather, 0, 8);
+            (void)hipMemsetAsync(c->sigDone, 0, 8, c->stream); (void)hipMemsetAsync(c->sigGather, 0, 8, c->stream);
             c->canWaitValue = true;
         } else (void)hipGetLastError();
         if (const char* e = std::getenv("AVBD_SHARD_PERSISTENT")) c->shardPersistent = std::atoi(e) != 0 ? 1 : 0;
@@ -1402,10 +1402,10 @@ int avbd_create(int device, AvbdContext** out)
     static_assert(sizeof(WarnRec) == 32 && sizeof(Counters) == 64, "warning log layout");
     if (c->dCnt.alloc(1 + kWarnCap * sizeof(WarnRec) / sizeof(Counters)) != hipSuccess || c->dDiag.alloc(1) != hipSuccess || c->dNext.alloc(1) != hipSuccess ||
         c->dPlan.alloc(1) != hipSuccess) { delete c; return AVBD_E_HIP; }
-    (void)hipMemset(c->dPlan.p, 0, sizeof(GroupPlan));
-    (void)hipMemset(c->dCnt.p, 0, sizeof(Counters));
-    (void)hipMemset(c->dDiag.p, 0, sizeof(DiagAccum));
-    (void)hipMemset(c->dNext.p, 0, sizeof(int));
+    (void)hipMemsetAsync(c->dPlan.p, 0, sizeof(GroupPlan), c->stream);
+    (void)hipMemsetAsync(c->dCnt.p, 0, sizeof(Counters), c->stream);
+    (void)hipMemsetAsync(c->dDiag.p, 0, sizeof(DiagAccum), c->stream);
+    (void)hipMemsetAsync(c->dNext.p, 0, sizeof(int), c->stream);
     if (ensure_capacity(c, 0) != AVBD_OK || ensure_topology_capacity(c) != AVBD_OK) { g_createError = "initial allocation failed: " + c->err; delete c; return AVBD_E_HIP; }
     {   /* k_iterate needs every workgroup resident.  One workgroup (4 waves = one per SIMD) per CU: a spinning
          * second wave on a SIMD steals issue slots from the wave that is on the critical path.  Padding the LDS
@@ -1526,8 +1526,8 @@ int avbd_clear(AvbdContext* c)
     c->bodiesStale = true; c->deviceAhead = false; c->gStale = true; c->gDeviceAhead = false; c->adjDirty = true;
     c->stepIndex = 0; c->hostKeyCounter = 1; c->numStatic = 0;
     c->stats = AvbdStepStats{};
-    HIPCHK(c, hipMemset(c->dCnt.p, 0, sizeof(Counters)));
-    HIPCHK(c, hipMemset(c->dDiag.p, 0, sizeof(DiagAccum)));
+    HIPCHK(c, hipMemsetAsync(c->dCnt.p, 0, sizeof(Counters), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dDiag.p, 0, sizeof(DiagAccum), c->stream));
     return AVBD_OK;
 }
 
@@ -2277,7 +2277,7 @@ static int run_row_api(AvbdContext* c, int force_index, float alpha, int mode, i
     if ((rc = upload_gforces_if_stale(c))) return rc;
     DevArr<float> d;
     HIPCHK(c, d.alloc(48));
-    HIPCHK(c, hipMemset(d.p, 0, 48 * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(d.p, 0, 48 * sizeof(float), c->stream));
     hipLaunchKernelGGL(k_row_api, dim3(1), dim3(64), 0, c->stream, body_table(c), c->mbuf[c->cur].view(), c->dG.p, ref.kind, ref.index, alpha, mode, body, row, d.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(host_out, d.p, nfloats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -2344,7 +2344,7 @@ int avbd_kat_collide(AvbdContext* c, int n, const float* posA, const float* quat
     HIPCHK(c, hipMemcpy(dpA.p, posA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dqA.p, quatA, 16 * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dsA.p, sizeA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dpB.p, posB, 12 * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dqB.p, quatB, 16 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dsB.p, sizeB, 12 * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemset(dout.p, 0, sizeof(KatContact) * 4 * n));
+    HIPCHK(c, hipMemsetAsync(dout.p, 0, sizeof(KatContact) * 4 * n, c->stream));
     hipLaunchKernelGGL(k_kat_collide, dim3(grid_for(n, kPairsPerWave, 1 << 20)), dim3(64), 0, c->stream, n, dpA.p, dqA.p, dsA.p, dpB.p, dqB.p, dsB.p, dout.p, dcnt.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
