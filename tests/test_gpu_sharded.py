@@ -5,7 +5,8 @@ Two forms of that schedule give the same bits (both are Jacobi across the cut, o
   persistent  (default)  ONE launch per rank and step (k_iterate_groups<false, true>); the exchange runs beside it on a second
               stream: hipStreamWaitValue32 on the rank's iteration counter -> gather -> hipStreamWriteValue32 releases the
               tasks that read remote rows; tasks without a remote partner never wait for it.  stats.schedule == 4.
-  per-iteration (AVBD_SHARD_PERSISTENT=0, or when a rank's bodies do not fit a sub-group each) one launch per iteration."""
+              A rank with more bodies than sub-groups keeps this form with several bodies per sub-group (k_iterate_groups<true, true>).
+  per-iteration (AVBD_SHARD_PERSISTENT=0, joints / springs, more than four contexts on one device) one launch per iteration."""
 import numpy as np
 import pytest
 
