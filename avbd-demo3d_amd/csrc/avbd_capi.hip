@@ -680,14 +680,15 @@ int refresh_stats(AvbdContext* c, bool withLevels)
 
 /* ---- one Solver::step() split into phases so that several contexts (GPUs) can be driven in lock-step ---- */
 
+constexpr int kShardFreeSlots = 16;   /* workgroup slots a persistent sharded launch leaves to the collective's kernel (avbd_comm_init caps its channels at 8) */
 int groups_waves(const AvbdContext* c)
 {
     int all = 2 * c->iterBlocks * kGrpWavesPerBlock;                   /* two workgroups of four waves per CU */
     if (c->nranks > 1 || c->forceSharded) {
         /* a sharded step: contexts that share this device split the waves (avbd_group_step sets shardWaves); with a real
-         * collective its kernel needs room beside the persistent launch: four workgroup slots stay free */
+         * collective its kernel needs room beside the persistent launch: kShardFreeSlots workgroup slots stay free */
         if (c->shardWaves > 0) all = std::min(all, c->shardWaves);
-        else if (c->comm) all -= 4 * kGrpWavesPerBlock;
+        else if (c->comm) all -= kShardFreeSlots * kGrpWavesPerBlock;
     }
     return c->groupsWaves > 0 ? std::min(c->groupsWaves, all) : all;
 }
@@ -2508,6 +2509,10 @@ int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
     if (!load_rccl()) return c->fail(AVBD_E_COMM, "librccl.so could not be loaded");
     Id128 u; std::memcpy(u.b, id, 128);
     void* comm = nullptr;
+    /* The all-gather of a persistent sharded step runs BESIDE the launch that waits for it, on the workgroup slots that launch
+     * leaves free (kShardFreeSlots): its kernel must not need more workgroups than that.  The exchange is at most a few MB and
+     * latency-bound, so few channels cost nothing.  (A caller that sets NCCL_MAX_NCHANNELS itself keeps its value.) */
+    if (nranks > 1) setenv("NCCL_MAX_NCHANNELS", "8", 0);
     int r = g_rccl.CommInitRank(&comm, nranks, u, rank);
     if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclCommInitRank failed");
     c->comm = comm;

@@ -196,26 +196,60 @@ def main():
         pkg.build()
     if args.force_dist and world_size == 1:
         os.environ["AVBD_FORCE_SHARDED"] = "1"                   # one rank, but the sharded schedule (exchange every iteration)
-    w = pkg.World(local_rank)
-
     # N = 1: BASELINE configs[1] (Stress1000).  N > 1: north_star's strong-scaling experiment, the SAME 64 000-cube scene sharded over
     # the N GPUs by slabs along x (configs[3]); value = steps/s of that one scene, never multiplied by N
     scene = args.scene or ("Stress1000" if not sharded else STRONG_SCENE)
     presim = args.presim if args.presim is not None else (0 if scene.startswith("Packed") else (STRONG_PRESIM if scene == STRONG_SCENE else 400))
-    w.scene(scene)
+
+    def make_world():
+        w = pkg.World(local_rank)
+        w.scene(scene)
+        if sharded:
+            b0 = w.bodies()
+            owner = pkg.partition_by_axis(b0["position"], b0["invMass"], world_size, axis=0)
+            w.set_ownership(world_size, rank, owner)
+            uid = [pkg.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            w.comm_init(world_size, rank, uid[0])
+        return w
+
+    def settle(w):
+        if presim:
+            w.step(presim)
+        w.step(args.warmup)
+        w.synchronize()
+
+    w = make_world()
     iterations = int(w.params()["iterations"])
-    if sharded:
+    shard_form = None
+    if world_size > 1:
+        # The persistent sharded step runs its collective BESIDE the launch that waits for it; that form could not be
+        # validated on a multi-GPU box.  The untimed steps are its trial: if any rank fails them (a wait that times out, an RCCL
+        # error), every rank rebuilds its world with one launch per iteration — the form without that coupling — and the line says
+        # which form was measured.
         import torch
-        b0 = w.bodies()
-        owner = pkg.partition_by_axis(b0["position"], b0["invMass"], world_size, axis=0)
-        w.set_ownership(world_size, rank, owner)
-        uid = [pkg.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        w.comm_init(world_size, rank, uid[0])
-    if presim:
-        w.step(presim)
-    w.step(args.warmup)
-    w.synchronize()
+        shard_form = "one launch per iteration" if os.environ.get("AVBD_SHARD_PERSISTENT") == "0" else "persistent"
+        ok = 1
+        try:
+            settle(w)
+        except Exception as e:
+            ok = 0
+            print(f"bench.py rank {rank}: sharded steps failed in the {shard_form} form ({e})", file=sys.stderr)
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            if shard_form != "persistent":
+                sys.exit("bench.py: the sharded run failed in the one-launch-per-iteration form")
+            shard_form = "one launch per iteration (the persistent form failed its untimed steps)"
+            os.environ["AVBD_SHARD_PERSISTENT"] = "0"
+            try:
+                w.close()
+            except Exception:
+                pass
+            w = make_world()
+            settle(w)
+    else:
+        settle(w)
 
     # snapshot for the CPU leg / parity (rank 0, N=1 only)
     want_cpu = (rank == 0 and not sharded and not args.no_cpu)
@@ -352,6 +386,7 @@ def main():
                        "mode": "exact (bit-identical to the reference CPU solver)" if world_size == 1 else
                                "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)",
                        "parallelism": "1 GPU" if not sharded else f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene",
+                       "shard_form": shard_form,
                        "strong_scaling_n1": strong_n1,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
                        "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
