@@ -117,3 +117,23 @@ def test_grid_broadphase_matches_the_n2_loop_on_mixed_sizes(monkeypatch):
         monkeypatch.delenv("AVBD_BROADPHASE")
         H.assert_same_world_fast(o, g, f"mixed sizes, broadphase={mode}")
     assert int(g.w.stats()["numManifolds"]) > 800 and int(g.w.stats()["numCandidates"]) > 0
+
+
+def test_22000_cubes_several_bodies_per_sub_group_match_the_parked_sweep(monkeypatch):
+    """21 952 falling cubes, steps 0..230 (the pile lands from step ~130): the group schedule with several bodies per sub-group
+    (three rounds, plan scanned over six tiles of 4096 bodies by six workgroups, out-of-order picks) and the resident schedule's
+    parked sweep are both exact, so they must agree bit for bit — bodies and forces — deep into the landing."""
+    finals = {}
+    for groups in ("default", "0"):
+        if groups == "0":
+            monkeypatch.setenv("AVBD_GROUPS", "0")
+        g = H.HipWorld(); g.scene("StressN:28")
+        g.step(230); g.w.synchronize()
+        st = g.w.stats()
+        assert int(st["schedule"]) == (4 if groups == "default" else 3), st
+        assert int(st["numManifolds"]) > 20000
+        finals[groups] = (g.bodies(), g.forces())
+        if groups == "0":
+            monkeypatch.delenv("AVBD_GROUPS")
+    assert finals["default"][0].tobytes() == finals["0"][0].tobytes(), "body state differs between the two schedules"
+    assert finals["default"][1].tobytes() == finals["0"][1].tobytes(), "force state differs between the two schedules"
