@@ -91,7 +91,9 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
     for (int k = 0; k < 4; ++k)
         if (body[k] >= 0) {
             const int ne = incStart[body[k] + 1] - incStart[body[k]];
-            cl[k] = ne <= 16 ? 0 : (ne <= 32 ? 1 : 2);
+            /* fewer bodies than waves (small ranks of a sharded run): a whole wave per body — no other sub-group ever holds its
+             * wave while its inputs arrive */
+            cl[k] = (nd <= W || ne > 32) ? 2 : (ne <= 16 ? 0 : 1);
             mine4 += 1ull << (21 * cl[k]);
         }
     const unsigned long long incl = block_scan_inclusive_u64(mine4, sWaveTotals);
