@@ -181,7 +181,11 @@ struct AvbdContext {
     bool canWaitValue = false;     /* hipStreamWaitValue32 / WriteValue32 work on this device */
     hipStream_t stream2 = nullptr; /* exchange stream: wait for an iteration -> all-gather -> release its readers */
     hipEvent_t evBegin = nullptr, evGathered = nullptr;
-    unsigned* sigDone = nullptr; unsigned* sigGather = nullptr;   /* hipMallocSignalMemory words */
+    unsigned* sigDone = nullptr;   /* hipMallocSignalMemory word: what the exchange stream waits on (one system-scope atomic per iteration raises it) */
+    unsigned* sigGather = nullptr; /* UNCACHED device memory (hipDeviceMallocUncached): written by hipStreamWriteValue32 behind every all-gather, POLLED by every
+                                    * wave that reads a remote row.  Not signal memory (thousands of waves polling it made a sharded iteration take 0.7 ms) and not
+                                    * plain device memory (the command processor's write does not reach a line an XCD's L2 already holds: the waves of that
+                                    * XCD kept reading the old value and the launch timed out) */
     DevArr<unsigned> dDone; DevArr<float4> dGather[2]; DevArr<int> dRow; size_t gatherRows = 0;
     int shardWaves = 0;            /* waves the plan of a sharded step may use (contexts that share a device split them; room for the collective's kernel) */
     bool shardRanPersistent = false;
@@ -672,22 +676,32 @@ int refresh_stats(AvbdContext* c, bool withLevels)
         return c->fail(AVBD_E_CAPACITY, buf);
     }
     if (iterError) {
-        (void)hipMemsetAsync(c->dFlags.p + 2 * (size_t)c->bodyCap, 0, sizeof(int), c->stream);   /* reported once */
-        return c->fail(AVBD_E_HIP, "k_iterate: dependency wait timed out (grid not resident?)");
+        int why[16] = {0};
+        (void)hipMemcpy(why, c->dFlags.p + 2 * (size_t)c->bodyCap, sizeof(why), hipMemcpyDeviceToHost);
+        (void)hipMemsetAsync(c->dFlags.p + 2 * (size_t)c->bodyCap, 0, sizeof(why), c->stream);   /* reported once */
+        char buf[320];
+        if (why[1])   /* the group schedule says what its first wave to give up was waiting for */
+            std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?) [rank %d wave %d class %d: body %d iteration %d partner %d; lanes missing pose %08x%08x visit %08x%08x dual %08x%08x gather %08x%08x, timed out %08x%08x]",
+                          c->rank, why[1] - 1, why[15], why[2], why[4], why[3], (unsigned)why[6], (unsigned)why[5], (unsigned)why[8], (unsigned)why[7], (unsigned)why[10], (unsigned)why[9], (unsigned)why[12], (unsigned)why[11], (unsigned)why[14], (unsigned)why[13]);
+        else std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?)");
+        return c->fail(AVBD_E_HIP, buf);
     }
     return AVBD_OK;
 }
 
 /* ---- one Solver::step() split into phases so that several contexts (GPUs) can be driven in lock-step ---- */
 
-constexpr int kShardFreeSlots = 16;   /* workgroup slots a persistent sharded launch leaves to the collective's kernel (avbd_comm_init caps its channels at 8) */
+constexpr int kShardFreeSlots = 4;    /* workgroup slots a persistent sharded launch leaves to the collective's kernel (avbd_comm_init caps its channels at 4);
+                                       * more would push a rank of 8 000 bodies — an eighth of the 64 000-cube scene — out of the one-body-per-sub-group form */
 int groups_waves(const AvbdContext* c)
 {
     int all = 2 * c->iterBlocks * kGrpWavesPerBlock;                   /* two workgroups of four waves per CU */
     if (c->nranks > 1 || c->forceSharded) {
         /* a sharded step: contexts that share this device split the waves (avbd_group_step sets shardWaves); with a real
          * collective its kernel needs room beside the persistent launch: kShardFreeSlots workgroup slots stay free */
-        if (c->shardWaves > 0) all = std::min(all, c->shardWaves);
+        /* (avbd_group_step's device copies are kernels too: every context leaves a few slots of its share free as well — a plan with
+         * several bodies per sub-group uses every wave it is given) */
+        if (c->shardWaves > 0) all = std::max(kGrpWavesPerBlock, std::min(all, c->shardWaves) - 4 * kGrpWavesPerBlock);
         else if (c->comm) all -= kShardFreeSlots * kGrpWavesPerBlock;
     }
     return c->groupsWaves > 0 ? std::min(c->groupsWaves, all) : all;
@@ -1036,6 +1050,9 @@ int shard_plan_accepted(AvbdContext* c, bool& ok)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const GroupPlan& p = c->hRb->plan;
     ok = p.bad == 0;
+    if (std::getenv("AVBD_DEBUG_PLAN"))
+        std::fprintf(stderr, "[avbd rank %d step %d] plan: classes %d/%d/%d waves %d/%d/%d rounds %d/%d/%d bad %d nd %d (W %d)\n", c->rank, c->stepIndex, p.nClass[0], p.nClass[1], p.nClass[2],
+                     p.waves[0], p.waves[1], p.waves[2], p.rounds[0], p.rounds[1], p.rounds[2], p.bad, p.nd, groups_waves(c));
     c->shardMulti = p.rounds[0] > 1 || p.rounds[1] > 1 || p.rounds[2] > 1;     /* several bodies per sub-group: k_iterate_groups<true, true> */
     return AVBD_OK;
 }
@@ -1095,6 +1112,7 @@ int shard_launch_persistent(AvbdContext* c)
     Z.gatherBytes = (unsigned)(2 * c->gatherRows * sizeof(float4));
     Z.row = c->dRow.p; Z.done = c->dDone.p; Z.doneSignal = c->sigDone; Z.gatherWord = c->sigGather;
     Z.nOwned = c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank];
+    Z.keepExchangeWaiting = std::getenv("AVBD_DEBUG_KEEP_EXCHANGE_WAITING") ? 1 : 0;
     HIPCHK(c, hipMemsetAsync(c->dDone.p, 0, 64 * sizeof(unsigned), c->stream));
     HIPCHK(c, hipEventRecord(c->evBegin, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evBegin, 0));
@@ -1392,7 +1410,7 @@ int avbd_create(int device, AvbdContext** out)
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
         if (can && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->evBegin, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGathered, hipEventDisableTiming) == hipSuccess &&
-            hipExtMallocWithFlags((void**)&c->sigDone, 8, hipMallocSignalMemory) == hipSuccess && hipExtMallocWithFlags((void**)&c->sigGather, 8, hipMallocSignalMemory) == hipSuccess) {
+            hipExtMallocWithFlags((void**)&c->sigDone, 8, hipMallocSignalMemory) == hipSuccess && hipExtMallocWithFlags((void**)&c->sigGather, 256, hipDeviceMallocUncached) == hipSuccess) {
             (void)hipMemsetAsync(c->sigDone, 0, 8, c->stream); (void)hipMemsetAsync(c->sigGather, 0, 8, c->stream);
             c->canWaitValue = true;
         } else (void)hipGetLastError();
@@ -2512,7 +2530,7 @@ int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
     /* The all-gather of a persistent sharded step runs BESIDE the launch that waits for it, on the workgroup slots that launch
      * leaves free (kShardFreeSlots): its kernel must not need more workgroups than that.  The exchange is at most a few MB and
      * latency-bound, so few channels cost nothing.  (A caller that sets NCCL_MAX_NCHANNELS itself keeps its value.) */
-    if (nranks > 1) setenv("NCCL_MAX_NCHANNELS", "8", 0);
+    if (nranks > 1) setenv("NCCL_MAX_NCHANNELS", "4", 0);
     int r = g_rccl.CommInitRank(&comm, nranks, u, rank);
     if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclCommInitRank failed");
     c->comm = comm;
@@ -2660,6 +2678,53 @@ int avbd_debug_group_task_times(AvbdContext* c, unsigned* out, int iterations)
     if (!c->xPrivN.p || c->privNCap * sizeof(float4) < words * sizeof(unsigned)) return c->fail(AVBD_E_INVALID, "no task time buffer");
     HIPCHK(c, hipMemcpy(out, c->xPrivN.p, words * sizeof(unsigned), hipMemcpyDeviceToHost));
     return AVBD_OK;
+}
+
+/* debug: after a sharded / group launch was abandoned (dependency time-out), what every body's sub-group was waiting for:
+ * out[4 * body] = {iteration, partner or -1, records missing (1 pose, 2 visit, 4 dual, 8 gather), wave} (tools/debug_sharded.py) */
+extern "C" int avbd_debug_wait_graph(AvbdContext* c, int* out)
+{
+    if (!c || !out || !c->xPrivPose.p) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    std::vector<float4> h((size_t)2 * c->hBodies.size());
+    if (hipMemcpy(h.data(), c->xPrivPose.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    for (size_t b = 0; b < c->hBodies.size(); ++b) std::memcpy(out + 8 * b, &h[2 * b], 32);
+    return AVBD_OK;
+}
+
+/* debug: the counters and words of the persistent sharded step: out[0..63] done[k], [64] signal word, [65] gather word, [66] stamp base, [67] owned bodies */
+extern "C" int avbd_debug_shard_words(AvbdContext* c, unsigned* out)
+{
+    if (!c || !out || !c->dDone.p || !c->sigDone || !c->sigGather) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(out, c->dDone.p, 64 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    if (hipMemcpy(out + 64, c->sigDone, 4, hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    if (hipMemcpy(out + 65, c->sigGather, 4, hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    out[66] = c->xSerial * 64u; out[67] = (unsigned)(c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank]);
+    return AVBD_OK;
+}
+
+/* debug: stamps (minus the launch's base) of the three pose records of every body: out[3 * body + k] */
+extern "C" int avbd_debug_pose_stamps(AvbdContext* c, int* out)
+{
+    if (!c || !out || !c->xPose.p) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    std::vector<float4> h((size_t)3 * c->hBodies.size());
+    if (hipMemcpy(h.data(), c->xPose.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    for (size_t i = 0; i < h.size(); ++i) { unsigned wv; std::memcpy(&wv, &h[i].w, 4); out[i] = (int)(wv - c->xSerial * 64u); }
+    return AVBD_OK;
+}
+
+/* debug (AVBD_DEBUG_KEEP_EXCHANGE_WAITING runs): let the exchange streams that wait for this rank go on */
+extern "C" int avbd_debug_release_exchange(AvbdContext* c)
+{
+    if (!c || !c->sigDone) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    const unsigned big = c->xSerial * 64u + 63u;
+    return hipMemcpy(c->sigDone, &big, 4, hipMemcpyHostToDevice) == hipSuccess ? AVBD_OK : AVBD_E_HIP;
 }
 
 int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)

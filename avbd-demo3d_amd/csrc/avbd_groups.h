@@ -55,6 +55,7 @@ struct ShardExchange {
     unsigned* doneSignal;     /* hipMallocSignalMemory: base + (iterations completed by this rank) */
     unsigned* gatherWord;     /* hipMallocSignalMemory: base + (all-gathers that have landed) */
     int nOwned;               /* swept bodies of this rank */
+    int keepExchangeWaiting;  /* debug (AVBD_DEBUG_KEEP_EXCHANGE_WAITING): an abandoned launch does not release the exchange stream, so the other ranks stay as they are */
 };
 
 constexpr int kGrpWavesPerBlock = 4;
@@ -567,19 +568,50 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         if (SHARD && !okR) okR = stamp_reached(xldw(rGW, 0), sR);
     };
     auto poll_records = [&]() __attribute__((always_inline)) { poll_issue(); poll_check(); };
+    int reported = 0;                                                 /* SHARD, one body per sub-group: iterations this wave has counted in Z.done */
     auto back_off = [&]() __attribute__((always_inline)) -> bool {     /* false: the launch is being abandoned */
         if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
         else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
-        if ((++spins & 1023u) == 0) {
+        /* (`spins` and `tIdle` are per sub-group — a task resets them for its lanes only —, so the lanes of a wave come here at
+         * different counts: the check itself is made by the whole wave, and the wave leaves as one) */
+        const bool chk = (++spins & 1023u) == 0;
+        if (__any(chk)) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (spins == 1024u) tIdle = now - 1024ull * 30ull;        /* first check since the last task: the wait began about here */
-            bool dead = (now - tIdle > kSpinTimeoutTicks) ||
-                        __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (chk && spins == 1024u) tIdle = now - 1024ull * 30ull;  /* first check since the last task: the wait began about here */
+            const bool waiting = MULTI || (valid && it < itStop);   /* (a sub-group that has finished its body's last task waits for nothing) */
+            const bool dead = (chk && waiting && now - tIdle > kSpinTimeoutTicks) ||
+                              __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (__any(dead)) {
+                {   /* what the first wave to give up was waiting for (errWord[1..15]; read by the host for its message) */
+                    const bool mine = chk && waiting && now - tIdle > kSpinTimeoutTicks;
+                    const unsigned long long mT = __ballot(mine), mP = __ballot(mine && !okP), mV = __ballot(mine && !okV), mD = __ballot(mine && !okD), mR = __ballot(mine && !okR);
+                    const int stuck = mT ? __ffsll((long long)((mP | mV | mD | mR) ? (mP | mV | mD | mR) : mT)) - 1 : 0;
+                    const int sb = __shfl(body, stuck, 64), so = __shfl(other, stuck, 64), si = __shfl(it, stuck, 64);
+                    if (lane == 0 && mT && __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicCAS(errWord + 1, 0, w + 1) == 0) {
+                        errWord[2] = sb; errWord[3] = so; errWord[4] = si; errWord[5] = (int)mP; errWord[6] = (int)(mP >> 32); errWord[7] = (int)mV; errWord[8] = (int)(mV >> 32);
+                        errWord[9] = (int)mD; errWord[10] = (int)(mD >> 32); errWord[11] = (int)mR; errWord[12] = (int)(mR >> 32); errWord[13] = (int)mT; errWord[14] = (int)(mT >> 32); errWord[15] = cls;
+                    }
+                }
+                if (!MULTI && X.privPose && valid) {
+                    /* wait graph of the abandoned launch (debug: avbd_debug_wait_graph): per body {iteration, first partner an entry
+                     * still waits for or -1, which records (1 pose, 2 visit, 4 dual, 8 gather), wave} */
+                    const unsigned long long miss = __ballot(!(okP & okV & okD & okR) && it < itStop) & gMask;
+                    const int f = miss ? __ffsll((long long)miss) - 1 : gBase;
+                    const int fo = __shfl(other, f, 64);
+                    const int fk = __shfl((okP ? 0 : 1) | (okV ? 0 : 2) | (okD ? 0 : 4) | (okR ? 0 : 8), f, 64);
+                    if (gl == 0) X.privPose[(size_t)body * 2] = make_float4(__int_as_float(it), __int_as_float(miss ? fo : -1), __int_as_float(miss ? fk : 0), __int_as_float(w | (reported << 16)));
+                    if (miss && lane == f) {
+                        /* the stamp of the partner's last pose record as three kinds of load see it, and what the lane waits for */
+                        const unsigned a = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rP, offP + 44, 0, 16);      /* sc1 (what the polls use) */
+                        const unsigned b2 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rP, offP + 44, 0, 17);     /* sc0 sc1 */
+                        const unsigned c2 = __hip_atomic_load(reinterpret_cast<const unsigned*>(X.pose) + (offP + 44) / 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        X.privPose[(size_t)body * 2 + 1] = make_float4(__int_as_float((int)(a - X.base)), __int_as_float((int)(b2 - X.base)), __int_as_float((int)(c2 - X.base)), __int_as_float((int)(sP - X.base)));
+                    }
+                }
                 if (lane == 0) {
                     __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     /* the exchange stream must not wait for iterations that will never complete */
-                    if (SHARD) __hip_atomic_fetch_max(Z.doneSignal, X.base + 63u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (SHARD && !Z.keepExchangeWaiting) __hip_atomic_fetch_max(Z.doneSignal, X.base + 63u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 return false;
             }
@@ -598,7 +630,6 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         if (valid) prepare_task();
         GS_STAMP(3);
-        int reported = 0;                                             /* SHARD: iterations this wave has counted in Z.done */
         for (;;) {
             const bool active = valid && it < itStop;
             if (__ballot(active) == 0) break;

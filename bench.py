@@ -213,81 +213,85 @@ def main():
             w.comm_init(world_size, rank, uid[0])
         return w
 
-    def settle(w):
+    want_cpu = (rank == 0 and not sharded and not args.no_cpu)
+    prof_steps = min(args.steps, 50)
+
+    def measure(w):
+        """untimed steps, the timed region (exactly K steps, barrier + synchronize on both sides, max over ranks), then the
+        profiled steps (HIP events around every launch on the solver's stream)"""
         if presim:
             w.step(presim)
         w.step(args.warmup)
         w.synchronize()
+        # snapshot for the CPU leg / parity (rank 0, N=1 only)
+        m = {"snap_b": None, "snap_f": None, "snap_step": w.step_index()}
+        if want_cpu:
+            m["snap_b"], m["snap_f"] = w.bodies(), w.forces()
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            w.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        w.step(args.steps)
+        w.synchronize()
+        m["elapsed"] = time.perf_counter() - t0
+        barrier()
+        m["end_b"] = w.bodies() if want_cpu else None
+        m["stats"] = w.stats()
+        w.profile_enable(True)
+        w.profile_reset()
+        w.step(prof_steps)
+        w.synchronize()
+        m["p"] = w.profile()
+        w.profile_enable(False)
+        return m
 
     w = make_world()
     iterations = int(w.params()["iterations"])
     shard_form = None
     if world_size > 1:
         # The persistent sharded step runs its collective BESIDE the launch that waits for it (DESIGN.md §7); that form could not be
-        # validated on a multi-GPU box.  The untimed steps are its trial: if any rank fails them (a wait that times out, an RCCL
-        # error), every rank rebuilds its world with one launch per iteration — the form without that coupling — and the line says
+        # validated on a multi-GPU box.  If any rank fails anywhere in the run (a wait that times out, an RCCL error), every rank
+        # rebuilds its world with one launch per iteration — the form without that coupling — and measures again; the line says
         # which form was measured.
         import torch
         shard_form = "one launch per iteration" if os.environ.get("AVBD_SHARD_PERSISTENT") == "0" else "persistent"
-        ok = 1
-        try:
-            settle(w)
-        except Exception as e:
-            ok = 0
-            print(f"bench.py rank {rank}: sharded steps failed in the {shard_form} form ({e})", file=sys.stderr)
-        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0:
-            if shard_form != "persistent":
+        m = None
+        for attempt in range(2):
+            ok = 1
+            try:
+                m = measure(w)
+            except Exception as e:
+                ok = 0
+                print(f"bench.py rank {rank}: the sharded run failed in the {shard_form} form ({e})", file=sys.stderr)
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                break
+            if attempt == 1 or shard_form != "persistent":
                 sys.exit("bench.py: the sharded run failed in the one-launch-per-iteration form")
-            shard_form = "one launch per iteration (the persistent form failed its untimed steps)"
+            shard_form = "one launch per iteration (the persistent form failed)"
             os.environ["AVBD_SHARD_PERSISTENT"] = "0"
             try:
                 w.close()
             except Exception:
                 pass
             w = make_world()
-            settle(w)
     else:
-        settle(w)
-
-    # snapshot for the CPU leg / parity (rank 0, N=1 only)
-    want_cpu = (rank == 0 and not sharded and not args.no_cpu)
-    snap_b = snap_f = None
-    snap_step = w.step_index()
-    if want_cpu:
-        snap_b, snap_f = w.bodies(), w.forces()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        w.synchronize()
-
-    # ---- timed region: exactly K steps -----------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    w.step(args.steps)
-    w.synchronize()
-    elapsed = time.perf_counter() - t0
+        m = measure(w)
+    snap_b, snap_f, snap_step, elapsed, end_b, stats, p = m["snap_b"], m["snap_f"], m["snap_step"], m["elapsed"], m["end_b"], m["stats"], m["p"]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    barrier()
-    end_b = w.bodies() if want_cpu else None
-    stats = w.stats()
     ab = algorithmic_bytes(stats, iterations)
 
-    # ---- roofline of the dominant kernel: HIP events around every launch on the solver's stream ----
+    # ---- roofline of the dominant kernel ----
     roof = None
-    prof_steps = min(args.steps, 50)
-    w.profile_enable(True)
-    w.profile_reset()
-    w.step(prof_steps)
-    w.synchronize()
-    p = w.profile()
-    w.profile_enable(False)
     if p["launches_primal"] > 0 and p["ms_primal"] > 0:
         per_launch_s = p["ms_primal"] * 1e-3 / p["launches_primal"]
         bytes_per_launch = p["algorithmic_bytes_primal"] / p["launches_primal"]
