@@ -1040,6 +1040,12 @@ int step_end(AvbdContext* c, bool haveCounts)
 int rccl_allgather(AvbdContext* c); /* below, next to the communicator set-up */
 int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream);
 
+/* debug (AVBD_DEBUG_COPY_KERNEL): the device copy of avbd_group_step's exchange as a two-workgroup kernel of this library */
+__global__ void k_copy_rows(float4* dst, const float4* src, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 /* Sharded step, persistent form: has the device accepted the plan (every owned body in a sub-group of its own)?  One small
  * readback; the per-iteration schedule is the fallback. */
 int shard_plan_accepted(AvbdContext* c, bool& ok)
@@ -2588,6 +2594,9 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
                             if (src == dst) continue;
                             AvbdContext* q = ctxs[src];
                             HIPCHK(d, hipStreamWaitValue32(d->stream2, q->sigDone, q->xSerial * 64u + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                            if (std::getenv("AVBD_DEBUG_COPY_KERNEL"))
+                                hipLaunchKernelGGL(k_copy_rows, dim3(2), dim3(256), 0, d->stream2, d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, (int)rows);
+                            else
                             HIPCHK(d, hipMemcpyAsync(d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream2));
                         }
                         HIPCHK(d, hipStreamWriteValue32(d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u, 0));
@@ -2715,6 +2724,17 @@ extern "C" int avbd_debug_pose_stamps(AvbdContext* c, int* out)
     std::vector<float4> h((size_t)3 * c->hBodies.size());
     if (hipMemcpy(h.data(), c->xPose.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
     for (size_t i = 0; i < h.size(); ++i) { unsigned wv; std::memcpy(&wv, &h[i].w, 4); out[i] = (int)(wv - c->xSerial * 64u); }
+    return AVBD_OK;
+}
+
+extern "C" int avbd_debug_shard_words_nosync(AvbdContext* c, unsigned* out)
+{
+    if (!c || !out || !c->dDone.p || !c->sigDone || !c->sigGather) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (hipMemcpy(out, c->dDone.p, 64 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    if (hipMemcpy(out + 64, c->sigDone, 4, hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    if (hipMemcpy(out + 65, c->sigGather, 4, hipMemcpyDeviceToHost) != hipSuccess) return AVBD_E_HIP;
+    out[66] = c->xSerial * 64u; out[67] = 0;
     return AVBD_OK;
 }
 

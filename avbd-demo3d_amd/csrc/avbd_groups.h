@@ -600,7 +600,14 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                     const int fo = __shfl(other, f, 64);
                     const int fk = __shfl((okP ? 0 : 1) | (okV ? 0 : 2) | (okD ? 0 : 4) | (okR ? 0 : 8), f, 64);
                     if (gl == 0) X.privPose[(size_t)body * 2] = make_float4(__int_as_float(it), __int_as_float(miss ? fo : -1), __int_as_float(miss ? fk : 0), __int_as_float(w | (reported << 16)));
-                    if (miss && lane == f) {
+                    if (SHARD && miss && lane == f && !okR) {
+                        /* the gather word as four kinds of access see it */
+                        const unsigned a = xldw(rGW, 0);
+                        const unsigned b2 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rGW, 0, 0, 17);
+                        const unsigned c2 = __hip_atomic_load(Z.gatherWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const unsigned d2 = __hip_atomic_fetch_add(Z.gatherWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        X.privPose[(size_t)body * 2 + 1] = make_float4(__int_as_float((int)(a - X.base)), __int_as_float((int)(b2 - X.base)), __int_as_float((int)(c2 - X.base)), __int_as_float((int)(d2 - X.base) | ((int)(sR - X.base) << 16)));
+                    } else if (miss && lane == f) {
                         /* the stamp of the partner's last pose record as three kinds of load see it, and what the lane waits for */
                         const unsigned a = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rP, offP + 44, 0, 16);      /* sc1 (what the polls use) */
                         const unsigned b2 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rP, offP + 44, 0, 17);     /* sc0 sc1 */
