@@ -194,6 +194,7 @@ struct AvbdContext {
     std::vector<HostRowsDev> hHostRows; DevArr<HostRowsDev> dHostRows;
     AvbdHostForceFn hostFn = nullptr; void* hostUser = nullptr;
     bool shardMulti = false;       /* the plan of the current sharded step has several rounds */
+    bool shardGateKernel = false;  /* AVBD_SHARD_GATE=kernel: the exchange stream waits and publishes with small kernels instead of hipStreamWaitValue32 / WriteValue32 */
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
@@ -1040,6 +1041,32 @@ int step_end(AvbdContext* c, bool haveCounts)
 int rccl_allgather(AvbdContext* c); /* below, next to the communicator set-up */
 int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream);
 
+/* Exchange stream without hipStreamWaitValue32 / WriteValue32 (AVBD_SHARD_GATE=kernel): a one-wave kernel that waits until a
+ * rank's signal word says all its bodies are past iteration `it` (raised by the wave that completes the count, after the rows
+ * have reached memory) — or until the launch is being abandoned —, optionally copies that rank's rows (avbd_group_step), and a one-thread
+ * kernel that publishes "all-gather it has landed" to the word the waves poll. */
+__global__ void k_exchange_gate(const unsigned* signal, unsigned target, const int* errWord, float4* dst, const float4* src, int rows)
+{
+    if (threadIdx.x == 0) {
+        /* (the signal word is a stamp that only grows: base + iterations completed — nothing to reset between steps) */
+        while ((int)(__hip_atomic_load(signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0 &&
+               __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+    if (dst) {
+        const tile_v4u* s4 = reinterpret_cast<const tile_v4u*>(src);
+        tile_v4u* d4 = reinterpret_cast<tile_v4u*>(dst);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)s4, 0, rows * 16, 0x00020000), rd = __builtin_amdgcn_make_buffer_rsrc((void*)d4, 0, rows * 16, 0x00020000);
+        for (int i = threadIdx.x; i < rows; i += blockDim.x)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16), rd, i * 16, 0, 16);
+    }
+}
+__global__ void k_exchange_publish(unsigned* word, unsigned value)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* debug (AVBD_DEBUG_COPY_KERNEL): the device copy of avbd_group_step's exchange as a two-workgroup kernel of this library */
 __global__ void k_copy_rows(float4* dst, const float4* src, int n)
 {
@@ -1337,9 +1364,11 @@ int step_once(AvbdContext* c)
             if ((rc = shard_launch_persistent(c))) return rc;
             const unsigned base = c->xSerial * 64u;
             for (int it = 0; it < totalIt; ++it) {
-                HIPCHK(c, hipStreamWaitValue32(c->stream2, c->sigDone, base + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                if (c->shardGateKernel) hipLaunchKernelGGL(k_exchange_gate, dim3(1), dim3(64), 0, c->stream2, c->sigDone, base + (unsigned)it + 1u, c->dFlags.p + 2 * (size_t)c->bodyCap, (float4*)nullptr, (const float4*)nullptr, 0);
+                else HIPCHK(c, hipStreamWaitValue32(c->stream2, c->sigDone, base + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
                 if ((rc = rccl_allgather_inplace(c, c->dGather[it & 1].p, c->stream2))) return rc;
-                HIPCHK(c, hipStreamWriteValue32(c->stream2, c->sigGather, base + (unsigned)it + 1u, 0));
+                if (c->shardGateKernel) hipLaunchKernelGGL(k_exchange_publish, dim3(1), dim3(1), 0, c->stream2, c->sigGather, base + (unsigned)it + 1u);
+                else HIPCHK(c, hipStreamWriteValue32(c->stream2, c->sigGather, base + (unsigned)it + 1u, 0));
             }
             if ((rc = shard_finish_persistent(c, totalIt))) return rc;
             return step_end(c, needReadback);
@@ -1445,6 +1474,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RACE_CHECK")) c->raceCheck = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_SINGLE_KERNEL")) c->singleKernel = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_SHARD_GATE")) c->shardGateKernel = std::strcmp(e, "kernel") == 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_GROUPS_WAVES")) c->groupsWaves = std::max(0, std::atoi(e));
@@ -2593,13 +2623,19 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
                         for (int src = 0; src < n; ++src) {
                             if (src == dst) continue;
                             AvbdContext* q = ctxs[src];
+                            if (d->shardGateKernel) {
+                                hipLaunchKernelGGL(k_exchange_gate, dim3(1), dim3(256), 0, d->stream2, q->sigDone, q->xSerial * 64u + (unsigned)it + 1u, q->dFlags.p + 2 * (size_t)q->bodyCap,
+                                                   d->dGather[it & 1].p + rows * src, (const float4*)(q->dGather[it & 1].p + rows * src), (int)rows);
+                                continue;
+                            }
                             HIPCHK(d, hipStreamWaitValue32(d->stream2, q->sigDone, q->xSerial * 64u + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
                             if (std::getenv("AVBD_DEBUG_COPY_KERNEL"))
                                 hipLaunchKernelGGL(k_copy_rows, dim3(2), dim3(256), 0, d->stream2, d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, (int)rows);
                             else
                             HIPCHK(d, hipMemcpyAsync(d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream2));
                         }
-                        HIPCHK(d, hipStreamWriteValue32(d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u, 0));
+                        if (d->shardGateKernel) hipLaunchKernelGGL(k_exchange_publish, dim3(1), dim3(1), 0, d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u);
+                        else HIPCHK(d, hipStreamWriteValue32(d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u, 0));
                     }
                 }
                 for (int r = 0; r < n; ++r) {
