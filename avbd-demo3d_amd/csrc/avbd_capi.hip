@@ -2615,11 +2615,16 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
             for (int r = 0; r < n; ++r) ctxs[r]->shardRanPersistent = false;
             if (all) {
                 for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = shard_launch_persistent(ctxs[r]))) return rc; }
-                for (int dst = 0; dst < n; ++dst) {
-                    AvbdContext* d = ctxs[dst];
-                    (void)hipSetDevice(d->device);
-                    const size_t rows = (size_t)2 * std::max(1, d->maxCount);
-                    for (int it = 0; it < totalIt; ++it) {
+                /* Iteration-major: exchange streams of contexts on one device may be mapped to the SAME hardware queue, which runs its
+                 * packets in order.  Queued rank by rank, rank 1's deliveries of iteration 0 could sit behind rank 0's wait for
+                 * iteration 1 — which needs rank 1 past iteration 1, which needs that delivery.  In this order every wait is preceded,
+                 * in any in-order merge of the streams, by everything it depends on.  (It does not cure the stall of two launches
+                 * that fill the device) */
+                for (int it = 0; it < totalIt; ++it) {
+                    for (int dst = 0; dst < n; ++dst) {
+                        AvbdContext* d = ctxs[dst];
+                        (void)hipSetDevice(d->device);
+                        const size_t rows = (size_t)2 * std::max(1, d->maxCount);
                         for (int src = 0; src < n; ++src) {
                             if (src == dst) continue;
                             AvbdContext* q = ctxs[src];
