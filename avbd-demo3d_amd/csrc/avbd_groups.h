@@ -569,6 +569,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     };
     auto poll_records = [&]() __attribute__((always_inline)) { poll_issue(); poll_check(); };
     int reported = 0;                                                 /* SHARD, one body per sub-group: iterations this wave has counted in Z.done */
+    bool grpWaiting = true;                                           /* several bodies per sub-group: the sub-group still has a body with tasks left */
     auto back_off = [&]() __attribute__((always_inline)) -> bool {     /* false: the launch is being abandoned */
         if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
         else if (sleepSel == 2) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
@@ -578,7 +579,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         if (__any(chk)) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (chk && spins == 1024u) tIdle = now - 1024ull * 30ull;  /* first check since the last task: the wait began about here */
-            const bool waiting = MULTI || (valid && it < itStop);   /* (a sub-group that has finished its body's last task waits for nothing) */
+            const bool waiting = MULTI ? grpWaiting : (valid && it < itStop);   /* (a sub-group that has finished its last task waits for nothing) */
             const bool dead = (chk && waiting && now - tIdle > kSpinTimeoutTicks) ||
                               __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (__any(dead)) {
@@ -726,6 +727,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         for (;;) {
             const bool activeK = itK < itStop;
             if (__ballot(activeK) == 0) break;
+            grpWaiting = (__ballot(activeK) & gMask) != 0;
             bool candK = activeK;
             if (activeK && blkOff >= 0) { const unsigned st = xldw(rP, blkOff); candK = stamp_reached(st, blkStamp); }
             if (SHARD && activeK && blkOff == -2) candK = stamp_reached(xldw(rGW, 0), blkStamp);   /* waiting for an all-gather */
