@@ -15,6 +15,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libavbd_hip.so")
+if os.environ.get("AVBD_LIB"):                       # measurement builds (tools/): libavbd_hip_stats.so, an older build for A/B runs
+    LIB_PATH = os.path.join(_HERE, os.environ["AVBD_LIB"]) if not os.path.isabs(os.environ["AVBD_LIB"]) else os.environ["AVBD_LIB"]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "avbd_hip.h")
 
 FLT_MAX = float(np.finfo(np.float32).max)

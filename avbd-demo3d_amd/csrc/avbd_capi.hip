@@ -198,6 +198,10 @@ struct AvbdContext {
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
+    /* chains of hand-offs share a workgroup (avbd_place.h): report of the last iteration launch, tails, this step's table */
+    DevArr<int2> dCrit; DevArr<int> dTail, dPlaceSlot, dPlace; DevArr<PlaceInfo> dPlaceInfo;
+    bool placeChains = true;       /* AVBD_PLACE=0: waves take the slots of the sweep order */
+    bool placeQueued = false;      /* this step: k_place_chains has been queued on the current topology */
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
     bool rowsStale = true;         /* ownership changed: the gather rows of the bodies must be uploaded again */
     bool groupsLaunched = false;   /* the last iteration loop was offered to k_iterate_groups (the device may still decline: GroupPlan.bad) */
@@ -337,6 +341,11 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, hipMemsetAsync(c->incStart.p, 0, (newCap + 1) * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(c->degForce.p, 0, newCap * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(c->degInc.p, 0, newCap * sizeof(int), c->stream));
+    HIPCHK(c, c->dCrit.alloc(newCap)); HIPCHK(c, c->dTail.alloc(newCap)); HIPCHK(c, c->dPlaceSlot.alloc(newCap));
+    HIPCHK(c, hipMemsetAsync(c->dCrit.p, 0xff, (size_t)newCap * sizeof(int2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dTail.p, 0, (size_t)newCap * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dPlaceSlot.p, 0xff, (size_t)newCap * sizeof(int), c->stream));
+    if (!c->dPlace.p) { HIPCHK(c, c->dPlace.alloc(1024)); HIPCHK(c, c->dPlaceInfo.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dPlaceInfo.p, 0, sizeof(PlaceInfo), c->stream)); }
     HIPCHK(c, c->dFlags.alloc((size_t)2 * newCap + 32 + 8192 * 32));
     HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, ((size_t)2 * newCap + 32 + 8192 * 32) * sizeof(int), c->stream));
     c->adjDirty = true;
@@ -903,7 +912,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         hipExtLaunchKernelGGL((k_iterate_groups<false, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
                               X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
         if (c->groupsMaxRounds > 1)
-            hipLaunchKernelGGL((k_iterate_groups<true, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
+            hipLaunchKernelGGL((k_iterate_groups<true, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytesMulti, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
                                X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
         runIf = &c->dPlan.p->bad;
         c->groupsLaunched = true;
@@ -921,6 +930,13 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
             /* every swept body has a resident wave: the kernel that holds nothing but that schedule; the launch below runs if the
              * device vetoed it */
             auto single = X.joints ? k_iterate_single<true> : k_iterate_single<false>;
+            X.crit = c->dCrit.p;
+            if (c->placeChains && blocks * kIterWaves <= 1024) {
+                /* this step's table from the last launch's report, on this step's sweep order */
+                hipLaunchKernelGGL(k_place_chains, dim3(1), dim3(1024), 0, c->stream, c->order.p, c->lvlStart.p, c->dCnt.p, c->dCrit.p, c->dTail.p, c->dPlaceSlot.p,
+                                   c->bodyCap, blocks * kIterWaves, c->dPlace.p, c->dPlaceInfo.p);
+                X.place = c->dPlace.p;
+            }
             hipExtLaunchKernelGGL(single, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, nullptr, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
                                   c->incStart.p, c->inc.p, P, S.error, c->dCnt.p, c->iterSleep, itEnd, X);
             runIf = &c->dCnt.p->residentBad;
@@ -1153,7 +1169,7 @@ int shard_launch_persistent(AvbdContext* c)
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
     X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
     auto kern = c->shardMulti ? k_iterate_groups<true, true> : k_iterate_groups<false, true>;
-    hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
+    hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
                           S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
     ++c->prof.launches_primal; ++c->prof.launches_total;
     HIPCHK(c, hipGetLastError());
@@ -1474,6 +1490,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT")) c->residentAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RACE_CHECK")) c->raceCheck = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_SINGLE_KERNEL")) c->singleKernel = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_PLACE")) c->placeChains = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_SHARD_GATE")) c->shardGateKernel = std::strcmp(e, "kernel") == 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
@@ -1497,9 +1514,9 @@ int avbd_create(int device, AvbdContext** out)
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate<2>, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         {   /* Every persistent launch spins on records that other workgroups of the same launch produce: ALL its workgroups must be
              * resident at once.  Ask the runtime how many workgroups of each kernel fit a CU with the exact dynamic LDS it is
@@ -1514,8 +1531,8 @@ int avbd_create(int device, AvbdContext** out)
             const int occ1 = std::min(std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad)),
                                       std::min(fits((const void*)k_iterate_single<false>, c->iterLdsPad), fits((const void*)k_iterate_single<true>, c->iterLdsPad)));
             const int occ2 = std::min(fits((const void*)k_iterate<2, false>, kIterWaves * kResProductBytesPerWaveLite), fits((const void*)k_iterate<2, true>, kIterWaves * kResProductBytesPerWaveLite));
-            const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, false>, kGrpLdsBytes)),
-                                      std::min(fits((const void*)k_iterate_groups<false, true>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, true>, kGrpLdsBytes)));
+            const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, false>, kGrpLdsBytesMulti)),
+                                      std::min(fits((const void*)k_iterate_groups<false, true>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, true>, kGrpLdsBytesMulti)));
             if (occ1 < 1) { c->mode = 0; c->residentAllowed = false; }      /* not even one workgroup per CU: one launch per level, nothing spins */
             c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
             if (occ2 * cus < 2 * c->iterBlocks) { c->residentLiteFrom = 0; c->residentForceLite = false; c->iterForceMode = c->iterForceMode == 2 ? 0 : c->iterForceMode; c->liteResident = false; }
@@ -2786,6 +2803,17 @@ extern "C" int avbd_debug_release_exchange(AvbdContext* c)
     (void)hipSetDevice(c->device);
     const unsigned big = c->xSerial * 64u + 63u;
     return hipMemcpy(c->sigDone, &big, 4, hipMemcpyHostToDevice) == hipSuccess ? AVBD_OK : AVBD_E_HIP;
+}
+
+/* debug: what k_place_chains decided for the last step {nd, groups, grouped bodies, valid} and, optionally, the table (1024 ints) */
+extern "C" int avbd_debug_place_info(AvbdContext* c, int* info4, int* place1024)
+{
+    if (!c || !info4) return AVBD_E_INVALID;
+    if (!c->dPlaceInfo.p) { info4[0] = info4[1] = info4[2] = info4[3] = 0; return AVBD_OK; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(info4, c->dPlaceInfo.p, sizeof(PlaceInfo), hipMemcpyDeviceToHost));
+    if (place1024) HIPCHK(c, hipMemcpy(place1024, c->dPlace.p, 1024 * sizeof(int), hipMemcpyDeviceToHost));
+    return AVBD_OK;
 }
 
 int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)

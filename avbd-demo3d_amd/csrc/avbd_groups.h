@@ -63,8 +63,13 @@ constexpr int kGrpSSlots = 6;             /* f | penalty | gyro.x | gyro.y | gyr
 constexpr int kGrpAccFloats = 64;         /* per 16 lanes: 27 accumulator entries, 21 floats of solve / inertia exchange */
 constexpr int kGrpConstFloats = 32;       /* per 16 lanes: inertial pose, mass, body-frame inertia and inverse inertia */
 constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAccFloats + kGrpConstFloats);
-constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 77 568 B: two workgroups per CU */
-static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytes <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
+constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 43 008 B: two workgroups per CU */
+/* several bodies per sub-group: who the entries of a sub-group's bodies are (incidence word, partner | moving << 24 | owned << 25) stays in LDS
+ * for the whole launch, hdr[round][lane]: examining a body costs no memory round trip for its header */
+constexpr int kGrpMaxRounds = 16;
+constexpr int kGrpHdrBytesPerWave = kGrpMaxRounds * 64 * 8;
+constexpr int kGrpLdsBytesMulti = kGrpLdsBytes + kGrpWavesPerBlock * kGrpHdrBytesPerWave;   /* 75 776 B */
+static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
 
 /* ---- plan: classes, waves per class, the bodies of each class in sweep order -----------------------------------------------
  * byClass[c * cap + r] = r-th body of class c in sweep order.  Sub-group j of wave w (the wl-th wave of its class, which has Wc
@@ -298,30 +303,29 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
 
     /* who the entries of a body are and whom they wait for: enough to tell whether a task can start.  `seen`: the body has been
      * examined before in this launch, its partners are in X.probe (partner | moving << 24 | owned << 25). */
-    auto load_header = [&](int b, int e0, int ne, bool seen) __attribute__((always_inline)) {
+    int2* const hdr = reinterpret_cast<int2*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes + wv * kGrpHdrBytesPerWave);   /* MULTI: [round][lane] */
+    auto load_header = [&](int b, int e0, int ne, int round) __attribute__((always_inline)) {
         body = b; valid = b >= 0; eBeg = e0;
         has = valid && gl < ne;
         nRows = ne * 3;
         idx = 0; other = 0; isA = false; owned = false; moving = false;
-        if (has) {
+        if (MULTI) {
+            const int2 h = hdr[round * 64 + lane];                     /* filled once, before the loop */
+            if (has) { idx = inc_index(h.x); isA = inc_isA(h.x) != 0; other = h.y & 0xffffff; moving = (h.y >> 24) & 1; owned = (h.y >> 25) & 1; }
+        } else if (has) {
             const int ent = inc[e0 + gl];
             idx = inc_index(ent); isA = inc_isA(ent) != 0;
-            if (seen) {
-                const int pw = X.probe[e0 + gl];
-                other = pw & 0xffffff; moving = (pw >> 24) & 1; owned = (pw >> 25) & 1;
-            } else {
-                const int2 pr = M.pair[idx >> 2];
-                other = isA ? pr.y : pr.x;
-                moving = B.solved[other] != 0;
-                owned = !moving || other > b;
-                if (multi) X.probe[e0 + gl] = other | ((moving ? 1 : 0) << 24) | ((owned ? 1 : 0) << 25);
-            }
+            const int2 pr = M.pair[idx >> 2];
+            other = isA ? pr.y : pr.x;
+            moving = B.solved[other] != 0;
+            owned = !moving || other > b;
         }
         offP = other * 48; offV = idx * 16; offD = idx * 32;
     };
     /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
      * wrote (first iteration), or what this sub-group parked after the body's previous task (several rounds, later iterations) */
     auto load_rest = [&]() __attribute__((always_inline)) {
+        AVBD_MARK(g_load_rest);
         fixedN = false;
         if (has) {
             oinv = massPlane[other].y;
@@ -358,6 +362,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     };
     /* several rounds: park the body's state until its next task (its last task has written the step's final state already) */
     auto park_body = [&]() __attribute__((always_inline)) {
+        AVBD_MARK(g_park);
         if (has) {
             int idxF = idx, slotF = eBeg + gl;
             asm volatile("" : "+v"(idxF), "+v"(slotF));
@@ -389,8 +394,10 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
 #define GS_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)
+#define GS_STAMP_ND(i) do { unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)   /* without draining memory operations */
 #else
 #define GS_STAMP(i) do { } while (0)
+#define GS_STAMP_ND(i) do { } while (0)
 #endif
 
     /* which records of other tasks this task reads, and the stamps they must carry (from the header and `it` alone) */
@@ -404,6 +411,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         okP = !needP; okV = !needV; okD = !needD;
     };
     auto prepare_task = [&]() __attribute__((always_inline)) {
+        AVBD_MARK(g_prepare);
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         BodyLocal L;
         L.pos = pos; L.rot = rot; L.invMass = invMass; L.invDt2 = invDt2;
@@ -445,6 +453,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
 
     bool allOnG = true;                                              /* what finish_visit leaves for the accumulation */
     auto finish_visit = [&]() __attribute__((always_inline)) {
+        AVBD_MARK(g_visit);
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;
@@ -492,6 +501,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     };
     /* the ordered sums by the lanes of the sub-group itself: two entries per lane in a 16-lane sub-group */
     auto finish_accumulate = [&]() __attribute__((always_inline)) {
+        AVBD_MARK(g_accumulate);
         if (cls == 0) { if (allOnG) grp_accumulate<true, true>(a0, a1, J, S, rowBase, nRows); else grp_accumulate<false, true>(a0, a1, J, S, rowBase, nRows); }
         else          { if (allOnG) grp_accumulate<true, false>(a0, a1, J, S, rowBase, nRows); else grp_accumulate<false, false>(a0, a1, J, S, rowBase, nRows); }
         if (gl < 27) accs[gl] = a0.acc;
@@ -502,6 +512,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;
+        AVBD_MARK(g_solve);
         GS_STAMP(8);
         BodyLocal L; L.pos = pos; L.rot = rot;
         f3 p; q4 q;
@@ -525,6 +536,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
 #ifdef AVBD_DF_STATS
         if (!MULTI && gl == 0 && X.privN) (reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)body) * 4)[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
+        AVBD_MARK(g_dual);
         GS_STAMP(9);
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
         if (doDual && has && owned) {
@@ -539,6 +551,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             }
         }
         /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
+        AVBD_MARK(g_final_store);
         if (it == itStop - 1) {
             /* (opaque copies of the indices: the nine table addresses of a contact are formed here, once, instead of living in
              * registers through the whole loop) */
@@ -633,7 +646,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             const int b = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), 0);
             int e0 = 0, ne = 0;
             if (b >= 0) { e0 = incStart[b]; ne = incStart[b + 1] - e0; }
-            load_header(b, e0, ne, false);
+            load_header(b, e0, ne, 0);
             load_rest();
         }
         if (valid) prepare_task();
@@ -716,21 +729,52 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
          * next iteration and ONE record to watch (the input that was missing when the body was last examined); a body is
          * examined in full only when that record has arrived.  Every pass of the wave runs the picks of all its sub-groups
          * together. ---- */
-        int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1, seenK = 0;
+        int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
             bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl);
             if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
         }
+        /* the header table: three dependent loads per entry (incidence word -> pair -> is the partner swept?), four rounds in flight */
+        for (int k0 = 0; k0 < rounds; k0 += 4) {
+            int ent[4], oth[4], bk[4]; bool hk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + q < rounds ? k0 + q : rounds - 1;
+                bk[q] = __shfl(bodyK, gBase + k, 64);
+                const int e0 = __shfl(eBegK, gBase + k, 64), ne = __shfl(nEntK, gBase + k, 64);
+                hk[q] = bk[q] >= 0 && gl < ne;
+                ent[q] = hk[q] ? inc[e0 + gl] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                oth[q] = 0;
+                if (hk[q]) { const int2 pr = M.pair[inc_index(ent[q]) >> 2]; oth[q] = inc_isA(ent[q]) ? pr.y : pr.x; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int w1 = 0;
+                if (hk[q]) { const bool mv = B.solved[oth[q]] != 0; w1 = oth[q] | ((mv ? 1 : 0) << 24) | (((!mv || oth[q] > bk[q]) ? 1 : 0) << 25); }
+                if (k0 + q < rounds) hdr[(k0 + q) * 64 + lane] = make_int2(ent[q], w1);
+            }
+        }
+        wave_sync();
         GS_STAMP(3);
+        /* (polling the watched words one pass ahead — issued before the pass's task, looked at when the next pass starts — was
+         * measured and not kept: 64 000 cubes 6.9 -> 7.6 ms per step; a body that has just become ready then waits a whole pass
+         * more, and the step is a chain of 372 such hops) */
+        unsigned watchVal = 0;
         for (;;) {
+            AVBD_MARK(g_examine);
             const bool activeK = itK < itStop;
             if (__ballot(activeK) == 0) break;
             grpWaiting = (__ballot(activeK) & gMask) != 0;
             bool candK = activeK;
-            if (activeK && blkOff >= 0) { const unsigned st = xldw(rP, blkOff); candK = stamp_reached(st, blkStamp); }
-            if (SHARD && activeK && blkOff == -2) candK = stamp_reached(xldw(rGW, 0), blkStamp);   /* waiting for an all-gather */
+            if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
+            if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
+            if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
+            GS_STAMP(12);                                              /* the look at the watched words (and whatever was still in flight) */
             bool sel = false, triedK = false;
             for (;;) {
                 int key = (candK && !triedK) ? ((itK << 6) | gl) : 0x7fffffff;
@@ -738,9 +782,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 const bool examine = !sel && key != 0x7fffffff;        /* uniform over the sub-group */
                 if (__ballot(examine) == 0) break;
                 if (examine) {
-                    const int k = gBase + (key & 63), t = key >> 6;
-                    load_header(__shfl(bodyK, k, 64), __shfl(eBegK, k, 64), __shfl(nEntK, k, 64), __shfl(seenK, k, 64) != 0);
-                    if (lane == k) seenK = 1;
+                    const int kk = key & 63, k = gBase + kk, t = key >> 6;
+                    load_header(__shfl(bodyK, k, 64), __shfl(eBegK, k, 64), __shfl(nEntK, k, 64), kk);
                     /* the records this task reads and the state the body parked after its last task travel together: one memory
                      * round trip tells whether the task can run and, if it can, has brought what it needs */
                     it = t;
@@ -749,6 +792,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                     load_rest();
                     if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }   /* the all-gather behind the previous iteration */
                     poll_check();
+                    AVBD_MARK(g_examine2);
                     const unsigned long long noPose = __ballot(!okP) & gMask, noRest = __ballot(!(okV & okD)) & gMask;
                     const unsigned long long noGather = SHARD ? (__ballot(!okR) & gMask) : 0ull;
                     if ((noPose | noRest | noGather) == 0) {
@@ -776,9 +820,13 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 finish_visit();
                 finish_accumulate();
                 finish_solve();
+                GS_STAMP_ND(13);                                       /* dual: arithmetic and issue of its stores */
+                GS_STAMP(3);                                           /* ... until they are acknowledged */
                 if (it < itStop - 1) park_body();
+                GS_STAMP_ND(15);                                       /* park: issue */
                 spins = 0;
             }
+            AVBD_MARK(g_pass_end);
             if (SHARD && __ballot(sel)) {
                 /* iteration k of this wave is complete when every body it serves is past it (see the one-body form above) */
                 int low = bodyK >= 0 ? itK : itStop;

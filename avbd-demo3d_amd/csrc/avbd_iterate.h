@@ -118,6 +118,9 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     if (cnt->residentBad != 0) return;
     __shared__ float sRows[kIterWaves][66 * kEntryRec];
     __shared__ float sAcc[kIterWaves][64];
+    __shared__ int sBodyOf[kIterWaves];
+    __shared__ v4u sPoseRec[kIterWaves][3];
+    __shared__ unsigned sPoseFlag[kIterWaves];
     extern __shared__ float4 sDynamic[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = gridDim.x * kIterWaves;
@@ -125,7 +128,14 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     const int nd = lvlStart[cnt->numLevels];
     float* products = reinterpret_cast<float*>(sDynamic) + wv * 27 * X.prStride;
     const int slot = X.spread ? wv * (int)gridDim.x + (int)blockIdx.x : w;
-    if (slot < nd) iterate_resident<false, JOINTS>(B, M, gf, order, nd, slot, W, incStart, inc, P, errWord, cntW, X, sleepSel, lane, sRows[wv], sAcc[wv], products, 0, itEnd);
+    /* the body of this wave: k_place_chains' table (chains of hand-offs share a workgroup) or the slot of the sweep order */
+    int mine = -1;
+    if (X.place) mine = __builtin_amdgcn_readfirstlane(X.place[w]);
+    else if (slot < nd) mine = __builtin_amdgcn_readfirstlane(order[slot]);
+    if (lane == 0) { sBodyOf[wv] = mine; sPoseFlag[wv] = X.base; }
+    __syncthreads();
+    CoLocal CL{(const volatile int AVBD_LDS*)sBodyOf, (volatile v4u AVBD_LDS*)&sPoseRec[0][0], (volatile unsigned AVBD_LDS*)sPoseFlag, wv};
+    if (mine >= 0) iterate_resident<false, JOINTS, true>(B, M, gf, order, nd, slot, W, incStart, inc, P, errWord, cntW, X, sleepSel, lane, sRows[wv], sAcc[wv], products, 0, itEnd, CL, mine);
 }
 
 /* WPE = wavefronts per SIMD the launch is sized for: 1 (latency mode, one workgroup per CU: the critical wave never shares

@@ -1,0 +1,103 @@
+/*
+ * avbd_place.h — which workgroup a body's wavefront sits in (one body per wave, k_iterate_single).
+ *
+ * Placement never changes a result: every wave runs the same arithmetic on the same records whatever CU it is on.  It changes
+ * the latency of the hand-offs: a pose that travels through LDS reaches its consumer in ~0.1 us, through memory in ~0.8 us,
+ * and Stress1000's step is a chain of ~200 such hand-offs.  So the bodies that wait for each other are put into
+ * the same workgroup, four at a time:
+ *
+ *   - every wave reports the later-created partner whose pose its last waiting task received LAST (ResidentExchange.crit):
+ *     an edge "pred -> body" of the graph of critical hand-offs (acyclic: pred is created later, i.e. swept earlier);
+ *   - tail[b] = length of the longest chain of such edges that starts at b, relaxed by one round per step (the graph changes
+ *     slowly; the value persists in memory between steps);
+ *   - a body that several others wait for keeps the successor with the longest tail (ties: the one that finished last): the
+ *     edges that are left form disjoint paths, which are cut into groups of kIterWaves from their heads;
+ *   - groups take whole workgroups; bodies without a group fill the slots that are left, spread over the workgroups in sweep
+ *     order like the unplaced launch does.
+ *
+ * One workgroup of 1024 threads, thread t = slot t of the sweep order.  Runs between the topology kernel and the iteration
+ * launch of a step, on the report of the previous step.
+ */
+#pragma once
+
+namespace avbd {
+
+struct PlaceInfo { int nd, groups, grouped, valid; };
+
+__global__ __launch_bounds__(1024) void k_place_chains(const int* __restrict__ order, const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
+                                                       const int2* __restrict__ crit, int* __restrict__ tail, int* __restrict__ slotOf, int bodyCap,
+                                                       int W, int* __restrict__ place, PlaceInfo* info)
+{
+    __shared__ unsigned long long sWaveTotals[16];
+    __shared__ unsigned long long sBest[1024];
+    __shared__ int sTail[1024], sNext[1024], sLead[1024], sFree[1024];
+    __shared__ unsigned char sAccepted[1024], sRank[1024], sSize[1024];
+    const int t = threadIdx.x;
+    const int nd = lvlStart[cnt->numLevels];
+    const int WG = W / kIterWaves;
+    if (nd <= 0 || nd > W || W > 1024 || cnt->residentBad != 0) {      /* nothing to place (the launch that would use the table declines too) */
+        for (int s = t; s < W; s += 1024) place[s] = -1;
+        if (t == 0) { info->nd = nd; info->groups = 0; info->grouped = 0; info->valid = 0; }
+        return;
+    }
+    const int body = t < nd ? order[t] : -1;
+    if (body >= 0) slotOf[body] = t;
+    sBest[t] = 0ull; sTail[t] = 1; sAccepted[t] = 0; sLead[t] = t; sRank[t] = 0; sSize[t] = 1;
+    for (int s = t; s < W; s += 1024) place[s] = -1;
+    __syncthreads();
+
+    /* the reported edge, if it still exists: the partner is swept this step and was created later */
+    int ps = -1; unsigned fin = 0;
+    if (body >= 0) {
+        const int2 c = crit[body];
+        fin = (unsigned)c.y;
+        if (c.x > body && c.x < bodyCap) { const int s = slotOf[c.x]; if (s >= 0 && s < nd && order[s] == c.x) ps = s; }
+    }
+    /* one round of tail[b] = 1 + max over the bodies that wait for b */
+    const int myTail = body >= 0 ? max(1, min(tail[body], 62)) : 1;
+    if (ps >= 0) atomicMax(&sTail[ps], myTail + 1);
+    __syncthreads();
+    if (body >= 0) tail[body] = sTail[t];
+    /* a body keeps the successor with the longest tail */
+    if (ps >= 0) atomicMax(&sBest[ps], ((unsigned long long)sTail[t] << 44) | ((unsigned long long)min(fin, 0xffffffu) << 12) | (unsigned long long)t);
+    __syncthreads();
+    const int nxt = sBest[t] ? (int)(sBest[t] & 0xfffull) : -1;
+    sNext[t] = nxt;
+    if (nxt >= 0) sAccepted[nxt] = 1;
+    __syncthreads();
+    /* heads walk their path and cut it into groups */
+    if (body >= 0 && nxt >= 0 && !sAccepted[t]) {
+        int leader = t, n = 0;
+        for (int k = t; k >= 0; k = sNext[k]) {
+            if (n == kIterWaves) { leader = k; n = 0; }
+            sLead[k] = leader; sRank[k] = (unsigned char)n; sSize[leader] = (unsigned char)(n + 1);
+            ++n;
+        }
+    }
+    __syncthreads();
+    /* groups of two and more take whole workgroups, in sweep order of their leaders (at most one group per workgroup) */
+    __shared__ int sGroupWg[1024];
+    __shared__ unsigned char sWgSize[256];
+    const bool leads = body >= 0 && sLead[t] == t && sSize[t] >= 2;
+    const int gidx = (int)block_scan_inclusive_u64(leads ? 1ull : 0ull, sWaveTotals) - (leads ? 1 : 0);
+    sGroupWg[t] = (leads && gidx < WG && gidx < 256) ? gidx : -1;
+    if (t < 256) sWgSize[t] = 0;
+    __syncthreads();
+    if (sGroupWg[t] >= 0) sWgSize[sGroupWg[t]] = sSize[t];
+    const int myWg = body >= 0 ? sGroupWg[sLead[t]] : -1;
+    const bool single = body >= 0 && myWg < 0;
+    __syncthreads();
+    if (myWg >= 0) place[myWg * kIterWaves + sRank[t]] = body;
+    /* the slots that are left, wave-major (the waves of a workgroup take bodies a quarter of the sweep apart) */
+    int slot = -1; bool isFree = false;
+    if (t < W) { const int wv = t / WG, wg = t % WG; slot = wg * kIterWaves + wv; isFree = wg >= 256 || wv >= (int)sWgSize[wg]; }
+    const unsigned long long mine = (isFree ? 1ull : 0ull) | (single ? (1ull << 32) : 0ull);
+    const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
+    const int freeRank = (int)(unsigned)(incl - mine), singleRank = (int)((incl - mine) >> 32);
+    if (isFree) sFree[freeRank] = slot;
+    __syncthreads();
+    if (single) place[sFree[singleRank]] = body;
+    if (t == 1023) { info->nd = nd; info->groups = min(gidx + (leads ? 1 : 0), min(WG, 256)); info->grouped = nd - (int)(incl >> 32); info->valid = 1; }
+}
+
+} // namespace avbd

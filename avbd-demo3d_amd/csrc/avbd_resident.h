@@ -42,6 +42,13 @@ namespace avbd {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+/* -DAVBD_ASM_MARKS: comments in the generated assembly that tools/kernel_resources.py splits the instruction mix at */
+#ifdef AVBD_ASM_MARKS
+#define AVBD_MARK(name) asm volatile("; AVBD_MARK " #name ::: "memory")
+#else
+#define AVBD_MARK(name) do { } while (0)
+#endif
+
 struct ResidentExchange {
     float4* pose;    /* [3 * bodyCap] */
     float4* visit;   /* [4 * manifoldCap] */
@@ -65,6 +72,22 @@ struct ResidentExchange {
     int outOfOrder;    /* MULTI: a wave runs whichever of its bodies has its inputs ready (oldest iteration first) instead of sweeping them in order */
     int patience;      /* out of order, nothing ready: ticks (10 ns) a wave waits on its oldest task, prepared, before it looks at its other bodies again (0: never blocks) */
     int* probe;        /* [incidence capacity] out of order: who an entry waits for (partner | moving << 24 | owned << 25 | hasA << 26), kept from a body's first examination */
+    const int* place;  /* one body per wave: body of wave w (-1: none) instead of the sweep order's slot — chains of bodies that hand their pose to each
+                        * other share a workgroup and pass it through LDS (k_place_chains); nullptr: slots of the sweep order */
+    int2* crit;        /* [bodyCap] one body per wave, out: {later-created partner whose pose arrived last in the final iterations or -1, ticks (10 ns)
+                        * from the launch's start to the body's last publish}: what k_place_chains builds next step's chains from */
+};
+
+/* Co-located hand-off (one body per wave): the four waves of a workgroup publish their pose in LDS as well; a lane whose partner's
+ * wave sits in the same workgroup polls a flag word there instead of the record in memory (50 ns instead of 0.8 us).
+ * Protocol: the producer writes the three records, waits for the LDS writes to complete (s_waitcnt lgkmcnt(0)) and then writes
+ * the flag; the LDS executes a CU's instructions in order, so a consumer that has seen the flag reads the records behind it. */
+#define AVBD_LDS __attribute__((address_space(3)))   /* explicit LDS pointers: a volatile access through a generic pointer becomes a flat, system-scope one */
+struct CoLocal {
+    const volatile int AVBD_LDS* bodyOf;    /* [kIterWaves] body of each wave of this workgroup, -1: none */
+    volatile v4u AVBD_LDS* rec;             /* [kIterWaves][3] pose records, as in memory */
+    volatile unsigned AVBD_LDS* flag;       /* [kIterWaves] stamp of the records' last complete publish */
+    int self;                               /* this wave */
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
@@ -247,12 +270,13 @@ __device__ __forceinline__ void store_joint_half(GForce& f, int part, const Cont
  * owner writes; the first visitor's copy of normal + tangent memo and the pose in arrays private to the wave).  Tasks are
  * taken in the order t = it * slots + slot, a linear extension of the dependency order, so the smallest unfinished task is
  * always at the head of a resident wave's list.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
-template <bool MULTI, bool JOINTS>
+template <bool MULTI, bool JOINTS, bool COLO = false>
 __device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, GForce* gf, const int* __restrict__ order, int nd, int w, int W,
                                                  const int* __restrict__ incStart, const int* __restrict__ inc, const SolverParams& P, int* errWord,
                                                  Counters* cntW, const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products,
-                                                 int itBegin, int itEnd)
+                                                 int itBegin, int itEnd, CoLocal CL = CoLocal{nullptr, nullptr, nullptr, 0}, int placedBody = -1)
 {
+    static_assert(!COLO || !MULTI, "the co-located hand-off is for one body per wave");
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     const float4* massPlane = B.plane(BP_MASS);
@@ -262,6 +286,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     bool has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
     bool isJoint = false, hasA = true;                               /* a lane holds one Manifold contact or one half (3 rows) of a Joint */
+    int co = -1;                                                     /* COLO: wave of this workgroup that holds the partner, -1: none */
     q4 jq0 = identq(); f3 jStiff = zero3(), jMotor = zero3(); int jPart = 0;
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
@@ -307,6 +332,11 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         }
         if (MULTI && !parked && X.outOfOrder && has) X.probe[eBeg + lane] = other | ((moving ? 1 : 0) << 24) | ((owned ? 1 : 0) << 25) | ((hasA ? 1 : 0) << 26);
         offP = other * 48; offV = idx * 16; offD = ((JOINTS && isJoint) ? X.jointRecBase + idx : idx) * 32;
+        if (COLO) {
+            co = -1;
+            if (has && moving)
+                for (int k = 0; k < kIterWaves; ++k) if (CL.bodyOf[k] == other) co = k;
+        }
     };
     /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this
      * step wrote (first iteration), or what this same wave parked after the body's previous task (MULTI, later iterations) */
@@ -355,7 +385,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         Jb = mkm(mk3(j0.x, j0.y, j0.z), mk3(j1.x, j1.y, j1.z), mk3(j2.x, j2.y, j2.z));
     };
     auto load_task = [&](int slot, int it) {
-        const int b = __builtin_amdgcn_readfirstlane(order[slot]);    /* wave-uniform: scalar loads and scalar branches below */
+        const int b = __builtin_amdgcn_readfirstlane((COLO && placedBody >= 0) ? placedBody : order[slot]);    /* wave-uniform: scalar loads and scalar branches below */
         const int e0 = __builtin_amdgcn_readfirstlane(incStart[b]);
         load_header(b, e0, __builtin_amdgcn_readfirstlane(incStart[b + 1]) - e0, false);
         load_rest(it);
@@ -382,6 +412,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     for (int r = lane; r < kResRows; r += 64) rows[kResJFloats + 6 * kResRows + r] = 0.0f;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned prevWait = 0;                                           /* ticks (10 ns) this wave waited in the previous iteration */
+    int critOther = -1;                                              /* COLO: the later-created partner whose pose arrived last in the most recent task that waited for one */
 #ifdef AVBD_DF_STATS
     unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = t0;
@@ -425,6 +456,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         unsigned* trec = RS_TREC(it);
         if (lane == 0) { trec[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[5] = (unsigned)body; }
 #endif
+        AVBD_MARK(prepare);
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const unsigned stampNow = X.base + (unsigned)it + 1u;        /* what this task publishes */
 
@@ -488,6 +520,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         const unsigned stampNow = X.base + (unsigned)it + 1u;
 
         /* ---- the wait IS the load: poll the records until every stamp is current ---- */
+        AVBD_MARK(wait);
         {
             /* A wave that waited w last iteration will wait about w again (the dependency pattern repeats every sweep): it
              * stays off the memory system for the first part of that time.  Polls of idle waves were measured to lengthen
@@ -497,9 +530,11 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 const unsigned quiet = (prevWait * (unsigned)X.quietPermille) / 1000u;
                 while ((unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0) < quiet) __builtin_amdgcn_s_sleep(8);
             }
-            bool okP = !needP, okV = !needV, okD = !needD;
+            const bool viaLds = COLO && needP && co >= 0;             /* the partner's wave shares this workgroup: its pose comes through LDS (second loop below) */
+            bool okP = !needP || viaLds, okV = !needV, okD = !needD;
             v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vv = p0, d0 = p0, d1 = p0;
             unsigned spins = 0;
+            unsigned long long lastMissing = 0;                       /* lanes that still missed a same-iteration pose in the round before the last */
             while (true) {
                 const bool lp = !okP, lv = !okV, ld = !okD;
                 if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
@@ -510,6 +545,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if (lv) okV = stamp_reached(vv.w, sV);
                 if (ld) okD = stamp_reached(d0.w, sD) & stamp_reached(d1.w >> 1, sD);
                 if (__all(okP & okV & okD)) break;
+                if (COLO) lastMissing = __ballot(!okP && owned);
 #ifdef AVBD_DF_STATS
                 stat[14] += 1;
 #endif
@@ -528,6 +564,28 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     return 2;
                 }
             }
+            if (COLO && __any(viaLds)) {
+                /* the poses that come through LDS: a short loop on the flag words alone (nothing is in flight any more, a round is
+                 * one LDS access), normally entered long before the flag rises — the placement puts the hand-off a task waits for
+                 * LAST into its own workgroup */
+                bool okL = !viaLds;
+                unsigned spinsL = 0;
+                while (true) {
+                    unsigned lf = 0;
+                    if (!okL) lf = CL.flag[co];
+                    asm volatile("" ::: "memory");
+                    if (!okL) okL = stamp_reached(lf, sP);
+                    if (__all(okL)) break;
+                    lastMissing = __ballot(!okL);
+                    if ((++spinsL & 8191u) == 0) {
+                        bool dead = (__builtin_amdgcn_s_memrealtime() - tWait0 > kSpinTimeoutTicks) ||
+                                    __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+                    }
+                }
+                spins += spinsL;
+            }
+            AVBD_MARK(post_visit);
             RS_STAMP(0);
 #ifdef AVBD_DF_STATS
             if (lane == 0) { trec[2] = (unsigned)tprev; trec[6] = spins; }
@@ -542,6 +600,15 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #ifdef AVBD_DF_STATS
             if (lane == 0) race_note_consumed(errWord - 2 * B.cap, body, it);
 #endif
+            if (COLO) {
+                asm volatile("" ::: "memory");
+                if (viaLds) {                                         /* behind the flag: the records it covers */
+                    const volatile v4u AVBD_LDS* r = CL.rec + co * 3;
+                    p0 = r[0]; p1 = r[1]; p2 = r[2];
+                }
+                /* whose pose did this task wait for last?  (a later-created partner: the hand-off a shared workgroup would shorten) */
+                if (lastMissing) critOther = __builtin_amdgcn_readlane(other, __ffsll((long long)lastMissing) - 1);
+            }
             if (needP) {
                 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
                 if (!(JOINTS && isJoint)) {
@@ -595,10 +662,12 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         }
         const bool allOn = __all(rowsOn);
         wave_sync();
+        AVBD_MARK(accumulate);
         RS_STAMP(1);
         if (allOn) accumulate_products<true, JOINTS, MULTI>(a, pr, prLine, S, nEnt * 3, J, X.prStride); else accumulate_products<false, JOINTS, MULTI>(a, pr, prLine, S, nEnt * 3, J, X.prStride);
         if (lane < 27) accs[lane] = a.acc;
         wave_sync();
+        AVBD_MARK(solve);
         RS_STAMP(2);
         f3 p; q4 q;
         solve_pose(accs, accs + 32, lane, L, p, q);
@@ -614,10 +683,13 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
             r2.y = (unsigned)__builtin_amdgcn_s_memrealtime();
             trec[3] = r2.y;
 #endif
+            if (COLO) { volatile v4u AVBD_LDS* r = CL.rec + CL.self * 3; r[0] = r0; r[1] = r1; r[2] = r2; }
             xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
+            if (COLO) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); CL.flag[CL.self] = stampNow; }
         }
         /* lane 0's result becomes the wave's (scalar) copy of the pose */
         L.pos = mk3(bcast0(p.x), bcast0(p.y), bcast0(p.z)); L.rot = mkq(bcast0(q.x), bcast0(q.y), bcast0(q.z), bcast0(q.w));
+        AVBD_MARK(dual);
         RS_STAMP(3);
 
         /* ---- dual update of the joint halves this body owns (solver.cpp:411-430 with Joint rows) ---- */
@@ -660,6 +732,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 xst(rD, offD, r0); xst(rD, offD + 16, r1);
             }
         }
+        AVBD_MARK(task_end);
         RS_STAMP(4);
 #ifdef AVBD_DF_STATS
         if (lane == 0) trec[4] = (unsigned)tprev;
@@ -789,6 +862,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         if (lane == 0) {
             B.plane(BP_POSR)[body] = pack3(L.pos, radius);
             B.plane(BP_QUAT)[body] = packq(L.rot);
+            if (COLO && X.crit) X.crit[body] = make_int2(critOther, (int)(unsigned)(__builtin_amdgcn_s_memrealtime() - t0));
         }
         if (has && owned) { if (JOINTS && isJoint) store_joint_half(gf[idx >> 1], jPart, c, true); else store_contact_dual<false>(M, idx, c, true); }
     }

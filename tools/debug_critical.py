@@ -38,7 +38,7 @@ while True:
     if it > 0: deps.append((tm(it - 1, b, 4), b, it - 1, "self"))
     if not deps: break
     d = max(deps)
-    path.append(dict(it=it, b=b, dep=d[3], t_dep=d[0], t_start=tm(it, b, 0), t_pre=tm(it, b, 1), t_det=tm(it, b, 2), t_pub=tm(it, b, 3), t_dual=tm(it, b, 4), spins=int(t[it, b2w[b], 6]), nn=len(nbr[b])))
+    path.append(dict(it=it, b=b, colo=int(b2w[b] // 4 == b2w[d[1]] // 4), dep=d[3], t_dep=d[0], t_start=tm(it, b, 0), t_pre=tm(it, b, 1), t_det=tm(it, b, 2), t_pub=tm(it, b, 3), t_dual=tm(it, b, 4), spins=int(t[it, b2w[b], 6]), nn=len(nbr[b])))
     b, it = d[1], d[2]
 path.reverse()
 print("hops", len(path))
@@ -55,17 +55,17 @@ for k, v in agg.items():
     v = np.array(v, float); ok = ~np.isnan(v)
     print(f"{k:32s} n={ok.sum():4d} mean {np.nanmean(v):6.2f} p50 {np.nanmedian(v):6.2f} max {np.nanmax(v):6.2f} sum {np.nansum(v):8.1f}")
 # same-XCD vs cross-XCD hand-offs (workgroups are dealt round-robin over the 8 XCDs; wave index = 4 * workgroup + wave)
-allh = {"same": [], "cross": []}
+allh = {"same": [], "cross": [], "workgroup": []}
 for it in range(IT):
     for b in b2w:
         for o in nbr[b]:
             if o > b:
                 d = tm(it, b, 2) - tm(it, o, 3)
                 if 0 < d < 3.0 and int(t[it, b2w[b], 6]) >= 2:
-                    allh["same" if (b2w[b] // 4) % 8 == (b2w[o] // 4) % 8 else "cross"].append(d)
+                    allh["workgroup" if b2w[b] // 4 == b2w[o] // 4 else ("same" if (b2w[b] // 4) % 8 == (b2w[o] // 4) % 8 else "cross")].append(d)
 for k, v in allh.items():
     if v: print(f"pose hand-offs that ended a real wait, {k}-XCD: n={len(v)} mean {np.mean(v):.3f} p50 {np.median(v):.3f} us")
-kinds = collections.Counter(p["dep"] for p in path)
+kinds = collections.Counter((p["dep"], p["colo"]) for p in path)
 print("dep kinds", kinds)
 for p in path[:40]:
     print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in p.items()})

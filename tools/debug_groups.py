@@ -16,7 +16,7 @@ act = buf[buf[:, 5] > 0].astype(np.float64)
 print("active waves", len(act), "passes/wave %.1f" % act[:, 5].mean(), "tasks/wave %.1f" % act[:, 4].mean(), "batch %.2f" % (act[:, 4].sum() / act[:, 5].sum()))
 print("wave total us: mean %.1f max %.1f" % ((act[:, 6] / 100).mean(), (act[:, 6] / 100).max()))
 for i, n in ((0, "poll+idle"), (7, "finish: records, post, S"), (8, "finish: accumulate"), (9, "finish: solve, publish"), (1, "finish: dual"),
-             (10, "prepare: constants, world inertia"), (11, "prepare: seeds, basis, Jacobians"), (12, "prepare: products of the first entry"), (13, "prepare: products of the second entry"), (2, "after prepare"), (3, "first prepare")):
+             (10, "prepare: constants, world inertia"), (11, "prepare: seeds, basis, Jacobians"), (12, "prepare: products of the first entry"), (13, "prepare: products of the second entry"), (2, "after prepare"), (3, "first prepare / multi: dual stores acknowledged"), (12, "multi: look at watched words (drained)"), (13, "multi: dual arithmetic + issue (not drained)"), (15, "multi: park issue (not drained)")):
     # (stamps inside a task are taken by lane 0 for ITS sub-group's tasks only: ~iterations of them per wave)
     print("  %-48s total us/wave %8.1f   per pass %6.2f   per task of lane 0's body %6.2f" % (n, (act[:, i] / 100).mean(), (act[:, i] / 100 / act[:, 5]).mean(), (act[:, i] / 100).mean() / 20.0))
 print("poll rounds per wave %.0f" % act[:, 14].mean())
