@@ -59,7 +59,7 @@ struct ShardExchange {
 };
 
 constexpr int kGrpWavesPerBlock = 4;
-constexpr int kGrpSSlots = 6;             /* f | penalty | gyro.x | gyro.y | gyro.z | zeros */
+constexpr int kGrpSSlots = 7;             /* f | penalty | gyro.x | gyro.y | gyro.z | +0.0f | -0.0f */
 constexpr int kGrpAccFloats = 64;         /* per 16 lanes: 27 accumulator entries, 21 floats of solve / inertia exchange */
 constexpr int kGrpConstFloats = 32;       /* per 16 lanes: inertial pose, mass, body-frame inertia and inverse inertia */
 constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAccFloats + kGrpConstFloats);
@@ -199,7 +199,9 @@ __device__ __forceinline__ GAccView grp_view(const GAcc& a, const float* Jt, con
     v.a4 = reinterpret_cast<const float4*>(Jt + a.opA * kResRows + rowBase);
     v.b4 = reinterpret_cast<const float4*>(Jt + (v.rhs ? a.opA : a.opB) * kResRows + rowBase);
     v.s4 = reinterpret_cast<const float4*>(S + (v.rhs ? 0 : kResRows) + rowBase);
-    v.g4 = reinterpret_cast<const float4*>(S + kResRows * (a.gy >= 0 ? a.gy - 6 : 5) + rowBase);   /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
+    /* behind the row term: the gyroscopic component (diagonal aa entries), +0.0f (off-diagonal aa entries, like the reference's
+     * diagonal() matrix) or -0.0f (every other entry: x + (-0.0f) == x for every x, so no lane needs a select around the addition) */
+    v.g4 = reinterpret_cast<const float4*>(S + kResRows * (a.gy >= 0 ? a.gy - 6 : (v.isAA ? 5 : 6)) + rowBase);
     return v;
 }
 template <bool ALLON>
@@ -208,8 +210,8 @@ __device__ __forceinline__ float grp_add_row(float acc, float va, float vb, floa
     const float pr = v.rhs ? va : va * vb;
     const float nv = acc + pr * sv;
     const float nvg = nv + gv;
+    if (ALLON) return nvg;
     const float nv2 = v.isAA ? nvg : nv;
-    if (ALLON) return nv2;
     const bool on = v.rhs || ((sv > 0.0f) & (fabsf(sv) <= FLT_MAX));   /* lhs entries scale by the penalty itself */
     return on ? nv2 : acc;
 }
@@ -376,7 +378,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         if (gl == 0) { X.privPose[(size_t)body * 2] = pack3(pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(rot); }
     };
 
-    for (int r = lane; r < kResRows; r += 64) S[5 * kResRows + r] = 0.0f;
+    for (int r = lane; r < kResRows; r += 64) { S[5 * kResRows + r] = 0.0f; S[6 * kResRows + r] = -0.0f; }
 
     /* ---- what the first half of a task leaves for the second ---- */
     GAcc a0, a1;

@@ -458,12 +458,49 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
 }
 
 /* ---- phase 3: solve6x6 (solver.cpp:68-83) + pose update (solver.cpp:402-405) ---------------------------
- * Lane-parallel evaluation of exactly the reference's expression trees:
- *   lanes 0..2: AinvB column j = solve(ll, la.col j), then Schur column j = aa.col j - al * column j
- *   lane  3   : x0 = solve(ll, b.l), then rhs_s = b.a - al * x0
- *   lane  0   : y = solve(schur, rhs_s), x = x0 - AinvB * y, pose update
- * `accs` holds the 27 accumulated entries; `xch` is a 16-float per-wave LDS exchange area.
- * The result (p, q) is valid in lane 0 only. */
+ * Lane-parallel evaluation of exactly the reference's expression trees.  A wavefront issues one instruction per ~4 cycles
+ * however few lanes are active, and an IEEE division is ~11 dependent instructions, so the INDEPENDENT divisions of a 3x3
+ * solve (maths.h:104: L10 | L20, then L21, then z.x | z.y | z.z) are made side by side by the lanes of a quad, each on its own
+ * operands — the same quotients of the same bits — and handed round with quad_perm DPP moves:
+ *   quad j = lanes 4j..4j+3 (j = 0..3): sol_j = solve(ll, la.col j) for j < 3, solve(ll, b.l) for j = 3;
+ *             then Schur column j = aa.col j - al * sol_j   |   rhs_s = b.a - al * x0
+ *   quad 0 : y = solve(schur, rhs_s), x = x0 - AinvB * y, pose update
+ * `accs` holds the 27 accumulated entries; `xch` is a 21-float LDS exchange area.  The result (p, q) is valid in lane 0 only
+ * (the other lanes run the same instruction stream on operands nobody reads). */
+__device__ __forceinline__ float quad_lane(float v, int c)            /* the value lane (lane & ~3) + c holds, c a constant */
+{
+    const int ctrl = c | (c << 2) | (c << 4) | (c << 6);              /* quad_perm:[c,c,c,c] */
+    int r;
+    switch (ctrl) {
+    case 0x00: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, true); break;
+    case 0x55: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xf, 0xf, true); break;
+    default:   r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xaa, 0xf, 0xf, true); break;
+    }
+    return __int_as_float(r);
+}
+
+/* maths.h:104 with the independent divisions spread over the lanes of a quad (c = lane & 3); every lane of the quad returns x */
+__device__ __forceinline__ f3 solve_ldlt3_quad(m33 A, f3 b, int c)
+{
+    const f3 L0 = A.c0;
+    bool bad = fabsf(L0.x) < FLT_EPSILON;
+    const float d0 = L0.x;
+    const float q1 = (c == 0 ? L0.y : L0.z) / d0;                     /* lane 0: L10, lane 1: L20 */
+    const float L10 = quad_lane(q1, 0), L20 = quad_lane(q1, 1);
+    const f3 L1 = A.c1 - L0 * L10;
+    bad |= fabsf(L1.y) < FLT_EPSILON;
+    const float d1 = L1.y;
+    const float L21 = L1.z / d1;
+    const f3 L2 = A.c2 - L0 * L20 - L1 * L21;
+    bad |= fabsf(L2.z) < FLT_EPSILON;
+    const float d2 = L2.z;
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    const float zq = (c == 0 ? y.x : (c == 1 ? y.y : y.z)) / (c == 0 ? d0 : (c == 1 ? d1 : d2));
+    f3 z; z.x = quad_lane(zq, 0); z.y = quad_lane(zq, 1); z.z = quad_lane(zq, 2);
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    return bad ? zero3() : x;
+}
+
 __device__ __forceinline__ void solve_pose(const float* accs, float* xch, int lane, const BodyLocal& L, f3& p, q4& q)
 {
     m33 ll, la, al;
@@ -471,25 +508,26 @@ __device__ __forceinline__ void solve_pose(const float* accs, float* xch, int la
     ll.c0 = mk3(accs[0], accs[1], accs[2]); ll.c1 = mk3(accs[1], accs[3], accs[4]); ll.c2 = mk3(accs[2], accs[4], accs[5]);
     la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
     al = mtranspose(la); /* al accumulates (Ja_i*Jl_j)*pen = la(j,i) bit for bit (solver.cpp:389-390) */
-    const int j = lane & 3;
-    /* each of the four lanes fetches its own right-hand side / Schur base straight from the accumulator area */
+    const int j = (lane >> 2) & 3, c = lane & 3;
+    /* each quad fetches its own right-hand side / Schur base straight from the accumulator area */
     const int ro = j < 3 ? 6 + 3 * j : 21;
     const f3 rhs = mk3(accs[ro], accs[ro + 1], accs[ro + 2]);
-    const f3 sol = solve_ldlt3_branchless(ll, rhs);  /* col0, col1, col2, x0 */
+    const f3 sol = solve_ldlt3_quad(ll, rhs, c);     /* col0, col1, col2, x0 */
     const f3 prod = al * sol;                        /* al * AinvB.col j  |  al * x0 */
     const int b0 = j == 0 ? 15 : (j == 1 ? 16 : (j == 2 ? 17 : 24)), b1 = j == 0 ? 16 : (j == 1 ? 18 : (j == 2 ? 19 : 25)),
               b2 = j == 0 ? 17 : (j == 1 ? 19 : (j == 2 ? 20 : 26));
     const f3 base = mk3(accs[b0], accs[b1], accs[b2]);
     const f3 out = base - prod;                      /* schur.col j  |  rhs_s */
-    if (lane < 4) {
+    if (lane < 16 && c == 0) {
         xch[j * 3 + 0] = out.x; xch[j * 3 + 1] = out.y; xch[j * 3 + 2] = out.z;
-        if (lane > 0) { xch[12 + (j - 1) * 3 + 0] = sol.x; xch[12 + (j - 1) * 3 + 1] = sol.y; xch[12 + (j - 1) * 3 + 2] = sol.z; }
+        if (j > 0) { xch[12 + (j - 1) * 3 + 0] = sol.x; xch[12 + (j - 1) * 3 + 1] = sol.y; xch[12 + (j - 1) * 3 + 2] = sol.z; }
     }
     wave_sync();
-    if (lane == 0) {
+    {
+        /* every lane runs this; quad 0 (whose `sol` is column 0 of AinvB) holds the result */
         const m33 schur = mkm(mk3(xch[0], xch[1], xch[2]), mk3(xch[3], xch[4], xch[5]), mk3(xch[6], xch[7], xch[8]));
         const f3 rhs_s = mk3(xch[9], xch[10], xch[11]);
-        const f3 y = solve_ldlt3_branchless(schur, rhs_s);
+        const f3 y = solve_ldlt3_quad(schur, rhs_s, c);
         const m33 AinvB = mkm(sol, mk3(xch[12], xch[13], xch[14]), mk3(xch[15], xch[16], xch[17]));
         const f3 x0 = mk3(xch[18], xch[19], xch[20]);
         const f3 dl = x0 - AinvB * y;

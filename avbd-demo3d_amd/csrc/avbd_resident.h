@@ -187,7 +187,10 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
      * rows only, solver.cpp:393). */
     const bool isAA = a.mode == 1, diag = a.gy >= 0, rhs = a.mode == 2;
     const float4* s4 = reinterpret_cast<const float4*>(S + (rhs ? 0 : kResRows));
-    const float4* g4 = reinterpret_cast<const float4*>(S + kResRows * (diag ? a.gy - 6 : 6));
+    /* what an entry adds behind the row term: its gyroscopic component (diagonal aa entries), +0.0f (off-diagonal aa entries, like
+     * the reference's diagonal() matrix), or — contacts-only kernels — -0.0f for every other entry: x + (-0.0f) == x for EVERY x,
+     * so those lanes need no select around the addition the aa lanes make (slot 7 holds -0.0f when the kernel has no joints) */
+    const float4* g4 = reinterpret_cast<const float4*>(S + kResRows * (diag ? a.gy - 6 : ((!JOINTS && !isAA) ? 7 : 6)));
     const float4* o4 = reinterpret_cast<const float4*>(S + kResRows * 5);
     const float4* m4 = reinterpret_cast<const float4*>(S + kResRows * 7);
     constexpr int NQ = kResRegRows / 4;
@@ -211,7 +214,7 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
                 const int r = e * 3 + k;
                 const float nv = a.acc + pr[r] * comp4(sv[r >> 2], r & 3);
                 const float nvg = nv + comp4(gv[r >> 2], r & 3);     /* off-diagonal aa entries add 0.0f like the reference's diagonal() */
-                if (ALLON) a.acc = isAA ? nvg : nv;
+                if (ALLON) a.acc = JOINTS ? (isAA ? nvg : nv) : nvg;
                 else {
                     const float nv2 = (isAA && (!JOINTS || comp4(mv[r >> 2], r & 3) != 0.0f)) ? nvg : nv;
                     a.acc = (rhs || comp4(ov[r >> 2], r & 3) != 0.0f) ? nv2 : a.acc;
@@ -245,7 +248,7 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
             if (r4 + k < nRows) {                                  /* wave-uniform */
                 const float nv = a.acc + comp4(pv, k) * comp4(sw, k);
                 const float nvg = nv + comp4(gw, k);
-                if (ALLON) a.acc = isAA ? nvg : nv;
+                if (ALLON) a.acc = JOINTS ? (isAA ? nvg : nv) : nvg;
                 else {
                     const float nv2 = (isAA && comp4(mw, k) != 0.0f) ? nvg : nv;
                     a.acc = (rhs || comp4(ow, k) != 0.0f) ? nv2 : a.acc;
@@ -409,7 +412,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         }
     };
 
-    for (int r = lane; r < kResRows; r += 64) rows[kResJFloats + 6 * kResRows + r] = 0.0f;
+    for (int r = lane; r < kResRows; r += 64) { rows[kResJFloats + 6 * kResRows + r] = 0.0f; if (!JOINTS) rows[kResJFloats + 7 * kResRows + r] = -0.0f; }
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned prevWait = 0;                                           /* ticks (10 ns) this wave waited in the previous iteration */
     int critOther = -1;                                              /* COLO: the later-created partner whose pose arrived last in the most recent task that waited for one */
