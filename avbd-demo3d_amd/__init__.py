@@ -309,6 +309,9 @@ class World:
         s = _f32(s, (-1, 13))
         self._chk(self.L.avbd_upload_state13(self.h, _fp(s), s.shape[0]))
 
+    def set_step_index(self, s):
+        self._chk(self.L.avbd_set_step_index(self.h, int(s)))
+
     def set_bodies(self, arr):
         arr = np.ascontiguousarray(arr, dtype=BODY_DT)
         self._chk(self.L.avbd_upload_bodies(self.h, arr.ctypes.data_as(C.c_void_p), len(arr)))

@@ -177,7 +177,10 @@ struct AvbdContext {
                                     * larger ones then take the resident schedule's parked sweep: 64 000 cubes 8.4 ms per iteration loop against 7.0 ms) */
     int groupsWaves = 0;           /* AVBD_GROUPS_WAVES: resident waves the plan may use (tests: few waves, many rounds); 0 = all */
     /* sharded runs as one persistent launch per step with the exchange on a second stream (ShardExchange, avbd_groups.h) */
-    int shardPersistent = -1;      /* AVBD_SHARD_PERSISTENT=0 never, 1 whenever the prerequisites hold (default) */
+    int shardPersistent = -1;      /* AVBD_SHARD_PERSISTENT=0 never, 1 whenever the prerequisites hold; default (-1): wherever the form has been validated —
+                                    * one rank, or the contexts of avbd_group_step on ONE device.  With a real communicator (one process per GPU) or contexts on
+                                    * different devices it is opt-in (=1) until it has run on a multi-GPU box: the exchange stream would wait on
+                                    * and read words that live on another device */
     bool canWaitValue = false;     /* hipStreamWaitValue32 / WriteValue32 work on this device */
     hipStream_t stream2 = nullptr; /* exchange stream: wait for an iteration -> all-gather -> release its readers */
     hipEvent_t evBegin = nullptr, evGathered = nullptr;
@@ -726,7 +729,8 @@ bool groups_eligible(const AvbdContext* c)
     if (totalIt <= 0 || totalIt > 60) return false;
     for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return false;
     if (c->nranks > 1 || c->forceSharded)                              /* sharded: the persistent launch IS the group schedule */
-        return c->shardPersistent != 0 && c->canWaitValue && c->sigDone && c->sigGather && c->stream2;
+        return c->shardPersistent != 0 && (c->shardPersistent == 1 || c->comm == nullptr || c->nranks == 1) &&
+               c->canWaitValue && c->sigDone && c->sigGather && c->stream2;
     const int dyn = (int)c->hBodies.size() - c->numStatic;
     return c->groupsMode == 1 || dyn > c->iterBlocks * kIterWaves;
 }
@@ -1083,6 +1087,13 @@ __global__ void k_exchange_publish(unsigned* word, unsigned value)
     __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+/* the stamp window wraps: the exchange stream's two words start from zero again (queued on the solver stream, before evBegin) */
+__global__ void k_reset_exchange_words(unsigned* sigDone, unsigned* sigGather)
+{
+    if (sigDone) __hip_atomic_store(sigDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (sigGather) __hip_atomic_store(sigGather, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* debug (AVBD_DEBUG_COPY_KERNEL): the device copy of avbd_group_step's exchange as a two-workgroup kernel of this library */
 __global__ void k_copy_rows(float4* dst, const float4* src, int n)
 {
@@ -1149,9 +1160,12 @@ int shard_launch_persistent(AvbdContext* c)
     X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
     X.enabled = 1;
     if (c->xSerial >= (1u << 24) - 2u) {
+        /* the stamps wrap: forget every old record AND the two words the exchange stream and the waves compare with stamps — left
+         * at ~2^30 they would satisfy every wait of the new window at once (the all-gathers would run ahead of the kernel) */
         HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));
         HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, visitBytes, c->stream));
         HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
+        hipLaunchKernelGGL(k_reset_exchange_words, dim3(1), dim3(1), 0, c->stream, c->sigDone, c->sigGather);
         c->xSerial = 0;
     }
     ++c->xSerial;
@@ -2605,7 +2619,11 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
             {   /* this context's share of its device's resident waves */
                 int sharing = 0;
                 for (int q = 0; q < n; ++q) sharing += ctxs[q] && ctxs[q]->device == c->device;
-                c->shardWaves = std::max(kGrpWavesPerBlock, (2 * c->iterBlocks * kGrpWavesPerBlock / std::max(1, sharing)) / kGrpWavesPerBlock * kGrpWavesPerBlock);
+                /* contexts that share a device keep a fifth of it free between them: with persistent launches in every workgroup slot
+                 * the exchange streams' waits / copies / writes were starved for seconds (two launches of 1 008 waves each timed out,
+                 * 800 each went through — DESIGN.md §7) */
+                const int usable = sharing > 1 ? (2 * c->iterBlocks * kGrpWavesPerBlock * 4) / 5 : 2 * c->iterBlocks * kGrpWavesPerBlock;
+                c->shardWaves = std::max(kGrpWavesPerBlock, (usable / std::max(1, sharing)) / kGrpWavesPerBlock * kGrpWavesPerBlock);
             }
             if ((rc = step_begin(c))) return rc;
             c->statsFresh = false;
@@ -2621,6 +2639,20 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
                     int sharing = 0;
                     for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
                     if (sharing > 4) all = false;
+                    /* contexts on different devices: every exchange stream would wait on, and copy from, memory of another device —
+                     * never validated on a multi-GPU box, so only on explicit request, and only with peer access in place */
+                    if (sharing != n) {
+                        if (ctxs[r]->shardPersistent != 1) all = false;
+                        for (int q = 0; q < n && all; ++q) {
+                            if (ctxs[q]->device == ctxs[r]->device) continue;
+                            int can = 0;
+                            if (hipDeviceCanAccessPeer(&can, ctxs[r]->device, ctxs[q]->device) != hipSuccess || !can) { all = false; break; }
+                            (void)hipSetDevice(ctxs[r]->device);
+                            const hipError_t pe = hipDeviceEnablePeerAccess(ctxs[q]->device, 0);
+                            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) all = false;
+                            (void)hipGetLastError();
+                        }
+                    }
                 }
             }
             for (int r = 0; r < n && all; ++r) {
@@ -2628,6 +2660,14 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
                 (void)hipSetDevice(ctxs[r]->device);
                 if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
                 all = ok;
+                /* several bodies per sub-group with more than two contexts on one device: four contexts of 16 000 bodies each stop making
+                 * progress on the step the first layer lands (waves that serve ground contacts never count their second iteration; two
+                 * contexts of 32 000 go through) — not understood yet, so that combination takes one launch per iteration */
+                if (ok && ctxs[r]->shardMulti) {
+                    int sharing = 0;
+                    for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
+                    if (sharing > 2) all = false;
+                }
             }
             for (int r = 0; r < n; ++r) ctxs[r]->shardRanPersistent = false;
             if (all) {

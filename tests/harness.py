@@ -342,6 +342,9 @@ class HipWorld:
     def set_forces(self, arr):
         self.w.set_forces(np.ascontiguousarray(arr).view(self.pkg.FORCE_DT))
 
+    def set_step_index(self, s):
+        self.w.set_step_index(s)
+
     def copy_scene_from(self, cpu, density=1.0):
         """Recreate `cpu`'s bodies (bit-exact initial state) in this world; dynamic bodies get `density`."""
         b = cpu.bodies()

@@ -137,3 +137,33 @@ def test_22000_cubes_several_bodies_per_sub_group_match_the_parked_sweep(monkeyp
             monkeypatch.delenv("AVBD_GROUPS")
     assert finals["default"][0].tobytes() == finals["0"][0].tobytes(), "body state differs between the two schedules"
     assert finals["default"][1].tobytes() == finals["0"][1].tobytes(), "force state differs between the two schedules"
+
+
+def test_64000_cubes_landed_pile_group_schedule_matches_the_parked_sweep_and_the_oracle(monkeypatch):
+    """The workload the strong-scaling line of bench.py times (StressN:40 from step 470: eight bodies per sub-group, out-of-order
+    picks, header table in LDS), at its own size: 50 steps of the default group schedule and of the resident schedule's parked sweep
+    (AVBD_GROUPS=0) from the same device state must agree bit for bit, bodies and forces; and ONE step of the CPU restatement from
+    that state (~20 s: its broadphase is O(n^2)) must agree with the device's first step of the window."""
+    g0 = H.HipWorld(); g0.scene("StressN:40"); g0.step(470); g0.w.synchronize()
+    assert int(g0.w.stats()["schedule"]) == 4 and int(g0.w.stats()["numManifolds"]) > 150000
+    b0, f0, s0 = g0.bodies(), g0.forces(), g0.step_index()
+    o = H.CpuWorld("orc"); o.scene("StressN:40")
+    o.set_bodies(b0); o.set_forces(f0); o.set_step_index(s0)
+    o.step()
+    g0.step()
+    H.assert_same_world_fast(o, g0, "StressN:40 step 471 (group schedule vs oracle)")
+    o.close()
+    finals = {}
+    for groups in ("default", "0"):
+        if groups == "0":
+            monkeypatch.setenv("AVBD_GROUPS", "0")
+        g = H.HipWorld(); g.scene("StressN:40")
+        g.set_bodies(b0); g.set_forces(f0); g.set_step_index(s0)
+        g.step(50); g.w.synchronize()
+        assert int(g.w.stats()["schedule"]) == (4 if groups == "default" else 3)
+        finals[groups] = (g.bodies(), g.forces())
+        g.close()
+        if groups == "0":
+            monkeypatch.delenv("AVBD_GROUPS")
+    assert finals["default"][0].tobytes() == finals["0"][0].tobytes(), "body state differs between the two schedules after 50 steps"
+    assert finals["default"][1].tobytes() == finals["0"][1].tobytes(), "force state differs between the two schedules after 50 steps"

@@ -214,3 +214,51 @@ def test_independent_shards_of_a_large_scene_are_bit_exact(shard_mode):
                 assert H.same_bits(bo[f], bg[f]), f"rank {r} field {f} after step {s + 1}"
     assert all(int(w.w.stats()["schedule"]) == (4 if shard_mode == "1" else 3) for w in worlds)
     assert sum(int(w.w.stats()["numManifolds"]) for w in worlds) == len(o.forces())
+
+
+def _cut_pile_finals(monkeypatch, env, steps=6, substeps=5):
+    """two ranks on a pile cut along z, avbd_group_step; returns per-rank (bodies, forces) bytes"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pkg = H.load_product()
+    worlds = [H.HipWorld(), H.HipWorld()]
+    for w in worlds:
+        w.scene("PackedGrid:4,3,8")
+    b = worlds[0].bodies()
+    owner = pkg.partition_by_axis(b["pos"], b["invMass"], 2, axis=2)
+    for r, w in enumerate(worlds):
+        w.w.set_ownership(2, r, owner)
+    for s in range(steps):
+        pkg.group_step([w.w for w in worlds], substeps)
+    out = [(w.bodies().tobytes(), w.forces().tobytes()) for w in worlds]
+    sched = [int(w.w.stats()["schedule"]) for w in worlds]
+    for w in worlds:
+        w.close()
+    for k in env:
+        monkeypatch.delenv(k)
+    return out, sched
+
+
+def test_exchange_stream_gated_by_kernels_gives_the_same_bits(monkeypatch):
+    """AVBD_SHARD_GATE=kernel (a form bench.py --gpus N measures): the exchange stream waits for an iteration and publishes the
+    gather word with one-wave kernels instead of hipStreamWaitValue32 / hipStreamWriteValue32.  Same iteration, same bits, on both
+    ranks, as the stream-value form and as one launch per iteration."""
+    a, sa = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": "1"})
+    b, sb = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": "1", "AVBD_SHARD_GATE": "kernel"})
+    c, sc = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": "0"})
+    assert sa == sb == [4, 4], (sa, sb)
+    for r in range(2):
+        assert a[r] == b[r], f"rank {r}: kernel-gated exchange differs from the stream-value form"
+        assert a[r] == c[r], f"rank {r}: persistent form differs from one launch per iteration"
+
+
+def test_stamp_wrap_in_the_persistent_sharded_form(monkeypatch):
+    """The stamps of the exchange records wrap every 2^24 steps; the persistent sharded form also compares them with the two words
+    of its exchange stream (iterations done / all-gathers landed), which must start from zero again with the records (ADVICE round
+    2).  AVBD_RESIDENT_SERIAL starts the contexts twelve steps before the wrap: 30 steps across it give the bits of a run that
+    never wraps, on both ranks."""
+    a, sa = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": "1"})
+    b, sb = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": "1", "AVBD_RESIDENT_SERIAL": str((1 << 24) - 12)})
+    assert sa == sb == [4, 4]
+    for r in range(2):
+        assert a[r] == b[r], f"rank {r}: the run across the stamp wrap differs"
