@@ -201,6 +201,13 @@ struct AvbdContext {
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
+    /* exact cuts (avbd_cuts.h): the stamped records of all ranks in one address space; the first context of a group owns it */
+    bool shardExact = false;       /* AVBD_SHARD_EXACT=1: avbd_group_step sweeps every rank's slab with the single-GPU protocol (bit-identical to one GPU) */
+    DevArr<float4> xsPose, xsVisit, xsDual; size_t xsLocalSlots = 0, xsTotalSlots = 0; int xsRanks = 0; unsigned xsSerial = 0;
+    DevArr<int> dOwner, dCutOf, dCutMan, dRecIdx; DevArr<unsigned long long> dCutKeys; DevArr<CutCounters> dCutCnt;
+    size_t cutOfCap = 0, recIdxCap = 0;
+    hipEvent_t evLoop = nullptr, evExact = nullptr;
+    std::vector<ExactRankArgs> hExactArgs; DevArr<ExactRankArgs> dExactArgs;
     /* chains of hand-offs share a workgroup (avbd_place.h): report of the last iteration launch, tails, this step's table */
     DevArr<int2> dCrit; DevArr<int> dTail, dPlaceSlot, dPlace; DevArr<PlaceInfo> dPlaceInfo;
     bool placeChains = true;       /* AVBD_PLACE=0: waves take the slots of the sweep order */
@@ -447,6 +454,8 @@ int upload_bodies_if_stale(AvbdContext* c)
         if (avbd_exchange_layout(n, c->hOwner.data(), c->nranks, c->hRankStart.data(), c->hPerm.data(), c->hRow.data(), &c->maxCount) != AVBD_OK)
             return c->fail(AVBD_E_INVALID, "exchange layout: owner index out of range");
         if (n) {
+            if (c->dOwner.n < (size_t)c->bodyCap) HIPCHK(c, c->dOwner.alloc((size_t)c->bodyCap));
+            HIPCHK(c, hipMemcpy(c->dOwner.p, c->hOwner.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpyAsync(c->dSolved.p, solved.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->dPerm.p, c->hPerm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
             {   /* row of each body this rank solves inside its all-gather block */
@@ -693,7 +702,10 @@ int refresh_stats(AvbdContext* c, bool withLevels)
         (void)hipMemcpy(why, c->dFlags.p + 2 * (size_t)c->bodyCap, sizeof(why), hipMemcpyDeviceToHost);
         (void)hipMemsetAsync(c->dFlags.p + 2 * (size_t)c->bodyCap, 0, sizeof(why), c->stream);   /* reported once */
         char buf[320];
-        if (why[1])   /* the group schedule says what its first wave to give up was waiting for */
+        if (why[1] && why[15] >= 100)   /* several bodies per sub-group: the first body of the first timed-out sub-group that still has tasks */
+            std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?) [rank %d wave %d class %d lane %d: body %d at iteration %d of %d watches record offset %d for stamp base%+d, last saw base%+d; timed out %08x%08x]",
+                          c->rank, why[1] - 1, why[15] - 100, why[8], why[2], why[4], why[7], why[3], why[5], why[6], (unsigned)why[14], (unsigned)why[13]);
+        else if (why[1])   /* the group schedule says what its first wave to give up was waiting for */
             std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?) [rank %d wave %d class %d: body %d iteration %d partner %d; lanes missing pose %08x%08x visit %08x%08x dual %08x%08x gather %08x%08x, timed out %08x%08x]",
                           c->rank, why[1] - 1, why[15], why[2], why[4], why[3], (unsigned)why[6], (unsigned)why[5], (unsigned)why[8], (unsigned)why[7], (unsigned)why[10], (unsigned)why[9], (unsigned)why[12], (unsigned)why[11], (unsigned)why[14], (unsigned)why[13]);
         else std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?)");
@@ -714,7 +726,8 @@ int groups_waves(const AvbdContext* c)
          * collective its kernel needs room beside the persistent launch: kShardFreeSlots workgroup slots stay free */
         /* (avbd_group_step's device copies are kernels too: every context leaves a few slots of its share free as well — a plan with
          * several bodies per sub-group uses every wave it is given) */
-        if (c->shardWaves > 0) all = std::max(kGrpWavesPerBlock, std::min(all, c->shardWaves) - 4 * kGrpWavesPerBlock);
+        if (c->shardWaves > 0 && c->shardExact && c->nranks > 1) all = std::max(kGrpWavesPerBlock, std::min(all, c->shardWaves));   /* exact cuts: no copies beside the launches */
+        else if (c->shardWaves > 0) all = std::max(kGrpWavesPerBlock, std::min(all, c->shardWaves) - 4 * kGrpWavesPerBlock);
         else if (c->comm) all -= kShardFreeSlots * kGrpWavesPerBlock;
     }
     return c->groupsWaves > 0 ? std::min(c->groupsWaves, all) : all;
@@ -728,6 +741,7 @@ bool groups_eligible(const AvbdContext* c)
     const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
     if (totalIt <= 0 || totalIt > 60) return false;
     for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return false;
+    if (c->nranks > 1 && c->shardExact) return true;                   /* exact cuts: the group schedule over the bodies this rank sweeps */
     if (c->nranks > 1 || c->forceSharded)                              /* sharded: the persistent launch IS the group schedule */
         return c->shardPersistent != 0 && (c->shardPersistent == 1 || c->comm == nullptr || c->nranks == 1) &&
                c->canWaitValue && c->sigDone && c->sigGather && c->stream2;
@@ -822,7 +836,7 @@ int step_begin(AvbdContext* c)
             if (c->probeCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap; }
         }
         hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
-                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min(16, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
+                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min((c->nranks > 1 && c->shardExact) ? kGrpMaxRounds / 2 : kGrpMaxRounds, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
         c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -913,10 +927,10 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     const int* runIf = nullptr;
     c->groupsLaunched = false;
     if (c->groupsPlanned && X.enabled && wholeLoop && !X.joints && !sharded) {
-        hipExtLaunchKernelGGL((k_iterate_groups<false, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
+        hipExtLaunchKernelGGL((k_iterate_groups<false, 0>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
                               X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
         if (c->groupsMaxRounds > 1)
-            hipLaunchKernelGGL((k_iterate_groups<true, false>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytesMulti, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
+            hipLaunchKernelGGL((k_iterate_groups<true, 0>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytesMulti, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
                                X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
         runIf = &c->dPlan.p->bad;
         c->groupsLaunched = true;
@@ -1113,7 +1127,7 @@ int shard_plan_accepted(AvbdContext* c, bool& ok)
     if (std::getenv("AVBD_DEBUG_PLAN"))
         std::fprintf(stderr, "[avbd rank %d step %d] plan: classes %d/%d/%d waves %d/%d/%d rounds %d/%d/%d bad %d nd %d (W %d)\n", c->rank, c->stepIndex, p.nClass[0], p.nClass[1], p.nClass[2],
                      p.waves[0], p.waves[1], p.waves[2], p.rounds[0], p.rounds[1], p.rounds[2], p.bad, p.nd, groups_waves(c));
-    c->shardMulti = p.rounds[0] > 1 || p.rounds[1] > 1 || p.rounds[2] > 1;     /* several bodies per sub-group: k_iterate_groups<true, true> */
+    c->shardMulti = p.rounds[0] > 1 || p.rounds[1] > 1 || p.rounds[2] > 1;     /* several bodies per sub-group: k_iterate_groups<true, 1> */
     return AVBD_OK;
 }
 
@@ -1182,7 +1196,7 @@ int shard_launch_persistent(AvbdContext* c)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
     X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
-    auto kern = c->shardMulti ? k_iterate_groups<true, true> : k_iterate_groups<false, true>;
+    auto kern = c->shardMulti ? k_iterate_groups<true, 1> : k_iterate_groups<false, 1>;
     hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
                           S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
     ++c->prof.launches_primal; ++c->prof.launches_total;
@@ -1505,6 +1519,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RACE_CHECK")) c->raceCheck = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_SINGLE_KERNEL")) c->singleKernel = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_PLACE")) c->placeChains = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_SHARD_EXACT")) c->shardExact = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_SHARD_GATE")) c->shardGateKernel = std::strcmp(e, "kernel") == 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
@@ -1527,10 +1542,13 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_iterate<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kIterWaves * kResProductBytesPerWaveLite);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate<2>, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
-        fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups_exact, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         {   /* Every persistent launch spins on records that other workgroups of the same launch produce: ALL its workgroups must be
              * resident at once.  Ask the runtime how many workgroups of each kernel fit a CU with the exact dynamic LDS it is
@@ -1545,8 +1563,8 @@ int avbd_create(int device, AvbdContext** out)
             const int occ1 = std::min(std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad)),
                                       std::min(fits((const void*)k_iterate_single<false>, c->iterLdsPad), fits((const void*)k_iterate_single<true>, c->iterLdsPad)));
             const int occ2 = std::min(fits((const void*)k_iterate<2, false>, kIterWaves * kResProductBytesPerWaveLite), fits((const void*)k_iterate<2, true>, kIterWaves * kResProductBytesPerWaveLite));
-            const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, false>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, false>, kGrpLdsBytesMulti)),
-                                      std::min(fits((const void*)k_iterate_groups<false, true>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, true>, kGrpLdsBytesMulti)));
+            const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, 0>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 0>, kGrpLdsBytesMulti)),
+                                      std::min(fits((const void*)k_iterate_groups<false, 1>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 1>, kGrpLdsBytesMulti)));
             if (occ1 < 1) { c->mode = 0; c->residentAllowed = false; }      /* not even one workgroup per CU: one launch per level, nothing spins */
             c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
             if (occ2 * cus < 2 * c->iterBlocks) { c->residentLiteFrom = 0; c->residentForceLite = false; c->iterForceMode = c->iterForceMode == 2 ? 0 : c->iterForceMode; c->liteResident = false; }
@@ -2604,6 +2622,110 @@ int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
     return AVBD_OK;
 }
 
+/* One step of all ranks with exact cuts (avbd_cuts.h): step_begin has run on every context.  Returns 1 when the step was queued,
+ * 0 when the prerequisites do not hold (the caller falls back to the all-gather forms), < 0 on errors. */
+static int group_step_exact(AvbdContext** ctxs, int n)
+{
+    AvbdContext* L = ctxs[0];
+    for (int r = 0; r < n; ++r) {
+        AvbdContext* c = ctxs[r];
+        if (!c->shardExact || c->device != L->device || !c->groupsPlanned || c->mCap != L->mCap || c->bodyCap != L->bodyCap) return 0;
+        for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return 0;
+    }
+    int rc;
+    (void)hipSetDevice(L->device);
+    const int totalIt = L->params.iterations + (L->params.postStabilize ? 1 : 0);
+    if (totalIt <= 0 || totalIt > 60) return 0;
+    constexpr int kCutManifolds = 16384;                                /* manifolds one cut (pair of ranks) may hold */
+    const size_t localSlots = (size_t)4 * L->mCap, total = (size_t)n * localSlots + (size_t)n * n * kCutManifolds * 4;
+    if (total * 32 >= (1ull << 31)) return 0;                           /* 32-bit record offsets */
+    if (L->xsRanks != n || L->xsLocalSlots != localSlots || L->xsPose.n < (size_t)3 * L->bodyCap) {
+        for (int r = 0; r < n; ++r) HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
+        HIPCHK(L, L->xsPose.alloc((size_t)3 * L->bodyCap)); HIPCHK(L, L->xsVisit.alloc(total)); HIPCHK(L, L->xsDual.alloc(2 * total));
+        HIPCHK(L, hipMemsetAsync(L->xsPose.p, 0, (size_t)3 * L->bodyCap * sizeof(float4), L->stream));
+        HIPCHK(L, hipMemsetAsync(L->xsVisit.p, 0, total * sizeof(float4), L->stream));
+        HIPCHK(L, hipMemsetAsync(L->xsDual.p, 0, 2 * total * sizeof(float4), L->stream));
+        HIPCHK(L, hipStreamSynchronize(L->stream));
+        L->xsRanks = n; L->xsLocalSlots = localSlots; L->xsTotalSlots = total; L->xsSerial = 0;
+    }
+    if (L->xsSerial >= (1u << 24) - 2u) {                               /* the stamps wrap: forget every old record (nothing is in flight between steps) */
+        for (int r = 0; r < n; ++r) HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
+        HIPCHK(L, hipMemsetAsync(L->xsPose.p, 0, (size_t)3 * L->bodyCap * sizeof(float4), L->stream));
+        HIPCHK(L, hipMemsetAsync(L->xsVisit.p, 0, total * sizeof(float4), L->stream));
+        HIPCHK(L, hipMemsetAsync(L->xsDual.p, 0, 2 * total * sizeof(float4), L->stream));
+        HIPCHK(L, hipStreamSynchronize(L->stream));
+        L->xsSerial = 0;
+    }
+    /* every rank's plan must fit its share of the device: all launches are resident together and wait for each other's records */
+    for (int r = 0; r < n; ++r) {
+        bool ok = false;
+        if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
+        if (!ok) return 0;
+    }
+    ++L->xsSerial;
+    if (L->hExactArgs.size() != (size_t)n) { L->hExactArgs.assign((size_t)n, ExactRankArgs{}); HIPCHK(L, L->dExactArgs.alloc((size_t)n)); }
+    int wgPerRank = 1; bool anyMulti = false;
+    for (int r = 0; r < n; ++r) {
+        AvbdContext* c = ctxs[r];
+        if (c->cutOfCap < (size_t)c->mCap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, c->dCutOf.alloc((size_t)c->mCap)); HIPCHK(c, c->dCutMan.alloc((size_t)n * kCutManifolds)); HIPCHK(c, c->dCutKeys.alloc((size_t)n * kCutManifolds));
+            HIPCHK(c, c->dCutCnt.alloc(1));
+            c->cutOfCap = (size_t)c->mCap;
+        }
+        if (c->recIdxCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRecIdx.alloc((size_t)c->incCap)); c->recIdxCap = (size_t)c->incCap; }
+        if (!c->evLoop) HIPCHK(c, hipEventCreateWithFlags(&c->evLoop, hipEventDisableTiming));
+        BodyTable B = body_table(c);
+        SolverParams P = solver_params(c);
+        ManifoldTable M = c->mbuf[c->cur].view();
+        const int cutCap = n * kCutManifolds;
+        HIPCHK(c, hipMemsetAsync(c->dCutCnt.p, 0, sizeof(CutCounters), c->stream));
+        hipLaunchKernelGGL(k_cut_list, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, M, c->dCnt.p, c->dOwner.p, n, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p);
+        hipLaunchKernelGGL(k_cut_rank, dim3(grid_for(cutCap, 128, 1024)), dim3(128), 0, c->stream, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p, kCutManifolds);
+        hipLaunchKernelGGL(k_cut_fill, dim3(grid_for(std::max(1, c->numSolved), 128, 4096)), dim3(128), 0, c->stream, B, M, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->inc.p,
+                           c->dOwner.p, n, c->rank, c->dCutOf.p, (int)localSlots, kCutManifolds, c->dRecIdx.p);
+        IterateState S;
+        S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
+        ResidentExchange X{};
+        X.pose = L->xsPose.p; X.visit = L->xsVisit.p; X.dual = L->xsDual.p;
+        X.poseBytes = (unsigned)((size_t)3 * L->bodyCap * sizeof(float4)); X.visitBytes = (unsigned)(total * sizeof(float4)); X.dualBytes = (unsigned)(2 * total * sizeof(float4));
+        X.enabled = 1; X.base = L->xsSerial * 64u;
+        X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.probe = c->xProbe.p;
+        ShardExchange Z{};
+        Z.xPose = L->xsPose.p; Z.xVisit = L->xsVisit.p; Z.xDual = L->xsDual.p;
+        Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;
+        Z.recIdx = c->dRecIdx.p;
+        ExactRankArgs& A = L->hExactArgs[(size_t)r];
+        A.B = B; A.M = M; A.incStart = c->incStart.p; A.inc = c->inc.p; A.P = P; A.errWord = S.error; A.cntW = c->dCnt.p; A.X = X; A.plan = c->dPlan.p; A.byClass = c->dUnit.p;
+        A.cap = c->bodyCap; A.sleepSel = c->iterSleep; A.Z = Z; A.multi = c->shardMulti ? 1 : 0;
+        wgPerRank = std::max(wgPerRank, std::max(1, groups_waves(c) / kGrpWavesPerBlock));
+        anyMulti |= c->shardMulti;
+        HIPCHK(c, hipEventRecord(c->evLoop, c->stream));              /* this rank's tables are ready */
+        c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true;
+    }
+    {   /* ONE launch for all ranks, on the first context's stream (k_iterate_groups_exact) */
+        for (int q = 1; q < n; ++q) HIPCHK(L, hipStreamWaitEvent(L->stream, ctxs[q]->evLoop, 0));
+        HIPCHK(L, hipMemcpyAsync(L->dExactArgs.p, L->hExactArgs.data(), (size_t)n * sizeof(ExactRankArgs), hipMemcpyHostToDevice, L->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (L->profiling) { size_t i0 = L->evUsed; e0 = next_event(L); e1 = next_event(L); L->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+        hipExtLaunchKernelGGL(k_iterate_groups_exact, dim3(n * wgPerRank), dim3(64 * kGrpWavesPerBlock), anyMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, L->stream, e0, e1, 0,
+                              (const ExactRankArgs*)L->dExactArgs.p, wgPerRank);
+        ++L->prof.launches_primal; ++L->prof.launches_total;
+        HIPCHK(L, hipGetLastError());
+        HIPCHK(L, hipStreamSynchronize(L->stream));                   /* (the host copy of the arguments is rewritten next step) */
+        if (!L->evExact) HIPCHK(L, hipEventCreateWithFlags(&L->evExact, hipEventDisableTiming));
+        HIPCHK(L, hipEventRecord(L->evExact, L->stream));
+    }
+    for (int r = 0; r < n; ++r) {
+        AvbdContext* c = ctxs[r];
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L->evExact, 0));
+        hipLaunchKernelGGL(k_unpack_records, dim3(grid_for((int)c->hBodies.size(), 256, 1024)), dim3(256), 0, c->stream, body_table(c), c->dOwner.p, c->rank, L->xsPose.p);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = step_end(c, false))) return rc;
+    }
+    return 1;
+}
+
 int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
 {
     /* Several contexts (one per shard, on one or several devices of this process) stepped in lock-step by one host
@@ -2622,11 +2744,17 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
                 /* contexts that share a device keep a fifth of it free between them: with persistent launches in every workgroup slot
                  * the exchange streams' waits / copies / writes were starved for seconds (two launches of 1 008 waves each timed out,
                  * 800 each went through — DESIGN.md §7) */
-                const int usable = sharing > 1 ? (2 * c->iterBlocks * kGrpWavesPerBlock * 4) / 5 : 2 * c->iterBlocks * kGrpWavesPerBlock;
+                const int usable = (sharing > 1 && !c->shardExact) ? (2 * c->iterBlocks * kGrpWavesPerBlock * 4) / 5 : 2 * c->iterBlocks * kGrpWavesPerBlock;
                 c->shardWaves = std::max(kGrpWavesPerBlock, (usable / std::max(1, sharing)) / kGrpWavesPerBlock * kGrpWavesPerBlock);
             }
             if ((rc = step_begin(c))) return rc;
             c->statsFresh = false;
+        }
+        if (n > 1 && ctxs[0]->shardExact) {
+            /* exact cuts: no exchange during the loop, results identical to the single-GPU sweep (avbd_cuts.h) */
+            rc = group_step_exact(ctxs, n);
+            if (rc < 0) return rc;
+            if (rc == 1) continue;
         }
         const int totalIt = ctxs[0]->params.iterations + (ctxs[0]->params.postStabilize ? 1 : 0);
         {   /* persistent form (one launch per rank and step, exchange on the second streams) when every rank's plan fits its share

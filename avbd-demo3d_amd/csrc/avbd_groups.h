@@ -56,6 +56,15 @@ struct ShardExchange {
     unsigned* gatherWord;     /* hipMallocSignalMemory: base + (all-gathers that have landed) */
     int nOwned;               /* swept bodies of this rank */
     int keepExchangeWaiting;  /* debug (AVBD_DEBUG_KEEP_EXCHANGE_WAITING): an abandoned launch does not release the exchange stream, so the other ranks stay as they are */
+    /* EXACT cuts (SHARDK == 2): no exchange at all during the loop.  Every rank sweeps the bodies it owns with the
+     * single-GPU protocol; the stamped records of ALL ranks live in one address space (one allocation shared by the contexts of a
+     * process; peer-to-peer windows between GPUs), so a body whose partner another rank sweeps polls that partner's pose / visit /
+     * dual records exactly as it polls a local one and the result is the single-GPU sweep, bit for bit.  Pose records are indexed
+     * by body; the visit / dual records of a contact by recIdx: this rank's own range, or — contacts across a cut — a slot both
+     * ranks of the cut compute alike (k_cut_rank: rank of the manifold among the cut's manifolds, ordered by body pair). */
+    float4 *xPose, *xVisit, *xDual; unsigned xPoseBytes, xVisitBytes, xDualBytes;
+    const int* recIdx;        /* [incidence entries]: record index of the entry's contact | bit 31: the contact's owner is swept by another rank
+                               * (this rank's copy of the contact takes the owner's last dual from its record when the loop ends) */
 };
 
 constexpr int kGrpWavesPerBlock = 4;
@@ -128,6 +137,10 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
             const long long U = (long long)n[0] + 2ll * n[1] + 4ll * n[2];
             wv[2] = n[2] ? (int)max(1ll, (4ll * n[2] * W) / U) : 0;
             wv[1] = n[1] ? (int)max(1ll, (2ll * n[1] * W) / U) : 0;
+            /* a class of a few bodies must not end up with more rounds than a sub-group can hold (19 bodies of 17..32 contacts on the
+             * one wave their share of the lanes gives them would be ten rounds): at least the waves that keep it within maxRounds */
+            wv[2] = max(wv[2], (n[2] + maxRounds - 1) / maxRounds);
+            wv[1] = max(wv[1], (n[1] + 2 * maxRounds - 1) / (2 * maxRounds));
             wv[0] = W - wv[2] - wv[1];
             if (wv[0] < (n[0] ? 1 : 0)) bad = 1;
             for (int c = 0; c < 3; ++c) if (n[c]) { const int per = wv[c] * (4 >> c); rounds[c] = (n[c] + per - 1) / per; }
@@ -256,16 +269,17 @@ __device__ __forceinline__ unsigned xldw(__amdgpu_buffer_rsrc_t r, int byteOff) 
  * (owned contacts in the Manifold tables, which only their owner writes; a first visitor's copy of normal + tangent memo
  * and the pose in arrays private to the sub-group).  The sub-groups of a wave pick independently and the wave runs their
  * picks together, so a wave that serves 4 x K bodies does several tasks per pass. */
-template <bool MULTI, bool SHARD>
-__global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
-                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z)
+template <bool MULTI, int SHARDK>      /* SHARDK 0: one GPU; 1: sharded, all-gather per iteration; 2: sharded, exact cuts */
+__device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
+                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z,
+                      int blockIndex /* workgroup of this rank's share of the launch */)
 {
     extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave Jt | S | accs | constants */
+    constexpr bool SHARD = SHARDK == 1, EXACT = SHARDK == 2;
     /* the host queues k_iterate_groups<false>, <true> and the fallback launch one behind the other; the plan says which one runs */
     if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;   /* (SHARD: the host has read the plan) */
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * kGrpWavesPerBlock + wv;
+    const int w = blockIndex * kGrpWavesPerBlock + wv;
     const int W2 = plan->waves[2], W1 = plan->waves[1], W0 = plan->waves[0];
     if (w >= W2 + W1 + W0) return;
     const int cls = w < W2 ? 2 : (w < W2 + W1 ? 1 : 0);              /* wave-uniform */
@@ -281,7 +295,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     float* const xch = accs + 32;
     float* const cst = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gBase >> 4) * kGrpConstFloats;
 
-    const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
+    const __amdgpu_buffer_rsrc_t rP = EXACT ? xrsrc(Z.xPose, Z.xPoseBytes) : xrsrc(X.pose, X.poseBytes),
+                                 rV = EXACT ? xrsrc(Z.xVisit, Z.xVisitBytes) : xrsrc(X.visit, X.visitBytes),
+                                 rD = EXACT ? xrsrc(Z.xDual, Z.xDualBytes) : xrsrc(X.dual, X.dualBytes);
     const __amdgpu_buffer_rsrc_t rG0 = xrsrc(SHARD ? (void*)Z.gather[0] : (void*)X.pose, SHARD ? Z.gatherBytes : 16u),
                                  rG1 = xrsrc(SHARD ? (void*)Z.gather[1] : (void*)X.pose, SHARD ? Z.gatherBytes : 16u),
                                  rGW = xrsrc(SHARD ? (void*)Z.gatherWord : (void*)X.pose, 4u);
@@ -295,6 +311,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     bool valid = false, has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
     bool remote = false; int offR = 0; int ownRow = 0;                /* SHARD: the partner is swept by another rank; its row / this body's row in a gather buffer */
+    bool finalD = false;                                              /* EXACT: the contact's owner is swept by another rank */
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
     c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
@@ -305,24 +322,30 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
 
     /* who the entries of a body are and whom they wait for: enough to tell whether a task can start.  `seen`: the body has been
      * examined before in this launch, its partners are in X.probe (partner | moving << 24 | owned << 25). */
-    int2* const hdr = reinterpret_cast<int2*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes + wv * kGrpHdrBytesPerWave);   /* MULTI: [round][lane] */
+    typedef typename std::conditional<EXACT, int4, int2>::type HdrT;   /* EXACT: + the record index (half as many rounds fit) */
+    HdrT* const hdr = reinterpret_cast<HdrT*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes + wv * kGrpHdrBytesPerWave);   /* MULTI: [round][lane] */
     auto load_header = [&](int b, int e0, int ne, int round) __attribute__((always_inline)) {
         body = b; valid = b >= 0; eBeg = e0;
         has = valid && gl < ne;
         nRows = ne * 3;
         idx = 0; other = 0; isA = false; owned = false; moving = false;
+        int rec = 0;
         if (MULTI) {
-            const int2 h = hdr[round * 64 + lane];                     /* filled once, before the loop */
+            const HdrT h = hdr[round * 64 + lane];                     /* filled once, before the loop */
             if (has) { idx = inc_index(h.x); isA = inc_isA(h.x) != 0; other = h.y & 0xffffff; moving = (h.y >> 24) & 1; owned = (h.y >> 25) & 1; }
+            if constexpr (EXACT) rec = has ? h.z : 0; else rec = idx;
         } else if (has) {
             const int ent = inc[e0 + gl];
             idx = inc_index(ent); isA = inc_isA(ent) != 0;
             const int2 pr = M.pair[idx >> 2];
             other = isA ? pr.y : pr.x;
-            moving = B.solved[other] != 0;
+            moving = EXACT ? massPlane[other].y > 0.0f : B.solved[other] != 0;   /* EXACT: whoever sweeps it, a dynamic partner moves */
             owned = !moving || other > b;
+            rec = EXACT ? Z.recIdx[e0 + gl] : idx;
         }
-        offP = other * 48; offV = idx * 16; offD = idx * 32;
+        finalD = EXACT && has && (rec < 0);
+        rec &= 0x7fffffff;
+        offP = other * 48; offV = rec * 16; offD = rec * 32;
     };
     /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
      * wrote (first iteration), or what this sub-group parked after the body's previous task (several rounds, later iterations) */
@@ -406,7 +429,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     auto set_needs = [&]() __attribute__((always_inline)) {
         const unsigned stampNow = X.base + (unsigned)it + 1u;
         needP = false; needV = false; needD = false; sP = 0; sV = 0; sD = 0;
-        if (has && moving) {
+        if (EXACT && it >= itStop) {                                   /* the task behind the last iteration: the owner's last dual */
+            if (finalD) { needD = true; sD = X.base + (unsigned)itStop; }
+        } else if (has && moving) {
             if (owned) { needV = true; sV = stampNow; needP = true; sP = stampNow; }
             else if (it > 0) { needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
         }
@@ -451,6 +476,22 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         wave_sync();
         GS_STAMP(11);
+    };
+
+    /* EXACT, the task behind a body's last iteration: a contact across a cut lives on both ranks of the cut; the rank that sweeps its
+     * owner has run the last dual (solver.cpp:411-430) — lambda, penalty and the stick flag go into this rank's copy from the
+     * owner's record, and the stored normal takes the two re-normalisations the owner's last visit and dual made (replay_normal),
+     * so that both copies enter the next step's Manifold::initialize with the same bits (manifold.cpp:76-84). */
+    auto final_store = [&]() __attribute__((always_inline)) {
+        if (finalD) {
+            c.lambda[0] = bitsf(vd.x); c.lambda[1] = bitsf(vd.y); c.lambda[2] = bitsf(vd.z);
+            c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
+            c.stick = (d1.w & 1u) != 0;
+            replay_normal(c, fixedN); replay_normal(c, fixedN);
+            int idxF = idx;
+            asm volatile("" : "+v"(idxF));
+            store_contact_dual<false>(M, idxF, c, false);
+        }
     };
 
     bool allOnG = true;                                              /* what finish_visit leaves for the accumulation */
@@ -584,6 +625,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
     };
     auto poll_records = [&]() __attribute__((always_inline)) { poll_issue(); poll_check(); };
     int reported = 0;                                                 /* SHARD, one body per sub-group: iterations this wave has counted in Z.done */
+    int dbgBody = -1, dbgIt = 0, dbgOff = 0, dbgStamp = 0, dbgSeen = 0;   /* several bodies per sub-group: what lane k's body waits for (time-out report) */
+    int itEndOne = itStop;                                            /* one body per sub-group: tasks of the body (EXACT: + the one behind the last iteration) */
     bool grpWaiting = true;                                           /* several bodies per sub-group: the sub-group still has a body with tasks left */
     auto back_off = [&]() __attribute__((always_inline)) -> bool {     /* false: the launch is being abandoned */
         if (sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (sleepSel == 1) __builtin_amdgcn_s_sleep(2);
@@ -594,7 +637,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         if (__any(chk)) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (chk && spins == 1024u) tIdle = now - 1024ull * 30ull;  /* first check since the last task: the wait began about here */
-            const bool waiting = MULTI ? grpWaiting : (valid && it < itStop);   /* (a sub-group that has finished its last task waits for nothing) */
+            const bool waiting = MULTI ? grpWaiting : (valid && it < itEndOne);   /* (a sub-group that has finished its last task waits for nothing) */
             const bool dead = (chk && waiting && now - tIdle > kSpinTimeoutTicks) ||
                               __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (__any(dead)) {
@@ -603,6 +646,18 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                     const unsigned long long mT = __ballot(mine), mP = __ballot(mine && !okP), mV = __ballot(mine && !okV), mD = __ballot(mine && !okD), mR = __ballot(mine && !okR);
                     const int stuck = mT ? __ffsll((long long)((mP | mV | mD | mR) ? (mP | mV | mD | mR) : mT)) - 1 : 0;
                     const int sb = __shfl(body, stuck, 64), so = __shfl(other, stuck, 64), si = __shfl(it, stuck, 64);
+                    int mPick = 0, mB = 0, mO = 0, mI = 0, mS = 0, mW = 0;
+                    if (MULTI) {
+                        /* the first body of the first timed-out sub-group that still has tasks: body, iteration | last << 8, watched offset, stamps minus base */
+                        const int g0 = mT ? ((__ffsll((long long)mT) - 1) & ~15) : 0;
+                        const unsigned long long act = __ballot(dbgBody >= 0 && (dbgIt & 255) < (dbgIt >> 8)) & (0xffffull << g0);
+                        mPick = act ? __ffsll((long long)act) - 1 : g0;
+                        mB = __shfl(dbgBody, mPick, 64); mO = __shfl(dbgOff, mPick, 64); mI = __shfl(dbgIt, mPick, 64); mS = __shfl(dbgStamp, mPick, 64); mW = __shfl(dbgSeen, mPick, 64);
+                    }
+                    if (MULTI && lane == 0 && mT && __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicCAS(errWord + 1, 0, w + 1) == 0) {
+                        errWord[2] = mB; errWord[3] = mO; errWord[4] = mI & 255; errWord[5] = mS; errWord[6] = mW; errWord[7] = mI >> 8; errWord[8] = mPick;
+                        errWord[9] = 0; errWord[10] = 0; errWord[11] = 0; errWord[12] = 0; errWord[13] = (int)mT; errWord[14] = (int)(mT >> 32); errWord[15] = cls + 100;
+                    } else
                     if (lane == 0 && mT && __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicCAS(errWord + 1, 0, w + 1) == 0) {
                         errWord[2] = sb; errWord[3] = so; errWord[4] = si; errWord[5] = (int)mP; errWord[6] = (int)(mP >> 32); errWord[7] = (int)mV; errWord[8] = (int)(mV >> 32);
                         errWord[9] = (int)mD; errWord[10] = (int)(mD >> 32); errWord[11] = (int)mR; errWord[12] = (int)(mR >> 32); errWord[13] = (int)mT; errWord[14] = (int)(mT >> 32); errWord[15] = cls;
@@ -652,13 +707,18 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             load_rest();
         }
         if (valid) prepare_task();
+        /* EXACT: a body with a contact whose owner another rank sweeps ends with one more task (final_store) */
+        const int itEnd = itStop + ((EXACT && (__ballot(finalD) & gMask) != 0) ? 1 : 0);
+        itEndOne = itEnd;
         GS_STAMP(3);
         for (;;) {
-            const bool active = valid && it < itStop;
+            const bool active = valid && it < itEnd;
             if (__ballot(active) == 0) break;
             if (active) poll_records();
             const bool laneOk = !active || (okP & okV & okD & okR);
-            const bool go = active && ((__ballot(laneOk) & gMask) == gMask);
+            const bool goAny = active && ((__ballot(laneOk) & gMask) == gMask);
+            const bool goF = EXACT && goAny && it >= itStop;
+            const bool go = goAny && !goF;
             GS_STAMP(0);
 #ifdef AVBD_DF_STATS
             stat[14] += 1;
@@ -693,12 +753,14 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 finish_solve();
                 ++it;
             }
+            if (goF) { final_store(); ++it; spins = 0; }
 #ifdef AVBD_DF_STATS
             if (go && gl == 0) { trec[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[3] = (unsigned)w; }
 #endif
             GS_STAMP(1);
             if (go) {
                 if (it < itStop) prepare_task();
+                else if (EXACT && it < itEnd) set_needs();            /* what the task behind the last iteration waits for */
                 spins = 0;
             }
             if (SHARD && __ballot(go)) {
@@ -721,7 +783,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 }
             }
             GS_STAMP(2);
-            if (__ballot(go) == 0 && !back_off()) return;
+            if (__ballot(goAny) == 0 && !back_off()) return;
         }
     } else {
         /* ---- several bodies per sub-group, out of order: a sub-group runs whichever of its bodies has its inputs published —
@@ -732,6 +794,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
          * examined in full only when that record has arrived.  Every pass of the wave runs the picks of all its sub-groups
          * together. ---- */
         int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
+        int itEndK = itStop;                                          /* EXACT: + the task that takes the owner's last dual (see the header table) */
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
@@ -740,12 +803,13 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         }
         /* the header table: three dependent loads per entry (incidence word -> pair -> is the partner swept?), four rounds in flight */
         for (int k0 = 0; k0 < rounds; k0 += 4) {
-            int ent[4], oth[4], bk[4]; bool hk[4];
+            int ent[4], oth[4], bk[4], e0s[4]; bool hk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = k0 + q < rounds ? k0 + q : rounds - 1;
                 bk[q] = __shfl(bodyK, gBase + k, 64);
                 const int e0 = __shfl(eBegK, gBase + k, 64), ne = __shfl(nEntK, gBase + k, 64);
+                e0s[q] = e0;
                 hk[q] = bk[q] >= 0 && gl < ne;
                 ent[q] = hk[q] ? inc[e0 + gl] : 0;
             }
@@ -756,9 +820,21 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                int w1 = 0;
-                if (hk[q]) { const bool mv = B.solved[oth[q]] != 0; w1 = oth[q] | ((mv ? 1 : 0) << 24) | (((!mv || oth[q] > bk[q]) ? 1 : 0) << 25); }
-                if (k0 + q < rounds) hdr[(k0 + q) * 64 + lane] = make_int2(ent[q], w1);
+                int w1 = 0, rc = 0;
+                if (hk[q]) {
+                    const bool mv = EXACT ? massPlane[oth[q]].y > 0.0f : B.solved[oth[q]] != 0;
+                    w1 = oth[q] | ((mv ? 1 : 0) << 24) | (((!mv || oth[q] > bk[q]) ? 1 : 0) << 25);
+                    if (EXACT) rc = Z.recIdx[e0s[q] + gl];
+                }
+                if (EXACT) {
+                    /* a body with a contact whose owner another rank sweeps ends with one more task: the owner's last dual into this rank's copy */
+                    const bool anyFinal = (__ballot(hk[q] && rc < 0) & gMask) != 0;
+                    if (anyFinal && k0 + q < rounds && gl == k0 + q) itEndK = itStop + 1;
+                }
+                if (k0 + q < rounds) {
+                    if constexpr (EXACT) hdr[(k0 + q) * 64 + lane] = make_int4(ent[q], w1, rc, 0);
+                    else hdr[(k0 + q) * 64 + lane] = make_int2(ent[q], w1);
+                }
             }
         }
         wave_sync();
@@ -769,13 +845,14 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         unsigned watchVal = 0;
         for (;;) {
             AVBD_MARK(g_examine);
-            const bool activeK = itK < itStop;
+            const bool activeK = itK < itEndK;
             if (__ballot(activeK) == 0) break;
             grpWaiting = (__ballot(activeK) & gMask) != 0;
             bool candK = activeK;
             if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
             if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
+            dbgBody = bodyK; dbgIt = itK | (itEndK << 8); dbgOff = blkOff; dbgStamp = (int)(blkStamp - X.base); dbgSeen = (int)(watchVal - X.base);
             GS_STAMP(12);                                              /* the look at the watched words (and whatever was still in flight) */
             bool sel = false, triedK = false;
             for (;;) {
@@ -799,7 +876,7 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                     const unsigned long long noGather = SHARD ? (__ballot(!okR) & gMask) : 0ull;
                     if ((noPose | noRest | noGather) == 0) {
                         sel = true;
-                        if (lane == k) { ++itK; ++blkStamp; }                /* the same partner is the likeliest to be late again */
+                        if (lane == k) { ++itK; ++blkStamp; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
                     } else if (noPose) {
                         /* watch the pose of the first partner that is late (its last record's stamp word) */
                         const int f = __ffsll((long long)noPose) - 1;
@@ -816,6 +893,9 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
             stat[14] += 1;
             if (__ballot(sel)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(sel && gl == 0)); }
 #endif
+            const bool selF = EXACT && sel && it >= itStop;             /* the owner's last dual into this rank's copy of the contact */
+            if (selF) { final_store(); spins = 0; }
+            if (EXACT) sel = sel && it < itStop;
             if (sel) prepare_task();
             GS_STAMP(2);
             if (sel) {
@@ -824,10 +904,11 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                 finish_solve();
                 GS_STAMP_ND(13);                                       /* dual: arithmetic and issue of its stores */
                 GS_STAMP(3);                                           /* ... until they are acknowledged */
-                if (it < itStop - 1) park_body();
+                if (it < itStop - 1 || (EXACT && (__ballot(finalD) & gMask) != 0)) park_body();   /* (EXACT: the task behind the last iteration reads the parked normal) */
                 GS_STAMP_ND(15);                                       /* park: issue */
                 spins = 0;
             }
+            if (EXACT) sel = sel || selF;
             AVBD_MARK(g_pass_end);
             if (SHARD && __ballot(sel)) {
                 /* iteration k of this wave is complete when every body it serves is past it (see the one-body form above) */
@@ -856,6 +937,32 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
         for (int i = 0; i < 16; ++i) o[i] = stat[i];
     }
 #endif
+}
+
+template <bool MULTI, int SHARDK>
+__global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
+                      Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z)
+{
+    iterate_groups<MULTI, SHARDK>(B, M, incStart, inc, P, errWord, cntW, X, plan, byClass, cap, sleepSel, Z, (int)blockIdx.x);
+}
+
+/* Exact cuts with several ranks on ONE device (the emulation of avbd_group_step): all ranks in one launch, `wgPerRank` workgroups
+ * each.  The ranks wait for each other's records, so their workgroups must all be resident at the same time; separate launches
+ * on separate streams are only that while every stream has a hardware queue of its own — a process with more streams than
+ * queues runs two of them one after the other, and the first then waits for the second forever.  (Between GPUs every rank is a
+ * launch of its own device.) */
+struct ExactRankArgs {
+    BodyTable B; ManifoldTable M; const int* incStart; const int* inc; SolverParams P; int* errWord; Counters* cntW; ResidentExchange X;
+    const GroupPlan* plan; const int* byClass; int cap; int sleepSel; ShardExchange Z; int multi;
+};
+__global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_iterate_groups_exact(const ExactRankArgs* __restrict__ args, int wgPerRank)
+{
+    const int rank = (int)blockIdx.x / wgPerRank, local = (int)blockIdx.x % wgPerRank;
+    const ExactRankArgs& A = args[rank];
+    if (A.multi) iterate_groups<true, 2>(A.B, A.M, A.incStart, A.inc, A.P, A.errWord, A.cntW, A.X, A.plan, A.byClass, A.cap, A.sleepSel, A.Z, local);
+    else iterate_groups<false, 2>(A.B, A.M, A.incStart, A.inc, A.P, A.errWord, A.cntW, A.X, A.plan, A.byClass, A.cap, A.sleepSel, A.Z, local);
 }
 
 } // namespace avbd

@@ -1197,6 +1197,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
 #include "avbd_iterate.h"
 #include "avbd_groups.h"
 #include "avbd_place.h"
+#include "avbd_cuts.h"
 namespace avbd {
 static_assert(kResLiteMaxEntriesDecl == kResLiteMaxEntries, "the topology kernels and the resident schedule must agree on the short product lines");
 

@@ -45,6 +45,12 @@ def main():
                 f.write(out)
     meta["trace_md5_300_steps"] = md5
 
+    # 1b. user-defined Force subclasses (tests/host/user_forces.h) compiled against the reference's own headers and sources:
+    #     the floats the reference computes for a user's Tether / Pin (oracle/user_force_ref.cpp, built by `make -C oracle ref`)
+    uf = os.path.join(H.ORACLE_DIR, "_ref", "user_force_ref")
+    subprocess.run([uf, os.path.join(HERE, "user_force_states.bin")], check=True)
+    meta["user_force_states.bin"] = "tests/host/user_forces.h against /root/reference/source: body states every 10 steps + the user force's rows"
+
     # 2. Stress1000: 13-float body state at the survey's checkpoints + the per-step diagnostics for 600 steps
     w = H.CpuWorld("ref")
     w.scene("Stress1000")

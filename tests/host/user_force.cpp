@@ -18,66 +18,8 @@
 static int checks = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } ++checks; } while (0)
 
-struct Tether : Force {                       // what a user would write against the reference's solver.h
-    vec3 rA, rB; float rest; int calls = 0;
-    Tether(Solver* s, Rigid* a, Rigid* b, const vec3& la, const vec3& lb, float k, float rest_) : Force(s, a, b), rA(la), rB(lb), rest(rest_)
-    {
-        stiffness[0] = k;
-        if (rest < 0) rest = length((a->position + rotate(a->orientation, rA)) - (b->position + rotate(b->orientation, rB)));
-        lambda[0] = 0.0f; penalty[0] = PENALTY_MIN; fmin[0] = -FLT_MAX; fmax[0] = FLT_MAX;
-    }
-    int getRowCount() const override { return 1; }
-    bool initialize() override { return true; }
-    vec3 delta() const { return (bodyA->position + rotate(bodyA->orientation, rA)) - (bodyB->position + rotate(bodyB->orientation, rB)); }
-    void computeConstraint(float) override { ++calls; C[0] = length(delta()) - rest; }
-    void computeDerivatives(vec3& Jl, vec3& Ja, const Rigid* body, int) const override
-    {
-        const vec3 d = delta();
-        const float len = length(d);
-        if (len < 1.0e-6f) { Jl = vec3(); Ja = vec3(); return; }
-        const vec3 n = d / len;
-        const float sign = body == bodyA ? 1.0f : -1.0f;
-        Jl = n * sign;
-        Ja = cross(body == bodyA ? rotate(body->orientation, rA) : rotate(body->orientation, rB), n) * sign;
-    }
-};
-
-struct Pin : Force {                          // five rows: anchor of bodyB held at a world point (3 hard rows), two soft angular rows with a motor
-    vec3 target, rB;
-    Pin(Solver* s, Rigid* b, const vec3& world, const vec3& local) : Force(s, nullptr, b), target(world), rB(local)
-    {
-        for (int i = 0; i < 5; ++i) { lambda[i] = 0.0f; penalty[i] = PENALTY_MIN; fmin[i] = -FLT_MAX; fmax[i] = FLT_MAX; stiffness[i] = i < 3 ? FLT_MAX : 200.0f; }
-        motor[4] = 0.25f;
-    }
-    int getRowCount() const override { return 5; }
-    bool initialize() override { return true; }
-    void computeConstraint(float) override
-    {
-        const vec3 d = target - (bodyB->position + rotate(bodyB->orientation, rB));
-        C[0] = d.x; C[1] = d.y; C[2] = d.z;
-        C[3] = 2.0f * bodyB->orientation.x; C[4] = 2.0f * bodyB->orientation.z;
-    }
-    void computeDerivatives(vec3& Jl, vec3& Ja, const Rigid* body, int row) const override
-    {
-        Jl = vec3(); Ja = vec3();
-        if (body != bodyB) return;
-        if (row < 3) {
-            const vec3 ax(row == 0 ? 1.0f : 0.0f, row == 1 ? 1.0f : 0.0f, row == 2 ? 1.0f : 0.0f);
-            Jl = ax * -1.0f;
-            Ja = cross(rotate(body->orientation, rB), ax) * -1.0f;
-        } else Ja = row == 3 ? vec3(1, 0, 0) : vec3(0, 0, 1);
-    }
-};
-
-static void buildScene(Solver* s, Rigid*& a, Rigid*& b)
-{
-    s->clear(); s->defaultParams();
-    new Rigid(s, {100, 1, 100}, 0.0f, 0.5f, {0, -0.5f, 0});
-    a = new Rigid(s, {1, 1, 1}, 1.0f, 0.5f, {0.0f, 0.5f, 0.0f}, quat(0.0f, 0.1f, 0.0f, 0.99498744f));
-    b = new Rigid(s, {1, 0.6f, 0.8f}, 2.0f, 0.4f, {0.2f, 1.9f, 0.1f}, quat(), {0.3f, 0.0f, -0.2f});
-    new Rigid(s, {0.7f, 0.7f, 0.7f}, 1.0f, 0.6f, {0.1f, 1.15f, 0.0f});            // a cube between them: contacts share the bodies with the tether
-    s->iterations = 8;
-}
+#define AVBD_SYNC_FORCES(s) (s)->syncForces()
+#include "user_forces.h"
 
 static bool sameState(Solver* x, Solver* y)
 {
@@ -89,7 +31,7 @@ static bool sameState(Solver* x, Solver* y)
     return !p && !q;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     for (float k : {400.0f, FLT_MAX}) {       // finite stiffness: primal rows only; FLT_MAX: lambda / penalty through the dual as well
         Solver* u = new Solver(); Solver* r = new Solver();
@@ -128,6 +70,19 @@ int main()
         for (Force* f = s->forces; f; f = f->next) seen += (f == pin) + (f == j);
         CHECK(seen == 2);
         delete s;
+    }
+    if (argc > 1) {   // the same classes compiled against the REFERENCE's headers produced this file (oracle/user_force_ref.cpp): bit for bit
+        std::vector<float> mine;
+        runUserForceScenes(mine);
+        std::vector<float> ref(mine.size() + 1);
+        FILE* f = std::fopen(argv[1], "rb");
+        CHECK(f != nullptr);
+        const size_t n = std::fread(ref.data(), sizeof(float), ref.size(), f);
+        std::fclose(f);
+        CHECK(n == mine.size());
+        for (size_t i = 0; i < n; ++i)
+            if (std::memcmp(&mine[i], &ref[i], 4)) { std::printf("FAILED: float %zu of the pinned user-force runs: device %a, reference %a\n", i, (double)mine[i], (double)ref[i]); return 1; }
+        ++checks;
     }
     std::printf("OK %d\n", checks);
     return 0;

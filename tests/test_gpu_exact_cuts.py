@@ -1,0 +1,109 @@
+"""Exact cuts between the ranks of a sharded scene (AVBD_SHARD_EXACT=1, csrc/avbd_cuts.h): every rank sweeps its slab
+with the single-GPU protocol and polls the stamped records of the bodies and contacts on the other side of a cut exactly as it
+polls local ones, so the result is THE single-GPU sweep — bit for bit — instead of the Jacobi coupling of the all-gather forms.
+Emulated on one MI355X: the ranks are contexts of one process driven by avbd_group_step, their persistent launches resident side
+by side, the records of all ranks in one allocation (between GPUs: peer-to-peer windows)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _ranks(scene, n, axis):
+    pkg = H.load_product()
+    worlds = [H.HipWorld() for _ in range(n)]
+    for w in worlds:
+        w.scene(scene)
+    b = worlds[0].bodies()
+    owner = pkg.partition_by_axis(b["pos"], b["invMass"], n, axis=axis)
+    for r, w in enumerate(worlds):
+        w.w.set_ownership(n, r, owner)
+    return pkg, worlds, owner
+
+
+def _same_forces(single_f, rank_f, owner, rank, what):
+    """the rank's manifolds that touch a body it sweeps == the single-GPU manifolds that touch such a body, in list order.  The copy
+    on the rank that does NOT sweep the contact's owner (the earlier-created body) takes lambda / penalty / stick / normal from the
+    owner's records; its C / fmin / fmax rows and `penetration` (outputs of the owner's last computeConstraint, never read by the
+    solver) are the owner rank's business and are not compared there."""
+    def touching(f):
+        a, b = f["bodyA"], f["bodyB"]
+        return (owner[np.maximum(a, 0)] == rank) | (owner[np.maximum(b, 0)] == rank)
+    s, g = single_f[touching(single_f)], rank_f[touching(rank_f)]
+    assert len(s) == len(g), f"{what}: {len(g)} manifolds on rank {rank}, {len(s)} expected"
+    assert np.array_equal(s["bodyA"], g["bodyA"]) and np.array_equal(s["bodyB"], g["bodyB"]), f"{what}: force list order differs on rank {rank}"
+    for fld in ("numContacts", "lambda", "penalty", "combinedFriction"):
+        assert H.same_bits(s[fld], g[fld]), f"{what}: {fld} differs on rank {rank}"
+    for fld in ("feature", "rA", "rB", "normal", "C0_n", "C0_t", "stick"):
+        assert H.same_bits(s["contacts"][fld], g["contacts"][fld]), f"{what}: contact {fld} differs on rank {rank}"
+    a, b = s["bodyA"], s["bodyB"]
+    dyn_a, dyn_b = owner[np.maximum(a, 0)] >= 0, owner[np.maximum(b, 0)] >= 0
+    own_body = np.where(dyn_a & dyn_b, np.minimum(a, b), np.where(dyn_a, a, b))      # the earlier-created dynamic endpoint runs the dual
+    mine = owner[own_body] == rank
+    for fld in ("C", "fmin", "fmax"):
+        assert H.same_bits(s[fld][mine], g[fld][mine]), f"{what}: rows {fld} of contacts this rank owns differ on rank {rank}"
+    assert H.same_bits(s["contacts"]["penetration"][mine], g["contacts"]["penetration"][mine])
+
+
+@pytest.mark.parametrize("nranks,axis", [(2, 2), (4, 2), (2, 0)])
+def test_cut_pile_exact_cuts_reproduce_the_single_gpu_sweep_bit_for_bit(monkeypatch, nranks, axis):
+    monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+    scene = "PackedGrid:4,4,8"
+    pkg, worlds, owner = _ranks(scene, nranks, axis)
+    monkeypatch.delenv("AVBD_SHARD_EXACT")
+    single = H.HipWorld(); single.scene(scene)
+    for s in range(8):
+        pkg.group_step([w.w for w in worlds], 5)
+        single.step(5)
+        bs, fs = single.bodies(), single.forces()
+        for r, w in enumerate(worlds):
+            assert int(w.w.stats()["schedule"]) == 4
+            assert H.same_bits(bs, w.bodies()), f"rank {r}: body state differs from the single-GPU sweep after {5 * (s + 1)} steps"
+            _same_forces(fs, w.forces(), owner, r, f"after {5 * (s + 1)} steps")
+    assert int(single.diag()["activeContacts"]) > 300
+
+
+def test_exact_cuts_with_several_bodies_per_sub_group(monkeypatch):
+    """few resident waves: every sub-group serves several bodies (k_iterate_groups<true, 2>: header table with record indices,
+    the task behind the last iteration examined like any other)"""
+    monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+    monkeypatch.setenv("AVBD_GROUPS_WAVES", "8")
+    scene = "PackedGrid:4,4,8"
+    pkg, worlds, owner = _ranks(scene, 2, 2)
+    monkeypatch.delenv("AVBD_SHARD_EXACT"); monkeypatch.delenv("AVBD_GROUPS_WAVES")
+    single = H.HipWorld(); single.scene(scene)
+    pkg.group_step([w.w for w in worlds], 30)
+    single.step(30)
+    bs, fs = single.bodies(), single.forces()
+    for r, w in enumerate(worlds):
+        assert H.same_bits(bs, w.bodies()), f"rank {r}: body state differs from the single-GPU sweep"
+        _same_forces(fs, w.forces(), owner, r, "after 30 steps")
+
+
+@pytest.mark.parametrize("scene,nranks,steps,min_manifolds", [("StressN:28", 4, 230, 30000), ("StressN:32", 4, 245, 45000), ("StressN:40", 2, 150, 20000)])
+def test_falling_piles_with_exact_cuts_reproduce_the_single_gpu_sweep(monkeypatch, scene, nranks, steps, min_manifolds):
+    """21 952 and 32 768 cubes over four ranks deep into the landing (every cut carries load; three to five bodies per sub-group),
+    and configs[3]'s 64 000 cubes over two ranks through the landing of the first layers (32 000 bodies per rank, eight per
+    sub-group — the most the exact form's header table holds, csrc/avbd_groups.h; deeper into the landing the plan no longer fits
+    ONE GPU's waves and the step falls back to the all-gather forms — with a GPU per rank it has eight times the room): all ranks
+    resident in one launch, no exchange during the loop, every rank bit-identical to the single-GPU sweep — bodies and forces."""
+    monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+    pkg, worlds, owner = _ranks(scene, nranks, 0)
+    monkeypatch.delenv("AVBD_SHARD_EXACT")
+    single = H.HipWorld(); single.scene(scene)
+    t0 = time.perf_counter(); pkg.group_step([w.w for w in worlds], steps)
+    for w in worlds:
+        w.w.synchronize()
+    t1 = time.perf_counter(); single.step(steps); single.w.synchronize(); t2 = time.perf_counter()
+    print(f"{scene}, {steps} steps: {nranks} ranks with exact cuts on one GPU {1e3 * (t1 - t0) / steps:.2f} ms/step, one context {1e3 * (t2 - t1) / steps:.2f} ms/step")
+    bs, fs = single.bodies(), single.forces()
+    assert int(single.w.stats()["numManifolds"]) > min_manifolds
+    for r, w in enumerate(worlds):
+        assert int(w.w.stats()["schedule"]) == 4
+        assert H.same_bits(bs, w.bodies()), f"rank {r}: body state differs from the single-GPU sweep after {steps} steps"
+        _same_forces(fs, w.forces(), owner, r, f"after {steps} steps")

@@ -145,7 +145,7 @@ def test_64000_cubes_landed_pile_group_schedule_matches_the_parked_sweep_and_the
     (AVBD_GROUPS=0) from the same device state must agree bit for bit, bodies and forces; and ONE step of the CPU restatement from
     that state (~20 s: its broadphase is O(n^2)) must agree with the device's first step of the window."""
     g0 = H.HipWorld(); g0.scene("StressN:40"); g0.step(470); g0.w.synchronize()
-    assert int(g0.w.stats()["schedule"]) == 4 and int(g0.w.stats()["numManifolds"]) > 150000
+    assert int(g0.w.stats()["schedule"]) == 4 and int(g0.w.stats()["numManifolds"]) > 120000
     b0, f0, s0 = g0.bodies(), g0.forces(), g0.step_index()
     o = H.CpuWorld("orc"); o.scene("StressN:40")
     o.set_bodies(b0); o.set_forces(f0); o.set_step_index(s0)

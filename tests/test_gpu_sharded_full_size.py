@@ -156,37 +156,45 @@ def test_config4_64000_cubes_and_10k_welds_over_eight_ranks():
     assert np.isfinite(err)
 
 
+_TWO_RANK_CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import harness as H
+pkg = H.load_product()
+worlds = [H.HipWorld() for _ in range(2)]
+for w in worlds:
+    w.scene("StressN:40")
+b0 = worlds[0].bodies()
+owner = pkg.partition_by_axis(b0["pos"], b0["invMass"], 2, axis=0)
+for r, w in enumerate(worlds):
+    w.w.set_ownership(2, r, owner)
+pkg.group_step([w.w for w in worlds], 170)
+for w in worlds:
+    w.w.synchronize()
+print("RESULT", repr(([int(w.w.stats()["schedule"]) for w in worlds], [int(w.w.stats()["numManifolds"]) for w in worlds],
+      [hashlib.md5(w.bodies().tobytes()).hexdigest() + hashlib.md5(w.forces().tobytes()).hexdigest() for w in worlds])))
+"""
+
+
 def test_config3_two_ranks_persistent_form_matches_one_launch_per_iteration_through_the_landing():
     """configs[3]'s scene cut in TWO (32 000 owned bodies per rank: ten bodies per sub-group, tasks with remote partners waiting on
     the gather word, interior tasks running ahead of the exchange), from the start of the fall through the landing of the first
     layers (contacts across the cut from step ~135): the persistent launch and one launch per iteration are the same iteration, so
     both ranks must hold the same bits, bodies and forces, after 170 steps.  (More than two contexts with several bodies per
-    sub-group on ONE device take one launch per iteration — avbd_group_step, csrc/avbd_capi.hip — so two is what exercises the
-    persistent form at this size on one GPU.)"""
+    sub-group on ONE device take one launch per iteration — avbd_group_step, csrc/avbd_capi.hip.)
+    Each form runs in a process of its own: the two persistent launches and their two exchange streams need a hardware queue each,
+    and a process that has created other streams before (this test session has) may be given shared ones — the launches then run
+    one after the other and the first waits for the second's rows for ever (one context per GPU has its own queues)."""
     import os
-    pkg = H.load_product()
-    finals = {}
+    import subprocess
+    import sys
+    out = {}
     for mode in ("1", "0"):
-        os.environ["AVBD_SHARD_PERSISTENT"] = mode
-        try:
-            worlds = [H.HipWorld() for _ in range(2)]
-            for w in worlds:
-                w.scene("StressN:40")
-            b0 = worlds[0].bodies()
-            owner = pkg.partition_by_axis(b0["pos"], b0["invMass"], 2, axis=0)
-            for r, w in enumerate(worlds):
-                w.w.set_ownership(2, r, owner)
-            pkg.group_step([w.w for w in worlds], 170)
-            for w in worlds:
-                w.w.synchronize()
-            if mode == "1":
-                assert all(int(w.w.stats()["schedule"]) == 4 for w in worlds), [int(w.w.stats()["schedule"]) for w in worlds]
-            assert all(int(w.w.stats()["numManifolds"]) > 10000 for w in worlds)
-            finals[mode] = [(w.bodies().tobytes(), w.forces().tobytes()) for w in worlds]
-            for w in worlds:
-                w.close()
-        finally:
-            del os.environ["AVBD_SHARD_PERSISTENT"]
-    for r in range(2):
-        assert finals["1"][r][0] == finals["0"][r][0], f"rank {r}: body state differs between the persistent and the per-iteration form"
-        assert finals["1"][r][1] == finals["0"][r][1], f"rank {r}: force state differs between the persistent and the per-iteration form"
+        env = dict(os.environ, AVBD_SHARD_PERSISTENT=mode)
+        r = subprocess.run([sys.executable, "-c", _TWO_RANK_CHILD, os.path.dirname(os.path.abspath(__file__))], env=env, capture_output=True, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+        out[mode] = eval(lines[-1][len("RESULT"):])
+    assert out["1"][0] == [4, 4], out["1"][0]
+    assert min(out["1"][1]) > 10000
+    assert out["1"][2] == out["0"][2], "the persistent and the per-iteration form differ (md5 of bodies + forces per rank)"
