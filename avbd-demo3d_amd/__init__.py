@@ -66,7 +66,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings",
+    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_device_count", "avbd_set_joint_angular_sign",
 ]
 
 
@@ -308,6 +308,12 @@ class World:
     def set_state13(self, s):
         s = _f32(s, (-1, 13))
         self._chk(self.L.avbd_upload_state13(self.h, _fp(s), s.shape[0]))
+
+    def set_joint_angular_sign(self, corrected):
+        self._chk(self.L.avbd_set_joint_angular_sign(self.h, int(corrected)))
+
+    def set_shard_mode(self, mode):
+        self._chk(self.L.avbd_set_shard_mode(self.h, int(mode)))
 
     def set_step_index(self, s):
         self._chk(self.L.avbd_set_step_index(self.h, int(s)))

@@ -202,6 +202,7 @@ struct AvbdContext {
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
     /* exact cuts (avbd_cuts.h): the stamped records of all ranks in one address space; the first context of a group owns it */
+    bool jointAngularFix = false;  /* avbd_set_joint_angular_sign(ctx, 1): Joint angular rows with J = dC/dtheta instead of the reference's sign */
     bool shardExact = false;       /* AVBD_SHARD_EXACT=1: avbd_group_step sweeps every rank's slab with the single-GPU protocol (bit-identical to one GPU) */
     DevArr<float4> xsPose, xsVisit, xsDual; size_t xsLocalSlots = 0, xsTotalSlots = 0; int xsRanks = 0; unsigned xsSerial = 0;
     DevArr<int> dOwner, dCutOf, dCutMan, dRecIdx; DevArr<unsigned long long> dCutKeys; DevArr<CutCounters> dCutCnt;
@@ -1711,7 +1712,34 @@ int avbd_add_joint(AvbdContext* c, int bodyA, int bodyB, const float rA[3], cons
     }
     for (int i = 0; i < 3; ++i) { g.stiffness[i] = linearStiffness; g.lambda[i] = 0; g.penalty[i] = kPenaltyMin; }
     for (int i = 3; i < 6; ++i) { g.stiffness[i] = angularStiffness; g.lambda[i] = 0; g.penalty[i] = kPenaltyMin; }
+    g.pad = c->jointAngularFix ? 1 : 0;
     return add_gforce(c, g);
+}
+
+int avbd_set_joint_angular_sign(AvbdContext* c, int corrected)
+{
+    if (!c) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = gforces_to_host(c);                                      /* the rows the device has advanced */
+    if (rc) return rc;
+    c->jointAngularFix = corrected != 0;
+    for (GForce& g : c->hG) if (g.kind == FK_JOINT) g.pad = c->jointAngularFix ? 1 : 0;
+    c->gStale = true;
+    return AVBD_OK;
+}
+
+int avbd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int avbd_set_shard_mode(AvbdContext* c, int mode)
+{
+    if (!c || mode < 0 || mode > 1) return AVBD_E_INVALID;
+    c->shardExact = mode == 1;
+    return AVBD_OK;
 }
 
 int avbd_add_spring(AvbdContext* c, int bodyA, int bodyB, const float rA[3], const float rB[3], float stiffness, float rest)
@@ -2327,6 +2355,7 @@ __global__ void k_row_api(BodyTable B, ManifoldTable M, GForce* gf, int kind, in
         if (kind == FK_JOINT) {
             JointRows j;
             j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+            j.fixAngular = (f.pad & 1) != 0;
             if (mode == 0) {
                 joint_compute_constraint(j, hasA, posA, rotA, posB, rotB);
                 for (int r = 0; r < 6; ++r) { f.C[r] = j.C[r]; f.fmin[r] = -FLT_MAX; f.fmax[r] = FLT_MAX; out[r] = j.C[r]; out[12 + r] = -FLT_MAX; out[24 + r] = FLT_MAX; out[36 + r] = f.lambda[r]; }

@@ -401,6 +401,7 @@ __device__ __forceinline__ void eval_entry(int ent, const BodyTable& B, const Ma
         JointRows j;
         j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
         j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+        j.fixAngular = (f.pad & 1) != 0;
         if (isA) joint_compute_constraint(j, hasA, L.pos, L.rot, opos, orot);
         else     joint_compute_constraint(j, hasA, opos, orot, L.pos, L.rot);
         for (int k = 0; k < 3; ++k) {

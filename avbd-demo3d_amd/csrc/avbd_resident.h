@@ -290,7 +290,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
     bool isJoint = false, hasA = true;                               /* a lane holds one Manifold contact or one half (3 rows) of a Joint */
     int co = -1;                                                     /* COLO: wave of this workgroup that holds the partner, -1: none */
-    q4 jq0 = identq(); f3 jStiff = zero3(), jMotor = zero3(); int jPart = 0;
+    q4 jq0 = identq(); f3 jStiff = zero3(), jMotor = zero3(); int jPart = 0; bool jFix = false;
     float oinv = 0.0f, fric = 0.0f;
     ContactRows c;
     c.rA = c.rB = c.normal = c.u1 = c.u2 = zero3(); c.C0n = c.C0t1 = c.C0t2 = 0.0f; c.penetration = 0.0f; c.stick = false;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
              * only the owner writes during the launch (and where it parks them between its tasks) */
             const GForce& f = gf[idx >> 1];
             c.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); c.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
-            jq0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
+            jq0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]); jFix = (f.pad & 1) != 0;
             for (int k = 0; k < 3; ++k) { c.lambda[k] = f.lambda[jPart * 3 + k]; c.penalty[k] = f.penalty[jPart * 3 + k]; c.C[k] = f.C[jPart * 3 + k]; }
             jStiff = mk3(f.stiffness[jPart * 3], f.stiffness[jPart * 3 + 1], f.stiffness[jPart * 3 + 2]);
             jMotor = mk3(f.motor[jPart * 3], f.motor[jPart * 3 + 1], f.motor[jPart * 3 + 2]);
@@ -477,7 +477,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 else needP = false;
             }
             /* Jacobians of this body's three rows (joint.cpp:108-139): functions of its own orientation only */
-            JointRows jr0; jr0.rA = c.rA; jr0.rB = c.rB; jr0.q0 = jq0;
+            JointRows jr0; jr0.rA = c.rA; jr0.rB = c.rB; jr0.q0 = jq0; jr0.fixAngular = jFix;
             for (int k = 0; k < 3; ++k) {
                 f3 Jl, Ja;
                 joint_compute_derivatives(jr0, isA, false, L.rot, jPart * 3 + k, Jl, Ja);

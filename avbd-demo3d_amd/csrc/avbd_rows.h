@@ -312,6 +312,7 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, const BoxPose& A, float fricti
 struct JointRows {
     f3 rA, rB; q4 q0;
     float C[6];
+    bool fixAngular = false;     /* non-default option (avbd_set_joint_angular_sign): angular rows with the sign that matches C */
 };
 
 AVBD_HD void joint_compute_constraint(JointRows& j, bool hasA, f3 posA, q4 rotA, f3 posB, q4 rotB)  /* joint.cpp:68-106 */
@@ -342,7 +343,9 @@ AVBD_HD void joint_compute_derivatives(const JointRows& j, bool isBodyA, bool bo
     } else {
         int k = row - 3;
         f3 ax = mk3(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
-        Ja = ax * sign;
+        /* joint.cpp:129-138 as written: +e_k for bodyA, -e_k for bodyB, although C_ang = 2 vec(qA* qB q0*) grows with bodyB's rotation —
+         * the reference's sign (bug-compatible default).  The option flips it so that J = dC/dtheta. */
+        Ja = ax * (j.fixAngular ? -sign : sign);
     }
 }
 

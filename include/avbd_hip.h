@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AVBD_ABI_VERSION 2   /* 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 is a subset) */
+#define AVBD_ABI_VERSION 3   /* 3: avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
 
 enum {
     AVBD_OK = 0,
@@ -286,6 +286,18 @@ int  avbd_comm_unique_id(char id[128]);                                   /* ncc
 int  avbd_comm_init(AvbdContext* ctx, int nranks, int rank, const char id[128]);  /* ncclCommInitRank; avbd_step then exchanges per iteration */
 /* the same sharded schedule for `n` contexts living in ONE process (exchange by device-to-device copies) */
 int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
+/* How the ranks of avbd_group_step couple across a cut.  0 (default; AVBD_SHARD_EXACT=1 changes it): the all-gather schedule above
+ * (north_star's form: Jacobi across the cut).  1: EXACT cuts — every rank sweeps its slab with the single-GPU protocol and polls
+ * the stamped pose / visit / dual records of the bodies and contacts across a cut exactly as it polls local ones (one address
+ * space for the records of all ranks: one allocation for contexts of one process, peer-to-peer windows between GPUs); no exchange
+ * during the iteration loop, one copy of the final poses per step, results bit-identical to the single-GPU sweep
+ * (tests/test_gpu_exact_cuts.py).  Contacts-only scenes whose ranks share a device; otherwise the step takes the all-gather form. */
+int  avbd_set_shard_mode(AvbdContext* ctx, int mode);
+int  avbd_device_count(void);                                            /* visible gfx950 devices (0 without one) */
+/* Joint (joint.cpp:108-139): 0 (default) keeps the reference's angular Jacobian sign — bug-compatible: body-body welds blow up,
+ * SURVEY.md §7-5 —, 1 uses J_angular = dC/dtheta (-e_k for bodyA, +e_k for bodyB), with which welds hold.  Applies to the
+ * joints that exist and to those added later.  There is no such switch in the reference. */
+int  avbd_set_joint_angular_sign(AvbdContext* ctx, int corrected);
 
 /* ---- measurement ---- */
 int  avbd_profile_enable(AvbdContext* ctx, int enable);

@@ -528,3 +528,36 @@ def test_debug_race_checker_accepts_every_schedule(monkeypatch):
             monkeypatch.delenv(k)
     g = H.HipWorld(); g.scene("Packed:12"); g.set_params(iterations=4); g.step(6); g.w.synchronize()
     assert int(g.w.stats()["schedule"]) == 4
+
+
+def test_corrected_joint_sign_option_welds_hold(monkeypatch):
+    """avbd_set_joint_angular_sign(ctx, 1) (no such switch in the reference): with J_angular = dC/dtheta two
+    cubes welded face to face fall, land and settle as ONE rigid body, and a tilted cube welded to the world hangs still; with the
+    reference's sign (default, bug-compatible — covered bit for bit by the joint fixtures) the same pair is flung apart."""
+    def build(g):
+        g.add_body((100, 1, 100), 0.0, 0.5, (0, -0.5, 0))
+        a = g.add_body((1, 1, 1), 1.0, 0.5, (0.0, 2.0, 0.0))
+        b = g.add_body((1, 1, 1), 1.0, 0.5, (1.0, 2.0, 0.0))
+        c = g.add_body((1, 1, 1), 1.0, 0.5, (5.0, 3.0, 0.0), quat=(0.0, 0.0, 0.19866933, 0.98006658))
+        return a, b, c
+    g = H.HipWorld()
+    a, b, c = build(g)
+    g.w.set_joint_angular_sign(1)
+    g.add_joint(a, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+    g.add_joint(-1, c, (5.0, 3.0, 0.0))
+    g.step(240)
+    bd = g.bodies()
+    assert np.isfinite(bd["pos"]).all() and np.isfinite(bd["quat"]).all()
+    rel = bd["pos"][b] - bd["pos"][a]
+    assert abs(float(np.linalg.norm(rel)) - 1.0) < 2e-2, rel                      # still one cube edge apart
+    assert abs(float(np.abs(np.dot(bd["quat"][a], bd["quat"][b]))) - 1.0) < 1e-3    # same orientation
+    assert float(np.abs(bd["linVel"][[a, b]]).max()) < 5e-2 and 0.4 < float(bd["pos"][a][1]) < 0.6   # at rest on the ground
+    assert float(np.linalg.norm(bd["pos"][c] - np.array([5.0, 3.0, 0.0], np.float32))) < 2e-2        # the world weld holds its anchor
+    assert float(np.abs(bd["angVel"][c]).max()) < 5e-2
+    # the default sign on the same scene: the welded pair does not stay together (the reference's behaviour)
+    r = H.HipWorld()
+    a, b, c = build(r)
+    r.add_joint(a, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+    r.step(60)
+    br = r.bodies()
+    assert not (abs(float(np.linalg.norm(br["pos"][b] - br["pos"][a])) - 1.0) < 2e-2 and abs(float(np.abs(np.dot(br["quat"][a], br["quat"][b]))) - 1.0) < 1e-3)
