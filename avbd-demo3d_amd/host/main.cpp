@@ -10,7 +10,10 @@
  * (checkpoint after the last step / resume from a checkpoint instead of building --scene: SURVEY.md §8 f3),
  * --remove-body <creation index> --remove-at <step> (`delete body` before that step, through the host mirror),
  * --pick ox,oy,oz,dx,dy,dz (after the last step: Solver::pick along that ray; prints one `Pick:` line with the body id,
- * creation index and body-local hit point, floats as hex so the line can be compared bit for bit).
+ * creation index and body-local hit point, floats as hex so the line can be compared bit for bit),
+ * --gpus N [--cuts exact|gather] (the scene sharded over N ranks of this process: N contexts on the visible devices, round robin
+ * — on one GPU they share it —, slabs along x, Solver::stepGroup; `gather` = one all-gather per iteration, Jacobi across the cuts
+ * (default, BASELINE configs[3..4]), `exact` = bit-identical to --gpus 1; implies --batch; state and --dump come from rank 0).
  */
 #include "solver.h"
 #include "joint.h"
@@ -34,6 +37,7 @@ int main(int argc, char** argv)
     int removeBody = -1, removeAt = -1;   /* --remove-body <creation index> --remove-at <step>: `delete body` mid-run */
     int steps = 300; /* main.cpp:192 */
     bool quiet = false, batch = false;
+    int gpus = 1; bool exactCuts = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--nogfx") || !strcmp(argv[i], "--headless")) { /* this build is always headless */ }
         else if ((!strcmp(argv[i], "--scene") || !strcmp(argv[i], "-s")) && i + 1 < argc) requested = argv[++i];
@@ -47,26 +51,43 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--remove-at") && i + 1 < argc) removeAt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--pick") && i + 1 < argc) pickRay = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) setenv("AVBD_DEVICE", argv[++i], 1);
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = atoi(argv[++i]); if (gpus < 1) gpus = 1; }
+        else if (!strcmp(argv[i], "--cuts") && i + 1 < argc) exactCuts = !strcmp(argv[++i], "exact");
     }
 
+    if (gpus > 1) { batch = true; quiet = true; }
     Solver* solver = new Solver();
     if (!quiet) { solver->enableDiagnostics = true; solver->logFrequency = 1; } /* main.cpp:206-209 */
+    std::vector<Solver*> ranks(1, solver);
+    for (int r = 1; r < gpus; ++r) {                                   /* one context per rank, devices round robin */
+        const int nd = avbd_device_count();
+        char dev[16]; snprintf(dev, sizeof(dev), "%d", nd > 0 ? r % nd : 0);
+        setenv("AVBD_DEVICE", dev, 1);
+        ranks.push_back(new Solver());
+    }
 
     /* unknown names silently select scene 0 "Empty" (main.cpp:211-219) */
     const char* shown = sceneNames[0];
-    if (loadPath) {
-        solver->loadSnapshot(loadPath);
-        shown = loadPath;
-    } else {
-        int idx = requested ? buildSceneByName(solver, requested) : -1;
-        if (idx < 0) scenes[0](solver);
-        else if (idx < sceneCount) shown = sceneNames[idx];
-        else shown = requested;
+    for (Solver* s : ranks) {
+        if (loadPath) {
+            s->loadSnapshot(loadPath);
+            shown = loadPath;
+        } else {
+            int idx = requested ? buildSceneByName(s, requested) : -1;
+            if (idx < 0) scenes[0](s);
+            else if (idx < sceneCount) shown = sceneNames[idx];
+            else shown = requested;
+        }
     }
+    if (gpus > 1) Solver::shardAcross(ranks.data(), gpus, 0, exactCuts);
 
     if (!quiet) printf("Running in headless mode: scene '%s', steps=%d\n", shown, steps);
     auto t0 = std::chrono::steady_clock::now();
-    if (batch) {
+    if (gpus > 1) {
+        for (Solver* s : ranks) s->hostSync = false;
+        Solver::stepGroup(ranks.data(), gpus, steps);
+        solver->pull();
+    } else if (batch) {
         solver->hostSync = false;
         solver->stepMany(steps);
         solver->pull();
@@ -91,8 +112,8 @@ int main(int argc, char** argv)
     auto t1 = std::chrono::steady_clock::now();
     if (quiet) {
         double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\"}\n", shown, steps, ms,
-               steps ? ms / steps : 0.0);
+        printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\", \"ranks\": %d, \"cuts\": \"%s\"}\n", shown, steps, ms,
+               steps ? ms / steps : 0.0, gpus, gpus > 1 ? (exactCuts ? "exact" : "all-gather per iteration") : "none");
     }
     if (pickRay) {
         float r[6] = {0, 0, 0, 0, 0, 0};
@@ -109,6 +130,6 @@ int main(int argc, char** argv)
         if (n) avbd_download_bodies(solver->context(), hb.data(), n);
         if (FILE* f = fopen(dumpPath, "wb")) { fwrite(hb.data(), sizeof(AvbdBody), (size_t)n, f); fclose(f); }
     }
-    delete solver;
+    for (size_t r = ranks.size(); r-- > 0;) delete ranks[r];
     return 0;
 }

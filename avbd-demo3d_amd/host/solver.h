@@ -185,6 +185,12 @@ struct Solver {
      * contact manifolds and joints/springs live on the device (syncForces() mirrors the manifolds on demand). */
     void saveSnapshot(const char* path);
     void loadSnapshot(const char* path);
+    /* One scene over several GPUs (BASELINE configs[3..4]; absent in the reference): `n` Solvers that hold the SAME scene, one per
+     * rank — shardAcross cuts the dynamic bodies into equal slabs along `axis` (avbd_partition_by_axis) and gives solver r slab r;
+     * stepGroup then steps all of them in lock-step (avbd_group_step) and downloads the state into every Solver's mirrors.
+     * exactCuts: results bit-identical to one GPU (avbd_set_shard_mode(ctx, 1)); otherwise one all-gather per iteration. */
+    static void shardAcross(Solver** solvers, int n, int axis, bool exactCuts);
+    static void stepGroup(Solver** solvers, int n, int steps);
     AvbdContext* context() const { return ctx; }
     int bodyCount() const { return numBodies; }
     Rigid* bodyByIndex(int i) const;

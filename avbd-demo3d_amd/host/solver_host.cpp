@@ -594,6 +594,43 @@ void Solver::stepMany(int n)
     if (mirrorManifolds) syncForces();
 }
 
+void Solver::shardAcross(Solver** solvers, int n, int axis, bool exactCuts)
+{
+    if (!solvers || n < 1) return;
+    Solver* s0 = solvers[0];
+    for (int r = 0; r < n; ++r) { solvers[r]->flush(); solvers[r]->pushParams(); }
+    const int nb = s0->numBodies;
+    std::vector<AvbdBody> hb((size_t)std::max(nb, 1));
+    if (nb) { int rc = avbd_download_bodies(s0->ctx, hb.data(), nb); if (rc < 0) s0->fail("avbd_download_bodies", rc); }
+    std::vector<float> pos((size_t)3 * nb), inv((size_t)nb);
+    for (int i = 0; i < nb; ++i) { pos[3 * i] = hb[i].position[0]; pos[3 * i + 1] = hb[i].position[1]; pos[3 * i + 2] = hb[i].position[2]; inv[i] = hb[i].invMass; }
+    std::vector<int> owner((size_t)std::max(nb, 1), -1);
+    int rc = avbd_partition_by_axis(nb, pos.data(), inv.data(), n, axis, owner.data());
+    if (rc) s0->fail("avbd_partition_by_axis", rc);
+    for (int r = 0; r < n; ++r) {
+        if (solvers[r]->numBodies != nb) solvers[r]->fail("shardAcross: the solvers do not hold the same scene", AVBD_E_INVALID);
+        if ((rc = avbd_set_ownership(solvers[r]->ctx, n, r, owner.data(), nb))) solvers[r]->fail("avbd_set_ownership", rc);
+        if ((rc = avbd_set_shard_mode(solvers[r]->ctx, exactCuts ? 1 : 0))) solvers[r]->fail("avbd_set_shard_mode", rc);
+    }
+}
+
+void Solver::stepGroup(Solver** solvers, int n, int steps)
+{
+    if (!solvers || n < 1) return;
+    std::vector<AvbdContext*> ctxs((size_t)n);
+    for (int r = 0; r < n; ++r) {
+        Solver* s = solvers[r];
+        s->flush(); s->pushParams();
+        if (s->hostSync) s->pushEditedBodies();
+        for (Manifold* m : s->impl->manifolds) m->listIndex = -1;
+        for (Force* f : s->impl->userForces) f->listIndex = -1;
+        ctxs[(size_t)r] = s->ctx;
+    }
+    int rc = avbd_group_step(ctxs.data(), n, steps);
+    if (rc) solvers[0]->fail("avbd_group_step", rc);
+    for (int r = 0; r < n; ++r) { solvers[r]->stepIndex += steps; if (solvers[r]->hostSync) solvers[r]->pull(); }
+}
+
 void Solver::step()                                                        /* solver.cpp:255-514 */
 {
     stepMany(1);
