@@ -711,9 +711,13 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         const int itEnd = itStop + ((EXACT && (__ballot(finalD) & gMask) != 0) ? 1 : 0);
         itEndOne = itEnd;
         GS_STAMP(3);
+        /* The first half of a sub-group's next task (0.9 us of wave time) is deferred by one pass when X.deferPrepare is set: the
+         * wave first looks whether another of its sub-groups has become ready meanwhile (its own next task cannot be: it waits for
+         * partners that wait for the pose just published). */
+        bool needPrep = false;
         for (;;) {
-            const bool active = valid && it < itEnd;
-            if (__ballot(active) == 0) break;
+            const bool active = valid && it < itEnd && !needPrep;
+            if (__ballot(valid && it < itEnd) == 0) break;
             if (active) poll_records();
             const bool laneOk = !active || (okP & okV & okD & okR);
             const bool goAny = active && ((__ballot(laneOk) & gMask) == gMask);
@@ -758,8 +762,9 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (go && gl == 0) { trec[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[3] = (unsigned)w; }
 #endif
             GS_STAMP(1);
+            if (needPrep) { prepare_task(); needPrep = false; }
             if (go) {
-                if (it < itStop) prepare_task();
+                if (it < itStop) { if (X.deferPrepare) needPrep = true; else prepare_task(); }
                 else if (EXACT && it < itEnd) set_needs();            /* what the task behind the last iteration waits for */
                 spins = 0;
             }
@@ -783,7 +788,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 }
             }
             GS_STAMP(2);
-            if (__ballot(goAny) == 0 && !back_off()) return;
+            if (__ballot(goAny || needPrep) == 0 && !back_off()) return;
         }
     } else {
         /* ---- several bodies per sub-group, out of order: a sub-group runs whichever of its bodies has its inputs published —

@@ -90,7 +90,7 @@ def dependency_chain_hops(forces, bodies, total_iterations):
     return longest
 
 
-PMC_SUMMARIES = {"Stress1000": "r2_resident_window_summary.json", "StressN:20": "r2_8k_window_summary.json", "StressN:40": "r2_64k_window_summary.json"}
+PMC_SUMMARIES = {"Stress1000": "r3_stress1000_cli_summary.json", "StressN:20": "r3_8k_cli_summary.json", "StressN:40": "r3_64k_cli_summary.json"}
 
 
 def pmc_traffic(scene, fused):
@@ -105,8 +105,9 @@ def pmc_traffic(scene, fused):
     if not os.path.exists(path):
         return None, None
     try:
-        d = json.load(open(path))
-        return round((2.0 * d["FETCH_SIZE_KB_last40"] + d["WRITE_SIZE_KB_last40"]) * 1024.0, 1), "committed profile profiles/" + name + " (not this run)"
+        d = json.load(open(path))["counters_per_dispatch_of_dominant_kernel"]     # profiles/collect_cli.sh + summarise_cli.py: KB per dispatch
+        return round((2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0, 1), \
+            "committed profile profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the CLI on the same build and window; FETCH_SIZE x2 on gfx950; not this run)"
     except Exception:
         return None, None
 
@@ -311,7 +312,7 @@ def main():
         fused = p["launches_primal"] <= 1.5 * max(1, p["steps"]) * max(1, world_size if world_size > 1 else 1) or os.environ.get("AVBD_MODE") != "levels"
         traffic, traffic_source = pmc_traffic(scene, fused and not sharded)
         sched = int(stats["schedule"])
-        roof = {"bound": "hbm", "kernel": ("k_iterate_groups" if sched == 4 else ("k_iterate_single" if sched == 2 and os.environ.get("AVBD_SINGLE_KERNEL", "1") != "0" else "k_iterate")) if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+        roof = {"bound": "hbm", "limited_by": "dependency latency (a chain of body solves, see latency_floor), not bytes", "kernel": ("k_iterate_groups" if sched == 4 else ("k_iterate_single" if sched == 2 and os.environ.get("AVBD_SINGLE_KERNEL", "1") != "0" else "k_iterate")) if fused else "k_primal", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": round(bytes_per_launch, 1), "us_per_launch": round(per_launch_s * 1e6, 3),
                 "launches_per_step": round(p["launches_primal"] / max(1, p["steps"]), 2),
@@ -324,6 +325,12 @@ def main():
             hops = dependency_chain_hops(w.forces(), w.bodies(), iterations)
             roof["dependency_chain"] = {"sequential_body_solves_per_step": hops,
                                         "us_per_solve_and_handoff": round(roof["us_per_launch"] / max(1, hops), 3)}
+            # what the launch cannot go below while results must equal the reference's: every hop of the chain hands a pose from one
+            # wavefront to another — 0.8 us through memory (sc1 store -> fabric -> sc1 load), ~0.2 us through LDS when producer and
+            # consumer share a workgroup (tools/debug_critical.py)
+            roof["latency_floor"] = {"hops": hops, "handoff_us": 0.8, "handoff_us_same_workgroup": 0.2,
+                                     "frac": round(hops * 0.8 / max(1e-9, roof["us_per_launch"]), 4),
+                                     "frac_all_hops_through_lds": round(hops * 0.2 / max(1e-9, roof["us_per_launch"]), 4)}
         except Exception as e:                                # informative only
             roof["dependency_chain"] = {"error": repr(e)}
 
@@ -387,6 +394,15 @@ def main():
             strong_n1 = {"workload": f"{STRONG_SCENE} (iterations={int(w3.params()['iterations'])}) steady window: steps {STRONG_PRESIM + 10}..{STRONG_PRESIM + 10 + k3}",
                          "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
                          "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"])}
+            # the launch where "% of HBM peak" means something: its own roofline object (HIP events around the launches of 20 more steps)
+            w3.profile_enable(True); w3.profile_reset(); w3.step(20); w3.synchronize(); p3 = w3.profile(); w3.profile_enable(False)
+            if p3["launches_primal"] > 0 and p3["ms_primal"] > 0:
+                s3 = p3["ms_primal"] * 1e-3 / p3["launches_primal"]
+                b3 = p3["algorithmic_bytes_primal"] / p3["launches_primal"]
+                t3r, t3s = pmc_traffic(STRONG_SCENE, True)
+                strong_n1["roofline"] = {"bound": "hbm", "kernel": "k_iterate_groups" if int(st3["schedule"]) == 4 else "k_iterate", "achieved": round(b3 / s3 / 1e9, 3), "peak": 8000.0,
+                                         "unit": "GB/s", "frac": round(b3 / s3 / 1e9 / 8000.0, 6), "traffic": t3r, "traffic_source": t3s,
+                                         "bytes_per_launch": round(b3, 1), "us_per_launch": round(s3 * 1e6, 3)}
             w3.close()
         except Exception as e:
             strong_n1 = {"error": repr(e)}
@@ -397,7 +413,7 @@ def main():
             "metric": "solver steps/sec + ms/step, Stress1000 @ iters=20, 1/2/4/8 MI355X",
             "value": round(total_steps / elapsed, 3), "unit": "steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if sharded else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene} (iterations={iterations}) steady window: steps {snap_step}..{snap_step + args.steps}",
                        "mode": "exact (bit-identical to the reference CPU solver)" if world_size == 1 else
                                "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)",
