@@ -145,6 +145,7 @@ struct AvbdContext {
     int iterForceMode = 0;     /* 0 auto, 1 latency (1 workgroup/CU), 2 throughput (2 workgroups/CU) */
     DevArr<float4> xPose, xVisit, xDual; /* stamped exchange records of the resident schedule (avbd_resident.h) */
     DevArr<float4> xPrivN, xPrivPose;   /* resident schedule with several bodies per wave: state parked between a body's tasks */
+    DevArr<float4> xParkC, xParkS, xParkB; size_t parkCap = 0, parkBodyCap = 0;   /* group schedule, several bodies per sub-group: packed parked records */
     size_t privNCap = 0, privPoseCap = 0;
     bool residentMultiAllowed = true;   /* AVBD_RESIDENT_MULTI=0: scenes with more swept bodies than waves use the task schedule */
     bool residentMultiLaunched = false;
@@ -175,7 +176,6 @@ struct AvbdContext {
     int groupsMode = -1;           /* AVBD_GROUPS=0 never, 1 for every eligible scene (tests), default: more swept bodies than one-body-per-wave waves */
     int groupsMaxRounds = 16;      /* AVBD_GROUPS_ROUNDS: most bodies one sub-group may serve, at most 16 (1: only scenes whose bodies all fit a sub-group of their own;
                                     * larger ones then take the resident schedule's parked sweep: 64 000 cubes 8.4 ms per iteration loop against 7.0 ms) */
-    int groupsDeferPrepare = 1;    /* AVBD_GROUPS_DEFER_PREPARE=0: a sub-group prepares its next task right behind the one it has finished (8 000 cubes: 1.21 against 1.15 ms per launch) */
     int groupsWaves = 0;           /* AVBD_GROUPS_WAVES: resident waves the plan may use (tests: few waves, many rounds); 0 = all */
     /* sharded runs as one persistent launch per step with the exchange on a second stream (ShardExchange, avbd_groups.h) */
     int shardPersistent = -1;      /* AVBD_SHARD_PERSISTENT=0 never, 1 whenever the prerequisites hold; default (-1): wherever the form has been validated —
@@ -836,6 +836,11 @@ int step_begin(AvbdContext* c)
             if (c->privNCap < needN) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivN.alloc(needN)); c->privNCap = needN; }
             if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
             if (c->probeCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap; }
+            if (c->parkCap < (size_t)c->incCap || c->parkBodyCap < (size_t)c->bodyCap) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, c->xParkC.alloc((size_t)5 * c->incCap)); HIPCHK(c, c->xParkS.alloc((size_t)4 * c->incCap)); HIPCHK(c, c->xParkB.alloc((size_t)10 * c->bodyCap));
+                c->parkCap = (size_t)c->incCap; c->parkBodyCap = (size_t)c->bodyCap;
+            }
         }
         hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
                            c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min((c->nranks > 1 && c->shardExact) ? kGrpMaxRounds / 2 : kGrpMaxRounds, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
@@ -896,7 +901,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         X.multi = 1;
         if (!wholeLoop) { X.forceMulti = 1; X.planesAlways = 1; }
     }
-    X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p;
+    X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p;
     X.send = (sharded && c->dSend.p && c->dSendSlot.p) ? c->dSend.p : nullptr; X.sendSlot = c->dSendSlot.p;
     c->residentMultiLaunched = X.multi != 0;
     c->packFused = X.send != nullptr;
@@ -924,7 +929,6 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     }
     X.probe = c->xProbe.p;
     X.patience = c->residentPatience;
-    X.deferPrepare = c->groupsDeferPrepare;
     const bool throughput = lite || (!X.enabled && c->liteResident && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
     /* group schedule first; the launch below then runs only if the device declined (runIf) */
     const int* runIf = nullptr;
@@ -1198,7 +1202,7 @@ int shard_launch_persistent(AvbdContext* c)
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evBegin, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
+    X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
     auto kern = c->shardMulti ? k_iterate_groups<true, 1> : k_iterate_groups<false, 1>;
     hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
                           S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
@@ -1527,7 +1531,6 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("AVBD_GROUPS_WAVES")) c->groupsWaves = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("AVBD_GROUPS_DEFER_PREPARE")) c->groupsDeferPrepare = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_MULTI")) c->residentMultiAllowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_FORCE_LITE")) c->residentForceLite = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_RESIDENT_LITE_FROM")) c->residentLiteFrom = std::max(0, std::atoi(e));
@@ -2722,7 +2725,7 @@ static int group_step_exact(AvbdContext** ctxs, int n)
         X.pose = L->xsPose.p; X.visit = L->xsVisit.p; X.dual = L->xsDual.p;
         X.poseBytes = (unsigned)((size_t)3 * L->bodyCap * sizeof(float4)); X.visitBytes = (unsigned)(total * sizeof(float4)); X.dualBytes = (unsigned)(2 * total * sizeof(float4));
         X.enabled = 1; X.base = L->xsSerial * 64u;
-        X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.probe = c->xProbe.p;
+        X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;
         ShardExchange Z{};
         Z.xPose = L->xsPose.p; Z.xVisit = L->xsVisit.p; Z.xDual = L->xsDual.p;
         Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;

@@ -70,7 +70,8 @@ struct ShardExchange {
 constexpr int kGrpWavesPerBlock = 4;
 constexpr int kGrpSSlots = 7;             /* f | penalty | gyro.x | gyro.y | gyro.z | +0.0f | -0.0f */
 constexpr int kGrpAccFloats = 64;         /* per 16 lanes: 27 accumulator entries, 21 floats of solve / inertia exchange */
-constexpr int kGrpConstFloats = 32;       /* per 16 lanes: inertial pose, mass, body-frame inertia and inverse inertia */
+constexpr int kGrpConstFloats = 40;       /* per 16 lanes, ten float4: inertial position | mass, inertial orientation, three rows of the body-frame inertia (w of the
+                                            * first: inverse mass), three of its inverse, position | radius, orientation — the layout of a body's parked record (parkB) */
 constexpr int kGrpWaveFloats = kResJFloats + kGrpSSlots * kResRows + 4 * (kGrpAccFloats + kGrpConstFloats);
 constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 43 008 B: two workgroups per CU */
 /* several bodies per sub-group: who the entries of a sub-group's bodies are (incidence word, partner | moving << 24 | owned << 25) stays in LDS
@@ -352,36 +353,62 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     auto load_rest = [&]() __attribute__((always_inline)) {
         AVBD_MARK(g_load_rest);
         fixedN = false;
+        if (MULTI && it > 0) {
+            /* a later task of a body that has been parked: ONE contiguous record per entry for what its tasks change (64 B: normal +
+             * tangent memo, lambda, penalty, stick), one for what they do not (80 B: anchors, bias terms, friction, the partner's inverse
+             * mass and — partners nobody sweeps — its contact point), one per body (160 B).  The planes of the Manifold tables cost a
+             * cache line per field and contact: the pass was bound by those transactions, not by bytes. */
+            if (has) {
+                const size_t e = (size_t)(eBeg + gl);
+                const float4 k0 = X.parkC[e * 5], k1 = X.parkC[e * 5 + 1], k2 = X.parkC[e * 5 + 2], k3 = X.parkC[e * 5 + 3], k4 = X.parkC[e * 5 + 4];
+                const float4 s0 = X.parkS[e * 4], s1 = X.parkS[e * 4 + 1], s2 = X.parkS[e * 4 + 2], s3 = X.parkS[e * 4 + 3];
+                c.rA = mk3(k0.x, k0.y, k0.z); c.C0n = k0.w; c.rB = mk3(k1.x, k1.y, k1.z); c.C0t1 = k1.w; c.C0t2 = k2.x; fric = k2.y; oinv = k2.z;
+                pOther = mk3(k3.x, k3.y, k3.z); wOther = mk3(k4.x, k4.y, k4.z);
+                c.normal = mk3(s0.x, s0.y, s0.z); c.stick = s0.w != 0.0f; c.u1 = mk3(s1.x, s1.y, s1.z); c.u2 = mk3(s2.x, s2.y, s2.z);
+                c.lambda[0] = s1.w; c.lambda[1] = s2.w; c.lambda[2] = s3.x; c.penalty[0] = s3.y; c.penalty[1] = s3.z; c.penalty[2] = s3.w;
+                c.penetration = 0.0f;                                      /* (an output of every computeConstraint call; the last task stores it) */
+                if (SHARD) { remote = !moving && oinv > 0.0f; offR = remote ? Z.row[other] * 32 : 0; }
+            }
+            if (SHARD && valid) ownRow = Z.row[body] * 32;
+            if (valid && gl < 10) reinterpret_cast<float4*>(cst)[gl] = X.parkB[(size_t)body * 10 + gl];
+            wave_sync();
+            if (valid) {
+                pos = mk3(cst[32], cst[33], cst[34]); radius = cst[35]; rot = mkq(cst[36], cst[37], cst[38], cst[39]);
+                invMass = cst[11];
+            }
+            return;
+        }
         if (has) {
             oinv = massPlane[other].y;
             fric = M.fric[idx >> 2];
-            load_contact<false>(M, idx, c);                           /* owned contacts: also what this sub-group's last dual left there */
-            if (multi && it > 0 && !owned) {                          /* this visitor's own copy of the normal and its memo */
-                const float4 pn = X.privN[(size_t)(eBeg + gl) * 3], p1 = X.privN[(size_t)(eBeg + gl) * 3 + 1], p2 = X.privN[(size_t)(eBeg + gl) * 3 + 2];
-                c.normal = mk3(pn.x, pn.y, pn.z); c.u1 = mk3(p1.x, p1.y, p1.z); c.u2 = mk3(p2.x, p2.y, p2.z);
-            }
+            load_contact<false>(M, idx, c);                           /* the tables the earlier kernels of this step wrote */
             const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];   /* predicted pose; constant for unswept partners */
             wOther = qrotate(mkq(oq.x, oq.y, oq.z, oq.w), isA ? c.rB : c.rA);
             pOther = mk3(op.x, op.y, op.z) + wOther;
             if (SHARD) { remote = !moving && oinv > 0.0f; offR = remote ? Z.row[other] * 32 : 0; }
+            if (MULTI) {                                               /* what the later tasks of this entry read instead of the tables */
+                const size_t e = (size_t)(eBeg + gl);
+                X.parkC[e * 5] = make_float4(c.rA.x, c.rA.y, c.rA.z, c.C0n); X.parkC[e * 5 + 1] = make_float4(c.rB.x, c.rB.y, c.rB.z, c.C0t1);
+                X.parkC[e * 5 + 2] = make_float4(c.C0t2, fric, oinv, 0.0f);
+                X.parkC[e * 5 + 3] = make_float4(pOther.x, pOther.y, pOther.z, 0.0f); X.parkC[e * 5 + 4] = make_float4(wOther.x, wOther.y, wOther.z, 0.0f);
+            }
         }
         if (SHARD && valid) ownRow = Z.row[body] * 32;
         if (valid) {
-            float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
+            const float4 pp = B.plane(BP_POSR)[body], pq = B.plane(BP_QUAT)[body];
             radius = pp.w;
-            if (multi && it > 0) { pp = X.privPose[(size_t)body * 2]; pq = X.privPose[(size_t)body * 2 + 1]; }
             pos = mk3(pp.x, pp.y, pp.z); rot = mkq(pq.x, pq.y, pq.z, pq.w);
             invMass = massPlane[body].y;
         }
         if (valid && gl == 0) {                                      /* constants of the body that every task needs again */
             const float4 snp = B.plane(BP_NPOS)[body], snq = B.plane(BP_NQUAT)[body], smp = massPlane[body];
-            cst[0] = snp.x; cst[1] = snp.y; cst[2] = snp.z; cst[3] = smp.x;
-            cst[4] = snq.x; cst[5] = snq.y; cst[6] = snq.z; cst[7] = snq.w;
+            float4* c4 = reinterpret_cast<float4*>(cst);
+            c4[0] = make_float4(snp.x, snp.y, snp.z, smp.x); c4[1] = snq;
             for (int k = 0; k < 3; ++k) {
                 const float4 ik = B.plane(BP_I0 + k)[body], jk = B.plane(BP_J0 + k)[body];
-                cst[8 + 3 * k] = ik.x; cst[9 + 3 * k] = ik.y; cst[10 + 3 * k] = ik.z;
-                cst[17 + 3 * k] = jk.x; cst[18 + 3 * k] = jk.y; cst[19 + 3 * k] = jk.z;
+                c4[2 + k] = make_float4(ik.x, ik.y, ik.z, k == 0 ? smp.y : 0.0f); c4[5 + k] = make_float4(jk.x, jk.y, jk.z, 0.0f);
             }
+            if (MULTI) for (int k = 0; k < 8; ++k) X.parkB[(size_t)body * 10 + k] = c4[k];
         }
         wave_sync();
     };
@@ -389,16 +416,15 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     auto park_body = [&]() __attribute__((always_inline)) {
         AVBD_MARK(g_park);
         if (has) {
-            int idxF = idx, slotF = eBeg + gl;
-            asm volatile("" : "+v"(idxF), "+v"(slotF));
-            if (owned) store_contact_dual<false>(M, idxF, c, false);
-            else {
-                X.privN[(size_t)slotF * 3] = make_float4(c.normal.x, c.normal.y, c.normal.z, 0.f);
-                X.privN[(size_t)slotF * 3 + 1] = make_float4(c.u1.x, c.u1.y, c.u1.z, 0.f);
-                X.privN[(size_t)slotF * 3 + 2] = make_float4(c.u2.x, c.u2.y, c.u2.z, 0.f);
-            }
+            int slotF = eBeg + gl;
+            asm volatile("" : "+v"(slotF));
+            float4* ps = X.parkS + (size_t)slotF * 4;
+            ps[0] = make_float4(c.normal.x, c.normal.y, c.normal.z, c.stick ? 1.0f : 0.0f);
+            ps[1] = make_float4(c.u1.x, c.u1.y, c.u1.z, c.lambda[0]);
+            ps[2] = make_float4(c.u2.x, c.u2.y, c.u2.z, c.lambda[1]);
+            ps[3] = make_float4(c.lambda[2], c.penalty[0], c.penalty[1], c.penalty[2]);
         }
-        if (gl == 0) { X.privPose[(size_t)body * 2] = pack3(pos, radius); X.privPose[(size_t)body * 2 + 1] = packq(rot); }
+        if (gl == 0) { X.parkB[(size_t)body * 10 + 8] = pack3(pos, radius); X.parkB[(size_t)body * 10 + 9] = packq(rot); }
     };
 
     for (int r = lane; r < kResRows; r += 64) { S[5 * kResRows + r] = 0.0f; S[6 * kResRows + r] = -0.0f; }
@@ -444,8 +470,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         L.pos = pos; L.rot = rot; L.invMass = invMass; L.invDt2 = invDt2;
         {
             L.npos = mk3(cst[0], cst[1], cst[2]); L.mass = cst[3]; L.nrot = mkq(cst[4], cst[5], cst[6], cst[7]);
-            const m33 Ib = mkm(mk3(cst[8], cst[9], cst[10]), mk3(cst[11], cst[12], cst[13]), mk3(cst[14], cst[15], cst[16]));
-            const m33 Jb = mkm(mk3(cst[17], cst[18], cst[19]), mk3(cst[20], cst[21], cst[22]), mk3(cst[23], cst[24], cst[25]));
+            const m33 Ib = mkm(mk3(cst[8], cst[9], cst[10]), mk3(cst[12], cst[13], cst[14]), mk3(cst[16], cst[17], cst[18]));
+            const m33 Jb = mkm(mk3(cst[20], cst[21], cst[22]), mk3(cst[24], cst[25], cst[26]), mk3(cst[28], cst[29], cst[30]));
             world_inertia_group(gl, rot, Ib, Jb, xch, L.Iw, L.invIw);     /* rigid.cpp:51-59 */
         }
         GS_STAMP(10);
@@ -711,7 +737,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         const int itEnd = itStop + ((EXACT && (__ballot(finalD) & gMask) != 0) ? 1 : 0);
         itEndOne = itEnd;
         GS_STAMP(3);
-        /* The first half of a sub-group's next task (0.9 us of wave time) is deferred by one pass when X.deferPrepare is set: the
+        /* The first half of a sub-group's next task (0.9 us of wave time) is deferred by one pass: the
          * wave first looks whether another of its sub-groups has become ready meanwhile (its own next task cannot be: it waits for
          * partners that wait for the pose just published). */
         bool needPrep = false;
@@ -762,12 +788,14 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (go && gl == 0) { trec[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); trec[3] = (unsigned)w; }
 #endif
             GS_STAMP(1);
-            if (needPrep) { prepare_task(); needPrep = false; }
+            bool prepNow = needPrep;                                   /* (one call site: the first half of a task is the largest piece of the kernel) */
+            needPrep = false;
             if (go) {
-                if (it < itStop) { if (X.deferPrepare) needPrep = true; else prepare_task(); }
+                if (it < itStop) needPrep = true;                     /* (measured: 8 000 cubes 1.21 -> 1.15 ms per launch) */
                 else if (EXACT && it < itEnd) set_needs();            /* what the task behind the last iteration waits for */
                 spins = 0;
             }
+            if (prepNow) prepare_task();
             if (SHARD && __ballot(go)) {
                 /* Count finished iterations per WAVE: iteration k of this wave is complete when all its sub-groups are past it; one
                  * atomic per wave and iteration (not per task: 8 000 returning atomics on one word per iteration cost 20 % of the
