@@ -1536,6 +1536,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_RESIDENT_LITE_FROM")) c->residentLiteFrom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_SERIAL")) c->xSerial = (unsigned)std::strtoul(e, nullptr, 10);   /* tests: start near the stamp wrap */
         if (const char* e = std::getenv("AVBD_RESIDENT_OOO")) c->residentOutOfOrder = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("AVBD_RESIDENT_PATIENCE")) c->residentPatience = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("AVBD_RESIDENT_QUIET")) c->residentQuiet = std::max(0, std::min(1000, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;
         if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;
@@ -2650,8 +2651,13 @@ int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
     /* The all-gather of a persistent sharded step runs BESIDE the launch that waits for it, on the workgroup slots that launch
      * leaves free (kShardFreeSlots): its kernel must not need more workgroups than that.  The exchange is at most a few MB and
      * latency-bound, so few channels cost nothing.  (A caller that sets NCCL_MAX_NCHANNELS itself keeps its value.) */
-    if (nranks > 1) setenv("NCCL_MAX_NCHANNELS", "4", 0);
+    /* Only for the communicator of a context that asked for the persistent form (AVBD_SHARD_PERSISTENT=1), and only while it is being
+     * created: RCCL reads the variable at ncclCommInitRank, so the process environment — and every communicator the application
+     * creates later — is left as it was. */
+    const bool cap = nranks > 1 && c->shardPersistent == 1 && std::getenv("NCCL_MAX_NCHANNELS") == nullptr;
+    if (cap) setenv("NCCL_MAX_NCHANNELS", "4", 1);
     int r = g_rccl.CommInitRank(&comm, nranks, u, rank);
+    if (cap) unsetenv("NCCL_MAX_NCHANNELS");
     if (r != 0) return c->fail(AVBD_E_COMM, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclCommInitRank failed");
     c->comm = comm;
     return AVBD_OK;

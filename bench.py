@@ -264,16 +264,18 @@ def main():
                 ["persistent", "persistent, exchange stream gated by kernels instead of stream wait / write values", "one launch per iteration"]
         results = {}
         for k, form in enumerate(forms):
-            if k > 0:
-                if form.startswith("persistent"):
-                    os.environ["AVBD_SHARD_GATE"] = "kernel"
-                else:
-                    os.environ["AVBD_SHARD_PERSISTENT"] = "0"
-                try:
-                    w.close()
-                except Exception:
-                    pass
-                w = make_world()
+            # (the library takes the persistent form with a real communicator only on request — it could not be validated on a
+            # multi-GPU box —, so every form is asked for explicitly, in a context of its own)
+            os.environ["AVBD_SHARD_PERSISTENT"] = "1" if form.startswith("persistent") else "0"
+            if form.startswith("persistent, exchange stream gated"):
+                os.environ["AVBD_SHARD_GATE"] = "kernel"
+            else:
+                os.environ.pop("AVBD_SHARD_GATE", None)
+            try:
+                w.close()
+            except Exception:
+                pass
+            w = make_world()
             ok, mk = 1, None
             try:
                 mk = measure(w)
