@@ -622,6 +622,7 @@ __global__ void k_copy_count(Counters* cnt, int* nextCount) { *nextCount = cnt->
 
 int launch_topology(AvbdContext* c, bool fromStep)
 {
+    c->placeQueued = false;
     BodyTable B = body_table(c);
     const int n = B.n;
     ManifoldTable M = c->mbuf[c->cur].view();
@@ -638,7 +639,10 @@ int launch_topology(AvbdContext* c, bool fromStep)
         /* small scene: scans, scatter, per-body order, levels, predictor and flag reset as one workgroup in LDS */
         hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
-                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap /* not the error word behind them: a failure stays visible until the next synchronising call */, c->orderByIndex ? 1 : 0);
+                           c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap /* not the error word behind them: a failure stays visible until the next synchronising call */, c->orderByIndex ? 1 : 0,
+                           (const int2*)c->dCrit.p, c->dTail.p, c->dPlaceSlot.p, c->iterBlocks * kIterWaves,
+                           (fromStep && c->placeChains && c->orderByIndex && c->iterBlocks * kIterWaves <= 1024) ? c->dPlace.p : nullptr, c->dPlaceInfo.p);
+        c->placeQueued = fromStep && c->placeChains && c->orderByIndex && c->iterBlocks * kIterWaves <= 1024;
         c->topologyDidPredict = true;
         c->orderValid = false;
         HIPCHK(c, hipGetLastError());
@@ -956,7 +960,8 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
              * device vetoed it */
             auto single = X.joints ? k_iterate_single<true> : k_iterate_single<false>;
             X.crit = c->dCrit.p;
-            if (c->placeChains && blocks * kIterWaves <= 1024) {
+            if (c->placeChains && blocks * kIterWaves <= 1024 && c->placeQueued && blocks == c->iterBlocks) X.place = c->dPlace.p;   /* k_topology_small built the table */
+            else if (c->placeChains && blocks * kIterWaves <= 1024) {
                 /* this step's table from the last launch's report, on this step's sweep order */
                 hipLaunchKernelGGL(k_place_chains, dim3(1), dim3(1024), 0, c->stream, c->order.p, c->lvlStart.p, c->dCnt.p, c->dCrit.p, c->dTail.p, c->dPlaceSlot.p,
                                    c->bodyCap, blocks * kIterWaves, c->dPlace.p, c->dPlaceInfo.p);

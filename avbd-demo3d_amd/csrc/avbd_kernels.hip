@@ -887,6 +887,9 @@ __global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
  * workgroup working in LDS.  Five dependent launches of a few microseconds each become phases separated by
  * workgroup barriers.  Same outputs (adjStart/adjRef/adjOther sorted newest-first, incStart/inc, level order).
  * ------------------------------------------------------------------------------------------ */
+} // namespace avbd
+#include "avbd_place.h"
+namespace avbd {
 constexpr int kTopoBodies = 4096, kTopoEntries = 6144;
 constexpr int kTopoIntWords = (kTopoBodies + 1) * 2 + kTopoBodies;            /* adjStart | incStart | cursor */
 constexpr int kTopoLdsBytes = kTopoIntWords * 4 + 8 /* align */ + kTopoEntries * 8 /* keys, later neighbour lists */ +
@@ -935,7 +938,8 @@ __global__ __launch_bounds__(1024) void k_order_by_index(BodyTable B, int* level
 __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTable M, const GForce* gf, int ng, Counters* cnt, const int* nextCount,
                                                           int* degForce, int* degInc, int* adjStart, int* incStart, int* adjRef, int* adjOther,
                                                           uint64_t* adjKey, int2* adjTmp, int* inc, int* level, int* lvlCount, int* lvlStart, int* order, int lvlCap,
-                                                          int residentWaves, SolverParams P, int* flags, int nFlags, int byIndex)
+                                                          int residentWaves, SolverParams P, int* flags, int nFlags, int byIndex,
+                                                          const int2* placeCrit, int* placeTail, int* placeSlotOf, int placeW, int* place, PlaceInfo* placeInfo)
 {
     extern __shared__ int sTopo[];
     __shared__ unsigned long long sWaveTotals[16];
@@ -1105,6 +1109,13 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             if (ndAll > residentWaves) bad |= 2;
             if (bad) atomicOr(&cnt->residentBad, bad);
         }
+        if (place) {
+            /* one body per wave: which workgroup every body's wave sits in (avbd_place.h), on the sweep order just written and the
+             * report of the last iteration launch; the staging area above is dead by now */
+            __syncthreads();
+            place_chains(order, ndAll, sBad != 0 || ndAll > residentWaves, placeCrit, placeTail, placeSlotOf, B.cap, placeW, place, placeInfo,
+                         reinterpret_cast<char*>(sTopo), sWaveTotals);
+        }
         return;
     }
     /* ---- phase 4: dependency levels (level = 1 + max level of the later-created swept neighbours), relaxed in LDS ---- */
@@ -1196,7 +1207,6 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
 #include "avbd_primal.h"
 #include "avbd_iterate.h"
 #include "avbd_groups.h"
-#include "avbd_place.h"
 #include "avbd_cuts.h"
 namespace avbd {
 static_assert(kResLiteMaxEntriesDecl == kResLiteMaxEntries, "the topology kernels and the resident schedule must agree on the short product lines");

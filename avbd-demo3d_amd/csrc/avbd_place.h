@@ -24,18 +24,22 @@ namespace avbd {
 
 struct PlaceInfo { int nd, groups, grouped, valid; };
 
-__global__ __launch_bounds__(1024) void k_place_chains(const int* __restrict__ order, const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
-                                                       const int2* __restrict__ crit, int* __restrict__ tail, int* __restrict__ slotOf, int bodyCap,
-                                                       int W, int* __restrict__ place, PlaceInfo* info)
+constexpr int kPlaceWaves = 4;                                     /* = kIterWaves (avbd_iterate.h, included later) */
+constexpr int kPlaceLdsBytes = 8192 + 6 * 4096 + 3 * 1024 + 256;   /* working storage of place_chains */
+
+/* the work of k_place_chains for one workgroup of 1024 threads; `lds` is kPlaceLdsBytes of 8-byte aligned LDS nobody else uses */
+__device__ __forceinline__ void place_chains(const int* __restrict__ order, int nd, bool declined, const int2* __restrict__ crit, int* __restrict__ tail,
+                                             int* __restrict__ slotOf, int bodyCap, int W, int* __restrict__ place, PlaceInfo* info, char* lds,
+                                             unsigned long long* sWaveTotals /* [16] */)
 {
-    __shared__ unsigned long long sWaveTotals[16];
-    __shared__ unsigned long long sBest[1024];
-    __shared__ int sTail[1024], sNext[1024], sLead[1024], sFree[1024];
-    __shared__ unsigned char sAccepted[1024], sRank[1024], sSize[1024];
+    unsigned long long* sBest = reinterpret_cast<unsigned long long*>(lds);
+    int* sTail = reinterpret_cast<int*>(lds + 8192);
+    int* sNext = sTail + 1024; int* sLead = sNext + 1024; int* sFree = sLead + 1024; int* sGroupWg = sFree + 1024; int* sMisc = sGroupWg + 1024;
+    unsigned char* sAccepted = reinterpret_cast<unsigned char*>(sMisc + 1024);
+    unsigned char* sRank = sAccepted + 1024; unsigned char* sSize = sRank + 1024; unsigned char* sWgSize = sSize + 1024;
     const int t = threadIdx.x;
-    const int nd = lvlStart[cnt->numLevels];
-    const int WG = W / kIterWaves;
-    if (nd <= 0 || nd > W || W > 1024 || cnt->residentBad != 0) {      /* nothing to place (the launch that would use the table declines too) */
+    const int WG = W / kPlaceWaves;
+    if (nd <= 0 || nd > W || W > 1024 || declined) {                    /* nothing to place (the launch that would use the table declines too) */
         for (int s = t; s < W; s += 1024) place[s] = -1;
         if (t == 0) { info->nd = nd; info->groups = 0; info->grouped = 0; info->valid = 0; }
         return;
@@ -69,15 +73,13 @@ __global__ __launch_bounds__(1024) void k_place_chains(const int* __restrict__ o
     if (body >= 0 && nxt >= 0 && !sAccepted[t]) {
         int leader = t, n = 0;
         for (int k = t; k >= 0; k = sNext[k]) {
-            if (n == kIterWaves) { leader = k; n = 0; }
+            if (n == kPlaceWaves) { leader = k; n = 0; }
             sLead[k] = leader; sRank[k] = (unsigned char)n; sSize[leader] = (unsigned char)(n + 1);
             ++n;
         }
     }
     __syncthreads();
     /* groups of two and more take whole workgroups, in sweep order of their leaders (at most one group per workgroup) */
-    __shared__ int sGroupWg[1024];
-    __shared__ unsigned char sWgSize[256];
     const bool leads = body >= 0 && sLead[t] == t && sSize[t] >= 2;
     const int gidx = (int)block_scan_inclusive_u64(leads ? 1ull : 0ull, sWaveTotals) - (leads ? 1 : 0);
     sGroupWg[t] = (leads && gidx < WG && gidx < 256) ? gidx : -1;
@@ -87,10 +89,10 @@ __global__ __launch_bounds__(1024) void k_place_chains(const int* __restrict__ o
     const int myWg = body >= 0 ? sGroupWg[sLead[t]] : -1;
     const bool single = body >= 0 && myWg < 0;
     __syncthreads();
-    if (myWg >= 0) place[myWg * kIterWaves + sRank[t]] = body;
+    if (myWg >= 0) place[myWg * kPlaceWaves + sRank[t]] = body;
     /* the slots that are left, wave-major (the waves of a workgroup take bodies a quarter of the sweep apart) */
     int slot = -1; bool isFree = false;
-    if (t < W) { const int wv = t / WG, wg = t % WG; slot = wg * kIterWaves + wv; isFree = wg >= 256 || wv >= (int)sWgSize[wg]; }
+    if (t < W) { const int wv = t / WG, wg = t % WG; slot = wg * kPlaceWaves + wv; isFree = wg >= 256 || wv >= (int)sWgSize[wg]; }
     const unsigned long long mine = (isFree ? 1ull : 0ull) | (single ? (1ull << 32) : 0ull);
     const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
     const int freeRank = (int)(unsigned)(incl - mine), singleRank = (int)((incl - mine) >> 32);
@@ -98,6 +100,16 @@ __global__ __launch_bounds__(1024) void k_place_chains(const int* __restrict__ o
     __syncthreads();
     if (single) place[sFree[singleRank]] = body;
     if (t == 1023) { info->nd = nd; info->groups = min(gidx + (leads ? 1 : 0), min(WG, 256)); info->grouped = nd - (int)(incl >> 32); info->valid = 1; }
+}
+
+/* stand-alone launch (scenes whose topology is not built by the one-workgroup kernel, which otherwise runs place_chains itself) */
+__global__ __launch_bounds__(1024) void k_place_chains(const int* __restrict__ order, const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
+                                                       const int2* __restrict__ crit, int* __restrict__ tail, int* __restrict__ slotOf, int bodyCap,
+                                                       int W, int* __restrict__ place, PlaceInfo* info)
+{
+    __shared__ unsigned long long sWaveTotals[16];
+    __shared__ __attribute__((aligned(8))) char sLds[kPlaceLdsBytes];
+    place_chains(order, lvlStart[cnt->numLevels], cnt->residentBad != 0, crit, tail, slotOf, bodyCap, W, place, info, sLds, sWaveTotals);
 }
 
 } // namespace avbd

@@ -249,7 +249,7 @@ def test_bench_line_contract():
               "roofline", "cpu_baseline"):
         assert k in b, k
     assert b["n_gpus"] == 1 and b["steps"] == 6 and b["warmup"] == 2 and b["higher_is_better"] is True and b["vs_baseline"] is None
-    assert b["unit"] == "steps/s" and b["dtype"] == "f32" and b["data"] == "synthetic" and b["scaling"] == "weak"
+    assert b["unit"] == "steps/s" and b["dtype"] == "f32" and b["data"] == "synthetic" and b["scaling"] is None   # one GPU: no scaling claim
     assert "workload" in b["config"] and "Stress1000" in b["config"]["workload"]
     assert abs(b["value"] - 1000.0 / b["ms_per_step"]) / b["value"] < 1e-3
     r = b["roofline"]
