@@ -229,6 +229,8 @@ struct AvbdContext {
     DevArr<int> dPerm, dRankStart, dSendSlot;
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
+    int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
+    DevArr<unsigned> dXchMismatch;      /* words of gathered velocities that differed from the re-derived ones (must stay 0) */
     void* comm = nullptr;               /* ncclComm_t (RCCL, loaded lazily) */
     bool forceSharded = false;          /* AVBD_FORCE_SHARDED=1: per-iteration exchange schedule even with one rank (tests) */
     Readback* hRb = nullptr; /* pinned */
@@ -1046,6 +1048,26 @@ int step_unpack(AvbdContext* c)
     return AVBD_OK;
 }
 
+/* 13-float exchange: the velocity half, once per step after k_tail (the rows reuse the pose buffers) */
+int step_pack_velocities(AvbdContext* c)
+{
+    const int first = c->hRankStart[(size_t)c->rank], count = c->hRankStart[(size_t)c->rank + 1] - first;
+    if (count > 0)
+        hipLaunchKernelGGL(k_pack_velocities, dim3(grid_for(count, 128, 1 << 20)), dim3(128), 0, c->stream, body_table(c), c->dPerm.p, first, count, c->dSend.p);
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
+int step_unpack_velocities(AvbdContext* c)
+{
+    if (!c->dXchMismatch.p) { HIPCHK(c, c->dXchMismatch.alloc(2)); HIPCHK(c, hipMemsetAsync(c->dXchMismatch.p, 0, 2 * sizeof(unsigned), c->stream)); }
+    if (c->maxCount > 0)
+        hipLaunchKernelGGL(k_unpack_velocities, dim3(grid_for(c->maxCount, 128, 1 << 20), c->nranks), dim3(128), 0, c->stream, body_table(c), c->dPerm.p,
+                           c->dRankStart.p, c->nranks, c->rank, c->maxCount, c->dRecv.p, c->dXchMismatch.p);
+    HIPCHK(c, hipGetLastError());
+    return AVBD_OK;
+}
+
 /* phases 5-6 of solver.cpp:434-497 */
 int step_end(AvbdContext* c, bool haveCounts)
 {
@@ -1085,6 +1107,7 @@ int step_end(AvbdContext* c, bool haveCounts)
 }
 
 int rccl_allgather(AvbdContext* c); /* below, next to the communicator set-up */
+int rccl_exchange_velocities(AvbdContext* c);
 int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream);
 
 /* Exchange stream without hipStreamWaitValue32 / WriteValue32 (AVBD_SHARD_GATE=kernel): a one-wave kernel that waits until a
@@ -1427,7 +1450,8 @@ int step_once(AvbdContext* c)
                 else HIPCHK(c, hipStreamWriteValue32(c->stream2, c->sigGather, base + (unsigned)it + 1u, 0));
             }
             if ((rc = shard_finish_persistent(c, totalIt))) return rc;
-            return step_end(c, needReadback);
+            if ((rc = step_end(c, needReadback))) return rc;
+            return rccl_exchange_velocities(c);
         }
         for (int it = 0; it < totalIt; ++it) {
             if ((rc = step_iterate(c, it, it + 1))) return rc;
@@ -1435,6 +1459,8 @@ int step_once(AvbdContext* c)
             if ((rc = rccl_allgather(c))) return rc;
             if ((rc = step_unpack(c))) return rc;
         }
+        if ((rc = step_end(c, needReadback))) return rc;
+        return rccl_exchange_velocities(c);
     } else if (c->mode == 0) {
         if ((rc = step_iterate_levels(c))) return rc;
     } else {
@@ -1602,7 +1628,7 @@ int avbd_destroy(AvbdContext* c)
     c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
     c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
-    c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release();
+    c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release(); c->dXchMismatch.release();
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release(); c->dHostRows.release();
@@ -1751,6 +1777,27 @@ int avbd_set_shard_mode(AvbdContext* c, int mode)
 {
     if (!c || mode < 0 || mode > 1) return AVBD_E_INVALID;
     c->shardExact = mode == 1;
+    return AVBD_OK;
+}
+
+int avbd_set_exchange_floats(AvbdContext* c, int floatsPerBody)
+{
+    if (!c || (floatsPerBody != 8 && floatsPerBody != 13)) return AVBD_E_INVALID;
+    c->exchangeFloats = floatsPerBody;
+    return AVBD_OK;
+}
+
+int avbd_exchange_mismatches(AvbdContext* c, unsigned* words, unsigned* rowsCompared)
+{
+    if (!c || !words) return AVBD_E_INVALID;
+    unsigned h[2] = {0, 0};
+    if (c->dXchMismatch.p) {
+        (void)hipSetDevice(c->device);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, c->dXchMismatch.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    *words = h[0];
+    if (rowsCompared) *rowsCompared = h[1];
     return AVBD_OK;
 }
 
@@ -2570,6 +2617,16 @@ int rccl_allgather(AvbdContext* c)
     return AVBD_OK;
 }
 
+int rccl_exchange_velocities(AvbdContext* c)
+{
+    /* the velocity half of the 13-float exchange (group_exchange_velocities has the contract): same row count as the poses */
+    if (c->exchangeFloats != 13 || c->nranks < 2) return AVBD_OK;
+    int rc;
+    if ((rc = step_pack_velocities(c))) return rc;
+    if ((rc = rccl_allgather(c))) return rc;
+    return step_unpack_velocities(c);
+}
+
 int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream)
 {
     /* in place: this rank's block of `buffer` is its contribution (sendbuff = recvbuff + rank * count) */
@@ -2772,13 +2829,12 @@ static int group_step_exact(AvbdContext** ctxs, int n)
     return 1;
 }
 
-int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
+static int group_exchange_velocities(AvbdContext** ctxs, int n);
+
+/* one step of avbd_group_step */
+static int group_step_one(AvbdContext** ctxs, int n)
 {
-    /* Several contexts (one per shard, on one or several devices of this process) stepped in lock-step by one host
-     * thread; the per-iteration pose exchange is done with device-to-device copies instead of RCCL.  Same schedule
-     * and same results as the one-process-per-GPU RCCL path. */
-    if (!ctxs || n < 1 || nsteps < 0) return AVBD_E_INVALID;
-    for (int s = 0; s < nsteps; ++s) {
+    {
         int rc;
         for (int r = 0; r < n; ++r) {
             AvbdContext* c = ctxs[r];
@@ -2800,7 +2856,7 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
             /* exact cuts: no exchange during the loop, results identical to the single-GPU sweep (avbd_cuts.h) */
             rc = group_step_exact(ctxs, n);
             if (rc < 0) return rc;
-            if (rc == 1) continue;
+            if (rc == 1) return AVBD_OK;
         }
         const int totalIt = ctxs[0]->params.iterations + (ctxs[0]->params.postStabilize ? 1 : 0);
         {   /* persistent form (one launch per rank and step, exchange on the second streams) when every rank's plan fits its share
@@ -2879,7 +2935,7 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
                     if ((rc = shard_finish_persistent(ctxs[r], totalIt))) return rc;
                     if ((rc = step_end(ctxs[r], false))) return rc;
                 }
-                continue;
+                return group_exchange_velocities(ctxs, n);
             }
         }
         for (int it = 0; it < totalIt; ++it) {
@@ -2915,6 +2971,42 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
             (void)hipSetDevice(ctxs[r]->device);
             if ((rc = step_end(ctxs[r], false))) return rc;
         }
+    }
+    return group_exchange_velocities(ctxs, n);
+}
+
+/* avbd_set_exchange_floats(13): the once-per-step gather of the velocities (pos3 + quat4 travel every iteration,
+ * linVel3 + angVel3 once per step).  Every rank has ALREADY re-derived every body's velocities from the gathered poses
+ * (k_tail runs over all bodies, solver.cpp:434-469), so the rows that arrive must equal what is there bit for bit:
+ * k_unpack_velocities counts the words that differ (avbd_debug_exchange_mismatches) before it stores them. */
+static int group_exchange_velocities(AvbdContext** ctxs, int n)
+{
+    if (n < 2 || ctxs[0]->exchangeFloats != 13) return AVBD_OK;
+    int rc;
+    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = step_pack_velocities(ctxs[r]))) return rc; }
+    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
+    for (int dst = 0; dst < n; ++dst) {
+        AvbdContext* d = ctxs[dst];
+        (void)hipSetDevice(d->device);
+        const size_t rows = (size_t)2 * std::max(1, d->maxCount);
+        for (int src = 0; src < n; ++src)
+            if (src != dst) HIPCHK(d, hipMemcpyAsync(d->dRecv.p + rows * src, ctxs[src]->dSend.p, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream));
+        if ((rc = step_unpack_velocities(d))) return rc;
+    }
+    /* dSend is the next step's pose rows: nobody may still be reading it */
+    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
+    return AVBD_OK;
+}
+
+int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
+{
+    /* Several contexts (one per shard, on one or several devices of this process) stepped in lock-step by one host
+     * thread; the per-iteration pose exchange is done with device-to-device copies instead of RCCL.  Same schedule
+     * and same results as the one-process-per-GPU RCCL path. */
+    if (!ctxs || n < 1 || nsteps < 0) return AVBD_E_INVALID;
+    for (int s = 0; s < nsteps; ++s) {
+        const int rc = group_step_one(ctxs, n);
+        if (rc) return rc;
     }
     return AVBD_OK;
 }

@@ -1361,6 +1361,36 @@ __global__ void k_unpack_poses(BodyTable B, const int* perm, const int* rankStar
     B.plane(BP_QUAT)[b] = recv[2 * ((size_t)r * maxCount + k) + 1];
 }
 
+/* the velocity half of the 13-float exchange (once per step, after K7): linear + angular velocity, 2 float4 per body like the poses */
+__global__ void k_pack_velocities(BodyTable B, const int* perm, int first, int count, float4* send)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int b = perm[first + k];
+    send[2 * k] = B.plane(BP_LINV)[b];
+    send[2 * k + 1] = B.plane(BP_ANGV)[b];
+}
+
+/* every rank has re-derived these velocities from the gathered poses already: count the words that differ, then store */
+__global__ void k_unpack_velocities(BodyTable B, const int* perm, const int* rankStart, int nranks, int myRank, int maxCount, const float4* recv, unsigned* mismatches)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (r == myRank) return;
+    const int first = rankStart[r], count = rankStart[r + 1] - first;
+    if (k >= count) return;
+    const int b = perm[first + k];
+    const float4 v = recv[2 * ((size_t)r * maxCount + k)], w = recv[2 * ((size_t)r * maxCount + k) + 1];
+    const float4 v0 = B.plane(BP_LINV)[b], w0 = B.plane(BP_ANGV)[b];
+    const unsigned bad = (__float_as_uint(v.x) != __float_as_uint(v0.x)) + (__float_as_uint(v.y) != __float_as_uint(v0.y)) + (__float_as_uint(v.z) != __float_as_uint(v0.z))
+                       + (__float_as_uint(w.x) != __float_as_uint(w0.x)) + (__float_as_uint(w.y) != __float_as_uint(w0.y)) + (__float_as_uint(w.z) != __float_as_uint(w0.z));
+    if (bad) atomicAdd(mismatches, bad);
+    const unsigned long long act = __ballot(1);                      /* rows compared, one atomic per wavefront */
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(mismatches + 1, (unsigned)__popcll(act));
+    B.plane(BP_LINV)[b] = v;
+    B.plane(BP_ANGV)[b] = w;
+}
+
 /* ---- debug race checker (AVBD_RACE_CHECK=1) --------------------------------------------------------
  * The schedules are race-free by construction; this kernel checks the construction, every step, from the topology the step
  * will run on:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AVBD_ABI_VERSION 3   /* 3: avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
+#define AVBD_ABI_VERSION 3   /* 3: avbd_set_exchange_floats, avbd_exchange_mismatches, avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
 
 enum {
     AVBD_OK = 0,
@@ -293,6 +293,13 @@ int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
  * during the iteration loop, one copy of the final poses per step, results bit-identical to the single-GPU sweep
  * (tests/test_gpu_exact_cuts.py).  Contacts-only scenes whose ranks share a device; otherwise the step takes the all-gather form. */
 int  avbd_set_shard_mode(AvbdContext* ctx, int mode);
+/* What the ranks exchange.  8 (default): {position + radius, orientation} every iteration, velocities re-derived by
+ * every rank from the gathered poses.  13: additionally ONE gather of {linear, angular velocity} per step, after the velocity
+ * stage (pos3 + quat4 + linVel3 + angVel3 = north_star's 13 floats per body); the arriving rows overwrite the re-derived ones and
+ * must equal them bit for bit — avbd_exchange_mismatches returns the number of 32-bit words that ever differed on this rank
+ * (tests/test_gpu_sharded.py keeps it at 0).  Exact cuts (avbd_set_shard_mode 1) exchange nothing during a step and ignore it. */
+int  avbd_set_exchange_floats(AvbdContext* ctx, int floatsPerBody);
+int  avbd_exchange_mismatches(AvbdContext* ctx, unsigned* words, unsigned* rowsCompared /* may be NULL: velocity rows received so far */);
 int  avbd_device_count(void);                                            /* visible gfx950 devices (0 without one) */
 /* Joint (joint.cpp:108-139): 0 (default) keeps the reference's angular Jacobian sign — bug-compatible: body-body welds blow up,
  * SURVEY.md §7-5 —, 1 uses J_angular = dC/dtheta (-e_k for bodyA, +e_k for bodyB), with which welds hold.  Applies to the

@@ -216,7 +216,7 @@ def test_independent_shards_of_a_large_scene_are_bit_exact(shard_mode):
     assert sum(int(w.w.stats()["numManifolds"]) for w in worlds) == len(o.forces())
 
 
-def _cut_pile_finals(monkeypatch, env, steps=6, substeps=5):
+def _cut_pile_finals(monkeypatch, env, steps=6, substeps=5, exchange_floats=None, mismatches=None):
     """two ranks on a pile cut along z, avbd_group_step; returns per-rank (bodies, forces) bytes"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -228,10 +228,14 @@ def _cut_pile_finals(monkeypatch, env, steps=6, substeps=5):
     owner = pkg.partition_by_axis(b["pos"], b["invMass"], 2, axis=2)
     for r, w in enumerate(worlds):
         w.w.set_ownership(2, r, owner)
+        if exchange_floats is not None:
+            w.w.set_exchange_floats(exchange_floats)
     for s in range(steps):
         pkg.group_step([w.w for w in worlds], substeps)
     out = [(w.bodies().tobytes(), w.forces().tobytes()) for w in worlds]
     sched = [int(w.w.stats()["schedule"]) for w in worlds]
+    if mismatches is not None:
+        mismatches.extend(w.w.exchange_mismatches() for w in worlds)
     for w in worlds:
         w.close()
     for k in env:
@@ -262,3 +266,24 @@ def test_stamp_wrap_in_the_persistent_sharded_form(monkeypatch):
     assert sa == sb == [4, 4]
     for r in range(2):
         assert a[r] == b[r], f"rank {r}: the run across the stamp wrap differs"
+
+
+@pytest.mark.parametrize("form", ["1", "0"], ids=["persistent", "per-iteration"])
+def test_thirteen_float_exchange_gathers_the_velocities_every_rank_re_derived(monkeypatch, form):
+    """avbd_set_exchange_floats(13) (pos3 + quat4 + linVel3 + angVel3): besides the poses of every iteration the ranks
+    gather the velocities once per step.  Every rank has re-derived them from the gathered poses already (solver.cpp:434-469), so
+    the rows that arrive equal what they overwrite bit for bit — the kernel that stores them counts the words that differ — and the
+    run ends with the bits of the 8-float exchange.  48 bodies per rank x 30 steps = 1 440 rows compared on each rank."""
+    mm = []
+    a, sa = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": form})
+    b, sb = _cut_pile_finals(monkeypatch, {"AVBD_SHARD_PERSISTENT": form}, exchange_floats=13, mismatches=mm)
+    assert sa == sb == ([4, 4] if form == "1" else [3, 3]), (sa, sb)
+    assert [m[0] for m in mm] == [0, 0], mm
+    assert all(m[1] == 48 * 30 for m in mm), mm
+    for r in range(2):
+        assert a[r] == b[r], f"rank {r}: the 13-float exchange changed the result"
+    pkg = H.load_product()
+    w = H.HipWorld()
+    with pytest.raises(Exception):
+        w.w.set_exchange_floats(7)
+    w.close()
