@@ -1283,6 +1283,7 @@ int host_force_call(AvbdContext* c, int ord, int phase, float alpha, int body, b
     }
     if (c->hostFn(c->hostUser, ord, phase, alpha, body, g.bodyA >= 0 ? pa : nullptr, pb, &R) != 0)
         return c->fail(AVBD_E_INVALID, "the host force callback reported an error");
+    if (R.rows == -1 && phase == AVBD_HOST_INITIALIZE) return AVBD_OK;  /* initialize() failed: the caller deletes the force */
     if (R.rows < 0 || R.rows > 12) return c->fail(AVBD_E_INVALID, "host force: row count out of range (0..12)");
     return AVBD_OK;
 }
@@ -1304,7 +1305,7 @@ int step_with_host_rows(AvbdContext* c)
 {
     if (!c->hostFn) return c->fail(AVBD_E_INVALID, "a user-defined Force is registered (avbd_add_host_force) but no callback (avbd_set_host_force_callback)");
     if (c->nranks > 1 || c->forceSharded) return c->fail(AVBD_E_INVALID, "user-defined Force subclasses are not supported in sharded runs");
-    const int nh = (int)c->hostForceG.size();
+    int nh = (int)c->hostForceG.size();
     const SolverParams P = solver_params(c);
     int rc;
     struct ModeGuard { AvbdContext* c; int saved; ~ModeGuard() { c->mode = saved; } } guard{c, c->mode};
@@ -1314,10 +1315,30 @@ int step_with_host_rows(AvbdContext* c)
     if ((rc = download_bodies_to_host(c))) return rc;
     if ((rc = gforces_to_host(c))) return rc;
     std::vector<AvbdHostRows> R((size_t)nh);
+    std::vector<decltype(GForce::key)> dead;                           /* forces deleted by this step (their initialize() failed) */
     for (int ord = 0; ord < nh; ++ord) {
         std::memset(&R[(size_t)ord], 0, sizeof(AvbdHostRows));
         if ((rc = host_force_call(c, ord, AVBD_HOST_INITIALIZE, P.alpha, -1, false, R[(size_t)ord]))) return rc;
         AvbdHostRows& h = R[(size_t)ord];
+        if (h.rows < 0) {
+            /* its initialize() returned false: deleted (solver.cpp:274-279).  The caller has dropped ordinal `ord` too; the ordinals
+             * behind it move up by one on both sides, so the next force to initialise is `ord` again.  The reference deletes it
+             * AFTER this step's broadphase, which therefore still saw the pair as constrained: the record stays for this step as an
+             * ignore-collision marker (no rows) and leaves the list at the end of the step. */
+            const int gi = c->hostForceG[(size_t)ord];
+            c->hG[(size_t)gi].kind = FK_IGNORE; c->hG[(size_t)gi].pad = 0;
+            dead.push_back(c->hG[(size_t)gi].key);
+            c->hostForceG.erase(c->hostForceG.begin() + ord);
+            c->hHostRows.erase(c->hHostRows.begin() + ord);
+            R.erase(R.begin() + ord);
+            for (size_t o = (size_t)ord; o < c->hostForceG.size(); ++o) {
+                GForce& g = c->hG[(size_t)c->hostForceG[o]];
+                g.pad = (int)o | (int)((unsigned)g.pad & 0xFF000000u);
+            }
+            c->gStale = true; c->adjDirty = true;
+            --nh; --ord;
+            continue;
+        }
         for (int i = 0; i < h.rows; ++i) {
             if (!P.postStabilize) h.lambda[i] *= P.alpha * P.gamma;
             h.penalty[i] = rclamp(h.penalty[i] * P.gamma, kPenaltyMin, kPenaltyMax);
@@ -1415,7 +1436,19 @@ int step_with_host_rows(AvbdContext* c)
         }
     }
     HIPCHK(c, hipGetLastError());
-    return step_end(c, true);
+    if ((rc = step_end(c, true))) return rc;
+    if (!dead.empty()) {
+        if ((rc = gforces_to_host(c))) return rc;
+        for (const auto key : dead)
+            for (size_t gi = 0; gi < c->hG.size(); ++gi)
+                if (c->hG[gi].key == key && c->hG[gi].kind == FK_IGNORE) {
+                    c->hG.erase(c->hG.begin() + (long)gi);
+                    for (int& x : c->hostForceG) if (x > (int)gi) --x;
+                    break;
+                }
+        c->gStale = true; c->adjDirty = true;
+    }
+    return AVBD_OK;
 }
 
 int step_once(AvbdContext* c)

@@ -451,7 +451,22 @@ int Solver::hostForceCallback(void* user, int hostForce, int phase, float alphaN
     };
     switch (phase) {
     case AVBD_HOST_INITIALIZE:
-        rows->rows = f->initialize() ? f->getRowCount() : 0;          /* (a force whose initialize() fails sits this step out) */
+        if (!f->initialize()) {
+            /* solver.cpp:274-279: the solver deletes it.  rows = -1 tells the library, which drops the ordinal as this side does. */
+            rows->rows = -1;
+            Impl* im = s->impl;
+            im->hostForces.erase(im->hostForces.begin() + hostForce);
+            for (size_t k = 0; k < im->userForces.size(); ++k)
+                if (im->userForces[k] == f) { im->userForces.erase(im->userForces.begin() + (long)k); if (k < im->flushedForces) --im->flushedForces; break; }
+            for (Force* u : im->userForces) u->listIndex = -1;             /* the device's force list has changed */
+            for (Manifold* m : im->manifolds) m->listIndex = -1;
+            const bool was = im->syncing;
+            im->syncing = true;                                            /* ~Force: the device side is taken care of, only unlink */
+            delete f;
+            im->syncing = was;
+            return 0;
+        }
+        rows->rows = f->getRowCount();
         if (rows->rows > MAX_CONSTRAINT_ROWS) return 1;
         copyOut();
         return 0;

@@ -193,7 +193,9 @@ int  avbd_upload_bodies(AvbdContext* ctx, const AvbdBody* in, int n_bodies);
  * with the host in the loop (exact, slow): before a level that visits one of its endpoints, and in every dual pass, the library
  * calls `fn` with the current poses of the two endpoints and the phase, and the callee fills / reads `rows`:
  *   AVBD_HOST_INITIALIZE  step begin (solver.cpp:273-296): call initialize(); return rows (rows = 0: the force sits this step out) and the row
- *                         state; the library applies the warm-start decay of solver.cpp:281-293 and hands lambda / penalty back with
+ *                         state — or rows = -1 when initialize() returned false: the force is DELETED as solver.cpp:274-279 does, the
+ *                         ordinals of the host forces created after it move down by one (the callee drops its entry in the same
+ *                         call) and no other phase is called for it; otherwise the library applies the warm-start decay of solver.cpp:281-293 and hands lambda / penalty back with
  *   AVBD_HOST_STORE       copy rows->lambda / rows->penalty into the object
  *   AVBD_HOST_PRIMAL      visit of `body` (solver.cpp:371-399): call computeConstraint(alpha), then computeDerivatives(Jl, Ja, body, row)
  *                         for every row into rows->JlA / JaA (body is endpoint A) or JlB / JaB; return C, fmin, fmax, lambda, penalty,

@@ -62,6 +62,13 @@ struct Pin : Force {                          // five rows: anchor of bodyB held
     }
 };
 
+struct Fuse : Tether {                        // a tether that burns out: initialize() fails at its `life`-th step and the solver deletes it (solver.cpp:274-279)
+    int life, inits = 0; int* destroyed;
+    Fuse(Solver* s, Rigid* a, Rigid* b, const vec3& la, const vec3& lb, float k, int life_, int* destroyed_) : Tether(s, a, b, la, lb, k, -1.0f), life(life_), destroyed(destroyed_) {}
+    ~Fuse() { ++*destroyed; }
+    bool initialize() override { return ++inits < life; }
+};
+
 static void buildScene(Solver* s, Rigid*& a, Rigid*& b)
 {
     s->clear(); s->defaultParams();
@@ -84,7 +91,8 @@ static void recordBodies(Solver* s, std::vector<float>& out)
 }
 
 // The pinned runs: Tether with finite and with infinite stiffness (40 steps each), then Pin + Joint + IgnoreCollision (60 steps);
-// body states every 10 steps and the user force's rows at the end.
+// body states every 10 steps and the user force's rows at the end.  Last: two Fuses (and a Tether created between them) — the first
+// burns out at step 12, the second at step 25; the solver deletes each at that step, the pair it constrained starts colliding.
 static void runUserForceScenes(std::vector<float>& out)
 {
     for (float k : {400.0f, FLT_MAX}) {
@@ -108,5 +116,30 @@ static void runUserForceScenes(std::vector<float>& out)
         AVBD_SYNC_FORCES(s);
         for (int r = 0; r < 5; ++r) { out.push_back(pin->lambda[r]); out.push_back(pin->penalty[r]); out.push_back(pin->C[r]); }
         delete s;
+    }
+    {
+        Solver* s = new Solver();
+        Rigid *a, *b;
+        buildScene(s, a, b);
+        Rigid* c = s->bodies;                                               // the small cube between them (created last)
+        int destroyed = 0;
+        new Fuse(s, a, b, {0.0f, 0.5f, 0.0f}, {0.0f, -0.3f, 0.0f}, FLT_MAX, 12, &destroyed);
+        Tether* t = new Tether(s, a, c, {0.3f, 0.0f, 0.0f}, {-0.2f, 0.0f, 0.0f}, 300.0f, -1.0f);
+        new Fuse(s, c, b, {0.0f, 0.1f, 0.0f}, {0.0f, 0.0f, 0.2f}, 500.0f, 25, &destroyed);
+        for (int step = 0; step < 40; ++step) {
+            s->step();
+            if (step % 10 == 9) {
+                recordBodies(s, out);
+                out.push_back((float)destroyed);
+                int generic = 0;
+                AVBD_SYNC_FORCES(s);
+                for (Force* f = s->forces; f; f = f->next) generic += f->getRowCount() == 1;
+                out.push_back((float)generic);
+            }
+        }
+        AVBD_SYNC_FORCES(s);
+        out.push_back(t->lambda[0]); out.push_back(t->penalty[0]); out.push_back(t->C[0]); out.push_back((float)t->calls);
+        delete s;
+        out.push_back((float)destroyed);
     }
 }

@@ -30,5 +30,7 @@ def test_user_defined_force_subclasses_run_through_host_evaluated_rows(tmp_path)
     keeps its virtuals on the host; the device fetches its rows before every visit.  A user re-statement of the distance
     constraint must give the same bits as the built-in Spring, and the runs of Tether and of the five-row Pin (with a Joint and an
     IgnoreCollision beside it) must give the bits the REFERENCE computes for the same classes: tests/host/user_forces.h compiles
-    against /root/reference/source as well (oracle/user_force_ref.cpp -> tests/golden/user_force_states.bin, make_golden.py)."""
+    against /root/reference/source as well (oracle/user_force_ref.cpp -> tests/golden/user_force_states.bin, make_golden.py).
+    The last pinned run holds two `Fuse`s whose initialize() returns false at steps 12 and 25: the solver deletes them
+    (solver.cpp:274-279; destructor calls and the length of the force list are part of the pinned floats), the pair starts colliding."""
     _build_and_run(tmp_path, "user_force", [os.path.join(H.ROOT, "tests", "golden", "user_force_states.bin")])
