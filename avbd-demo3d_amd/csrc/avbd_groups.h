@@ -874,7 +874,142 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         GS_STAMP(3);
         /* (polling the watched words one pass ahead — issued before the pass's task, looked at when the next pass starts — was
          * measured and not kept: 64 000 cubes 6.9 -> 7.6 ms per step; a body that has just become ready then waits a whole pass
-         * more, and the step is a chain of 372 such hops) */
+         * more, and the step is a chain of 372 such hops)
+         *
+         * A TASK IN HAND.  The step is that chain of hops, and a hop used to cost a whole pass: watched word (one round trip), the
+         * records and the parked state (a second), the first half of the task, then the second.  Now a sub-group that has nothing
+         * ready takes its OLDEST task in hand all the same — parked state loaded, first half done — and the next passes poll just the
+         * records it still misses, like the one-body form: when they arrive only the second half of the task is left before the pose
+         * goes out.  Nothing of a task in hand has been stored, so it is simply dropped when another body of the sub-group turns out
+         * to be ready first (the records alone carry the dependencies: any order that respects them gives the same bits). */
+        /* With many bodies per sub-group some body is ready soon and a task in hand is dropped before its records arrive (64 000 cubes,
+         * 8 per sub-group: 6.3 -> 6.7 ms per step; 13 800 and 22 000 cubes: 2.75 -> 2.28 and 3.29 -> 3.08): classes with more than
+         * X.specRounds bodies per sub-group run the loop without it, compiled separately (the poll state that lives across passes costs the
+         * other form registers it has no use for). */
+        const bool keepMode = X.specMode != 2 && rounds <= X.specRounds;
+        auto multi_loop = [&](auto keepTag) __attribute__((always_inline)) -> bool {
+        constexpr bool KEEP = decltype(keepTag)::value;
+        unsigned watchVal = 0;
+        bool prep = false;                                            /* uniform over the sub-group: a task is in hand (loaded, first half done) */
+        int kPrep = 0;                                                /* which of the sub-group's bodies it belongs to */
+        for (;;) {
+            AVBD_MARK(g_examine);
+            const bool activeK = itK < itEndK;
+            if (__ballot(activeK) == 0) break;
+            grpWaiting = (__ballot(activeK) & gMask) != 0;
+            if (!KEEP) prep = false;
+            /* one round trip: what the task in hand still misses, and the watched words of the other bodies */
+            if (prep) poll_issue();
+            if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
+            if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
+            if (prep) poll_check();
+            bool candK = activeK;
+            if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
+            if (prep && gl == kPrep) candK = false;
+            dbgBody = bodyK; dbgIt = itK | (itEndK << 8); dbgOff = blkOff; dbgStamp = (int)(blkStamp - X.base); dbgSeen = (int)(watchVal - X.base);
+            GS_STAMP(12);                                              /* the look at the watched words (and whatever was still in flight) */
+            bool ready = prep && ((__ballot(okP & okV & okD & okR) & gMask) == gMask);
+            /* another body can run first: the task in hand is given up (keeping it while a YOUNGER task of the sub-group was ready, for up
+             * to 5 / 20 / 100 us, was measured: 22 000 cubes 3.19 -> 3.25 / 3.35 / 5.2 ms — what a sub-group can run, it should run) */
+            if (prep && !ready && (__ballot(candK) & gMask) != 0) prep = false;
+            if (prep) candK = false;
+            /* (only a wave with nothing else to do in this pass takes a task in hand early: the load and the first half of a task that
+             * is not ready would hold up the ready tasks of the wave's other sub-groups — 64 000 cubes 6.3 -> 6.7 ms when every
+             * sub-group did it in every pass) */
+            const bool waveIdle = KEEP && (X.specMode == 1 || __ballot(ready || candK) == 0);
+            bool inHand = false, triedK = false, specTried = false;
+            int kHand = 0;
+            for (;;) {
+                int key = (candK && !triedK) ? ((itK << 6) | gl) : 0x7fffffff;
+                for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
+                if (key == 0x7fffffff && !prep && !inHand && !specTried && waveIdle) {
+                    /* nothing is known to be ready: the oldest task of the sub-group (not the task behind the last iteration, which prepares nothing) */
+                    specTried = true;
+                    key = (activeK && itK < itStop) ? ((itK << 6) | gl) : 0x7fffffff;
+                    for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
+                }
+                const bool examine = !prep && !ready && key != 0x7fffffff;   /* uniform over the sub-group */
+                if (__ballot(examine) == 0) break;
+                if (examine) {
+                    const int kk = key & 63, k = gBase + kk, t = key >> 6;
+                    load_header(__shfl(bodyK, k, 64), __shfl(eBegK, k, 64), __shfl(nEntK, k, 64), kk);
+                    /* the records this task reads and the state the body parked after its last task travel together: one memory
+                     * round trip tells whether the task can run and, if it can, has brought what it needs */
+                    it = t;
+                    set_needs();
+                    poll_issue();
+                    load_rest();
+                    if (SHARD) { needR = has && remote && it > 0; sR = X.base + (unsigned)it; okR = !needR; }   /* the all-gather behind the previous iteration */
+                    poll_check();
+                    AVBD_MARK(g_examine2);
+                    inHand = true; kHand = kk;
+                    const unsigned long long noPose = __ballot(!okP) & gMask, noRest = __ballot(!(okV & okD)) & gMask;
+                    const unsigned long long noGather = SHARD ? (__ballot(!okR) & gMask) : 0ull;
+                    if ((noPose | noRest | noGather) == 0) {
+                        ready = true;
+                    } else if (noPose) {
+                        /* watch the pose of the first partner that is late (its last record's stamp word) */
+                        const int f = __ffsll((long long)noPose) - 1;
+                        const int bo = __shfl(offP + 44, f, 64);
+                        const unsigned bs = (unsigned)__shfl((int)sP, f, 64);
+                        if (lane == k) { blkOff = bo; blkStamp = bs; candK = false; }
+                    } else if (noGather) {
+                        if (lane == k) { blkOff = -2; blkStamp = X.base + (unsigned)t; candK = false; }
+                    } else if (lane == k) triedK = true;                     /* visit / dual records follow their producer's pose within its task: next pass */
+                }
+            }
+            GS_STAMP(0);
+            /* the last task examined stays in hand, ready or not: its first half */
+            if (inHand && !(ready || KEEP)) inHand = false;
+            if (inHand) { prep = true; kPrep = kHand; }
+            if (inHand && it < itStop) prepare_task();
+            GS_STAMP(2);
+#ifdef AVBD_DF_STATS
+            stat[14] += 1;
+            if (__ballot(ready)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(ready && gl == 0)); }
+#endif
+            const bool runF = EXACT && ready && it >= itStop;           /* the owner's last dual into this rank's copy of the contact */
+            const bool run = ready && !runF;
+            if (runF) final_store();
+            if (run) {
+                finish_visit();
+                finish_accumulate();
+                finish_solve();
+                GS_STAMP_ND(13);                                       /* dual: arithmetic and issue of its stores */
+                GS_STAMP(3);                                           /* ... until they are acknowledged */
+                if (it < itStop - 1 || (EXACT && (__ballot(finalD) & gMask) != 0)) park_body();   /* (EXACT: the task behind the last iteration reads the parked normal) */
+                GS_STAMP_ND(15);                                       /* park: issue */
+            }
+            if (ready) {
+                if (gl == kPrep) { ++itK; ++blkStamp; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
+                prep = false;
+                spins = 0;
+            }
+            const bool sel = ready;
+            AVBD_MARK(g_pass_end);
+            if (SHARD && __ballot(sel)) {
+                /* iteration k of this wave is complete when every body it serves is past it (see the one-body form above) */
+                int low = bodyK >= 0 ? itK : itStop;
+                for (int o = 1; o < 64; o <<= 1) low = min(low, __shfl_xor(low, o, 64));
+                low = __builtin_amdgcn_readfirstlane(low);
+                if (reportedM < low) {
+                    const unsigned mine = (unsigned)__popcll(__ballot(bodyK >= 0));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        for (int k = reportedM; k < low; ++k) {
+                            const unsigned before = __hip_atomic_fetch_add(Z.done + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (before + mine == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    reportedM = low;
+                }
+            }
+            GS_STAMP(1);
+            if (__ballot(sel || inHand) == 0 && !back_off()) return false;
+        }
+        return true;
+        };
+        /* the loop without a task in hand (a sub-group examines a body when its watched word has arrived, and runs it at once) */
+        auto multi_loop_plain = [&]() __attribute__((always_inline)) -> bool {
         unsigned watchVal = 0;
         for (;;) {
             AVBD_MARK(g_examine);
@@ -960,8 +1095,12 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 }
             }
             GS_STAMP(1);
-            if (__ballot(sel) == 0 && !back_off()) return;
+            if (__ballot(sel) == 0 && !back_off()) return false;
         }
+        return true;
+        };
+        if (keepMode) { if (!multi_loop(std::true_type{})) return; }
+        else if (!multi_loop_plain()) return;
     }
 #ifdef AVBD_DF_STATS
     if (lane == 0) {

@@ -433,7 +433,10 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
 #endif
 }
 
-__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
+#ifndef AVBD_NARROW_WAVES
+#define AVBD_NARROW_WAVES 1
+#endif
+__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(AVBD_NARROW_WAVES, AVBD_NARROW_WAVES))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
                                                       int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
 {
     const int nOld = cnt->numManifolds;
@@ -447,6 +450,23 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         int a = 0, b = 0;
         if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
         narrow_pair_lane(B, src, dst, item < nOld ? item : -1, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+    }
+}
+
+/* the same with sixteen lanes per pair (avbd_collide_coop.h), four pairs per wavefront: a pair's serial chain is ~7x shorter and the
+ * kernel needs half the registers, so three times as many wavefronts are resident */
+__global__ __launch_bounds__(64) void k_narrowphase_coop(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
+                                                         int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
+{
+    __shared__ CoopScratch sWs[kPairsPerWave];
+    const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;
+    const int nOld = cnt->numManifolds;
+    int nCand = cnt->numCandidates; if (nCand > candCap) nCand = candCap;
+    const int total = nOld + nCand;
+    for (int item = blockIdx.x * kPairsPerWave + gj; item < total; item += gridDim.x * kPairsPerWave) {
+        int a = 0, b = 0;
+        if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
+        narrow_pair(B, src, dst, item < nOld ? item : -1, a, b, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase);
     }
 }
 
