@@ -229,8 +229,7 @@ struct AvbdContext {
     DevArr<int> dPerm, dRankStart, dSendSlot;
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
-    int groupSpecMode = 0, groupSpecRounds = 4;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
-    bool narrowCoop = false; int narrowCoopBlocks = 1 << 16;   /* grid scenes: sixteen lanes per pair (AVBD_NARROW_COOP=0: one lane per pair) */
+    int groupSpecMode = 0, groupSpecRounds = 4, groupMap = 0;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
     DevArr<unsigned> dXchMismatch;      /* words of gathered velocities that differed from the re-derived ones (must stay 0) */
     void* comm = nullptr;               /* ncclComm_t (RCCL, loaded lazily) */
@@ -771,7 +770,12 @@ int step_begin(AvbdContext* c)
     if (c->adjDirty && (rc = launch_topology(c, false))) return rc;
 
     ++c->stepIndex;
-    hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p);
+    {
+        /* (the grid broadphase's bucket heads are cleared by the same launch) */
+        const bool grid = !(c->fusedFront && n > 1 && n <= 4096) && !(n > 1 && n <= 4096) && n > 1 && c->gridBuckets > 0 && c->nBig <= 64;
+        if (grid) hipLaunchKernelGGL(k_begin_step, dim3(grid_for(c->gridBuckets, 256, 1024)), dim3(256), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p, c->dCellHead.p, c->gridBuckets);
+        else hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p, (int*)nullptr, 0);
+    }
     if (c->fusedFront && n > 1 && n <= 4096) {
         /* small scene: persistent manifolds and the broadphase (+ its own candidates) side by side in one launch */
         SpanGuard g(c, F_NARROW);
@@ -793,7 +797,6 @@ int step_begin(AvbdContext* c)
         } else if (n > 1 && c->gridBuckets > 0 && c->nBig <= 64) {
             const float invCell = 1.0f / c->gridCell;
             const unsigned mask = (unsigned)c->gridBuckets - 1u;
-            HIPCHK(c, hipMemsetAsync(c->dCellHead.p, 0xff, (size_t)c->gridBuckets * sizeof(int), c->stream));   /* -1: empty bucket */
             hipLaunchKernelGGL(k_grid_build, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0, c->stream, B, c->dIsBig.p, invCell, mask, c->dCellHead.p, c->dCellNext.p);
             hipLaunchKernelGGL(k_grid_pairs, dim3(grid_for((long long)n * 27, 256, 1 << 24)), dim3(256), 0, c->stream, B, c->dIsBig.p, c->dBigList.p, c->nBig, invCell, mask,
                                c->dCellHead.p, c->dCellNext.p, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
@@ -806,10 +809,6 @@ int step_begin(AvbdContext* c)
         SpanGuard g(c, F_NARROW);
         ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
         long long est = (long long)c->stats.numManifolds + std::max(c->stats.numCandidates, n) + 4096;
-        if (c->narrowCoop)
-            hipLaunchKernelGGL(k_narrowphase_coop, dim3(grid_for(est, kPairsPerWave, c->narrowCoopBlocks)), dim3(64), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
-                               c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex);
-        else
         hipLaunchKernelGGL(k_narrowphase, dim3(grid_for(est * 2, 32, 32768)), dim3(32), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
                            c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex);
         c->cur ^= 1;
@@ -822,10 +821,9 @@ int step_begin(AvbdContext* c)
     if (!c->topologyDidPredict) {
         {
             SpanGuard g(c, F_PREDICT);
-            hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p);
+            /* (with the done-counters of the task schedule; the error word behind them is sticky) */
+            hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p, c->mode != 0 ? c->dFlags.p : (int*)nullptr);
         }
-        if (c->mode != 0) /* done-counters and the error word of the data-flow kernel */
-            HIPCHK(c, hipMemsetAsync(c->dFlags.p, 0, (size_t)2 * c->bodyCap * sizeof(int), c->stream));   /* the error word behind them is sticky */
     }
     if (c->raceCheck && n > 0) {
         if (c->dSlotOf.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dSlotOf.alloc((size_t)c->bodyCap)); }
@@ -913,7 +911,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         X.multi = 1;
         if (!wholeLoop) { X.forceMulti = 1; X.planesAlways = 1; }
     }
-    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p;
+    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.groupMap = c->groupMap; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p;
     X.send = (sharded && c->dSend.p && c->dSendSlot.p) ? c->dSend.p : nullptr; X.sendSlot = c->dSendSlot.p;
     c->residentMultiLaunched = X.multi != 0;
     c->packFused = X.send != nullptr;
@@ -1236,7 +1234,7 @@ int shard_launch_persistent(AvbdContext* c)
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evBegin, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
+    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.groupMap = c->groupMap; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
     auto kern = c->shardMulti ? k_iterate_groups<true, 1> : k_iterate_groups<false, 1>;
     hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
                           S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
@@ -1598,8 +1596,7 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_PLACE")) c->placeChains = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_GROUP_SPEC")) c->groupSpecMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_GROUP_SPEC_ROUNDS")) c->groupSpecRounds = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("AVBD_NARROW_COOP")) c->narrowCoop = std::atoi(e) != 0;
-        if (const char* e = std::getenv("AVBD_NARROW_BLOCKS")) c->narrowCoopBlocks = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("AVBD_GROUP_MAP")) c->groupMap = std::max(0, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_SHARD_EXACT")) c->shardExact = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_SHARD_GATE")) c->shardGateKernel = std::strcmp(e, "kernel") == 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
@@ -2836,7 +2833,7 @@ static int group_step_exact(AvbdContext** ctxs, int n)
         X.pose = L->xsPose.p; X.visit = L->xsVisit.p; X.dual = L->xsDual.p;
         X.poseBytes = (unsigned)((size_t)3 * L->bodyCap * sizeof(float4)); X.visitBytes = (unsigned)(total * sizeof(float4)); X.dualBytes = (unsigned)(2 * total * sizeof(float4));
         X.enabled = 1; X.base = L->xsSerial * 64u;
-        X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;
+        X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.groupMap = c->groupMap; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;
         ShardExchange Z{};
         Z.xPose = L->xsPose.p; Z.xVisit = L->xsVisit.p; Z.xDual = L->xsDual.p;
         Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;

@@ -86,10 +86,13 @@ static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "t
  * waves of G = 4 >> c sub-groups) serves, in round k, rank r = (k * G + j) * Wc + wl — bodies that follow each other in the
  * sweep go to different waves.  One tile of 4096 slots of the sweep order per workgroup (tile_exclusive_prefix); the last
  * tile, which learns the totals from its look-back, writes the plan header. */
-__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round)
+__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round, int map = 0)
 {
     const int Wc = plan->waves[cls], G = 4 >> cls;
-    const int r = (round * G + j) * Wc + wl;
+    int r = (round * G + j) * Wc + wl;
+    if (map == 1) r = (round * Wc + wl) * G + j;                        /* the sub-groups of a wave serve neighbours of the sweep */
+    if (map == 2) r = (wl * G + j) * plan->rounds[cls] + round;          /* a sub-group serves a run of the sweep */
+    if (map == 3) r = (j * Wc + wl) * plan->rounds[cls] + round;         /* ... and the sub-groups of a wave runs that are far apart */
     return r < plan->nClass[cls] ? byClass[cls * cap + r] : -1;
 }
 
@@ -603,7 +606,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
 #ifdef AVBD_DF_STATS
-        if (!MULTI && gl == 0 && X.privN) (reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)body) * 4)[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+        if (gl == 0 && X.privN) (reinterpret_cast<unsigned*>(X.privN) + ((size_t)it * B.n + (size_t)body) * 4)[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
         AVBD_MARK(g_dual);
         GS_STAMP(9);
@@ -726,7 +729,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     if constexpr (!MULTI) {
         /* ---- one body per sub-group for the whole launch ---- */
         {
-            const int b = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), 0);
+            const int b = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), 0, X.groupMap);
             int e0 = 0, ne = 0;
             if (b >= 0) { e0 = incStart[b]; ne = incStart[b + 1] - e0; }
             load_header(b, e0, ne, 0);
@@ -831,7 +834,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
-            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl);
+            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl, X.groupMap);
             if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
         }
         /* the header table: three dependent loads per entry (incidence word -> pair -> is the partner swept?), four rounds in flight */
@@ -1064,7 +1067,14 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             const bool selF = EXACT && sel && it >= itStop;             /* the owner's last dual into this rank's copy of the contact */
             if (selF) { final_store(); spins = 0; }
             if (EXACT) sel = sel && it < itStop;
+#ifdef AVBD_DF_STATS
+            unsigned* trecM = reinterpret_cast<unsigned*>(X.privN) + ((size_t)(it < itStop ? it : 0) * B.n + (size_t)(body < 0 ? 0 : body)) * 4;   /* tools/debug_groups_critical.py */
+            if (sel && gl == 0 && X.privN) trecM[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
             if (sel) prepare_task();
+#ifdef AVBD_DF_STATS_PREP
+            if (sel && gl == 0 && X.privN) trecM[3] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
             GS_STAMP(2);
             if (sel) {
                 finish_visit();
@@ -1075,6 +1085,13 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 if (it < itStop - 1 || (EXACT && (__ballot(finalD) & gMask) != 0)) park_body();   /* (EXACT: the task behind the last iteration reads the parked normal) */
                 GS_STAMP_ND(15);                                       /* park: issue */
                 spins = 0;
+#ifdef AVBD_DF_STATS
+#ifdef AVBD_DF_STATS_PREP
+                if (gl == 0 && X.privN) trecM[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#else
+                if (gl == 0 && X.privN) { trecM[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); trecM[3] = (unsigned)w; }
+#endif
+#endif
             }
             if (EXACT) sel = sel || selF;
             AVBD_MARK(g_pass_end);

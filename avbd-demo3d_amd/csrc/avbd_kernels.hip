@@ -433,10 +433,9 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
 #endif
 }
 
-#ifndef AVBD_NARROW_WAVES
-#define AVBD_NARROW_WAVES 1
-#endif
-__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(AVBD_NARROW_WAVES, AVBD_NARROW_WAVES))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
+/* (one wave per SIMD: capped at 256 registers for two, the kernel spills 23 and runs at the same speed — 240 us at 64 000 cubes either way: it is
+ * bound by instruction issue, not by latency; sixteen lanes per pair, the small scenes' form, is 2.4x slower here) */
+__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
                                                       int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
 {
     const int nOld = cnt->numManifolds;
@@ -450,23 +449,6 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(AVBD_NARROW_
         int a = 0, b = 0;
         if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
         narrow_pair_lane(B, src, dst, item < nOld ? item : -1, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
-    }
-}
-
-/* the same with sixteen lanes per pair (avbd_collide_coop.h), four pairs per wavefront: a pair's serial chain is ~7x shorter and the
- * kernel needs half the registers, so three times as many wavefronts are resident */
-__global__ __launch_bounds__(64) void k_narrowphase_coop(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
-                                                         int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
-{
-    __shared__ CoopScratch sWs[kPairsPerWave];
-    const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;
-    const int nOld = cnt->numManifolds;
-    int nCand = cnt->numCandidates; if (nCand > candCap) nCand = candCap;
-    const int total = nOld + nCand;
-    for (int item = blockIdx.x * kPairsPerWave + gj; item < total; item += gridDim.x * kPairsPerWave) {
-        int a = 0, b = 0;
-        if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
-        narrow_pair(B, src, dst, item < nOld ? item : -1, a, b, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase);
     }
 }
 
@@ -894,10 +876,12 @@ __device__ __forceinline__ void predict_body(const BodyTable& B, int i, const So
     B.plane(BP_QUAT)[i] = packq(rot);
 }
 
-__global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt)
+/* (+ the done-counters of the task schedule: primalDone[cap] | dualDone[cap], nullptr in the level mode — a fill launch less per step) */
+__global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt, int* doneFlags)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B.n) return;
+    if (doneFlags) { doneFlags[i] = 0; doneFlags[B.cap + i] = 0; }
     predict_body(B, i, P, cnt);
 }
 
@@ -1348,8 +1332,11 @@ __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* c
 }
 
 /* start-of-step reset of the per-step counters */
-__global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount)
+__global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount, int* cellHead, int buckets)
 {
+    /* grid scenes: the broadphase's bucket heads start empty (-1); one launch instead of a fill behind it */
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < buckets; i += gridDim.x * blockDim.x) cellHead[i] = -1;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     cnt->numCandidates = 0; cnt->numContacts = 0; cnt->numIncidences = 0; cnt->warnings = 0; cnt->dynamicBodies = 0;
     cnt->numLevels = 0; cnt->residentBad = 0;
     *nextCount = 0;

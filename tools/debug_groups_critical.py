@@ -45,3 +45,31 @@ for k in set(kinds):
     print("  after a %-5s dependency: wait %.2f, compute %.2f (%d hops)" % (k, hand[sel].mean(), comp[sel].mean(), sel.sum()))
 dual = (end - pub)[:, dyn] / 100.0
 print("pose published -> task end (dual, park of the next first half): mean %.2f us" % dual.mean())
+# ---- where the long waits come from: what the consumer's wave did between the producer's publish and the moment it saw its inputs
+print("wait histogram (us):", {f"<{e}": int((hand < e).sum()) for e in (2, 5, 10, 20, 40, 80, 160, 1e9)})
+order = np.argsort(-hand)[:12]
+flat_wave = wave.reshape(-1); flat_seen = seen.reshape(-1); flat_end = end.reshape(-1)
+chain = []
+it, body = int(last[0]), int(last[1])
+# (re-walk to keep the (body, it, dep time) of every hop)
+while True:
+    best = None
+    for o in nb[body]:
+        if o > body: cand = (pub[it, o], o, it, "pose")
+        elif it > 0: cand = (end[it - 1, o], o, it - 1, "dual")
+        else: continue
+        if best is None or cand[0] > best[0]: best = cand
+    own = (end[it - 1, body], body, it - 1, "self") if it > 0 else None
+    if own is not None and (best is None or own[0] > best[0]): best = own
+    if best is None: break
+    chain.append((body, it, int(best[0]), best[3], best[1]))
+    body, it = best[1], best[2]
+for k in order:
+    b_, i_, tdep, kind, dep = chain[k]
+    wv_ = int(wave[i_, b_])
+    mine = (flat_wave == wv_) & (flat_seen > 0)
+    between = mine & (flat_seen >= tdep) & (flat_seen < seen[i_, b_])
+    running = mine & (flat_seen < tdep) & (flat_end > tdep)
+    its = np.nonzero(between)[0] // n
+    print("  wait %6.1f us: body %5d it %2d after %s of %5d | its wave %4d started %2d other tasks meanwhile (iterations %s), was inside a task at the publish: %s"
+          % (hand[k], b_, i_, kind, dep, wv_, int(between.sum()), sorted(set(its.tolist()))[:6], bool(running.any())))
