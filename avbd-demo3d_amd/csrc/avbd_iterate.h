@@ -110,6 +110,11 @@ __device__ __forceinline__ bool wait_dependencies(int body, int it, int lane, co
  * allocation of the loop that bounds the headline workload does not carry the other schedules' state.  Declines (returns at once)
  * when the topology kernels raised any veto bit; the k_iterate launch queued behind it with runIf = &cnt->residentBad then does
  * the step. */
+#ifndef AVBD_TWOSTAGE
+#define AVBD_TWOSTAGE 0             /* 1: solve_pose_pre during the wait, solve_pose_post behind it (avbd_primal.h).  Built, bit-identical (golden traces), and
+                                     * not faster: 85 instructions leave the hop but only the 24 of two division levels were on its dependent chain — 2.92 -> 2.86 us from
+                                     * detect to publish in the stamped build, 0.583 -> 0.586 ms per launch in the product (44 AGPRs instead of 4 carry the rest) */
+#endif
 template <bool JOINTS>
 __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_iterate_single(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                               const int* __restrict__ lvlStart, const Counters* __restrict__ cnt, const int* __restrict__ incStart,
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
 {
     if (cnt->residentBad != 0) return;
     __shared__ float sRows[kIterWaves][66 * kEntryRec];
-    __shared__ float sAcc[kIterWaves][64];
+    __shared__ float sAcc[kIterWaves][96];                           /* [64..88]: what stage one of the solve leaves for stage two (solve_pose_pre) */
     __shared__ int sBodyOf[kIterWaves];
     __shared__ v4u sPoseRec[kIterWaves][3];
     __shared__ unsigned sPoseFlag[kIterWaves];
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
     if (lane == 0) { sBodyOf[wv] = mine; sPoseFlag[wv] = X.base; }
     __syncthreads();
     CoLocal CL{(const volatile int AVBD_LDS*)sBodyOf, (volatile v4u AVBD_LDS*)&sPoseRec[0][0], (volatile unsigned AVBD_LDS*)sPoseFlag, wv};
-    if (mine >= 0) iterate_resident<false, JOINTS, true>(B, M, gf, order, nd, slot, W, incStart, inc, P, errWord, cntW, X, sleepSel, lane, sRows[wv], sAcc[wv], products, 0, itEnd, CL, mine);
+    if (mine >= 0) iterate_resident<false, JOINTS, true, !JOINTS && AVBD_TWOSTAGE>(B, M, gf, order, nd, slot, W, incStart, inc, P, errWord, cntW, X, sleepSel, lane, sRows[wv], sAcc[wv], products, 0, itEnd, CL, mine);
 }
 
 /* WPE = wavefronts per SIMD the launch is sized for: 1 (latency mode, one workgroup per CU: the critical wave never shares

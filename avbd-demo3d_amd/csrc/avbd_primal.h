@@ -502,6 +502,86 @@ __device__ __forceinline__ f3 solve_ldlt3_quad(m33 A, f3 b, int c)
     return bad ? zero3() : x;
 }
 
+/* ---- the same solve in two stages (one body per wave, contacts only) ---------------------------------------------------------
+ * lhsLin (ll) and the coupling block (la) are sums of penalty * J J^T: they are final as soon as the body's dual records are in,
+ * usually long before the last pose it waits for.  Stage one runs in that wait: the LDL^T factors of ll, AinvB = ll^-1 la and
+ * al * AinvB — everything solve6x6 (solver.cpp:68-83) derives from ll and la alone.  Stage two, behind the wait, substitutes the
+ * right-hand side through the stored factors (same operations on the same bits as solve_ldlt3_quad) and solves the Schur system:
+ * two of the eight division levels and the L1 / L2 rows leave the hop.
+ * pre[0..8] AinvB (columns), pre[9..17] al * AinvB (columns), pre[18..20] L10 L20 L21, pre[21..23] d0 d1 d2, pre[24] bad. */
+constexpr int kSolvePreFloats = 25;
+__device__ __forceinline__ void solve_pose_pre(const float* accs, float* pre, int lane)
+{
+    m33 ll, la, al;
+    ll.c0 = mk3(accs[0], accs[1], accs[2]); ll.c1 = mk3(accs[1], accs[3], accs[4]); ll.c2 = mk3(accs[2], accs[4], accs[5]);
+    la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
+    al = mtranspose(la);
+    const int j = (lane >> 2) & 3, c = lane & 3;
+    const int ro = j < 3 ? 6 + 3 * j : 6;
+    const f3 b = mk3(accs[ro], accs[ro + 1], accs[ro + 2]);
+    /* solve_ldlt3_quad, keeping the factors */
+    const f3 L0 = ll.c0;
+    bool bad = fabsf(L0.x) < FLT_EPSILON;
+    const float d0 = L0.x;
+    const float q1 = (c == 0 ? L0.y : L0.z) / d0;
+    const float L10 = quad_lane(q1, 0), L20 = quad_lane(q1, 1);
+    const f3 L1 = ll.c1 - L0 * L10;
+    bad |= fabsf(L1.y) < FLT_EPSILON;
+    const float d1 = L1.y;
+    const float L21 = L1.z / d1;
+    const f3 L2 = ll.c2 - L0 * L20 - L1 * L21;
+    bad |= fabsf(L2.z) < FLT_EPSILON;
+    const float d2 = L2.z;
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    const float zq = (c == 0 ? y.x : (c == 1 ? y.y : y.z)) / (c == 0 ? d0 : (c == 1 ? d1 : d2));
+    f3 z; z.x = quad_lane(zq, 0); z.y = quad_lane(zq, 1); z.z = quad_lane(zq, 2);
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    const f3 sol = bad ? zero3() : x;
+    const f3 prod = al * sol;
+    if (lane < 12 && c == 0) {
+        pre[j * 3 + 0] = sol.x; pre[j * 3 + 1] = sol.y; pre[j * 3 + 2] = sol.z;
+        pre[9 + j * 3 + 0] = prod.x; pre[9 + j * 3 + 1] = prod.y; pre[9 + j * 3 + 2] = prod.z;
+    }
+    if (lane == 0) { pre[18] = L10; pre[19] = L20; pre[20] = L21; pre[21] = d0; pre[22] = d1; pre[23] = d2; pre[24] = bad ? 1.0f : 0.0f; }
+    wave_sync();
+}
+
+__device__ __forceinline__ void solve_pose_post(const float* accs, float* xch, const float* pre, int lane, const BodyLocal& L, f3& p, q4& q)
+{
+    m33 la, al;
+    la.c0 = mk3(accs[6], accs[7], accs[8]); la.c1 = mk3(accs[9], accs[10], accs[11]); la.c2 = mk3(accs[12], accs[13], accs[14]);
+    al = mtranspose(la);
+    const int j = (lane >> 2) & 3, c = lane & 3;
+    const float L10 = pre[18], L20 = pre[19], L21 = pre[20], d0 = pre[21], d1 = pre[22], d2 = pre[23];
+    const bool bad = pre[24] != 0.0f;
+    /* x0 = solve(ll, b.l) through the stored factors: forward substitution, the three divisions side by side, back substitution */
+    const f3 b = mk3(accs[21], accs[22], accs[23]);
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    const float zq = (c == 0 ? y.x : (c == 1 ? y.y : y.z)) / (c == 0 ? d0 : (c == 1 ? d1 : d2));
+    f3 z; z.x = quad_lane(zq, 0); z.y = quad_lane(zq, 1); z.z = quad_lane(zq, 2);
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    const f3 x0 = bad ? zero3() : x;
+    /* Schur column j = aa.col j - al * AinvB.col j   |   rhs_s = b.a - al * x0 */
+    const f3 prodX = al * x0;
+    const f3 prod = j < 3 ? mk3(pre[9 + j * 3], pre[9 + j * 3 + 1], pre[9 + j * 3 + 2]) : prodX;
+    const int b0 = j == 0 ? 15 : (j == 1 ? 16 : (j == 2 ? 17 : 24)), b1 = j == 0 ? 16 : (j == 1 ? 18 : (j == 2 ? 19 : 25)),
+              b2 = j == 0 ? 17 : (j == 1 ? 19 : (j == 2 ? 20 : 26));
+    const f3 base = mk3(accs[b0], accs[b1], accs[b2]);
+    const f3 out = base - prod;
+    if (lane < 16 && c == 0) { xch[j * 3 + 0] = out.x; xch[j * 3 + 1] = out.y; xch[j * 3 + 2] = out.z; }
+    wave_sync();
+    {
+        const m33 schur = mkm(mk3(xch[0], xch[1], xch[2]), mk3(xch[3], xch[4], xch[5]), mk3(xch[6], xch[7], xch[8]));
+        const f3 rhs_s = mk3(xch[9], xch[10], xch[11]);
+        const f3 ys = solve_ldlt3_quad(schur, rhs_s, c);
+        const m33 AinvB = mkm(mk3(pre[0], pre[1], pre[2]), mk3(pre[3], pre[4], pre[5]), mk3(pre[6], pre[7], pre[8]));
+        const f3 dl = x0 - AinvB * ys;
+        p = L.pos - dl;                                               /* solver.cpp:403-405 */
+        q4 dq = mkq(ys.x, ys.y, ys.z, 0.0f);
+        q = qnormalize(L.rot - (dq * L.rot) * 0.5f);
+    }
+}
+
 __device__ __forceinline__ void solve_pose(const float* accs, float* xch, int lane, const BodyLocal& L, f3& p, q4& q)
 {
     m33 ll, la, al;

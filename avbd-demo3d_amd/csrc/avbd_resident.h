@@ -277,13 +277,14 @@ __device__ __forceinline__ void store_joint_half(GForce& f, int part, const Cont
  * owner writes; the first visitor's copy of normal + tangent memo and the pose in arrays private to the wave).  Tasks are
  * taken in the order t = it * slots + slot, a linear extension of the dependency order, so the smallest unfinished task is
  * always at the head of a resident wave's list.  `rows` / `accs` are the wave's LDS staging areas of k_iterate. */
-template <bool MULTI, bool JOINTS, bool COLO = false>
+template <bool MULTI, bool JOINTS, bool COLO = false, bool TWOSTAGE = false>      /* TWOSTAGE: accs has 96 floats, [64..88] for solve_pose_pre */
 __device__ __forceinline__ void iterate_resident(const BodyTable& B, const ManifoldTable& M, GForce* gf, const int* __restrict__ order, int nd, int w, int W,
                                                  const int* __restrict__ incStart, const int* __restrict__ inc, const SolverParams& P, int* errWord,
                                                  Counters* cntW, const ResidentExchange& X, int sleepSel, int lane, float* rows, float* accs, float* products,
                                                  int itBegin, int itEnd, CoLocal CL = CoLocal{nullptr, nullptr, nullptr, 0}, int placedBody = -1)
 {
     static_assert(!COLO || !MULTI, "the co-located hand-off is for one body per wave");
+    static_assert(!TWOSTAGE || (!MULTI && !JOINTS), "the two-stage solve is for one body per wave, contacts only");
     const __amdgpu_buffer_rsrc_t rP = xrsrc(X.pose, X.poseBytes), rV = xrsrc(X.visit, X.visitBytes), rD = xrsrc(X.dual, X.dualBytes);
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     const float4* massPlane = B.plane(BP_MASS);
@@ -525,6 +526,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
         const unsigned stampNow = X.base + (unsigned)it + 1u;
+        bool preDone = false;                                        /* TWOSTAGE: stage one of the solve was made during the wait */
 
         /* ---- the wait IS the load: poll the records until every stamp is current ---- */
         AVBD_MARK(wait);
@@ -537,11 +539,16 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 const unsigned quiet = (prevWait * (unsigned)X.quietPermille) / 1000u;
                 while ((unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0) < quiet) __builtin_amdgcn_s_sleep(8);
             }
+            preDone = false;
             const bool viaLds = COLO && needP && co >= 0;             /* the partner's wave shares this workgroup: its pose comes through LDS (second loop below) */
             bool okP = !needP || viaLds, okV = !needV, okD = !needD;
             v4u p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, vv = p0, d0 = p0, d1 = p0;
             unsigned spins = 0;
             unsigned long long lastMissing = 0;                       /* lanes that still missed a same-iteration pose in the round before the last */
+            /* TWOSTAGE: once the dual records (the penalties) are in and a pose or visit record is still out, the sums and the part of the
+             * solve that depend on nothing else are made while waiting (solve_pose_pre); the poll then goes on */
+            for (int pass = 0; pass < (TWOSTAGE ? 2 : 1); ++pass) {
+            bool allIn = false;
             while (true) {
                 const bool lp = !okP, lv = !okV, ld = !okD;
                 if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
@@ -551,7 +558,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if (lp) okP = stamp_reached(p0.w, sP) & stamp_reached(p1.w, sP) & stamp_reached(p2.w, sP);
                 if (lv) okV = stamp_reached(vv.w, sV);
                 if (ld) okD = stamp_reached(d0.w, sD) & stamp_reached(d1.w >> 1, sD);
-                if (__all(okP & okV & okD)) break;
+                if (__all(okP & okV & okD)) { allIn = true; break; }
+                if (TWOSTAGE && pass == 0 && __all(okD)) break;
                 if (COLO) lastMissing = __ballot(!okP && owned);
 #ifdef AVBD_DF_STATS
                 stat[14] += 1;
@@ -570,6 +578,38 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     tmoStamp = (unsigned)__builtin_amdgcn_readlane((int)sP, f);
                     return 2;
                 }
+            }
+            if (TWOSTAGE && pass == 0) {
+                bool early = !allIn;
+                if (COLO && allIn && __any(viaLds)) {                   /* everything from memory is in: is a pose that comes through LDS still out? */
+                    unsigned lf = 0;
+                    if (viaLds) lf = CL.flag[co];
+                    asm volatile("" ::: "memory");
+                    early = !__all(!viaLds || stamp_reached(lf, sP));
+                }
+                if (early) {
+                    AVBD_MARK(stage_one);
+                    if (needD) { c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z); }
+                    bool rowsOnA = true;
+                    if (has) {
+                        for (int k = 0; k < 3; ++k) {
+                            const bool penOk = (c.penalty[k] > 0.0f) & (fabsf(c.penalty[k]) <= FLT_MAX);   /* solver.cpp:387 */
+                            const int r = lane * 3 + k;
+                            S[kResRows + r] = c.penalty[k]; S[5 * kResRows + r] = penOk ? 1.0f : 0.0f;
+                            rowsOnA &= penOk;
+                        }
+                    }
+                    const bool allOnA = __all(rowsOnA);
+                    wave_sync();
+                    AccLane a1 = a;                                      /* (entries 15..26 read slots of the previous task here: nobody reads their sums) */
+                    if (allOnA) accumulate_products<true, JOINTS, MULTI>(a1, pr, prLine, S, nEnt * 3, J, X.prStride); else accumulate_products<false, JOINTS, MULTI>(a1, pr, prLine, S, nEnt * 3, J, X.prStride);
+                    if (lane < 15) accs[lane] = a1.acc;
+                    wave_sync();
+                    solve_pose_pre(accs, accs + 64, lane);
+                    preDone = true;
+                }
+            }
+            if (allIn) break;
             }
             if (COLO && __any(viaLds)) {
                 /* the poses that come through LDS: a short loop on the flag words alone (nothing is in flight any more, a round is
@@ -677,7 +717,11 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
         AVBD_MARK(solve);
         RS_STAMP(2);
         f3 p; q4 q;
-        solve_pose(accs, accs + 32, lane, L, p, q);
+#ifdef AVBD_DF_STATS
+        if (TWOSTAGE) stat[15] += preDone ? 1 : 0;                   /* tools/two_stage_check.py */
+#endif
+        if (TWOSTAGE && preDone) solve_pose_post(accs, accs + 32, accs + 64, lane, L, p, q);
+        else solve_pose(accs, accs + 32, lane, L, p, q);
 #ifdef AVBD_DF_STATS
         race_check_publish(errWord - 2 * B.cap, cntW, body, other, has && moving && !(JOINTS && isJoint), it);
 #endif
