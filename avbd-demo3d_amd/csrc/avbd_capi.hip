@@ -781,10 +781,10 @@ int step_begin(AvbdContext* c)
         SpanGuard g(c, F_NARROW);
         ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
         const int slices = (n + kFrontSlice - 1) / kFrontSlice;
-        const int ppw = kPairsPerWave;                                /* sixteen lanes per pair */
+        const int ppw = kFrontPairs;                                  /* sixteen lanes per pair */
         const int persistBlocks = std::max(1, std::min(16384, (c->stats.numManifolds + c->stats.numCandidates + n + ppw - 1) / ppw));
-        const int broadBlocks = (int)(((long long)n * slices + 63) / 64);
-        hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(64), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
+        const int broadBlocks = (int)(((long long)n * slices + kFrontThreads - 1) / kFrontThreads);
+        hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(kFrontThreads), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
                            c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices);
         c->cur ^= 1;
     } else {

@@ -456,16 +456,24 @@ __global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void
  * manifolds (they do not depend on the broadphase); every other workgroup enumerates 32 (body, 32-body slice) pair sets,
  * keeps its sphere-overlapping, unconstrained pairs in LDS and then collides them itself, one pair per lane.  Creation
  * keys make the order in which manifolds are appended irrelevant (avbd_types.h: make_manifold_key). */
-constexpr int kFrontSlice = 8;      /* bodies one thread of the fused broadphase tests: short slices = few candidates per workgroup, and a workgroup collides its own */
-constexpr int kFrontHits = 64 * kFrontSlice;   /* a workgroup can never find more */
-__global__ __launch_bounds__(64) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
+#ifndef AVBD_FRONT_SLICE
+#define AVBD_FRONT_SLICE 8
+#endif
+constexpr int kFrontSlice = AVBD_FRONT_SLICE;      /* bodies one thread of the fused broadphase tests: short slices = few candidates per workgroup, and a workgroup collides its own */
+#ifndef AVBD_FRONT_THREADS
+#define AVBD_FRONT_THREADS 128
+#endif
+constexpr int kFrontThreads = AVBD_FRONT_THREADS;   /* (2 650 one-wave workgroups took 27 us to dispatch at Stress1000: the pairs of block 0 were done after 8) */
+constexpr int kFrontPairs = kPairsPerWave * (kFrontThreads / 64);   /* pairs a workgroup collides side by side */
+constexpr int kFrontHits = kFrontThreads * kFrontSlice;   /* a workgroup can never find more */
+__global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
                                                     const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
                                                     int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
 {
-    __shared__ CoopScratch sWs[kPairsPerWave];
+    __shared__ CoopScratch sWs[kFrontPairs];
     __shared__ int2 sHits[kFrontHits];
     __shared__ int sNumHits;
-    const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;
+    const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;   /* gBase: first lane of the group inside its wave */
     if ((int)blockIdx.x < persistBlocks) {
 #ifdef AVBD_DF_STATS
         unsigned long long* dbg = (blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<unsigned long long*>(dst.cC + (size_t)dst.cap * 4 - 8) : nullptr;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(64) void k_front_small(BodyTable B, ManifoldTable s
 #endif
         const int nOld = cnt->numManifolds;
         /* four pairs per wavefront, sixteen lanes each (avbd_collide_coop.h) */
-        for (int item = blockIdx.x * kPairsPerWave + gj; item < nOld; item += persistBlocks * kPairsPerWave)
+        for (int item = blockIdx.x * kFrontPairs + gj; item < nOld; item += persistBlocks * kFrontPairs)
             narrow_pair(B, src, dst, item, 0, 0, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase
 #ifdef AVBD_DF_STATS
                         , dbg
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(64) void k_front_small(BodyTable B, ManifoldTable s
     __syncthreads();
     const float4* posr = B.plane(BP_POSR);
     const int n = B.n;
-    const int t = ((int)blockIdx.x - persistBlocks) * 64 + threadIdx.x;
+    const int t = ((int)blockIdx.x - persistBlocks) * kFrontThreads + threadIdx.x;
     const int i = t / slices, sl = t - i * slices;
     const int jBeg = sl * kFrontSlice;
     int jEnd = jBeg + kFrontSlice; if (jEnd > i) jEnd = i;
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(64) void k_front_small(BodyTable B, ManifoldTable s
     __syncthreads();
     const int nHits = sNumHits;
     if (threadIdx.x == 0 && nHits) atomicAdd(&cnt->numCandidates, nHits);
-    for (int h = gj; h < nHits; h += kPairsPerWave) {
+    for (int h = gj; h < nHits; h += kFrontPairs) {
         const int2 pr = sHits[h];
         narrow_pair(B, src, dst, -1, pr.x, pr.y, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase);
     }
