@@ -289,7 +289,6 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     const int cls = w < W2 ? 2 : (w < W2 + W1 ? 1 : 0);              /* wave-uniform */
     const int wl = w - (cls == 2 ? 0 : (cls == 1 ? W2 : W2 + W1));    /* which wave of its class */
     const int rounds = __builtin_amdgcn_readfirstlane(plan->rounds[cls]);
-    constexpr bool multi = MULTI;                                    /* (a class of a several-round plan may have one round: same code, state parked) */
     const int gw = 16 << cls, gl = lane & (gw - 1), gBase = lane & ~(gw - 1);
     const unsigned long long gMask = (cls == 2 ? ~0ull : ((1ull << gw) - 1ull)) << gBase;
     float* const J = reinterpret_cast<float*>(sGroups) + wv * kGrpWaveFloats;
