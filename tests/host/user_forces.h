@@ -92,7 +92,8 @@ static void recordBodies(Solver* s, std::vector<float>& out)
 
 // The pinned runs: Tether with finite and with infinite stiffness (40 steps each), then Pin + Joint + IgnoreCollision (60 steps);
 // body states every 10 steps and the user force's rows at the end.  Last: two Fuses (and a Tether created between them) — the first
-// burns out at step 12, the second at step 25; the solver deletes each at that step, the pair it constrained starts colliding.
+// burns out at step 12, the second at step 25; the solver deletes each at that step, the pair it constrained starts colliding.  Then two Fuses
+// that burn out in the SAME step, first and last of the user forces of a scene that also holds a world-anchored Joint.
 static void runUserForceScenes(std::vector<float>& out)
 {
     for (float k : {400.0f, FLT_MAX}) {
@@ -136,6 +137,25 @@ static void runUserForceScenes(std::vector<float>& out)
                 for (Force* f = s->forces; f; f = f->next) generic += f->getRowCount() == 1;
                 out.push_back((float)generic);
             }
+        }
+        AVBD_SYNC_FORCES(s);
+        out.push_back(t->lambda[0]); out.push_back(t->penalty[0]); out.push_back(t->C[0]); out.push_back((float)t->calls);
+        delete s;
+        out.push_back((float)destroyed);
+    }
+    {   // two Fuses that burn out in the SAME step (the first and the last of three user forces), a Joint between them in the list
+        Solver* s = new Solver();
+        Rigid *a, *b;
+        buildScene(s, a, b);
+        Rigid* c = s->bodies;
+        int destroyed = 0;
+        new Fuse(s, a, b, {0.0f, 0.5f, 0.0f}, {0.0f, -0.3f, 0.0f}, 800.0f, 7, &destroyed);
+        new Joint(s, c, {0.1f, 1.15f, 0.0f}, 50.0f, 20.0f);
+        Tether* t = new Tether(s, a, c, {0.3f, 0.0f, 0.0f}, {-0.2f, 0.0f, 0.0f}, FLT_MAX, -1.0f);
+        new Fuse(s, c, b, {0.0f, 0.1f, 0.0f}, {0.0f, 0.0f, 0.2f}, FLT_MAX, 7, &destroyed);
+        for (int step = 0; step < 20; ++step) {
+            s->step();
+            if (step % 5 == 4) { recordBodies(s, out); out.push_back((float)destroyed); }
         }
         AVBD_SYNC_FORCES(s);
         out.push_back(t->lambda[0]); out.push_back(t->penalty[0]); out.push_back(t->C[0]); out.push_back((float)t->calls);

@@ -73,3 +73,10 @@ for k in order:
     its = np.nonzero(between)[0] // n
     print("  wait %6.1f us: body %5d it %2d after %s of %5d | its wave %4d started %2d other tasks meanwhile (iterations %s), was inside a task at the publish: %s"
           % (hand[k], b_, i_, kind, dep, wv_, int(between.sum()), sorted(set(its.tolist()))[:6], bool(running.any())))
+# ---- which neighbour the chain runs through: creation-index distance between a body and the later-created partner it waited for
+import collections
+dist = collections.Counter(int(dep) - int(b_) for (b_, i_, tdep, kind, dep) in chain if kind == "pose")
+print("index distance of the awaited partner on the chain (pose hops):", dict(sorted(dist.items(), key=lambda kv: -kv[1])[:8]))
+same_wg = sum(1 for (b_, i_, tdep, kind, dep) in chain if kind == "pose" and int(wave[i_, b_]) // 4 == int(wave[i_, dep]) // 4)
+same_wave = sum(1 for (b_, i_, tdep, kind, dep) in chain if kind == "pose" and int(wave[i_, b_]) == int(wave[i_, dep]))
+print("pose hops whose two bodies share a workgroup: %d, a wave: %d, of %d" % (same_wg, same_wave, sum(1 for x in chain if x[3] == "pose")))
