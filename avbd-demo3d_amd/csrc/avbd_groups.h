@@ -445,6 +445,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
 
 #ifdef AVBD_DF_STATS
     unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned dbgTasks = 0, dbgOldest = 0;                            /* several bodies per sub-group: tasks run | of which the oldest of their sub-group */
     unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
 #define GS_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)
 #define GS_STAMP_ND(i) do { unsigned long long _n = __builtin_amdgcn_s_memrealtime(); stat[i] += _n - tprev; tprev = _n; } while (0)   /* without draining memory operations */
@@ -1046,6 +1047,13 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     const unsigned long long noGather = SHARD ? (__ballot(!okR) & gMask) : 0ull;
                     if ((noPose | noRest | noGather) == 0) {
                         sel = true;
+#ifdef AVBD_DF_STATS
+                        {   /* was the task that runs the OLDEST task of its sub-group (what a speculative load would have fetched)? */
+                            int keyO = activeK ? ((itK << 6) | gl) : 0x7fffffff;
+                            for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(keyO, o, 64); keyO = other_ < keyO ? other_ : keyO; }
+                            if (lane == k) { dbgTasks += 1; dbgOldest += (keyO == key) ? 1 : 0; }
+                        }
+#endif
                         if (lane == k) { ++itK; ++blkStamp; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
                     } else if (noPose) {
                         /* watch the pose of the first partner that is late (its last record's stamp word) */
@@ -1123,6 +1131,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         unsigned long long* o = reinterpret_cast<unsigned long long*>(errWord + 16) + (size_t)w * 16;
         stat[6] = __builtin_amdgcn_s_memrealtime() - t0;
         for (int i = 0; i < 16; ++i) o[i] = stat[i];
+        if (MULTI) { unsigned a = dbgTasks, b = dbgOldest; for (int q = 1; q < 64; ++q) { a += (unsigned)__builtin_amdgcn_readlane((int)dbgTasks, q); b += (unsigned)__builtin_amdgcn_readlane((int)dbgOldest, q); } o[10] = a; o[11] = b; }
     }
 #endif
 }

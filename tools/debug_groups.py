@@ -20,3 +20,5 @@ for i, n in ((0, "poll+idle"), (7, "finish: records, post, S"), (8, "finish: acc
     # (stamps inside a task are taken by lane 0 for ITS sub-group's tasks only: ~iterations of them per wave)
     print("  %-48s total us/wave %8.1f   per pass %6.2f   per task of lane 0's body %6.2f" % (n, (act[:, i] / 100).mean(), (act[:, i] / 100 / act[:, 5]).mean(), (act[:, i] / 100).mean() / 20.0))
 print("poll rounds per wave %.0f" % act[:, 14].mean())
+if act[:, 10].sum() > 0 and act[:, 10].sum() < 1e9:   # several bodies per sub-group, plain loop: o[10] tasks, o[11] tasks that were the oldest of their sub-group
+    print("tasks %d, of which the oldest task of their sub-group when they ran: %.1f %%" % (act[:, 10].sum(), 100.0 * act[:, 11].sum() / act[:, 10].sum()))
