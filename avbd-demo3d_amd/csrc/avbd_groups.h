@@ -366,7 +366,10 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 const float4 s0 = X.parkS[e * 4], s1 = X.parkS[e * 4 + 1], s2 = X.parkS[e * 4 + 2], s3 = X.parkS[e * 4 + 3];
                 c.rA = mk3(k0.x, k0.y, k0.z); c.C0n = k0.w; c.rB = mk3(k1.x, k1.y, k1.z); c.C0t1 = k1.w; c.C0t2 = k2.x; fric = k2.y; oinv = k2.z;
                 pOther = mk3(k3.x, k3.y, k3.z); wOther = mk3(k4.x, k4.y, k4.z);
-                c.normal = mk3(s0.x, s0.y, s0.z); c.stick = s0.w != 0.0f; c.u1 = mk3(s1.x, s1.y, s1.z); c.u2 = mk3(s2.x, s2.y, s2.z);
+                /* (w: stick | normal is a fixed point of its normalisation << 1 — what one body per sub-group keeps in a register for the whole launch:
+                 * without it every task replays one or two normalisations per contact, square root and division included) */
+                const int fl = (int)s0.w;
+                c.normal = mk3(s0.x, s0.y, s0.z); c.stick = (fl & 1) != 0; fixedN = (fl & 2) != 0; c.u1 = mk3(s1.x, s1.y, s1.z); c.u2 = mk3(s2.x, s2.y, s2.z);
                 c.lambda[0] = s1.w; c.lambda[1] = s2.w; c.lambda[2] = s3.x; c.penalty[0] = s3.y; c.penalty[1] = s3.z; c.penalty[2] = s3.w;
                 c.penetration = 0.0f;                                      /* (an output of every computeConstraint call; the last task stores it) */
                 if (SHARD) { remote = !moving && oinv > 0.0f; offR = remote ? Z.row[other] * 32 : 0; }
@@ -421,7 +424,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             int slotF = eBeg + gl;
             asm volatile("" : "+v"(slotF));
             float4* ps = X.parkS + (size_t)slotF * 4;
-            ps[0] = make_float4(c.normal.x, c.normal.y, c.normal.z, c.stick ? 1.0f : 0.0f);
+            ps[0] = make_float4(c.normal.x, c.normal.y, c.normal.z, (float)((c.stick ? 1 : 0) | (fixedN ? 2 : 0)));
             ps[1] = make_float4(c.u1.x, c.u1.y, c.u1.z, c.lambda[0]);
             ps[2] = make_float4(c.u2.x, c.u2.y, c.u2.z, c.lambda[1]);
             ps[3] = make_float4(c.lambda[2], c.penalty[0], c.penalty[1], c.penalty[2]);
