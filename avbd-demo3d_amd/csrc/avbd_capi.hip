@@ -714,6 +714,9 @@ int refresh_stats(AvbdContext* c, bool withLevels)
         if (why[1] && why[15] >= 100)   /* several bodies per sub-group: the first body of the first timed-out sub-group that still has tasks */
             std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?) [rank %d wave %d class %d lane %d: body %d at iteration %d of %d watches record offset %d for stamp base%+d, last saw base%+d; timed out %08x%08x]",
                           c->rank, why[1] - 1, why[15] - 100, why[8], why[2], why[4], why[7], why[3], why[5], why[6], (unsigned)why[14], (unsigned)why[13]);
+        else if (why[1] && why[15] == 50)   /* the resident schedule: the first wave to give up */
+            std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?) [resident schedule, rank %d wave %d (workgroup %d of %d, %s): body %d iteration %d partner %d; lanes missing pose %08x%08x visit %08x%08x dual %08x%08x; %d polls]",
+                          c->rank, why[1] - 1, why[11], why[12], why[13] ? "several bodies per wave" : "one body per wave", why[2], why[4], why[3], (unsigned)why[6], (unsigned)why[5], (unsigned)why[8], (unsigned)why[7], (unsigned)why[10], (unsigned)why[9], why[14]);
         else if (why[1])   /* the group schedule says what its first wave to give up was waiting for */
             std::snprintf(buf, sizeof(buf), "k_iterate: dependency wait timed out (grid not resident?) [rank %d wave %d class %d: body %d iteration %d partner %d; lanes missing pose %08x%08x visit %08x%08x dual %08x%08x gather %08x%08x, timed out %08x%08x]",
                           c->rank, why[1] - 1, why[15], why[2], why[4], why[3], (unsigned)why[6], (unsigned)why[5], (unsigned)why[8], (unsigned)why[7], (unsigned)why[10], (unsigned)why[9], (unsigned)why[12], (unsigned)why[11], (unsigned)why[14], (unsigned)why[13]);
@@ -2891,6 +2894,16 @@ static int group_step_one(AvbdContext** ctxs, int n)
             }
             if ((rc = step_begin(c))) return rc;
             c->statsFresh = false;
+        }
+        for (int r = 0; r < n; ++r) {
+            /* Contexts that share a device (several ranks emulated on one GPU): the front ends of ALL of them have finished before the first
+             * iteration launch is queued.  Rank 0's first launch used to start beside the other contexts' broad / narrow phase and topology
+             * kernels — it needs every workgroup resident and spins until it is, some of those kernels wait for earlier workgroups of their own
+             * (decoupled look-back): one run in five of the eight-context tests ended in a dependency time-out in iteration 0 of rank 0
+             * (0 of 40 with this; tests/test_gpu_sharded_full_size.py).  One context per device: no wait. */
+            bool shares = false;
+            for (int q = 0; q < n; ++q) shares |= q != r && ctxs[q]->device == ctxs[r]->device;
+            if (shares) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
         }
         if (n > 1 && ctxs[0]->shardExact) {
             /* exact cuts: no exchange during the loop, results identical to the single-GPU sweep (avbd_cuts.h) */

@@ -569,7 +569,21 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 if ((++spins & 1023u) == 0) {
                     bool dead = (__builtin_amdgcn_s_memrealtime() - tWait0 > kSpinTimeoutTicks) ||   /* measured from the start of THIS wait */
                                 __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    if (__any(dead)) { if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+                    if (__any(dead)) {
+                        {   /* what the first wave to give up was waiting for (errWord[1..15]; read by the host for its message) */
+                            const bool mine = __builtin_amdgcn_s_memrealtime() - tWait0 > kSpinTimeoutTicks;
+                            const unsigned long long mP = __ballot(!okP), mV = __ballot(!okV), mD = __ballot(!okD);
+                            const unsigned long long mAny = mP | mV | mD;
+                            const int stuck = mAny ? __ffsll((long long)mAny) - 1 : 0;
+                            const int so = __builtin_amdgcn_readlane(other, stuck);
+                            if (lane == 0 && mine && __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicCAS(errWord + 1, 0, w + 1) == 0) {
+                                errWord[2] = body; errWord[3] = so; errWord[4] = it; errWord[5] = (int)mP; errWord[6] = (int)(mP >> 32); errWord[7] = (int)mV; errWord[8] = (int)(mV >> 32);
+                                errWord[9] = (int)mD; errWord[10] = (int)(mD >> 32); errWord[11] = (int)blockIdx.x; errWord[12] = (int)gridDim.x; errWord[13] = MULTI ? 1 : 0; errWord[14] = (int)spins; errWord[15] = 50;
+                            }
+                        }
+                        if (lane == 0) __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return 0;
+                    }
                 }
                 if (MULTI && patience && (unsigned)(__builtin_amdgcn_s_memrealtime() - tWait0) > patience) {
                     /* give the wave back to its other bodies; remember one record this task was still missing */
