@@ -23,6 +23,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
 
 using namespace avbd;
 
@@ -230,6 +231,7 @@ struct AvbdContext {
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
     int groupSpecMode = 0, groupSpecRounds = 4, groupMap = 0;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
+    bool turnReleased = false;          /* avbd_destroy has taken this context out of its device's count (turn_begin / turn_end) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
     DevArr<unsigned> dXchMismatch;      /* words of gathered velocities that differed from the re-derived ones (must stay 0) */
     void* comm = nullptr;               /* ncclComm_t (RCCL, loaded lazily) */
@@ -1548,6 +1550,41 @@ int avbd_default_params(AvbdParams* p)
     return AVBD_OK;
 }
 
+/* ---- contexts that share a device take turns ------------------------------------------------------------------------------------
+ * The iteration loop of a step is ONE launch that needs every workgroup resident and spins until the others have published; a second
+ * launch of that kind beside it — or a topology kernel of another context, whose tiles wait for earlier tiles — can leave both
+ * half-resident for ever (two worlds of one process stepped without a synchronize in between: a dependency time-out in five runs
+ * out of nine).  avbd_step / avbd_group_step calls of different contexts on one device are therefore ordered on the device with one
+ * event per device: a call waits for the call that used the device last (another context's), and records when it has queued its
+ * own work.  A process with one context per device never waits and never records. */
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_turnMu;
+int g_turnLive[kMaxDevices] = {};              /* contexts alive per device */
+hipEvent_t g_turnEv[kMaxDevices] = {};         /* end of the last call that used the device */
+AvbdContext* g_turnLast[kMaxDevices] = {};     /* whose call that was */
+
+void turn_begin(AvbdContext* c, AvbdContext* const* group = nullptr, int ngroup = 0)
+{
+    const int d = c->device;
+    if (d < 0 || d >= kMaxDevices) return;
+    std::lock_guard<std::mutex> lk(g_turnMu);
+    if (g_turnLive[d] < 2 || !g_turnLast[d] || g_turnLast[d] == c || !g_turnEv[d]) return;
+    for (int k = 0; k < ngroup; ++k) if (group[k] == g_turnLast[d]) return;   /* the contexts of one avbd_group_step run side by side by design */
+    (void)hipStreamWaitEvent(c->stream, g_turnEv[d], 0);
+}
+void turn_end(AvbdContext* c)
+{
+    const int d = c->device;
+    if (d < 0 || d >= kMaxDevices) return;
+    std::lock_guard<std::mutex> lk(g_turnMu);
+    if (g_turnLive[d] < 2) return;
+    if (!g_turnEv[d] && hipEventCreateWithFlags(&g_turnEv[d], hipEventDisableTiming) != hipSuccess) { g_turnEv[d] = nullptr; return; }
+    (void)hipEventRecord(g_turnEv[d], c->stream);
+    g_turnLast[d] = c;
+}
+} // namespace
+
 int avbd_create(int device, AvbdContext** out)
 {
     if (!out) return AVBD_E_INVALID;
@@ -1657,6 +1694,7 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_levels, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
     }
+    if (device < kMaxDevices) { std::lock_guard<std::mutex> lk(g_turnMu); ++g_turnLive[device]; }
     *out = c;
     return AVBD_OK;
 }
@@ -1666,6 +1704,11 @@ int avbd_destroy(AvbdContext* c)
     if (!c) return AVBD_E_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->device >= 0 && c->device < kMaxDevices) {
+        std::lock_guard<std::mutex> lk(g_turnMu);
+        if (!c->turnReleased) { --g_turnLive[c->device]; c->turnReleased = true; }
+        if (g_turnLast[c->device] == c) g_turnLast[c->device] = nullptr;      /* (its work has finished: nothing to wait for) */
+    }
     for (auto e : c->evPool) (void)hipEventDestroy(e);
     c->dPlanes.release(); c->mbuf[0].release(); c->mbuf[1].release(); c->dG.release();
     c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
@@ -2090,11 +2133,11 @@ int avbd_step(AvbdContext* c, int nsteps)
 {
     if (!c || nsteps < 0) return AVBD_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return c->fail(AVBD_E_NODEVICE, "hipSetDevice failed");
-    for (int s = 0; s < nsteps; ++s) {
-        int rc = step_once(c);
-        if (rc) return rc;
-    }
-    return AVBD_OK;
+    turn_begin(c);
+    int rc = AVBD_OK;
+    for (int s = 0; s < nsteps && !rc; ++s) rc = step_once(c);
+    turn_end(c);
+    return rc;
 }
 
 int avbd_synchronize(AvbdContext* c)
@@ -3057,11 +3100,25 @@ int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
      * thread; the per-iteration pose exchange is done with device-to-device copies instead of RCCL.  Same schedule
      * and same results as the one-process-per-GPU RCCL path. */
     if (!ctxs || n < 1 || nsteps < 0) return AVBD_E_INVALID;
-    for (int s = 0; s < nsteps; ++s) {
-        const int rc = group_step_one(ctxs, n);
-        if (rc) return rc;
+    for (int r = 0; r < n; ++r) if (!ctxs[r]) return AVBD_E_INVALID;
+    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); turn_begin(ctxs[r], ctxs, n); }
+    int rc = AVBD_OK;
+    for (int s = 0; s < nsteps && !rc; ++s) rc = group_step_one(ctxs, n);
+    /* the end of the call on a device: its first context's stream, behind the streams of the others */
+    for (int r = 0; r < n; ++r) {
+        bool first = true;
+        for (int q = 0; q < r; ++q) first &= ctxs[q]->device != ctxs[r]->device;
+        if (!first) continue;
+        (void)hipSetDevice(ctxs[r]->device);
+        for (int q = r + 1; q < n; ++q)
+            if (ctxs[q]->device == ctxs[r]->device) {
+                if (!ctxs[q]->iterDone && hipEventCreateWithFlags(&ctxs[q]->iterDone, hipEventDisableTiming) != hipSuccess) continue;
+                (void)hipEventRecord(ctxs[q]->iterDone, ctxs[q]->stream);
+                (void)hipStreamWaitEvent(ctxs[r]->stream, ctxs[q]->iterDone, 0);
+            }
+        turn_end(ctxs[r]);
     }
-    return AVBD_OK;
+    return rc;
 }
 
 /* ---- measurement ------------------------------------------------------------------------ */

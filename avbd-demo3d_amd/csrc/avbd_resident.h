@@ -570,7 +570,8 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                     bool dead = (__builtin_amdgcn_s_memrealtime() - tWait0 > kSpinTimeoutTicks) ||   /* measured from the start of THIS wait */
                                 __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                     if (__any(dead)) {
-                        {   /* what the first wave to give up was waiting for (errWord[1..15]; read by the host for its message) */
+                        if constexpr (MULTI) {   /* what the first wave to give up was waiting for (errWord[1..15]; read by the host for its message); not in the
+                                                  * one-body-per-wave kernels: the extra live values cost the headline launch 1.6 % */
                             const bool mine = __builtin_amdgcn_s_memrealtime() - tWait0 > kSpinTimeoutTicks;
                             const unsigned long long mP = __ballot(!okP), mV = __ballot(!okV), mD = __ballot(!okD);
                             const unsigned long long mAny = mP | mV | mD;

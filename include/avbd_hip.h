@@ -171,7 +171,10 @@ int  avbd_add_force(AvbdContext* ctx, const AvbdForce* record);
  * the scene index (>= 0) or AVBD_E_INVALID for an unknown name. ---- */
 int  avbd_build_scene(AvbdContext* ctx, const char* name);
 
-/* ---- Solver::step() (solver.cpp:255-514), nsteps times back to back on the device. ---- */
+/* ---- Solver::step() (solver.cpp:255-514), nsteps times back to back on the device.
+ * Several contexts on ONE device (two Solvers in one program): their avbd_step / avbd_group_step calls take turns on the device —
+ * a call is ordered behind the call of another context that used the device last (one event per device, no host wait); the
+ * iteration loop of a step needs the whole device.  One context per device never waits. ---- */
 int  avbd_step(AvbdContext* ctx, int nsteps);
 int  avbd_synchronize(AvbdContext* ctx);
 int  avbd_step_index(const AvbdContext* ctx);                       /* Solver::stepIndex */

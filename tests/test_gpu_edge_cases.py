@@ -561,3 +561,27 @@ def test_corrected_joint_sign_option_welds_hold(monkeypatch):
     r.step(60)
     br = r.bodies()
     assert not (abs(float(np.linalg.norm(br["pos"][b] - br["pos"][a])) - 1.0) < 2e-2 and abs(float(np.abs(np.dot(br["quat"][a], br["quat"][b]))) - 1.0) < 1e-3)
+
+
+def test_worlds_of_one_process_stepped_without_a_synchronize_in_between():
+    """Two Solvers in one program (nothing in the reference forbids it): their steps are queued back to back on one device, no
+    synchronize in between.  Every step's iteration loop is a launch that needs all its workgroups resident; two of them beside
+    each other — or beside the other world's topology kernels — used to end in a dependency time-out in more than half of the runs.
+    avbd_step / avbd_group_step calls of different contexts on one device now take turns on the device (one event per device), and
+    each world ends with the bits it reaches alone."""
+    scenes = ["Stress1000", "StressN:12", "Pyramid"]
+    alone = []
+    for s in scenes:
+        w = H.HipWorld(); w.scene(s); w.step(200); w.w.synchronize()
+        alone.append((w.bodies().tobytes(), w.forces().tobytes()))
+        w.close()
+    ws = [H.HipWorld() for _ in scenes]
+    for w, s in zip(ws, scenes):
+        w.scene(s)
+    for k in range(40):
+        for w in ws:
+            w.step(5)                                    # queued, not waited for
+    for w, s, ref in zip(ws, scenes, alone):
+        w.w.synchronize()
+        assert w.bodies().tobytes() == ref[0] and w.forces().tobytes() == ref[1], s
+        w.close()
