@@ -13,6 +13,12 @@
  */
 #include "../../include/avbd_hip.h"
 #include "avbd_kernels.hip"
+namespace avbd {   /* instantiated in avbd_single.hip (compiled with -O3) */
+extern template __global__ void k_iterate_single<false>(BodyTable, ManifoldTable, GForce*, const int* __restrict__, const int* __restrict__, const Counters* __restrict__,
+                                                        const int* __restrict__, const int* __restrict__, SolverParams, int*, Counters*, int, int, ResidentExchange);
+extern template __global__ void k_iterate_single<true>(BodyTable, ManifoldTable, GForce*, const int* __restrict__, const int* __restrict__, const Counters* __restrict__,
+                                                       const int* __restrict__, const int* __restrict__, SolverParams, int*, Counters*, int, int, ResidentExchange);
+}
 #include <hip/hip_ext.h>
 
 #include <dlfcn.h>

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64 * kIterWaves) __attribute__((amdgpu_waves_per_eu
 #endif
 }
 
+#ifndef AVBD_TU_SINGLE
 /* Forces with no dynamic endpoint (static-static manifolds, joints between statics) take no part in any
  * primal visit; their dual updates (which only feed the diagnostics and the API-visible rows) run here. */
 __global__ void k_dual_static(BodyTable B, ManifoldTable M, const Counters* cnt, GForce* gf, int ng, SolverParams P)
@@ -418,5 +419,7 @@ __global__ void k_dual_static(BodyTable B, ManifoldTable M, const Counters* cnt,
         }
     }
 }
+
+#endif
 
 } // namespace avbd

@@ -15,6 +15,7 @@
 #pragma once
 #include "avbd_types.h"
 #include "avbd_rows.h"
+#include "avbd_util.h"
 
 #pragma clang fp contract(off)
 
@@ -734,6 +735,7 @@ __device__ __forceinline__ void dual_gforce(const BodyTable& B, GForce& f, const
  * ========================================================================================== */
 constexpr int kWavesPerBlock = 4;
 
+#ifndef AVBD_TU_SINGLE   /* (avbd_single.hip compiles only k_iterate_single from these headers: the plain kernels belong to the main translation unit) */
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_primal(BodyTable B, ManifoldTable M, GForce* gf, const int* __restrict__ order,
                                                                  const int* __restrict__ lvlStart, int level, const int* __restrict__ incStart,
                                                                  const int* __restrict__ inc, SolverParams P, float alpha, int writeRows, Counters* cnt, int it,
@@ -788,5 +790,7 @@ __global__ void k_dual_gforce(BodyTable B, GForce* gf, int ng, SolverParams P)
     if (g >= ng) return;
     dual_gforce<false>(B, gf[g], P, true);
 }
+
+#endif
 
 } // namespace avbd
