@@ -49,7 +49,10 @@ def main():
     #     the floats the reference computes for a user's Tether / Pin (oracle/user_force_ref.cpp, built by `make -C oracle ref`)
     uf = os.path.join(H.ORACLE_DIR, "_ref", "user_force_ref")
     subprocess.run([uf, os.path.join(HERE, "user_force_states.bin")], check=True)
-    meta["user_force_states.bin"] = "tests/host/user_forces.h against /root/reference/source: body states every 10 steps + the user force's rows"
+    import hashlib
+    meta["user_force_states.bin"] = {"what": "tests/host/user_forces.h (Tether, Pin, Fuse) compiled against /root/reference/source by oracle/user_force_ref.cpp: "
+                                             "body states every 10 steps + the user force's rows",
+                                     "md5": hashlib.md5(open(os.path.join(HERE, "user_force_states.bin"), "rb").read()).hexdigest()}
 
     # 2. Stress1000: 13-float body state at the survey's checkpoints + the per-step diagnostics for 600 steps
     w = H.CpuWorld("ref")

@@ -33,4 +33,10 @@ def test_user_defined_force_subclasses_run_through_host_evaluated_rows(tmp_path)
     against /root/reference/source as well (oracle/user_force_ref.cpp -> tests/golden/user_force_states.bin, make_golden.py).
     The last pinned run holds two `Fuse`s whose initialize() returns false at steps 12 and 25: the solver deletes them
     (solver.cpp:274-279; destructor calls and the length of the force list are part of the pinned floats), the pair starts colliding."""
-    _build_and_run(tmp_path, "user_force", [os.path.join(H.ROOT, "tests", "golden", "user_force_states.bin")])
+    fixture = os.path.join(H.ROOT, "tests", "golden", "user_force_states.bin")
+    assert os.path.exists(fixture), ("tests/golden/user_force_states.bin is missing: it is a tracked fixture (see .gitignore's exception for "
+                                     "tests/golden/*.bin); regenerate it with `make -C oracle ref && python tests/golden/make_golden.py`")
+    import hashlib, json
+    meta = json.load(open(os.path.join(H.ROOT, "tests", "golden", "golden_meta.json")))
+    assert hashlib.md5(open(fixture, "rb").read()).hexdigest() == meta["user_force_states.bin"]["md5"]
+    _build_and_run(tmp_path, "user_force", [fixture])
