@@ -49,7 +49,7 @@ PARAMS_DT = np.dtype([
 ])
 STATS_DT = np.dtype([(n, "<i4") for n in (
     "numBodies", "numDynamic", "numManifolds", "numContacts", "numIncidences", "numCandidates", "numLevels",
-    "numJoints", "numSprings", "numIgnores", "warnings", "schedule")])
+    "numJoints", "numSprings", "numIgnores", "warnings", "schedule", "cutMode")])
 PROFILE_DT = np.dtype([
     ("ms_broadphase", "<f8"), ("ms_narrowphase", "<f8"), ("ms_topology", "<f8"), ("ms_predict", "<f8"),
     ("ms_primal", "<f8"), ("ms_dual", "<f8"), ("ms_velocity", "<f8"),

@@ -211,6 +211,8 @@ struct AvbdContext {
     DevArr<int> dSlotOf;
     /* exact cuts (avbd_cuts.h): the stamped records of all ranks in one address space; the first context of a group owns it */
     bool jointAngularFix = false;  /* avbd_set_joint_angular_sign(ctx, 1): Joint angular rows with J = dC/dtheta instead of the reference's sign */
+    bool shardExactStrict = true;  /* avbd_set_shard_mode 1: a step that cannot run exact cuts FAILS (AVBD_E_INVALID + reason); 2: it takes the all-gather form, AvbdStepStats.cutMode says so */
+    int cutModeRan = 0;            /* AvbdStepStats.cutMode of the last step */
     bool shardExact = false;       /* AVBD_SHARD_EXACT=1: avbd_group_step sweeps every rank's slab with the single-GPU protocol (bit-identical to one GPU) */
     DevArr<float4> xsPose, xsVisit, xsDual; size_t xsLocalSlots = 0, xsTotalSlots = 0; int xsRanks = 0; unsigned xsSerial = 0;
     DevArr<int> dOwner, dCutOf, dCutMan, dRecIdx; DevArr<unsigned long long> dCutKeys; DevArr<CutCounters> dCutCnt;
@@ -236,6 +238,9 @@ struct AvbdContext {
     DevArr<int> dPerm, dRankStart, dSendSlot;
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
+    int groupDepKeep = 1;          /* AVBD_GROUP_DEP_KEEP=0: classes that take a task in hand keep the watched records of round 3 (ResidentExchange::depKeep) */
+    int groupDep = 1;              /* several bodies per sub-group on one GPU: arrival counters instead of watched records (AVBD_GROUP_DEP=0: the watched records of round 3) */
+    DevArr<unsigned> xDepCnt;
     int groupSpecMode = 0, groupSpecRounds = 4, groupMap = 0;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
     bool turnReleased = false;          /* avbd_destroy has taken this context out of its device's count (turn_begin / turn_end) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
@@ -862,9 +867,11 @@ int step_begin(AvbdContext* c)
                 HIPCHK(c, c->xParkC.alloc((size_t)5 * c->incCap)); HIPCHK(c, c->xParkS.alloc((size_t)4 * c->incCap)); HIPCHK(c, c->xParkB.alloc((size_t)10 * c->bodyCap));
                 c->parkCap = (size_t)c->incCap; c->parkBodyCap = (size_t)c->bodyCap;
             }
+            if (c->xDepCnt.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xDepCnt.alloc((size_t)c->bodyCap)); }
         }
         hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
-                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min((c->nranks > 1 && c->shardExact) ? kGrpMaxRounds / 2 : kGrpMaxRounds, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp);
+                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min((c->nranks > 1 && c->shardExact) ? kGrpMaxRounds / 2 : kGrpMaxRounds, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp,
+                           (c->groupDep && c->nranks == 1 && !c->forceSharded) ? c->xDepCnt.p : (unsigned*)nullptr);
         c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -923,6 +930,8 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
         if (!wholeLoop) { X.forceMulti = 1; X.planesAlways = 1; }
     }
     X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.groupMap = c->groupMap; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p;
+    X.depCnt = (c->groupDep && !sharded && c->groupsPlanned) ? c->xDepCnt.p : nullptr;
+    X.depKeep = c->groupDepKeep;
     X.send = (sharded && c->dSend.p && c->dSendSlot.p) ? c->dSend.p : nullptr; X.sendSlot = c->dSendSlot.p;
     c->residentMultiLaunched = X.multi != 0;
     c->packFused = X.send != nullptr;
@@ -1485,6 +1494,7 @@ int step_once(AvbdContext* c)
         bool persistent = false;
         c->shardRanPersistent = false;
         if ((rc = shard_plan_accepted(c, persistent))) return rc;
+        c->cutModeRan = persistent ? 2 : 1;
         if (persistent) {
             /* ONE launch for the whole loop; the exchange runs beside it on the second stream: wait until this rank has finished
              * iteration it (every rank does the same), all-gather the rows in place, release the tasks that read them */
@@ -1642,8 +1652,10 @@ int avbd_create(int device, AvbdContext** out)
         if (const char* e = std::getenv("AVBD_PLACE")) c->placeChains = std::atoi(e) != 0;
         if (const char* e = std::getenv("AVBD_GROUP_SPEC")) c->groupSpecMode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("AVBD_GROUP_SPEC_ROUNDS")) c->groupSpecRounds = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("AVBD_GROUP_DEP")) c->groupDep = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_GROUP_DEP_KEEP")) c->groupDepKeep = std::atoi(e);
         if (const char* e = std::getenv("AVBD_GROUP_MAP")) c->groupMap = std::max(0, std::min(3, std::atoi(e)));
-        if (const char* e = std::getenv("AVBD_SHARD_EXACT")) c->shardExact = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AVBD_SHARD_EXACT")) { c->shardExact = std::atoi(e) != 0; c->shardExactStrict = std::atoi(e) != 2; }
         if (const char* e = std::getenv("AVBD_SHARD_GATE")) c->shardGateKernel = std::strcmp(e, "kernel") == 0;
         if (const char* e = std::getenv("AVBD_GROUPS")) c->groupsMode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("AVBD_GROUPS_ROUNDS")) c->groupsMaxRounds = std::max(1, std::atoi(e));
@@ -1867,8 +1879,9 @@ int avbd_device_count(void)
 
 int avbd_set_shard_mode(AvbdContext* c, int mode)
 {
-    if (!c || mode < 0 || mode > 1) return AVBD_E_INVALID;
-    c->shardExact = mode == 1;
+    if (!c || mode < 0 || mode > 2) return AVBD_E_INVALID;
+    c->shardExact = mode != 0;
+    c->shardExactStrict = mode != 2;
     return AVBD_OK;
 }
 
@@ -2195,6 +2208,7 @@ int avbd_get_step_stats(AvbdContext* c, AvbdStepStats* out)
     if (!c->statsFresh) { int rc = refresh_stats(c, false); if (rc) return rc; }
     *out = c->stats;
     out->warnings = c->hRb ? c->hRb->cnt.warnings : 0;
+    out->cutMode = c->nranks > 1 ? c->cutModeRan : 0;
     return AVBD_OK;
 }
 
@@ -2819,21 +2833,24 @@ int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
 
 /* One step of all ranks with exact cuts (avbd_cuts.h): step_begin has run on every context.  Returns 1 when the step was queued,
  * 0 when the prerequisites do not hold (the caller falls back to the all-gather forms), < 0 on errors. */
-static int group_step_exact(AvbdContext** ctxs, int n)
+static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
 {
     AvbdContext* L = ctxs[0];
     for (int r = 0; r < n; ++r) {
         AvbdContext* c = ctxs[r];
-        if (!c->shardExact || c->device != L->device || !c->groupsPlanned || c->mCap != L->mCap || c->bodyCap != L->bodyCap) return 0;
-        for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return 0;
+        if (!c->shardExact) { *why = "not every rank was put into shard mode 1 / 2"; return 0; }
+        if (c->device != L->device) { *why = "the ranks' contexts live on different devices (the in-process record space is one allocation of one device)"; return 0; }
+        for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) { *why = "the scene has joints or springs (exact cuts carry contacts only)"; return 0; }
+        if (!c->groupsPlanned) { *why = "a rank did not plan the group schedule (levels mode, more than 60 iterations, or no swept body)"; return 0; }
+        if (c->mCap != L->mCap || c->bodyCap != L->bodyCap) { *why = "the ranks' pools differ in size (every rank must hold the same scene)"; return 0; }
     }
     int rc;
     (void)hipSetDevice(L->device);
     const int totalIt = L->params.iterations + (L->params.postStabilize ? 1 : 0);
-    if (totalIt <= 0 || totalIt > 60) return 0;
+    if (totalIt <= 0 || totalIt > 60) { *why = "more than 60 iterations"; return 0; }
     constexpr int kCutManifolds = 16384;                                /* manifolds one cut (pair of ranks) may hold */
     const size_t localSlots = (size_t)4 * L->mCap, total = (size_t)n * localSlots + (size_t)n * n * kCutManifolds * 4;
-    if (total * 32 >= (1ull << 31)) return 0;                           /* 32-bit record offsets */
+    if (total * 32 >= (1ull << 31)) { *why = "the record space of all ranks exceeds 32-bit offsets"; return 0; }   /* 32-bit record offsets */
     if (L->xsRanks != n || L->xsLocalSlots != localSlots || L->xsPose.n < (size_t)3 * L->bodyCap) {
         for (int r = 0; r < n; ++r) HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
         HIPCHK(L, L->xsPose.alloc((size_t)3 * L->bodyCap)); HIPCHK(L, L->xsVisit.alloc(total)); HIPCHK(L, L->xsDual.alloc(2 * total));
@@ -2855,7 +2872,7 @@ static int group_step_exact(AvbdContext** ctxs, int n)
     for (int r = 0; r < n; ++r) {
         bool ok = false;
         if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
-        if (!ok) return 0;
+        if (!ok) { *why = "a rank's plan does not fit its share of the device (a body with more than 64 contacts, or more than 8 bodies per sub-group)"; return 0; }
     }
     ++L->xsSerial;
     if (L->hExactArgs.size() != (size_t)n) { L->hExactArgs.assign((size_t)n, ExactRankArgs{}); HIPCHK(L, L->dExactArgs.alloc((size_t)n)); }
@@ -2896,7 +2913,7 @@ static int group_step_exact(AvbdContext** ctxs, int n)
         wgPerRank = std::max(wgPerRank, std::max(1, groups_waves(c) / kGrpWavesPerBlock));
         anyMulti |= c->shardMulti;
         HIPCHK(c, hipEventRecord(c->evLoop, c->stream));              /* this rank's tables are ready */
-        c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true;
+        c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true; c->cutModeRan = 3;
     }
     {   /* ONE launch for all ranks, on the first context's stream (k_iterate_groups_exact) */
         for (int q = 1; q < n; ++q) HIPCHK(L, hipStreamWaitEvent(L->stream, ctxs[q]->evLoop, 0));
@@ -2956,9 +2973,17 @@ static int group_step_one(AvbdContext** ctxs, int n)
         }
         if (n > 1 && ctxs[0]->shardExact) {
             /* exact cuts: no exchange during the loop, results identical to the single-GPU sweep (avbd_cuts.h) */
-            rc = group_step_exact(ctxs, n);
+            const char* why = "";
+            rc = group_step_exact(ctxs, n, &why);
             if (rc < 0) return rc;
             if (rc == 1) return AVBD_OK;
+            /* declined: with mode 1 that is an error — the caller asked for results bit-identical to one GPU and must not get a Jacobi
+             * coupling under that name; mode 2 takes the all-gather form and AvbdStepStats.cutMode reports it */
+            if (ctxs[0]->shardExactStrict) {
+                char msg[384];
+                snprintf(msg, sizeof(msg), "exact cuts were requested (avbd_set_shard_mode 1) and this step cannot run them: %s; mode 2 would fall back to the all-gather form", why);
+                return ctxs[0]->fail(AVBD_E_INVALID, msg);
+            }
         }
         const int totalIt = ctxs[0]->params.iterations + (ctxs[0]->params.postStabilize ? 1 : 0);
         {   /* persistent form (one launch per rank and step, exchange on the second streams) when every rank's plan fits its share
@@ -3003,7 +3028,7 @@ static int group_step_one(AvbdContext** ctxs, int n)
             }
             for (int r = 0; r < n; ++r) ctxs[r]->shardRanPersistent = false;
             if (all) {
-                for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = shard_launch_persistent(ctxs[r]))) return rc; }
+                for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = shard_launch_persistent(ctxs[r]))) return rc; ctxs[r]->cutModeRan = 2; }
                 /* Iteration-major: exchange streams of contexts on one device may be mapped to the SAME hardware queue, which runs its
                  * packets in order.  Queued rank by rank, rank 1's deliveries of iteration 0 could sit behind rank 0's wait for
                  * iteration 1 — which needs rank 1 past iteration 1, which needs that delivery.  In this order every wait is preceded,
@@ -3040,6 +3065,7 @@ static int group_step_one(AvbdContext** ctxs, int n)
                 return group_exchange_velocities(ctxs, n);
             }
         }
+        for (int r = 0; r < n; ++r) ctxs[r]->cutModeRan = 1;
         for (int it = 0; it < totalIt; ++it) {
             for (int r = 0; r < n; ++r) {
                 AvbdContext* c = ctxs[r];

@@ -98,7 +98,7 @@ __device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int*
 
 __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __restrict__ order, const int* __restrict__ lvlStart, Counters* cnt,
                                                      const int* __restrict__ incStart, GroupPlan* plan, int* __restrict__ byClass, int cap, int W, int maxRounds,
-                                                     tile_v4u* agg, unsigned stamp)
+                                                     tile_v4u* agg, unsigned stamp, unsigned* __restrict__ depCnt)
 {
     __shared__ unsigned long long sWaveTotals[16];
     __shared__ unsigned long long sBcast, sTileSum;
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
     const int s0 = tile * kTileBodies + 4 * t;
     int cl[4], body[4]; unsigned long long mine4 = 0;                 /* class counts, 21 bits each */
     for (int k = 0; k < 4; ++k) { body[k] = s0 + k < nd ? order[s0 + k] : -1; cl[k] = -1; }
+    if (depCnt) for (int k = 0; k < 4; ++k) if (body[k] >= 0) depCnt[body[k]] = 0u;   /* arrival counters of the several-bodies loop (iterate_groups) */
     for (int k = 0; k < 4; ++k)
         if (body[k] >= 0) {
             const int ne = incStart[body[k] + 1] - incStart[body[k]];
@@ -583,6 +584,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         if (cls == 0 && gl + 16 < 27) accs[gl + 16] = a1.acc;
         wave_sync();
     };
+    bool depSig = false;                                             /* several bodies per sub-group, arrival counters (see there): this task signals its partners */
     auto finish_solve = [&]() __attribute__((always_inline)) {
         const float alpha = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
         const bool doDual = it < P.iterations;
@@ -606,6 +608,10 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 if (it & 1) { xst(rG1, ownRow, s0); xst(rG1, ownRow + 16, s1); } else { xst(rG0, ownRow, s0); xst(rG0, ownRow + 16, s1); }
             }
         }
+        /* arrivals at the earlier-created partners (their task `it` reads this pose and the visit record, both on their way): as early as possible,
+         * the hop from a publish to the consumer's examination is what the launch is a chain of */
+        if (SHARDK == 0 && MULTI && depSig && has && moving && !owned && (idx & 3) == 0)
+            __hip_atomic_fetch_add(X.depCnt + other, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
 #ifdef AVBD_DF_STATS
@@ -623,6 +629,9 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
                 v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), (stampNow << 1) | (c.stick ? 1u : 0u)};
                 xst(rD, offD, r0); xst(rD, offD + 16, r1);
+                /* ... and at the later-created partner, whose task it + 1 reads this dual */
+                if (SHARDK == 0 && MULTI && depSig && (idx & 3) == 0 && it + 1 < itStop)
+                    __hip_atomic_fetch_add(X.depCnt + other, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
@@ -833,6 +842,20 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
          * examined in full only when that record has arrived.  Every pass of the wave runs the picks of all its sub-groups
          * together. ---- */
         int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
+        /* ARRIVAL COUNTERS (one GPU): instead of watching ONE record of a body that was missing when it was last examined — and finding, after the
+         * round trip that fetches records and parked state, that another one is missing too (two examinations out of five ended that way: 1.6 GB of
+         * the 4.2 GB a 64 000-cube launch read, and a whole round trip of the wave's pass each) — lane k watches the number of partners that have
+         * published what its body's next task reads.  A task that ends adds one to the counter of every moving partner whose NEXT task reads its
+         * records: partner o > body (the body owns the contact, o is swept first): o's task it + 1 reads this dual; partner o < body: o's task `it`
+         * reads this pose and visit record.  So task `it` of a body with nOwn later-created and nOth earlier-created moving partners (manifolds,
+         * not contacts: the first contact of a manifold signals) is ready exactly when nOwn * (it + 1) + nOth * it arrivals have been counted —
+         * none of the arrivals for task it + 1 can come before task `it` has run (each of them needs its records).  The counter is a hint that is
+         * almost always right, not a proof: the adds are not ordered behind the record stores, so the stamps of the records still decide, and an
+         * examination that finds one missing is simply repeated in the next pass. */
+        constexpr bool DEPC = SHARDK == 0;
+        const bool dep = DEPC && X.depCnt != nullptr && (X.depKeep || !(X.specMode != 2 && rounds <= X.specRounds));   /* (depKeep 0: classes that take a task in hand keep the watched records) */
+        const __amdgpu_buffer_rsrc_t rC = xrsrc(dep ? (void*)X.depCnt : (void*)X.pose, dep ? (unsigned)B.cap * 4u : 16u);
+        unsigned depPerIt = 0, depNeed = 0;                           /* lane k: arrivals per iteration, arrivals its body's next task waits for */
         int itEndK = itStop;                                          /* EXACT: + the task that takes the owner's last dual (see the header table) */
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
@@ -870,6 +893,11 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     const bool anyFinal = (__ballot(hk[q] && rc < 0) & gMask) != 0;
                     if (anyFinal && k0 + q < rounds && gl == k0 + q) itEndK = itStop + 1;
                 }
+                if (DEPC) {
+                    const bool first = hk[q] && ((w1 >> 24) & 1) && (inc_index(ent[q]) & 3) == 0;     /* one arrival per manifold with a moving partner */
+                    const unsigned nOwn = (unsigned)__popcll(__ballot(first && ((w1 >> 25) & 1)) & gMask), nOth = (unsigned)__popcll(__ballot(first && !((w1 >> 25) & 1)) & gMask);
+                    if (k0 + q < rounds && gl == k0 + q) { depPerIt = nOwn + nOth; depNeed = nOwn; }
+                }
                 if (k0 + q < rounds) {
                     if constexpr (EXACT) hdr[(k0 + q) * 64 + lane] = make_int4(ent[q], w1, rc, 0);
                     else hdr[(k0 + q) * 64 + lane] = make_int2(ent[q], w1);
@@ -906,11 +934,15 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (!KEEP) prep = false;
             /* one round trip: what the task in hand still misses, and the watched words of the other bodies */
             if (prep) poll_issue();
+            if (dep) { if (activeK && depNeed != 0u) watchVal = xldw(rC, bodyK * 4); }
+            else {
             if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
+            }
             if (prep) poll_check();
             bool candK = activeK;
-            if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
+            if (dep) { if (activeK && depNeed != 0u) candK = watchVal >= depNeed; }
+            else if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
             if (prep && gl == kPrep) candK = false;
             dbgBody = bodyK; dbgIt = itK | (itEndK << 8); dbgOff = blkOff; dbgStamp = (int)(blkStamp - X.base); dbgSeen = (int)(watchVal - X.base);
             GS_STAMP(12);                                              /* the look at the watched words (and whatever was still in flight) */
@@ -932,12 +964,15 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     /* nothing is known to be ready: the oldest task of the sub-group (not the task behind the last iteration, which prepares nothing) */
                     specTried = true;
                     key = (activeK && itK < itStop) ? ((itK << 6) | gl) : 0x7fffffff;
+                    /* arrival counters: the body that misses the fewest arrivals is the likeliest to run next (the oldest one was the next
+                     * to run in one case out of five at eight bodies per sub-group) */
+                    if (dep && activeK && itK < itStop) key = (int)(((depNeed - min(watchVal, depNeed)) << 12) | ((unsigned)itK << 6) | (unsigned)gl);
                     for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
                 }
                 const bool examine = !prep && !ready && key != 0x7fffffff;   /* uniform over the sub-group */
                 if (__ballot(examine) == 0) break;
                 if (examine) {
-                    const int kk = key & 63, k = gBase + kk, t = key >> 6;
+                    const int kk = key & 63, k = gBase + kk, t = __shfl(itK, k, 64);
                     load_header(__shfl(bodyK, k, 64), __shfl(eBegK, k, 64), __shfl(nEntK, k, 64), kk);
                     /* the records this task reads and the state the body parked after its last task travel together: one memory
                      * round trip tells whether the task can run and, if it can, has brought what it needs */
@@ -953,6 +988,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     const unsigned long long noGather = SHARD ? (__ballot(!okR) & gMask) : 0ull;
                     if ((noPose | noRest | noGather) == 0) {
                         ready = true;
+                    } else if (dep) {
+                        if (lane == k) { triedK = true; candK = false; }     /* in hand; the next passes poll the records it misses */
                     } else if (noPose) {
                         /* watch the pose of the first partner that is late (its last record's stamp word) */
                         const int f = __ffsll((long long)noPose) - 1;
@@ -987,7 +1024,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 GS_STAMP_ND(15);                                       /* park: issue */
             }
             if (ready) {
-                if (gl == kPrep) { ++itK; ++blkStamp; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
+                if (gl == kPrep) { ++itK; ++blkStamp; depNeed += depPerIt; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
                 prep = false;
                 spins = 0;
             }
@@ -1023,10 +1060,14 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (__ballot(activeK) == 0) break;
             grpWaiting = (__ballot(activeK) & gMask) != 0;
             bool candK = activeK;
+            if (dep) {
+                if (activeK && depNeed != 0u) { watchVal = xldw(rC, bodyK * 4); candK = watchVal >= depNeed; }
+            } else {
             if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
             if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
-            dbgBody = bodyK; dbgIt = itK | (itEndK << 8); dbgOff = blkOff; dbgStamp = (int)(blkStamp - X.base); dbgSeen = (int)(watchVal - X.base);
+            }
+            dbgBody = bodyK; dbgIt = itK | (itEndK << 8); dbgOff = dep ? -3 : blkOff; dbgStamp = dep ? (int)depNeed : (int)(blkStamp - X.base); dbgSeen = dep ? (int)watchVal : (int)(watchVal - X.base);
             GS_STAMP(12);                                              /* the look at the watched words (and whatever was still in flight) */
             bool sel = false, triedK = false;
             for (;;) {
@@ -1057,7 +1098,9 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                             if (lane == k) { dbgTasks += 1; dbgOldest += (keyO == key) ? 1 : 0; }
                         }
 #endif
-                        if (lane == k) { ++itK; ++blkStamp; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
+                        if (lane == k) { ++itK; ++blkStamp; depNeed += depPerIt; if (EXACT && itK >= itStop) blkOff = -1; }   /* the same partner is the likeliest to be late again (the task behind the last iteration waits for no pose) */
+                    } else if (dep) {
+                        if (lane == k) triedK = true;                       /* counted, but a record's store is still on its way: next pass */
                     } else if (noPose) {
                         /* watch the pose of the first partner that is late (its last record's stamp word) */
                         const int f = __ffsll((long long)noPose) - 1;
@@ -1126,6 +1169,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         }
         return true;
         };
+        depSig = DEPC && X.depCnt != nullptr;                        /* every task signals, whichever loop its class runs: the partners may be counting */
         if (keepMode) { if (!multi_loop(std::true_type{})) return; }
         else if (!multi_loop_plain()) return;
     }

@@ -76,6 +76,9 @@ struct ResidentExchange {
     int specRounds;    /* ... only in classes with at most this many bodies per sub-group */
     int specMode;      /* group schedule, several bodies per sub-group: when a sub-group with nothing ready takes its oldest task in hand (0: when its wave has nothing else to do in the pass, 1: always, 2: never) */
     float4 *parkC, *parkS, *parkB;   /* group schedule, several bodies per sub-group: packed records of a parked body (k_iterate_groups::load_rest) */
+    int depKeep;       /* arrival counters also in classes that take a task in hand (which they then pick by the fewest missing arrivals) */
+    unsigned* depCnt;  /* [bodyCap] group schedule, several bodies per sub-group on one GPU: arrivals at a body — every task that ends adds one to each moving
+                        * partner whose NEXT task reads what it has just published (k_group_plan zeroes the words of the swept bodies every step); nullptr: off */
     const int* place;  /* one body per wave: body of wave w (-1: none) instead of the sweep order's slot — chains of bodies that hand their pose to each
                         * other share a workgroup and pass it through LDS (k_place_chains); nullptr: slots of the sweep order */
     int2* crit;        /* [bodyCap] one body per wave, out: {later-created partner whose pose arrived last in the final iterations or -1, ticks (10 ns)

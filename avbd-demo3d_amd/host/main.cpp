@@ -59,9 +59,13 @@ int main(int argc, char** argv)
     Solver* solver = new Solver();
     if (!quiet) { solver->enableDiagnostics = true; solver->logFrequency = 1; } /* main.cpp:206-209 */
     std::vector<Solver*> ranks(1, solver);
-    for (int r = 1; r < gpus; ++r) {                                   /* one context per rank, devices round robin */
+    /* one context per rank.  All-gather form: devices round robin from --device on.  Exact cuts between ranks of ONE process need the
+     * records of all ranks in one allocation, so every rank stays on rank 0's device (a step that cannot run exact cuts is an error,
+     * never a silent Jacobi coupling: avbd_set_shard_mode 1). */
+    const int dev0 = getenv("AVBD_DEVICE") ? atoi(getenv("AVBD_DEVICE")) : 0;
+    for (int r = 1; r < gpus; ++r) {
         const int nd = avbd_device_count();
-        char dev[16]; snprintf(dev, sizeof(dev), "%d", nd > 0 ? r % nd : 0);
+        char dev[16]; snprintf(dev, sizeof(dev), "%d", exactCuts ? dev0 : (nd > 0 ? (dev0 + r) % nd : 0));
         setenv("AVBD_DEVICE", dev, 1);
         ranks.push_back(new Solver());
     }
@@ -112,8 +116,12 @@ int main(int argc, char** argv)
     auto t1 = std::chrono::steady_clock::now();
     if (quiet) {
         double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        /* what the last step RAN (AvbdStepStats.cutMode), not what was asked for */
+        static const char* const cutNames[4] = {"none", "all-gather per iteration (one launch per iteration)", "all-gather per iteration (persistent launch)", "exact"};
+        AvbdStepStats st{};
+        if (steps > 0) avbd_get_step_stats(solver->context(), &st);
         printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\", \"ranks\": %d, \"cuts\": \"%s\"}\n", shown, steps, ms,
-               steps ? ms / steps : 0.0, gpus, gpus > 1 ? (exactCuts ? "exact" : "all-gather per iteration") : "none");
+               steps ? ms / steps : 0.0, gpus, cutNames[st.cutMode >= 0 && st.cutMode < 4 ? st.cutMode : 0]);
     }
     if (pickRay) {
         float r[6] = {0, 0, 0, 0, 0, 0};

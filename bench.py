@@ -379,35 +379,43 @@ def main():
         whole = {"steps": 600, "steps_per_s": round(600 / tw, 3), "ms_per_step": round(tw / 600 * 1e3, 5)}
         w2.close()
 
-    # N = 1 point of the strong-scaling experiment: the 64 000-cube scene on this one GPU, same window as the N > 1 runs
-    strong_n1 = None
-    if rank == 0 and not sharded and args.scene is None and not args.no_strong_n1:
+    # Nested N = 1 lines of the larger configurations, each with a roofline object of its own (the launches where "% of HBM peak" means
+    # something): BASELINE configs[3]'s scene on this one GPU = the N = 1 point of the strong-scaling experiment, and configs[2]
+    # (StressN:20, 8 000 cubes: "HBM roofline measurement"), driver-timed since round 4.
+    def nested_line(nscene, npresim, k3):
         try:
             w3 = pkg.World(local_rank)
-            w3.scene(STRONG_SCENE)
-            w3.step(STRONG_PRESIM + 10)
+            w3.scene(nscene)
+            w3.step(npresim)
             w3.synchronize()
-            k3 = 50
             t0 = time.perf_counter()
             w3.step(k3)
             w3.synchronize()
             t3 = time.perf_counter() - t0
             st3 = w3.stats()
-            strong_n1 = {"workload": f"{STRONG_SCENE} (iterations={int(w3.params()['iterations'])}) steady window: steps {STRONG_PRESIM + 10}..{STRONG_PRESIM + 10 + k3}",
-                         "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
-                         "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"])}
-            # the launch where "% of HBM peak" means something: its own roofline object (HIP events around the launches of 20 more steps)
+            out = {"workload": f"{nscene} (iterations={int(w3.params()['iterations'])}) steady window: steps {npresim}..{npresim + k3}",
+                   "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
+                   "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"])}
+            # HIP events around the launches of 20 more steps
             w3.profile_enable(True); w3.profile_reset(); w3.step(20); w3.synchronize(); p3 = w3.profile(); w3.profile_enable(False)
             if p3["launches_primal"] > 0 and p3["ms_primal"] > 0:
                 s3 = p3["ms_primal"] * 1e-3 / p3["launches_primal"]
                 b3 = p3["algorithmic_bytes_primal"] / p3["launches_primal"]
-                t3r, t3s = pmc_traffic(STRONG_SCENE, True)
-                strong_n1["roofline"] = {"bound": "hbm", "kernel": "k_iterate_groups" if int(st3["schedule"]) == 4 else "k_iterate", "achieved": round(b3 / s3 / 1e9, 3), "peak": 8000.0,
-                                         "unit": "GB/s", "frac": round(b3 / s3 / 1e9 / 8000.0, 6), "traffic": t3r, "traffic_source": t3s,
-                                         "bytes_per_launch": round(b3, 1), "us_per_launch": round(s3 * 1e6, 3)}
+                t3r, t3s = pmc_traffic(nscene, True)
+                out["roofline"] = {"bound": "hbm", "kernel": "k_iterate_groups" if int(st3["schedule"]) == 4 else "k_iterate", "achieved": round(b3 / s3 / 1e9, 3), "peak": 8000.0,
+                                   "unit": "GB/s", "frac": round(b3 / s3 / 1e9 / 8000.0, 6), "traffic": t3r, "traffic_source": t3s,
+                                   "bytes_per_launch": round(b3, 1), "us_per_launch": round(s3 * 1e6, 3),
+                                   "kernel_ms_per_step": {k[3:]: round(float(p3[k]) / max(1, p3["steps"]), 4) for k in
+                                                          ("ms_broadphase", "ms_narrowphase", "ms_topology", "ms_predict", "ms_primal", "ms_dual", "ms_velocity")}}
             w3.close()
+            return out
         except Exception as e:
-            strong_n1 = {"error": repr(e)}
+            return {"error": repr(e)}
+
+    strong_n1 = roofline_8k = None
+    if rank == 0 and not sharded and args.scene is None and not args.no_strong_n1:
+        strong_n1 = nested_line(STRONG_SCENE, STRONG_PRESIM + 10, 50)
+        roofline_8k = nested_line("StressN:20", 410, 50)
 
     if rank == 0:
         total_steps = args.steps                                 # steps of the one scene every rank works on
@@ -421,7 +429,7 @@ def main():
                                "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)",
                        "parallelism": "1 GPU" if not sharded else f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene",
                        "shard_form": shard_form, "shard_other_form": shard_other,
-                       "strong_scaling_n1": strong_n1,
+                       "strong_scaling_n1": strong_n1, "roofline_8k": roofline_8k,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
                        "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
                        "whole_run_from_scratch": whole},

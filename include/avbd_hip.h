@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AVBD_ABI_VERSION 3   /* 3: avbd_set_exchange_floats, avbd_exchange_mismatches, avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
+#define AVBD_ABI_VERSION 4   /* 4: AvbdStepStats.cutMode, avbd_set_shard_mode 2, avbd_set_option / avbd_get_option; 3: avbd_set_exchange_floats, avbd_exchange_mismatches, avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
 
 enum {
     AVBD_OK = 0,
@@ -112,7 +112,11 @@ typedef struct AvbdStepStats {
     int warnings;           /* non-finite sanitizer hits this step (solver.cpp:51-66) */
     int schedule;           /* how the iteration loop of that step ran: 0 one launch per level, 1 data-flow tasks (k_iterate),
                                2 resident (one wavefront per body for the whole loop, avbd_resident.h),
-                               3 resident with several bodies per wavefront (more swept bodies than resident waves) */
+                               3 resident with several bodies per wavefront (more swept bodies than resident waves),
+                               4 group schedule (several bodies in flight per wavefront, avbd_groups.h) */
+    int cutMode;            /* how the ranks of a sharded step were coupled across their cuts (ABI 4): 0 not sharded, 1 all-gather, one launch
+                               per iteration, 2 all-gather beside ONE persistent launch (both: Jacobi across the cut), 3 exact cuts
+                               (bit-identical to one GPU).  What RAN, whatever avbd_set_shard_mode asked for */
 } AvbdStepStats;
 
 /* Accumulated device time per kernel family since the last avbd_profile_reset, measured with HIP
@@ -296,7 +300,10 @@ int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
  * the stamped pose / visit / dual records of the bodies and contacts across a cut exactly as it polls local ones (one address
  * space for the records of all ranks: one allocation for contexts of one process, peer-to-peer windows between GPUs); no exchange
  * during the iteration loop, one copy of the final poses per step, results bit-identical to the single-GPU sweep
- * (tests/test_gpu_exact_cuts.py).  Contacts-only scenes whose ranks share a device; otherwise the step takes the all-gather form. */
+ * (tests/test_gpu_exact_cuts.py).  Exact cuts carry contacts only (no joints / springs), at most 8 bodies per sub-group, and the
+ * ranks of one avbd_group_step call must share a device.  A step that cannot run them FAILS with AVBD_E_INVALID and the reason in
+ * avbd_last_error — a caller that asked for single-GPU bits never gets a Jacobi coupling under that name.
+ * 2: exact cuts when the step can run them, the all-gather form otherwise; AvbdStepStats.cutMode tells which one ran. */
 int  avbd_set_shard_mode(AvbdContext* ctx, int mode);
 /* What the ranks exchange.  8 (default): {position + radius, orientation} every iteration, velocities re-derived by
  * every rank from the gathered poses.  13: additionally ONE gather of {linear, angular velocity} per step, after the velocity

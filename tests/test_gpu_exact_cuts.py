@@ -116,12 +116,42 @@ def test_cli_gpus_flag_exact_cuts_give_the_single_gpu_dump(tmp_path):
     import subprocess
     exe = os.path.join(H.ROOT, "avbd-demo3d_amd", "avbd_demo3d")
     dumps = {}
+    # (--device 0 pins rank 0; with --cuts exact every rank stays there, with the all-gather form the others go round robin over
+    #  the visible devices: HIP_VISIBLE_DEVICES=0 keeps this test the same test on an 8-GPU node)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    want = {"one": '"cuts": "none"', "exact": '"cuts": "exact"', "gather": '"cuts": "all-gather per iteration'}
     for tag, extra in (("one", []), ("exact", ["--gpus", "2", "--cuts", "exact"]), ("gather", ["--gpus", "2"])):
         d = str(tmp_path / (tag + ".bin"))
-        r = subprocess.run([exe, "--nogfx", "--scene", "Stress1000", "--steps", "170", "--batch", "--dump", d] + extra, capture_output=True, text=True)
+        r = subprocess.run([exe, "--nogfx", "--scene", "Stress1000", "--steps", "170", "--batch", "--device", "0", "--dump", d] + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
         assert ('"ranks": %d' % (1 if tag == "one" else 2)) in r.stdout
+        assert want[tag] in r.stdout, r.stdout[-400:]          # the CLI prints the coupling that RAN (AvbdStepStats.cutMode)
         dumps[tag] = np.fromfile(d, dtype=H.load_product().BODY_DT)
     assert dumps["exact"].tobytes() == dumps["one"].tobytes()
     assert dumps["gather"].tobytes() != dumps["one"].tobytes()
     assert np.isfinite(dumps["gather"]["position"]).all() and float(dumps["gather"]["position"][1:, 1].min()) > 0.3   # (forty steps into a tumbling landing the Jacobi coupling of the cut has long diverged from the exact sweep: only sanity is asserted)
+
+
+def test_a_declined_exact_step_is_an_error_and_mode_2_reports_the_fall_back():
+    """`avbd_set_shard_mode(ctx, 1)` promises the single-GPU bits; a step that cannot keep that promise (here: a scene
+    with a Joint — exact cuts carry contacts only) must FAIL with AVBD_E_INVALID and say why, never run the Jacobi all-gather form
+    under the name "exact".  Mode 2 is the explicit "exact if possible": it falls back and AvbdStepStats.cutMode says which form ran."""
+    def pair(mode, joint):
+        pkg, worlds, owner = _ranks("PackedGrid:4,4,4", 2, 0)
+        for w in worlds:
+            if joint:
+                w.w.add_joint(1, 2, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+            w.w.set_shard_mode(mode)
+        return pkg, worlds
+    pkg, ws = pair(1, True)
+    with pytest.raises(pkg.AvbdError) as e:
+        pkg.group_step([w.w for w in ws], 1)
+    assert "exact cuts were requested" in str(e.value) and "joints or springs" in str(e.value)
+    pkg, ws = pair(2, True)
+    pkg.group_step([w.w for w in ws], 3)
+    assert all(int(w.w.stats()["cutMode"]) in (1, 2) for w in ws)
+    pkg, ws = pair(1, False)                       # contacts only: the same request runs exact cuts and says so
+    pkg.group_step([w.w for w in ws], 3)
+    assert all(int(w.w.stats()["cutMode"]) == 3 for w in ws)
+    one = H.HipWorld(); one.scene("PackedGrid:4,4,4"); one.step(3)
+    assert int(one.w.stats()["cutMode"]) == 0
