@@ -66,7 +66,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign",
+    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign",
 ]
 
 
@@ -314,6 +314,19 @@ class World:
 
     def set_shard_mode(self, mode):
         self._chk(self.L.avbd_set_shard_mode(self.h, int(mode)))
+
+    def exact_window_export(self):
+        """this rank's record window for exact cuts between processes: the 64 opaque bytes of its hipIpcMemHandle_t"""
+        h = (C.c_ubyte * 64)()
+        n = C.c_ulonglong(0)
+        self._chk(self.L.avbd_exact_window_export(self.h, h, C.byref(n)))
+        return bytes(h)
+
+    def exact_window_attach(self, handles, ranks_on_this_device=1):
+        blob = b"".join(handles)
+        assert len(blob) == 64 * len(handles)
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        self._chk(self.L.avbd_exact_window_attach(self.h, len(handles), buf, int(ranks_on_this_device)))
 
     def set_exchange_floats(self, floats_per_body):
         self._chk(self.L.avbd_set_exchange_floats(self.h, int(floats_per_body)))

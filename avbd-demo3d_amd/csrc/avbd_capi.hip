@@ -238,6 +238,9 @@ struct AvbdContext {
     DevArr<int> dPerm, dRankStart, dSendSlot;
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
+    /* exact cuts between processes: this rank's window, the peers' windows as this process sees them (own window at [rank]) */
+    float4* xwOwn = nullptr; float4* xwPeer[kMaxExactRanks] = {}; bool xwAttached = false; bool xwSharedDevice = false; unsigned xwSerial = 0; int xwBodyCap = 0, xwMCap = 0, xwRanks = 0;
+    int cutRanks = 0;
     int groupDepKeep = 1;          /* AVBD_GROUP_DEP_KEEP=0: classes that take a task in hand keep the watched records of round 3 (ResidentExchange::depKeep) */
     int groupDep = 1;              /* several bodies per sub-group on one GPU: arrival counters instead of watched records (AVBD_GROUP_DEP=0: the watched records of round 3) */
     DevArr<unsigned> xDepCnt;
@@ -1475,6 +1478,108 @@ int step_with_host_rows(AvbdContext* c)
     return AVBD_OK;
 }
 
+/* per-step tables of the exact cuts (avbd_cuts.h), sized by the manifold pool AND the number of ranks */
+int exact_cut_buffers(AvbdContext* c, int n, int cutManifolds)
+{
+    if (c->cutOfCap < (size_t)c->mCap || c->cutRanks != n) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->dCutOf.alloc((size_t)c->mCap)); HIPCHK(c, c->dCutMan.alloc((size_t)n * cutManifolds)); HIPCHK(c, c->dCutKeys.alloc((size_t)n * cutManifolds));
+        HIPCHK(c, c->dCutCnt.alloc(1));
+        HIPCHK(c, hipMemsetAsync(c->dCutCnt.p, 0, sizeof(CutCounters), c->stream));
+        c->cutOfCap = (size_t)c->mCap; c->cutRanks = n;
+    }
+    return AVBD_OK;
+}
+
+/* ---- exact cuts between ranks that are PROCESSES (avbd_exact_window_export / _attach) -------------------------------------------
+ * Window of a rank = one hipMalloc'ed block, the same layout on every rank:
+ *   [ head: 64 words, word 0 = last step whose records are complete ][ pose: 2 sets of 3 per body ][ visit: L + cuts ][ dual: 2 * (L + cuts) ]
+ * with L = 4 * manifold capacity local record slots and n * n * kExactCutManifolds * 4 slots for the contacts across cuts, at the index
+ * k_cut_fill gives both ranks of a cut alike.  A rank writes into its own window and reads a partner's records from the window of the
+ * rank that sweeps the partner (ShardExchange::peerPose / peerVisit / peerDual). */
+constexpr int kExactCutManifolds = 16384;
+constexpr size_t kWindowHeadFloat4 = 16;
+size_t exact_window_slots(const AvbdContext* c, int n) { return (size_t)4 * c->mCap + (size_t)n * n * kExactCutManifolds * 4; }
+size_t exact_window_float4(const AvbdContext* c, int n) { return kWindowHeadFloat4 + (size_t)6 * c->bodyCap + 3 * exact_window_slots(c, n); }
+
+int exact_process_step(AvbdContext* c, bool needReadback)
+{
+    int rc;
+    const int n = c->nranks;
+    const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
+    const char* why = nullptr;
+    for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) why = "the scene has joints or springs (exact cuts carry contacts only)";
+    if (!why && !c->groupsPlanned) why = "the group schedule was not planned (levels mode, more than 60 iterations, or no swept body)";
+    if (!why && (c->xwBodyCap != c->bodyCap || c->xwMCap != c->mCap)) why = "the pools have grown since the window was exported: export and attach again";
+    bool ok = false;
+    if (!why) { if ((rc = shard_plan_accepted(c, ok))) return rc; if (!ok) why = "the plan does not fit this rank's share of the device (a body with more than 64 contacts, or more than 8 bodies per sub-group)"; }
+    if (why) {
+        char msg[384];
+        std::snprintf(msg, sizeof(msg), "exact cuts between processes (avbd_exact_window_attach) cannot run this step: %s", why);
+        return c->fail(AVBD_E_INVALID, msg);
+    }
+    const size_t localSlots = (size_t)4 * c->mCap, total = exact_window_slots(c, n);
+    if ((rc = exact_cut_buffers(c, n, kExactCutManifolds))) return rc;
+    if (c->recIdxCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRecIdx.alloc((size_t)c->incCap)); c->recIdxCap = (size_t)c->incCap; }
+    BodyTable B = body_table(c);
+    SolverParams P = solver_params(c);
+    ManifoldTable M = c->mbuf[c->cur].view();
+    const int cutCap = n * kExactCutManifolds;
+    HIPCHK(c, hipMemsetAsync(c->dCutCnt.p, 0, sizeof(CutCounters), c->stream));
+    hipLaunchKernelGGL(k_cut_list, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, M, c->dCnt.p, c->dOwner.p, n, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p);
+    hipLaunchKernelGGL(k_cut_rank, dim3(grid_for(cutCap, 128, 1024)), dim3(128), 0, c->stream, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p, kExactCutManifolds);
+    hipLaunchKernelGGL(k_cut_fill, dim3(grid_for(std::max(1, c->numSolved), 128, 4096)), dim3(128), 0, c->stream, B, M, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->inc.p,
+                       c->dOwner.p, n, c->rank, c->dCutOf.p, 0, (int)localSlots, kExactCutManifolds, c->dRecIdx.p);
+    /* stamps: 64 per step, the same on every rank (all ranks step together from the attach on).  A window is never cleared once attached —
+     * a peer may be reading it — so the stamps must not wrap: 2^26 steps, then the ranks must attach fresh windows. */
+    if (c->xwSerial >= (1u << 26) - 2u) return c->fail(AVBD_E_INVALID, "exact cuts between processes: the stamps of this window are used up (2^26 steps): export and attach fresh windows");
+    ++c->xwSerial;
+    IterateState S;
+    S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
+    /* TWO sets of pose records, by the parity of the step: a peer copies this rank's final poses of step s (k_unpack_records, behind its wait
+     * for this rank's "step s complete") while this rank may already be publishing the poses of step s + 1 — it cannot be two steps ahead, its
+     * own wait for the peer's "step s + 1 complete" stands in between.  Visit / dual records are only read inside the peers' loop kernels. */
+    const size_t poseSet = (size_t)(c->xwSerial & 1u) * 3 * c->bodyCap;
+    auto posePtr = [&](float4* w) { return w + kWindowHeadFloat4 + poseSet; };
+    auto visitPtr = [&](float4* w) { return w + kWindowHeadFloat4 + (size_t)6 * c->bodyCap; };
+    auto dualPtr = [&](float4* w) { return w + kWindowHeadFloat4 + (size_t)6 * c->bodyCap + total; };
+    ResidentExchange X{};
+    X.pose = posePtr(c->xwPeer[c->rank]); X.visit = visitPtr(c->xwPeer[c->rank]); X.dual = dualPtr(c->xwPeer[c->rank]);
+    X.poseBytes = (unsigned)((size_t)3 * c->bodyCap * sizeof(float4)); X.visitBytes = (unsigned)(total * sizeof(float4)); X.dualBytes = (unsigned)(2 * total * sizeof(float4));
+    X.enabled = 1; X.base = c->xwSerial * 64u;
+    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.groupMap = c->groupMap; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;
+    ShardExchange Z{};
+    Z.xPose = X.pose; Z.xVisit = X.visit; Z.xDual = X.dual;
+    Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;
+    Z.recIdx = c->dRecIdx.p; Z.nPeers = n; Z.owner = c->dOwner.p;
+    PeerWindows PW{}; PW.n = n;
+    for (int q = 0; q < n; ++q) {
+        Z.peerPose[q] = posePtr(c->xwPeer[q]); Z.peerVisit[q] = visitPtr(c->xwPeer[q]); Z.peerDual[q] = dualPtr(c->xwPeer[q]);
+        PW.pose[q] = Z.peerPose[q]; PW.head[q] = reinterpret_cast<volatile unsigned*>(c->xwPeer[q]);
+    }
+    if (c->xwSharedDevice) {
+        /* Ranks that share a device: no loop kernel starts before EVERY rank's front end has run.  The loop kernels of the other ranks leave
+         * 256 free registers on every SIMD they sit on, k_narrowphase needs 278: a rank whose front end is still queued when the others' loops
+         * are resident never gets to run it, and they wait for its records (one run in three of the four-process test ended in that time-out).
+         * Word 1 of the window heads: "the tables of step s are built".  One rank per device has the device to itself and skips this. */
+        hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, c->stream, PW.head[c->rank], 1, c->xwSerial);
+        hipLaunchKernelGGL(k_wait_peers, dim3(1), dim3(64), 0, c->stream, PW, c->rank, 1, c->xwSerial, S.error, (unsigned long long)kSpinTimeoutTicks * 2ull);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
+    auto kern = c->shardMulti ? k_iterate_groups<true, 2> : k_iterate_groups<false, 2>;
+    const int wg = std::max(1, groups_waves(c) / kGrpWavesPerBlock);
+    hipExtLaunchKernelGGL(kern, dim3(wg), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
+                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
+    ++c->prof.launches_primal; ++c->prof.launches_total;
+    c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true; c->cutModeRan = 3;
+    hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, c->stream, PW.head[c->rank], 0, c->xwSerial);
+    hipLaunchKernelGGL(k_wait_peers, dim3(1), dim3(64), 0, c->stream, PW, c->rank, 0, c->xwSerial, S.error, (unsigned long long)kSpinTimeoutTicks * 2ull);
+    hipLaunchKernelGGL(k_unpack_records, dim3(grid_for((int)c->hBodies.size(), 256, 1024)), dim3(256), 0, c->stream, B, c->dOwner.p, c->rank, PW);
+    HIPCHK(c, hipGetLastError());
+    return step_end(c, needReadback);
+}
+
 int step_once(AvbdContext* c)
 {
     int rc;
@@ -1490,6 +1595,7 @@ int step_once(AvbdContext* c)
     }
     if (c->nranks > 1 || c->forceSharded) {
         if (c->mode == 0) return c->fail(AVBD_E_INVALID, "sharded runs need the data-flow mode");
+        if (c->xwAttached && c->shardExact && c->nranks > 1) return exact_process_step(c, needReadback);   /* ranks are processes, exact cuts through their windows */
         if (!c->comm) return c->fail(AVBD_E_COMM, "context is sharded (avbd_set_ownership) but has no communicator: call avbd_comm_init or drive it through avbd_group_step");
         bool persistent = false;
         c->shardRanPersistent = false;
@@ -1551,6 +1657,7 @@ q4 HQ(const float* p) { return mkq(p[0], p[1], p[2], p[3]); }
 } // namespace
 
 static std::string g_createError = "null context";
+static void exact_window_release(AvbdContext* c);
 static void destroy_comm(void* comm);
 
 /* ========================================================================================== */
@@ -1741,6 +1848,7 @@ int avbd_destroy(AvbdContext* c)
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
+    exact_window_release(c);
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);
     (void)hipStreamDestroy(c->stream);
@@ -1882,6 +1990,64 @@ int avbd_set_shard_mode(AvbdContext* c, int mode)
     if (!c || mode < 0 || mode > 2) return AVBD_E_INVALID;
     c->shardExact = mode != 0;
     c->shardExactStrict = mode != 2;
+    return AVBD_OK;
+}
+
+/* ---- exact cuts between ranks that are processes ---- */
+static void exact_window_release(AvbdContext* c)
+{
+    for (int q = 0; q < kMaxExactRanks; ++q) {
+        if (c->xwPeer[q] && c->xwPeer[q] != c->xwOwn) (void)hipIpcCloseMemHandle(c->xwPeer[q]);
+        c->xwPeer[q] = nullptr;
+    }
+    if (c->xwOwn) { (void)hipFree(c->xwOwn); c->xwOwn = nullptr; }
+    c->xwAttached = false;
+}
+
+int avbd_exact_window_export(AvbdContext* c, unsigned char handle[64], unsigned long long* bytes)
+{
+    if (!c || !handle) return AVBD_E_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI carries a hipIpcMemHandle_t as 64 opaque bytes");
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(AVBD_E_NODEVICE, "hipSetDevice failed");
+    if (c->nranks < 2 || c->nranks > kMaxExactRanks) return c->fail(AVBD_E_INVALID, "avbd_exact_window_export: set the ownership first (avbd_set_ownership, 2..8 ranks)");
+    int rc;
+    if ((rc = upload_bodies_if_stale(c))) return rc;
+    if ((rc = upload_gforces_if_stale(c))) return rc;
+    const size_t slots = exact_window_slots(c, c->nranks), f4 = exact_window_float4(c, c->nranks);
+    if (slots * 32 >= (1ull << 31) || (size_t)3 * c->bodyCap * 16 >= (1ull << 31)) return c->fail(AVBD_E_INVALID, "avbd_exact_window_export: the window exceeds 32-bit record offsets");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    exact_window_release(c);
+    HIPCHK(c, hipMalloc((void**)&c->xwOwn, f4 * sizeof(float4)));
+    HIPCHK(c, hipMemsetAsync(c->xwOwn, 0, f4 * sizeof(float4), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipIpcMemHandle_t h;
+    HIPCHK(c, hipIpcGetMemHandle(&h, c->xwOwn));
+    std::memcpy(handle, &h, 64);
+    if (bytes) *bytes = (unsigned long long)(f4 * sizeof(float4));
+    c->xwBodyCap = c->bodyCap; c->xwMCap = c->mCap; c->xwRanks = c->nranks; c->xwSerial = 0;
+    return AVBD_OK;
+}
+
+int avbd_exact_window_attach(AvbdContext* c, int nranks, const unsigned char* handles, int ranksOnThisDevice)
+{
+    if (!c || !handles || ranksOnThisDevice < 1) return AVBD_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(AVBD_E_NODEVICE, "hipSetDevice failed");
+    if (!c->xwOwn || nranks != c->nranks || nranks != c->xwRanks) return c->fail(AVBD_E_INVALID, "avbd_exact_window_attach: export this rank's window first (same number of ranks)");
+    for (int q = 0; q < nranks; ++q) {
+        if (q == c->rank) { c->xwPeer[q] = c->xwOwn; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)q * 64, 64);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); return c->fail(AVBD_E_HIP, "hipIpcOpenMemHandle (a peer's window; windows of the same process cannot be opened — use avbd_group_step there)", e); }
+        c->xwPeer[q] = (float4*)p;
+    }
+    /* ranks that share a device share its resident waves: every rank's loop kernel must be resident while the others' are */
+    const int all = 2 * c->iterBlocks * kGrpWavesPerBlock;
+    c->shardWaves = ranksOnThisDevice > 1 ? std::max(kGrpWavesPerBlock, (all / ranksOnThisDevice) / kGrpWavesPerBlock * kGrpWavesPerBlock) : 0;
+    c->shardExact = true; c->shardExactStrict = true;
+    c->xwSharedDevice = ranksOnThisDevice > 1;
+    c->xwAttached = true;
     return AVBD_OK;
 }
 
@@ -2879,12 +3045,7 @@ static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
     int wgPerRank = 1; bool anyMulti = false;
     for (int r = 0; r < n; ++r) {
         AvbdContext* c = ctxs[r];
-        if (c->cutOfCap < (size_t)c->mCap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, c->dCutOf.alloc((size_t)c->mCap)); HIPCHK(c, c->dCutMan.alloc((size_t)n * kCutManifolds)); HIPCHK(c, c->dCutKeys.alloc((size_t)n * kCutManifolds));
-            HIPCHK(c, c->dCutCnt.alloc(1));
-            c->cutOfCap = (size_t)c->mCap;
-        }
+        if ((rc = exact_cut_buffers(c, n, kCutManifolds))) return rc;
         if (c->recIdxCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRecIdx.alloc((size_t)c->incCap)); c->recIdxCap = (size_t)c->incCap; }
         if (!c->evLoop) HIPCHK(c, hipEventCreateWithFlags(&c->evLoop, hipEventDisableTiming));
         BodyTable B = body_table(c);
@@ -2895,7 +3056,7 @@ static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
         hipLaunchKernelGGL(k_cut_list, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, M, c->dCnt.p, c->dOwner.p, n, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p);
         hipLaunchKernelGGL(k_cut_rank, dim3(grid_for(cutCap, 128, 1024)), dim3(128), 0, c->stream, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p, kCutManifolds);
         hipLaunchKernelGGL(k_cut_fill, dim3(grid_for(std::max(1, c->numSolved), 128, 4096)), dim3(128), 0, c->stream, B, M, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->inc.p,
-                           c->dOwner.p, n, c->rank, c->dCutOf.p, (int)localSlots, kCutManifolds, c->dRecIdx.p);
+                           c->dOwner.p, n, c->rank, c->dCutOf.p, c->rank * (int)localSlots, n * (int)localSlots, kCutManifolds, c->dRecIdx.p);
         IterateState S;
         S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
         ResidentExchange X{};
@@ -2906,7 +3067,7 @@ static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
         ShardExchange Z{};
         Z.xPose = L->xsPose.p; Z.xVisit = L->xsVisit.p; Z.xDual = L->xsDual.p;
         Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;
-        Z.recIdx = c->dRecIdx.p;
+        Z.recIdx = c->dRecIdx.p; Z.nPeers = 1; Z.owner = c->dOwner.p;
         ExactRankArgs& A = L->hExactArgs[(size_t)r];
         A.B = B; A.M = M; A.incStart = c->incStart.p; A.inc = c->inc.p; A.P = P; A.errWord = S.error; A.cntW = c->dCnt.p; A.X = X; A.plan = c->dPlan.p; A.byClass = c->dUnit.p;
         A.cap = c->bodyCap; A.sleepSel = c->iterSleep; A.Z = Z; A.multi = c->shardMulti ? 1 : 0;
@@ -2931,7 +3092,8 @@ static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
     for (int r = 0; r < n; ++r) {
         AvbdContext* c = ctxs[r];
         HIPCHK(c, hipStreamWaitEvent(c->stream, L->evExact, 0));
-        hipLaunchKernelGGL(k_unpack_records, dim3(grid_for((int)c->hBodies.size(), 256, 1024)), dim3(256), 0, c->stream, body_table(c), c->dOwner.p, c->rank, L->xsPose.p);
+        PeerWindows PW{}; PW.n = 1; PW.pose[0] = L->xsPose.p;
+        hipLaunchKernelGGL(k_unpack_records, dim3(grid_for((int)c->hBodies.size(), 256, 1024)), dim3(256), 0, c->stream, body_table(c), c->dOwner.p, c->rank, PW);
         HIPCHK(c, hipGetLastError());
         if ((rc = step_end(c, false))) return rc;
     }

@@ -51,7 +51,7 @@ __global__ void k_cut_rank(const unsigned long long* __restrict__ keys, const in
 
 __global__ void k_cut_fill(BodyTable B, ManifoldTable M, const int* __restrict__ order, const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                            const int* __restrict__ incStart, const int* __restrict__ inc, const int* __restrict__ owner, int nranks, int rank,
-                           const int* __restrict__ cutOf, int localSlots, int slotsPerCut, int* recIdx)
+                           const int* __restrict__ cutOf, int localBase, int cutBase, int slotsPerCut, int* recIdx)
 {
     const int nd = lvlStart[cnt->numLevels];
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nd; s += gridDim.x * blockDim.x) {
@@ -61,10 +61,10 @@ __global__ void k_cut_fill(BodyTable B, ManifoldTable M, const int* __restrict__
             const int2 pr = M.pair[m];
             const int other = inc_isA(ent) ? pr.y : pr.x;
             const int co = cutOf[m];
-            int rec = rank * localSlots + idx;
+            int rec = localBase + idx;                                    /* (one allocation for all ranks: rank * L; a window per rank: 0) */
             if (co >= 0) {
                 const int ro = owner[other];
-                rec = nranks * localSlots + (min(rank, ro) * nranks + max(rank, ro)) * slotsPerCut * 4 + co * 4 + k;
+                rec = cutBase + (min(rank, ro) * nranks + max(rank, ro)) * slotsPerCut * 4 + co * 4 + k;   /* the same slot in both ranks' index spaces */
                 if (other < b) rec |= 0x80000000;                      /* the earlier-created body owns the contact: swept by the other rank */
             }
             recIdx[e] = rec;
@@ -72,15 +72,45 @@ __global__ void k_cut_fill(BodyTable B, ManifoldTable M, const int* __restrict__
     }
 }
 
-__global__ void k_unpack_records(BodyTable B, const int* __restrict__ owner, int rank, const float4* __restrict__ pose)
+struct PeerWindows { const float4* pose[8]; volatile unsigned* head[8]; int n; };   /* n == 1: one allocation for all ranks */
+
+__global__ void k_unpack_records(BodyTable B, const int* __restrict__ owner, int rank, PeerWindows W)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B.n; i += gridDim.x * blockDim.x) {
         const int o = owner[i];
         if (o < 0 || o == rank) continue;
-        const float4 r0 = pose[3 * (size_t)i], r1 = pose[3 * (size_t)i + 1], r2 = pose[3 * (size_t)i + 2];
+        /* (system-scope loads: the records were written by another process, perhaps another device, and this XCD's L2 may still hold the
+         * lines it read a step ago) */
+        const unsigned* pw = reinterpret_cast<const unsigned*>(W.pose[W.n > 1 ? o : 0] + 3 * (size_t)i);
+        auto ldw = [&](int k) { return __uint_as_float(__hip_atomic_load(pw + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); };
+        const float4 r0 = make_float4(ldw(0), ldw(1), ldw(2), 0.0f), r1 = make_float4(ldw(4), ldw(5), ldw(6), 0.0f), r2 = make_float4(ldw(8), 0.0f, 0.0f, 0.0f);
         const float radius = B.plane(BP_POSR)[i].w;
         B.plane(BP_POSR)[i] = make_float4(r0.x, r0.y, r0.z, radius);
         B.plane(BP_QUAT)[i] = make_float4(r1.x, r1.y, r1.z, r2.x);
+    }
+}
+
+/* Ranks that are processes: a rank's loop kernel is followed by k_step_done — "every record of step `serial` that this rank will ever write is
+ * in its window" — and the kernel that copies the other ranks' final poses waits for that word of every peer first (k_wait_peers; bounded, the
+ * error word of the context is raised on a time-out).  Besides the final poses this is what makes the windows reusable: no rank starts the
+ * records of step s + 1 while a peer can still read those of step s (the last read is the owner's last dual, final_store). */
+__global__ void k_step_done(volatile unsigned* head, int word, unsigned serial)
+{
+    __hip_atomic_store(const_cast<unsigned*>(head) + word, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_wait_peers(PeerWindows W, int rank, int word, unsigned serial, int* errWord, unsigned long long timeoutTicks)
+{
+    const int p = threadIdx.x;
+    if (p >= W.n || p == rank) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(const_cast<unsigned*>(W.head[p]) + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(v - serial) >= 0) return;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeoutTicks || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
     }
 }
 

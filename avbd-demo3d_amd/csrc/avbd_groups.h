@@ -26,6 +26,8 @@
 
 namespace avbd {
 
+constexpr int kMaxExactRanks = 8;
+
 struct GroupPlan {
     int nClass[3];     /* swept bodies with <= 16 / <= 32 / <= 64 incidence entries */
     int waves[3];      /* resident waves of each class; layout in the launch: class 2 (64 lanes) | class 1 | class 0 */
@@ -63,6 +65,13 @@ struct ShardExchange {
      * by body; the visit / dual records of a contact by recIdx: this rank's own range, or — contacts across a cut — a slot both
      * ranks of the cut compute alike (k_cut_rank: rank of the manifold among the cut's manifolds, ordered by body pair). */
     float4 *xPose, *xVisit, *xDual; unsigned xPoseBytes, xVisitBytes, xDualBytes;
+    /* Ranks that are PROCESSES (one per GPU, or several on one device): every rank WRITES its records into a window of its own memory and READS
+     * the records of a partner body — pose, and the visit / dual records of the contacts it shares with it — from the window of the rank that
+     * sweeps that body, opened with hipIpcOpenMemHandle (avbd_exact_window_export / _attach).  All windows have the same layout, so a record has
+     * the same offset in each of them.  nPeers == 1: the in-process emulation, one allocation for all ranks (xPose / xVisit / xDual). */
+    float4 *peerPose[kMaxExactRanks], *peerVisit[kMaxExactRanks], *peerDual[kMaxExactRanks];
+    int nPeers;
+    const int* owner;         /* [bodies]: rank that sweeps a body (-1: static) — which window a partner's records are read from */
     const int* recIdx;        /* [incidence entries]: record index of the entry's contact | bit 31: the contact's owner is swept by another rank
                                * (this rank's copy of the contact takes the owner's last dual from its record when the loop ends) */
 };
@@ -299,6 +308,13 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     float* const xch = accs + 32;
     float* const cst = S + kGrpSSlots * kResRows + 4 * kGrpAccFloats + (gBase >> 4) * kGrpConstFloats;
 
+    /* EXACT: the records cross process (and device) boundaries — system scope (sc0 sc1) instead of device scope (sc1); the same price on one
+     * device (tools/ubench/ipc_pingpong.hip: 0.53 us per hop either way, plain or uncached memory) */
+    constexpr int AUX = EXACT ? 17 : 16;
+    auto xldA = [](__amdgpu_buffer_rsrc_t r, int byteOff) __attribute__((always_inline)) -> v4u { return __builtin_amdgcn_raw_buffer_load_b128(r, byteOff, 0, AUX); };
+    auto xstA = [](__amdgpu_buffer_rsrc_t r, int byteOff, v4u v) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, AUX); };
+    auto xldwA = [](__amdgpu_buffer_rsrc_t r, int byteOff) __attribute__((always_inline)) -> unsigned { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byteOff, 0, AUX); };
+    int peer = 0;                                                     /* EXACT: whose window this lane's partner publishes in */
     const __amdgpu_buffer_rsrc_t rP = EXACT ? xrsrc(Z.xPose, Z.xPoseBytes) : xrsrc(X.pose, X.poseBytes),
                                  rV = EXACT ? xrsrc(Z.xVisit, Z.xVisitBytes) : xrsrc(X.visit, X.visitBytes),
                                  rD = EXACT ? xrsrc(Z.xDual, Z.xDualBytes) : xrsrc(X.dual, X.dualBytes);
@@ -349,6 +365,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         }
         finalD = EXACT && has && (rec < 0);
         rec &= 0x7fffffff;
+        if constexpr (EXACT) { peer = 0; if (Z.nPeers > 1 && has && moving) { if constexpr (MULTI) peer = hdr[round * 64 + lane].w; else peer = max(Z.owner[other], 0); } }
         offP = other * 48; offV = rec * 16; offD = rec * 32;
     };
     /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
@@ -559,7 +576,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         if (has) {
             const f3 pOwn = pos + wOwn;
             contact_constraint_post(c, pre, isA ? pOwn : pOther, isA ? pOther : pOwn, fric);
-            if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xst(rV, offV, r); }
+            if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xstA(rV, offV, r); }
             for (int k = 0; k < 3; ++k) {
                 const float desired = c.penalty[k] * c.C[k] + c.lambda[k] + 0.0f;     /* solver.cpp:379-381 with stiffness FLT_MAX, motor 0 */
                 const float f = rclamp(desired, c.fmin[k], c.fmax[k]);
@@ -602,7 +619,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             sanitizeq(q, cntW, warn_key(1, it, body, 1), body, WK_ROT);
             const int o = body * 48;
             v4u r0 = {fbits(p.x), fbits(p.y), fbits(p.z), stampNow}, r1 = {fbits(q.x), fbits(q.y), fbits(q.z), stampNow}, r2 = {fbits(q.w), 0u, 0u, stampNow};
-            xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
+            xstA(rP, o, r0); xstA(rP, o + 16, r1); xstA(rP, o + 32, r2);
             if (SHARD) {                                              /* this rank's row of the all-gather behind iteration `it` */
                 v4u s0 = {fbits(p.x), fbits(p.y), fbits(p.z), fbits(radius)}, s1 = {fbits(q.x), fbits(q.y), fbits(q.z), fbits(q.w)};
                 if (it & 1) { xst(rG1, ownRow, s0); xst(rG1, ownRow + 16, s1); } else { xst(rG0, ownRow, s0); xst(rG0, ownRow + 16, s1); }
@@ -628,7 +645,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (moving) {
                 v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
                 v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), (stampNow << 1) | (c.stick ? 1u : 0u)};
-                xst(rD, offD, r0); xst(rD, offD + 16, r1);
+                xstA(rD, offD, r0); xstA(rD, offD + 16, r1);
                 /* ... and at the later-created partner, whose task it + 1 reads this dual */
                 if (SHARDK == 0 && MULTI && depSig && (idx & 3) == 0 && it + 1 < itStop)
                     __hip_atomic_fetch_add(X.depCnt + other, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -652,9 +669,42 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     /* the poll of a prepared task: the records ARE the payload (avbd_resident.h); only lanes that still miss something load */
     auto poll_issue = [&]() __attribute__((always_inline)) {
         const bool lp = !okP, lv = !okV, ld = !okD;
-        if (lp) { p0 = xld(rP, offP); p1 = xld(rP, offP + 16); p2 = xld(rP, offP + 32); }
-        if (lv) vd = xld(rV, offV);
-        if (ld) { vd = xld(rD, offD); d1 = xld(rD, offD + 16); }
+        if constexpr (EXACT) {
+            if (Z.nPeers > 1) {
+                /* one round of loads per window some lane reads from (a slab has two neighbours: one to three rounds) */
+                unsigned long long todo = __ballot(lp | lv | ld);
+                while (todo) {
+                    const int pr = __builtin_amdgcn_readlane(peer, __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1));
+                    const __amdgpu_buffer_rsrc_t qP = xrsrc(Z.peerPose[pr], Z.xPoseBytes), qV = xrsrc(Z.peerVisit[pr], Z.xVisitBytes), qD = xrsrc(Z.peerDual[pr], Z.xDualBytes);
+                    const bool m = peer == pr;
+                    if (lp && m) { p0 = xldA(qP, offP); p1 = xldA(qP, offP + 16); p2 = xldA(qP, offP + 32); }
+                    if (lv && m) vd = xldA(qV, offV);
+                    if (ld && m) { vd = xldA(qD, offD); d1 = xldA(qD, offD + 16); }
+                    todo &= ~__ballot(m);
+                }
+                return;
+            }
+        }
+        if (lp) { p0 = xldA(rP, offP); p1 = xldA(rP, offP + 16); p2 = xldA(rP, offP + 32); }
+        if (lv) vd = xldA(rV, offV);
+        if (ld) { vd = xldA(rD, offD); d1 = xldA(rD, offD + 16); }
+    };
+    /* the stamp word of a pose record some lanes watch (several bodies per sub-group), from the window of the rank that writes it */
+    auto watch_pose = [&](bool want, int off, int pk, unsigned& val) __attribute__((always_inline)) {
+        if constexpr (EXACT) {
+            if (Z.nPeers > 1) {
+                unsigned long long todo = __ballot(want);
+                while (todo) {
+                    const int pr = __builtin_amdgcn_readlane(pk, __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1));
+                    const __amdgpu_buffer_rsrc_t qP = xrsrc(Z.peerPose[pr], Z.xPoseBytes);
+                    const bool m = want && pk == pr;
+                    if (m) val = xldwA(qP, off);
+                    todo &= ~__ballot(m);
+                }
+                return;
+            }
+        }
+        if (want) val = xldwA(rP, off);
     };
     auto poll_check = [&]() __attribute__((always_inline)) {
         const bool lp = !okP, lv = !okV, ld = !okD;
@@ -842,6 +892,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
          * examined in full only when that record has arrived.  Every pass of the wave runs the picks of all its sub-groups
          * together. ---- */
         int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
+        int blkPeer = 0;                                              /* EXACT: the window the watched pose record lives in */
         /* ARRIVAL COUNTERS (one GPU): instead of watching ONE record of a body that was missing when it was last examined — and finding, after the
          * round trip that fetches records and parked state, that another one is missing too (two examinations out of five ended that way: 1.6 GB of
          * the 4.2 GB a 64 000-cube launch read, and a whole round trip of the wave's pass each) — lane k watches the number of partners that have
@@ -899,7 +950,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     if (k0 + q < rounds && gl == k0 + q) { depPerIt = nOwn + nOth; depNeed = nOwn; }
                 }
                 if (k0 + q < rounds) {
-                    if constexpr (EXACT) hdr[(k0 + q) * 64 + lane] = make_int4(ent[q], w1, rc, 0);
+                    if constexpr (EXACT) hdr[(k0 + q) * 64 + lane] = make_int4(ent[q], w1, rc, (Z.nPeers > 1 && hk[q]) ? max(Z.owner[oth[q]], 0) : 0);
                     else hdr[(k0 + q) * 64 + lane] = make_int2(ent[q], w1);
                 }
             }
@@ -936,7 +987,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (prep) poll_issue();
             if (dep) { if (activeK && depNeed != 0u) watchVal = xldw(rC, bodyK * 4); }
             else {
-            if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
+            watch_pose(activeK && blkOff >= 0, blkOff, blkPeer, watchVal);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
             }
             if (prep) poll_check();
@@ -995,7 +1046,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                         const int f = __ffsll((long long)noPose) - 1;
                         const int bo = __shfl(offP + 44, f, 64);
                         const unsigned bs = (unsigned)__shfl((int)sP, f, 64);
-                        if (lane == k) { blkOff = bo; blkStamp = bs; candK = false; }
+                        const int bp = __shfl(peer, f, 64);
+                        if (lane == k) { blkOff = bo; blkStamp = bs; blkPeer = bp; candK = false; }
                     } else if (noGather) {
                         if (lane == k) { blkOff = -2; blkStamp = X.base + (unsigned)t; candK = false; }
                     } else if (lane == k) triedK = true;                     /* visit / dual records follow their producer's pose within its task: next pass */
@@ -1063,7 +1115,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (dep) {
                 if (activeK && depNeed != 0u) { watchVal = xldw(rC, bodyK * 4); candK = watchVal >= depNeed; }
             } else {
-            if (activeK && blkOff >= 0) watchVal = xldw(rP, blkOff);
+            watch_pose(activeK && blkOff >= 0, blkOff, blkPeer, watchVal);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
             if (activeK && blkOff != -1) candK = stamp_reached(watchVal, blkStamp);
             }
@@ -1106,7 +1158,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                         const int f = __ffsll((long long)noPose) - 1;
                         const int bo = __shfl(offP + 44, f, 64);
                         const unsigned bs = (unsigned)__shfl((int)sP, f, 64);
-                        if (lane == k) { blkOff = bo; blkStamp = bs; candK = false; }
+                        const int bp = __shfl(peer, f, 64);
+                        if (lane == k) { blkOff = bo; blkStamp = bs; blkPeer = bp; candK = false; }
                     } else if (noGather) {
                         if (lane == k) { blkOff = -2; blkStamp = X.base + (unsigned)t; candK = false; }
                     } else if (lane == k) triedK = true;                     /* visit / dual records follow their producer's pose within its task: next pass */

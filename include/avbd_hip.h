@@ -305,6 +305,20 @@ int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
  * avbd_last_error — a caller that asked for single-GPU bits never gets a Jacobi coupling under that name.
  * 2: exact cuts when the step can run them, the all-gather form otherwise; AvbdStepStats.cutMode tells which one ran. */
 int  avbd_set_shard_mode(AvbdContext* ctx, int mode);
+/* Exact cuts between ranks that are PROCESSES — one per GPU, or several on one device (how they are validated: N processes on one
+ * MI355X reproduce the single-GPU sweep bit for bit, tests/test_gpu_exact_processes.py).  Every rank holds the whole scene and has
+ * set the same ownership (avbd_set_ownership).  avbd_exact_window_export allocates this rank's record window — its pose records
+ * and the visit / dual records of its contacts, cuts included — and returns the window's hipIpcMemHandle_t as 64 opaque bytes;
+ * the caller exchanges the handles of all ranks by whatever means it has (bench.py: torch.distributed) and hands the table,
+ * rank-major, to avbd_exact_window_attach, which opens the peers' windows (hipIpcOpenMemHandle with lazy peer access) and puts
+ * the context into shard mode 1.  From then on avbd_step(ctx, n) on every rank runs exact cuts: a rank writes into its own
+ * window and reads a partner's records from the window of the rank that sweeps the partner, with system-scope accesses; nothing
+ * is exchanged during the loop, and a one-word handshake per step (a rank's "records of step s complete") lets the ranks copy
+ * each other's final poses.  All ranks must call avbd_step with the same step counts.  `ranksOnThisDevice`: how many of the
+ * ranks' loop kernels share this context's device (they are resident together, so each takes that share of the wavefronts).
+ * The reference has no counterpart (solver.cpp is one thread); the loop being cut is solver.cpp:340-431. */
+int  avbd_exact_window_export(AvbdContext* ctx, unsigned char handle[64], unsigned long long* bytes /* may be NULL */);
+int  avbd_exact_window_attach(AvbdContext* ctx, int nranks, const unsigned char* handles /* nranks x 64 */, int ranksOnThisDevice);
 /* What the ranks exchange.  8 (default): {position + radius, orientation} every iteration, velocities re-derived by
  * every rank from the gathered poses.  13: additionally ONE gather of {linear, angular velocity} per step, after the velocity
  * stage (pos3 + quat4 + linVel3 + angVel3 = north_star's 13 floats per body); the arriving rows overwrite the re-derived ones and
