@@ -2017,7 +2017,9 @@ int avbd_exact_window_export(AvbdContext* c, unsigned char handle[64], unsigned 
     if (slots * 32 >= (1ull << 31) || (size_t)3 * c->bodyCap * 16 >= (1ull << 31)) return c->fail(AVBD_E_INVALID, "avbd_exact_window_export: the window exceeds 32-bit record offsets");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     exact_window_release(c);
-    HIPCHK(c, hipMalloc((void**)&c->xwOwn, f4 * sizeof(float4)));
+    /* uncached device memory: the peers may sit on other devices (tools/ubench/ipc_pingpong.hip: a hop through it costs 0.58 us against 0.53 us
+     * through plain memory; every access to a record is a system-scope one anyway) */
+    HIPCHK(c, hipExtMallocWithFlags((void**)&c->xwOwn, f4 * sizeof(float4), hipDeviceMallocUncached));
     HIPCHK(c, hipMemsetAsync(c->xwOwn, 0, f4 * sizeof(float4), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipIpcMemHandle_t h;

@@ -189,8 +189,17 @@ def main():
     if sharded:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # AVBD_BENCH_ONE_DEVICE=1: every rank on device 0 (how the multi-process path is exercised on a one-GPU box: RCCL refuses two ranks on
+        # one device, so rendezvous goes over gloo and only the exact-cut form — which needs no collective — can run)
+        one_device = os.environ.get("AVBD_BENCH_ONE_DEVICE") == "1"
+        if one_device:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    tdev = "cpu" if (sharded and os.environ.get("AVBD_BENCH_ONE_DEVICE") == "1") else "cuda"
 
     pkg = load_pkg()
     if not os.path.exists(pkg.LIB_PATH):
@@ -202,16 +211,42 @@ def main():
     scene = args.scene or ("Stress1000" if not sharded else STRONG_SCENE)
     presim = args.presim if args.presim is not None else (0 if scene.startswith("Packed") else (STRONG_PRESIM if scene == STRONG_SCENE else 400))
 
-    def make_world():
+    EXACT_FORM = "exact cuts (one process per GPU, record windows over hipIpc; bit-identical to one GPU)"
+
+    def make_world(form=None, bare=False):
         w = pkg.World(local_rank)
         w.scene(scene)
-        if sharded:
+        if sharded and not bare:
             b0 = w.bodies()
             owner = pkg.partition_by_axis(b0["position"], b0["invMass"], world_size, axis=0)
             w.set_ownership(world_size, rank, owner)
-            uid = [pkg.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            w.comm_init(world_size, rank, uid[0])
+            if form == EXACT_FORM:
+                # every rank exports its record window, all ranks open all windows: nothing is exchanged during a step, every rank polls
+                # its neighbours' stamped records where they are written.  (Collective-safe: a rank that fails to
+                # export or to attach still takes part in both gathers, then every rank raises.)
+                import torch
+                handles, devs, oks = [None] * world_size, [None] * world_size, [None] * world_size
+                try:
+                    mine = w.exact_window_export()
+                except Exception as e:
+                    mine = repr(e)
+                dist.all_gather_object(handles, mine)
+                dist.all_gather_object(devs, (os.uname().nodename, torch.cuda.current_device()))
+                err = next((h for h in handles if not isinstance(h, bytes)), None)
+                if err is None:
+                    try:
+                        w.exact_window_attach(handles, ranks_on_this_device=sum(1 for d in devs if d == devs[rank]))
+                    except Exception as e:
+                        err = repr(e)
+                dist.all_gather_object(oks, err)
+                err = next((o for o in oks if o is not None), None)
+                if err is not None:
+                    raise RuntimeError(f"exact-cut windows could not be set up on every rank: {err}")
+            else:
+                uid = [pkg.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                w.comm_init(world_size, rank, uid[0])
+            dist.barrier()                                           # the ranks start stepping together (a wave gives up after 4 s without progress)
         return w
 
     want_cpu = (rank == 0 and not sharded and not args.no_cpu)
@@ -250,7 +285,7 @@ def main():
         w.profile_enable(False)
         return m
 
-    w = make_world()
+    w = make_world(bare=sharded)                                     # (sharded: every form gets a world of its own below)
     iterations = int(w.params()["iterations"])
     shard_form = None
     shard_other = None
@@ -262,6 +297,10 @@ def main():
         import torch
         forms = ["one launch per iteration"] if os.environ.get("AVBD_SHARD_PERSISTENT") == "0" else \
                 ["persistent", "persistent, exchange stream gated by kernels instead of stream wait / write values", "one launch per iteration"]
+        if world_size > 1 and os.environ.get("AVBD_BENCH_EXACT", "1") != "0":
+            forms = [EXACT_FORM] + forms
+        if os.environ.get("AVBD_BENCH_ONE_DEVICE") == "1":
+            forms = [EXACT_FORM]
         results = {}
         for k, form in enumerate(forms):
             # (the library takes the persistent form with a real communicator only on request — it could not be validated on a
@@ -275,17 +314,17 @@ def main():
                 w.close()
             except Exception:
                 pass
-            w = make_world()
             ok, mk = 1, None
             try:
+                w = make_world(form)
                 mk = measure(w)
             except Exception as e:
                 ok = 0
                 print(f"bench.py rank {rank}: the sharded run failed in the form '{form}' ({e})", file=sys.stderr)
-            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            t = torch.tensor([ok], dtype=torch.int32, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if int(t.item()) == 1:
-                te = torch.tensor([mk["elapsed"]], dtype=torch.float64, device="cuda")
+                te = torch.tensor([mk["elapsed"]], dtype=torch.float64, device=tdev)
                 dist.all_reduce(te, op=dist.ReduceOp.MAX)
                 mk["elapsed"] = float(te.item())
                 results[form] = mk
@@ -299,7 +338,7 @@ def main():
         m = measure(w)
         if dist is not None:
             import torch
-            te = torch.tensor([m["elapsed"]], dtype=torch.float64, device="cuda")
+            te = torch.tensor([m["elapsed"]], dtype=torch.float64, device=tdev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             m["elapsed"] = float(te.item())
     snap_b, snap_f, snap_step, elapsed, end_b, stats, p = m["snap_b"], m["snap_f"], m["snap_step"], m["elapsed"], m["end_b"], m["stats"], m["p"]
@@ -426,8 +465,12 @@ def main():
             "scaling": "strong" if sharded else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene} (iterations={iterations}) steady window: steps {snap_step}..{snap_step + args.steps}",
                        "mode": "exact (bit-identical to the reference CPU solver)" if world_size == 1 else
-                               "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)",
-                       "parallelism": "1 GPU" if not sharded else f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene",
+                               ("sharded with exact cuts: every rank sweeps its slab with the single-GPU protocol and polls its neighbours' stamped records in their windows (bit-identical to one GPU)"
+                                if shard_form == EXACT_FORM else
+                                "sharded: exact sweep inside every GPU's slab, poses of the other slabs from the last all-gather (Jacobi across the cut)"),
+                       "parallelism": "1 GPU" if not sharded else
+                                      (f"{world_size} x-slabs of one scene, no exchange during a step (peer windows over xGMI); value = steps/s of that scene" if shard_form == EXACT_FORM else
+                                       f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene"),
                        "shard_form": shard_form, "shard_other_form": shard_other,
                        "strong_scaling_n1": strong_n1, "roofline_8k": roofline_8k,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
