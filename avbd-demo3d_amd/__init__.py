@@ -66,7 +66,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign",
+    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_set_option", "avbd_get_option", "avbd_option_count", "avbd_option_key", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign",
 ]
 
 
@@ -97,8 +97,10 @@ def lib():
     L.avbd_last_error.argtypes = [C.c_void_p]
     L.avbd_stream.restype = C.c_void_p
     L.avbd_stream.argtypes = [C.c_void_p]
+    L.avbd_option_key.restype = C.c_char_p
+    L.avbd_option_key.argtypes = [C.c_int]
     for name in EXPORTS:
-        if name in ("avbd_last_error", "avbd_stream"):
+        if name in ("avbd_last_error", "avbd_stream", "avbd_option_key"):
             continue
         getattr(L, name).restype = C.c_int
     _lib = L
@@ -116,6 +118,12 @@ def _f32(a, shape=None):
     if shape is not None:
         a = a.reshape(shape)
     return a
+
+
+def option_keys():
+    """the keys avbd_set_option accepts"""
+    L = lib()
+    return [L.avbd_option_key(i).decode() for i in range(L.avbd_option_count())]
 
 
 def partition_by_axis(position, inv_mass, nranks, axis=0):
@@ -314,6 +322,14 @@ class World:
 
     def set_shard_mode(self, mode):
         self._chk(self.L.avbd_set_shard_mode(self.h, int(mode)))
+
+    def set_option(self, key, value):
+        self._chk(self.L.avbd_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        self._chk(self.L.avbd_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def exact_window_export(self):
         """this rank's record window for exact cuts between processes: the 64 opaque bytes of its hipIpcMemHandle_t"""

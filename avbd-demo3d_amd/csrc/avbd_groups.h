@@ -95,13 +95,12 @@ static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "t
  * waves of G = 4 >> c sub-groups) serves, in round k, rank r = (k * G + j) * Wc + wl — bodies that follow each other in the
  * sweep go to different waves.  One tile of 4096 slots of the sweep order per workgroup (tile_exclusive_prefix); the last
  * tile, which learns the totals from its look-back, writes the plan header. */
-__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round, int map = 0)
+__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round)
 {
+    /* (other assignments — the sub-groups of a wave serve neighbours of the sweep, a sub-group serves a run of the sweep — were measured in round 3
+     * and removed in round 4: neighbours of the sweep are ready together, and a wave runs its ready sub-groups one pass at a time) */
     const int Wc = plan->waves[cls], G = 4 >> cls;
-    int r = (round * G + j) * Wc + wl;
-    if (map == 1) r = (round * Wc + wl) * G + j;                        /* the sub-groups of a wave serve neighbours of the sweep */
-    if (map == 2) r = (wl * G + j) * plan->rounds[cls] + round;          /* a sub-group serves a run of the sweep */
-    if (map == 3) r = (j * Wc + wl) * plan->rounds[cls] + round;         /* ... and the sub-groups of a wave runs that are far apart */
+    const int r = (round * G + j) * Wc + wl;
     return r < plan->nClass[cls] ? byClass[cls * cap + r] : -1;
 }
 
@@ -791,7 +790,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     if constexpr (!MULTI) {
         /* ---- one body per sub-group for the whole launch ---- */
         {
-            const int b = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), 0, X.groupMap);
+            const int b = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), 0);
             int e0 = 0, ne = 0;
             if (b >= 0) { e0 = incStart[b]; ne = incStart[b + 1] - e0; }
             load_header(b, e0, ne, 0);
@@ -911,7 +910,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
-            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl, X.groupMap);
+            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl);
             if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
         }
         /* the header table: three dependent loads per entry (incidence word -> pair -> is the partner swept?), four rounds in flight */

@@ -72,7 +72,6 @@ struct ResidentExchange {
     int outOfOrder;    /* MULTI: a wave runs whichever of its bodies has its inputs ready (oldest iteration first) instead of sweeping them in order */
     int patience;      /* out of order, nothing ready: ticks (10 ns) a wave waits on its oldest task, prepared, before it looks at its other bodies again (0: never blocks) */
     int* probe;        /* [incidence capacity] out of order: who an entry waits for (partner | moving << 24 | owned << 25 | hasA << 26), kept from a body's first examination */
-    int groupMap;      /* group schedule, several bodies per sub-group: which bodies of the sweep a sub-group serves (group_unit_body) */
     int specRounds;    /* ... only in classes with at most this many bodies per sub-group */
     int specMode;      /* group schedule, several bodies per sub-group: when a sub-group with nothing ready takes its oldest task in hand (0: when its wave has nothing else to do in the pass, 1: always, 2: never) */
     float4 *parkC, *parkS, *parkB;   /* group schedule, several bodies per sub-group: packed records of a parked body (k_iterate_groups::load_rest) */

@@ -189,6 +189,9 @@ def main():
     if sharded:
         import torch
         import torch.distributed as dist
+        # the persistent all-gather form runs its collective beside a launch that fills the device but four workgroup slots: RCCL reads the
+        # channel cap once per process, when the first communicator is created — that is the one below
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
         # AVBD_BENCH_ONE_DEVICE=1: every rank on device 0 (how the multi-process path is exercised on a one-GPU box: RCCL refuses two ranks on
         # one device, so rendezvous goes over gloo and only the exact-cut form — which needs no collective — can run)
         one_device = os.environ.get("AVBD_BENCH_ONE_DEVICE") == "1"

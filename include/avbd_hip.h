@@ -325,6 +325,15 @@ int  avbd_exact_window_attach(AvbdContext* ctx, int nranks, const unsigned char*
  * must equal them bit for bit — avbd_exchange_mismatches returns the number of 32-bit words that ever differed on this rank
  * (tests/test_gpu_sharded.py keeps it at 0).  Exact cuts (avbd_set_shard_mode 1) exchange nothing during a step and ignore it. */
 int  avbd_set_exchange_floats(AvbdContext* ctx, int floatsPerBody);
+/* Schedule options (ABI 4).  Everything that chooses HOW the sweep of solver.cpp:340-431 is run — which schedule, which form of a
+ * kernel, how many workgroups — is one (key, value) pair; none of them changes a result bit (tests/test_gpu_options.py runs every
+ * key against the oracle).  avbd_option_count / avbd_option_key enumerate the keys; DESIGN.md "Options" documents them.  The
+ * environment variables AVBD_<KEY IN CAPITALS> are a debug override read when a context is created.  There is no counterpart in the
+ * reference (one thread, one schedule). */
+int  avbd_set_option(AvbdContext* ctx, const char* key, int value);
+int  avbd_get_option(AvbdContext* ctx, const char* key, int* value);
+int  avbd_option_count(void);
+const char* avbd_option_key(int index);
 int  avbd_exchange_mismatches(AvbdContext* ctx, unsigned* words, unsigned* rowsCompared /* may be NULL: velocity rows received so far */);
 int  avbd_device_count(void);                                            /* visible gfx950 devices (0 without one) */
 /* Joint (joint.cpp:108-139): 0 (default) keeps the reference's angular Jacobian sign — bug-compatible: body-body welds blow up,
