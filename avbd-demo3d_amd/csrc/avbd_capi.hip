@@ -241,6 +241,7 @@ struct AvbdContext {
     /* exact cuts between processes: this rank's window, the peers' windows as this process sees them (own window at [rank]) */
     float4* xwOwn = nullptr; float4* xwPeer[kMaxExactRanks] = {}; bool xwAttached = false; bool xwSharedDevice = false; unsigned xwSerial = 0; int xwBodyCap = 0, xwMCap = 0, xwRanks = 0;
     int cutRanks = 0;
+    bool debugSharedMulti = false;
     int iterBlocksMax = 0;         /* what the occupancy query allows (avbd_create) */
     bool exactAllowed = true;      /* the exact-cut kernels fit two workgroups per CU on this device / this build */
     int groupDepKeep = 1;          /* AVBD_GROUP_DEP_KEEP=0: classes that take a task in hand keep the watched records of round 3 (ResidentExchange::depKeep) */
@@ -1749,7 +1750,8 @@ void turn_end(AvbdContext* c)
     BOOL("grid_broadphase", gridBroadphase)       /* 0: the n^2 tile kernel (SURVEY section 8 f1's parity reference) */                     \
     BOOL("order_by_index", orderByIndex)          /* 0: sweep order by dependency level */                                                 \
     BOOL("fused_topology", fusedTopology)                                                                                                  \
-    BOOL("fused_front", fusedFront)
+    BOOL("fused_front", fusedFront)                                                                                                        \
+    BOOL("debug_shared_multi", debugSharedMulti)  /* debug: more than two contexts of one device in the persistent several-bodies all-gather form (see avbd_group_step) */
 
 static int option_access(AvbdContext* c, const char* key, int* v, bool set)
 {
@@ -3181,6 +3183,8 @@ static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
 }
 
 static int group_exchange_velocities(AvbdContext** ctxs, int n);
+/* hardware queues the HIP runtime maps this process's streams onto (its GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise) */
+static int hw_queues() { const char* e = std::getenv("GPU_MAX_HW_QUEUES"); const int q = e ? std::atoi(e) : 4; return q > 0 ? q : 4; }
 
 /* one step of avbd_group_step */
 static int group_step_one(AvbdContext** ctxs, int n)
@@ -3237,7 +3241,7 @@ static int group_step_one(AvbdContext** ctxs, int n)
                 for (int r = 0; r < n; ++r) {
                     int sharing = 0;
                     for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
-                    if (sharing > 4) all = false;
+                    if (sharing > 4 && 2 * sharing > hw_queues()) all = false;
                     /* contexts on different devices: every exchange stream would wait on, and copy from, memory of another device —
                      * never validated on a multi-GPU box, so only on explicit request, and only with peer access in place */
                     if (sharing != n) {
@@ -3259,13 +3263,17 @@ static int group_step_one(AvbdContext** ctxs, int n)
                 (void)hipSetDevice(ctxs[r]->device);
                 if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
                 all = ok;
-                /* several bodies per sub-group with more than two contexts on one device: four contexts of 16 000 bodies each stop making
-                 * progress on the step the first layer lands (waves that serve ground contacts never count their second iteration; two
-                 * contexts of 32 000 go through) — not understood yet, so that combination takes one launch per iteration */
+                /* Several bodies per sub-group with more than two contexts on one device: four contexts of 16 000 bodies each stopped making
+                 * progress on the step the first layer lands — waves that serve ground contacts waited for an all-gather that never landed.
+                 * Explained in round 4 (tools/stall_4x16000.py): four contexts have EIGHT streams (a persistent launch and an exchange
+                 * stream each) and a HIP process maps its streams onto GPU_MAX_HW_QUEUES = 4 hardware queues; an exchange stream that
+                 * shares a queue with another context's persistent launch sits behind a kernel that waits for that very exchange.  With
+                 * GPU_MAX_HW_QUEUES=16 the same run goes through (test_four_contexts_persistent_with_a_hardware_queue_per_stream).  So:
+                 * without a hardware queue per stream that combination takes one launch per iteration. */
                 if (ok && ctxs[r]->shardMulti) {
                     int sharing = 0;
                     for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
-                    if (sharing > 2) all = false;
+                    if (sharing > 2 && 2 * sharing > hw_queues() && !ctxs[r]->debugSharedMulti) all = false;
                 }
             }
             for (int r = 0; r < n; ++r) ctxs[r]->shardRanPersistent = false;

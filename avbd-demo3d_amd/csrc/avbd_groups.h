@@ -498,18 +498,22 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             world_inertia_group(gl, rot, Ib, Jb, xch, L.Iw, L.invIw);     /* rigid.cpp:51-59 */
         }
         GS_STAMP(10);
+        AVBD_MARK(g_prep_gacc);
         a0 = make_gacc(gl < 27 ? gl : 63, L);
         a1 = make_gacc((cls == 0 && gl + 16 < 27) ? gl + 16 : 63, L);
         wOwn = zero3();
         if (!MULTI) set_needs();                                      /* (several bodies per sub-group: set, and polled, when the body was examined) */
+        AVBD_MARK(g_prep_replay);
         if (has) {
             wOwn = qrotate(rot, isA ? c.rA : c.rB);                    /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
                 if (owned) replay_normal(c, fixedN);
                 else if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); }
             }
+            AVBD_MARK(g_prep_pre);
             ContactBasis db;
             contact_constraint_pre(c, alpha, isA ? invMass : oinv, isA ? oinv : invMass, pre, db);
+            AVBD_MARK(g_prep_deriv);
             f3 Jl[3], Ja[3];
             contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
             for (int k = 0; k < 3; ++k) {
