@@ -246,7 +246,8 @@ struct AvbdContext {
     bool exactAllowed = true;      /* the exact-cut kernels fit two workgroups per CU on this device / this build */
     int groupDepKeep = 1;          /* AVBD_GROUP_DEP_KEEP=0: classes that take a task in hand keep the watched records of round 3 (ResidentExchange::depKeep) */
     int groupDep = 1;              /* several bodies per sub-group on one GPU: arrival counters instead of watched records (AVBD_GROUP_DEP=0: the watched records of round 3) */
-    DevArr<unsigned> xDepCnt;
+    DevArr<unsigned> xDepCnt; DevArr<int> xRankOf;
+    int groupPool = 1, groupPoolMinRounds = 5;   /* ResidentExchange::poolMode / poolMinRounds (classes with fewer bodies per sub-group take a task in hand instead) */
     int groupSpecMode = 0, groupSpecRounds = 4;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
     bool turnReleased = false;          /* avbd_destroy has taken this context out of its device's count (turn_begin / turn_end) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
@@ -873,11 +874,11 @@ int step_begin(AvbdContext* c)
                 HIPCHK(c, c->xParkC.alloc((size_t)5 * c->incCap)); HIPCHK(c, c->xParkS.alloc((size_t)4 * c->incCap)); HIPCHK(c, c->xParkB.alloc((size_t)10 * c->bodyCap));
                 c->parkCap = (size_t)c->incCap; c->parkBodyCap = (size_t)c->bodyCap;
             }
-            if (c->xDepCnt.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xDepCnt.alloc((size_t)c->bodyCap)); }
+            if (c->xDepCnt.n < (size_t)3 * c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xDepCnt.alloc((size_t)3 * c->bodyCap)); HIPCHK(c, c->xRankOf.alloc((size_t)c->bodyCap)); }
         }
         hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
                            c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min((c->nranks > 1 && c->shardExact) ? kGrpMaxRounds / 2 : kGrpMaxRounds, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp,
-                           (c->groupDep && c->nranks == 1 && !c->forceSharded) ? c->xDepCnt.p : (unsigned*)nullptr);
+                           (c->groupDep && c->nranks == 1 && !c->forceSharded) ? c->xDepCnt.p : (unsigned*)nullptr, c->xRankOf.p);
         c->groupsPlanned = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -937,7 +938,7 @@ int step_iterate(AvbdContext* c, int itBegin, int itEnd)
     }
     X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p;
     X.depCnt = (c->groupDep && !sharded && c->groupsPlanned) ? c->xDepCnt.p : nullptr;
-    X.depKeep = c->groupDepKeep;
+    X.depKeep = c->groupDepKeep; X.rankOf = c->xRankOf.p; X.poolMode = c->groupPool; X.poolMinRounds = c->groupPoolMinRounds;
     X.send = (sharded && c->dSend.p && c->dSendSlot.p) ? c->dSend.p : nullptr; X.sendSlot = c->dSendSlot.p;
     c->residentMultiLaunched = X.multi != 0;
     c->packFused = X.send != nullptr;
@@ -1737,6 +1738,8 @@ void turn_end(AvbdContext* c)
     INT("group_spec_rounds", groupSpecRounds, 0, 64)                                                                                       \
     BOOL("group_dep", groupDep)                   /* arrival counters */                                                                   \
     BOOL("group_dep_keep", groupDepKeep)                                                                                                   \
+    BOOL("group_pool", groupPool)                 /* several bodies per sub-group: the sub-groups of a class-0 workgroup share their bodies */  \
+    INT("group_pool_min_rounds", groupPoolMinRounds, 2, 16)                                                                                \
     BOOL("shard_gate_kernel", shardGateKernel)                                                                                             \
     INT("groups", groupsMode, -1, 1)              /* 1: the group schedule for every scene it can run, 0: never, -1: by size */            \
     INT("groups_rounds", groupsMaxRounds, 1, 16)                                                                                           \

@@ -30,7 +30,7 @@ constexpr int kMaxExactRanks = 8;
 
 struct GroupPlan {
     int nClass[3];     /* swept bodies with <= 16 / <= 32 / <= 64 incidence entries */
-    int waves[3];      /* resident waves of each class; layout in the launch: class 2 (64 lanes) | class 1 | class 0 */
+    int waves[3];      /* resident waves of each class; layout in the launch: class 0 (16 lanes per body) | class 1 | class 2 */
     int rounds[3];     /* bodies per sub-group */
     int bad;           /* != 0: this step cannot run in the group schedule (the launch queued behind it runs instead) */
     int nd;            /* swept bodies */
@@ -87,7 +87,12 @@ constexpr int kGrpLdsBytes = kGrpWavesPerBlock * kGrpWaveFloats * 4;    /* 43 00
  * for the whole launch, hdr[round][lane]: examining a body costs no memory round trip for its header */
 constexpr int kGrpMaxRounds = 16;
 constexpr int kGrpHdrBytesPerWave = kGrpMaxRounds * 64 * 8;
-constexpr int kGrpLdsBytesMulti = kGrpLdsBytes + kGrpWavesPerBlock * kGrpHdrBytesPerWave;   /* 75 776 B */
+/* The pool of a workgroup (iterate_groups, pool loop) has four words per slot — body, first incidence entry, arrivals the next task waits for,
+ * and next iteration | claimed << 8 | entries << 16 | arrivals per iteration << 24 — in the tails of the four waves' header tables, which a plan
+ * of at most kGrpPoolMaxRounds bodies per sub-group leaves free: no LDS of its own. */
+constexpr int kGrpPoolMaxRounds = 12;
+constexpr int kGrpLdsBytesMulti = kGrpLdsBytes + kGrpWavesPerBlock * kGrpHdrBytesPerWave;   /* 79 360 B */
+static_assert((kGrpMaxRounds - kGrpPoolMaxRounds) * 64 * 8 >= 16 * kGrpPoolMaxRounds * 4, "a pool's slot array fits the tail of a header table");
 static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
 
 /* ---- plan: classes, waves per class, the bodies of each class in sweep order -----------------------------------------------
@@ -95,18 +100,31 @@ static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "t
  * waves of G = 4 >> c sub-groups) serves, in round k, rank r = (k * G + j) * Wc + wl — bodies that follow each other in the
  * sweep go to different waves.  One tile of 4096 slots of the sweep order per workgroup (tile_exclusive_prefix); the last
  * tile, which learns the totals from its look-back, writes the plan header. */
-__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round)
+/* Which body a sub-group serves.  Layout of the launch's waves: class 0 (16 lanes per body) | class 1 | class 2, so that the class-0 waves
+ * fill whole workgroups from wave 0 on.  Classes 1 and 2, and the class-0 waves behind the last FULL class-0 workgroup: sub-group j of the wl-th
+ * wave serves, in round k, rank r = (k * G + j) * Wc + wl of its class — bodies that follow each other in the sweep go to different waves
+ * (other static assignments were measured in round 3 and removed: neighbours of the sweep are ready together, and a wave runs its ready
+ * sub-groups one pass at a time).  `pools` > 0: the first `pools` class-0 workgroups each serve a contiguous run of 16 * rounds ranks as a POOL —
+ * any of a pool's 16 sub-groups runs any of its bodies (iterate_groups, pool loop) — and the waves behind them share the rest. */
+__device__ __forceinline__ int group_unit_rank(const GroupPlan* plan, int cls, int wl, int j, int round, int pools)
 {
-    /* (other assignments — the sub-groups of a wave serve neighbours of the sweep, a sub-group serves a run of the sweep — were measured in round 3
-     * and removed in round 4: neighbours of the sweep are ready together, and a wave runs its ready sub-groups one pass at a time) */
     const int Wc = plan->waves[cls], G = 4 >> cls;
-    const int r = (round * G + j) * Wc + wl;
+    if (cls == 0 && pools > 0) {
+        const int S = 16 * plan->rounds[0];
+        if (wl < 4 * pools) return (wl >> 2) * S + ((wl & 3) * 4 + j) * plan->rounds[0] + round;      /* slot (wave-in-workgroup, sub-group, round) of pool wl / 4 */
+        return pools * S + (round * G + j) * (Wc - 4 * pools) + (wl - 4 * pools);
+    }
+    return (round * G + j) * Wc + wl;
+}
+__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round, int pools = 0)
+{
+    const int r = group_unit_rank(plan, cls, wl, j, round, pools);
     return r < plan->nClass[cls] ? byClass[cls * cap + r] : -1;
 }
 
 __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __restrict__ order, const int* __restrict__ lvlStart, Counters* cnt,
                                                      const int* __restrict__ incStart, GroupPlan* plan, int* __restrict__ byClass, int cap, int W, int maxRounds,
-                                                     tile_v4u* agg, unsigned stamp, unsigned* __restrict__ depCnt)
+                                                     tile_v4u* agg, unsigned stamp, unsigned* __restrict__ depCnt, int* __restrict__ rankOf)
 {
     __shared__ unsigned long long sWaveTotals[16];
     __shared__ unsigned long long sBcast, sTileSum;
@@ -115,7 +133,6 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
     const int s0 = tile * kTileBodies + 4 * t;
     int cl[4], body[4]; unsigned long long mine4 = 0;                 /* class counts, 21 bits each */
     for (int k = 0; k < 4; ++k) { body[k] = s0 + k < nd ? order[s0 + k] : -1; cl[k] = -1; }
-    if (depCnt) for (int k = 0; k < 4; ++k) if (body[k] >= 0) depCnt[body[k]] = 0u;   /* arrival counters of the several-bodies loop (iterate_groups) */
     for (int k = 0; k < 4; ++k)
         if (body[k] >= 0) {
             const int ne = incStart[body[k] + 1] - incStart[body[k]];
@@ -135,6 +152,9 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
         const int r = (int)((off >> (21 * c)) & 0x1fffff);
         off += 1ull << (21 * c);
         byClass[c * cap + r] = body[k];
+        /* arrival counters of the several-bodies loops (iterate_groups) live at the body's class-major rank: the bodies of a pool are
+         * neighbours there, one poll of a pool's counters touches a few cache lines */
+        if (depCnt) { depCnt[c * cap + r] = 0u; rankOf[body[k]] = c * cap + r; }
     }
     if (t == 1023 && tile == (int)gridDim.x - 1) {
         const unsigned long long all = before + incl;
@@ -295,9 +315,11 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     const int w = blockIndex * kGrpWavesPerBlock + wv;
     const int W2 = plan->waves[2], W1 = plan->waves[1], W0 = plan->waves[0];
     if (w >= W2 + W1 + W0) return;
-    const int cls = w < W2 ? 2 : (w < W2 + W1 ? 1 : 0);              /* wave-uniform */
-    const int wl = w - (cls == 2 ? 0 : (cls == 1 ? W2 : W2 + W1));    /* which wave of its class */
+    const int cls = w < W0 ? 0 : (w < W0 + W1 ? 1 : 2);              /* wave-uniform; class 0 first: its waves fill whole workgroups (pools) */
+    const int wl = w - (cls == 0 ? 0 : (cls == 1 ? W0 : W0 + W1));    /* which wave of its class */
     const int rounds = __builtin_amdgcn_readfirstlane(plan->rounds[cls]);
+    /* class-0 workgroups that run as pools (several bodies per sub-group, one GPU, arrival counters); the same number for every wave of the launch */
+    const int pools = (MULTI && SHARDK == 0 && X.depCnt != nullptr && X.poolMode != 0 && plan->rounds[0] >= X.poolMinRounds && plan->rounds[0] <= kGrpPoolMaxRounds) ? (W0 >> 2) : 0;
     const int gw = 16 << cls, gl = lane & (gw - 1), gBase = lane & ~(gw - 1);
     const unsigned long long gMask = (cls == 2 ? ~0ull : ((1ull << gw) - 1ull)) << gBase;
     float* const J = reinterpret_cast<float*>(sGroups) + wv * kGrpWaveFloats;
@@ -314,6 +336,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     auto xstA = [](__amdgpu_buffer_rsrc_t r, int byteOff, v4u v) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, AUX); };
     auto xldwA = [](__amdgpu_buffer_rsrc_t r, int byteOff) __attribute__((always_inline)) -> unsigned { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byteOff, 0, AUX); };
     int peer = 0;                                                     /* EXACT: whose window this lane's partner publishes in */
+    int ctrO = 0;                                                     /* arrival counters: where this lane's partner counts (its class-major rank, k_group_plan's rankOf) */
     const __amdgpu_buffer_rsrc_t rP = EXACT ? xrsrc(Z.xPose, Z.xPoseBytes) : xrsrc(X.pose, X.poseBytes),
                                  rV = EXACT ? xrsrc(Z.xVisit, Z.xVisitBytes) : xrsrc(X.visit, X.visitBytes),
                                  rD = EXACT ? xrsrc(Z.xDual, Z.xDualBytes) : xrsrc(X.dual, X.dualBytes);
@@ -343,6 +366,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
      * examined before in this launch, its partners are in X.probe (partner | moving << 24 | owned << 25). */
     typedef typename std::conditional<EXACT, int4, int2>::type HdrT;   /* EXACT: + the record index (half as many rounds fit) */
     HdrT* const hdr = reinterpret_cast<HdrT*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes + wv * kGrpHdrBytesPerWave);   /* MULTI: [round][lane] */
+    const HdrT* hdrRow = nullptr;                                     /* pool loop: the header row of the slot in hand (any wave's table) */
     auto load_header = [&](int b, int e0, int ne, int round) __attribute__((always_inline)) {
         body = b; valid = b >= 0; eBeg = e0;
         has = valid && gl < ne;
@@ -350,7 +374,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         idx = 0; other = 0; isA = false; owned = false; moving = false;
         int rec = 0;
         if (MULTI) {
-            const HdrT h = hdr[round * 64 + lane];                     /* filled once, before the loop */
+            const HdrT h = hdrRow ? hdrRow[gl] : hdr[round * 64 + lane];   /* filled once, before the loop */
             if (has) { idx = inc_index(h.x); isA = inc_isA(h.x) != 0; other = h.y & 0xffffff; moving = (h.y >> 24) & 1; owned = (h.y >> 25) & 1; }
             if constexpr (EXACT) rec = has ? h.z : 0; else rec = idx;
         } else if (has) {
@@ -372,6 +396,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     auto load_rest = [&]() __attribute__((always_inline)) {
         AVBD_MARK(g_load_rest);
         fixedN = false;
+        if (SHARDK == 0 && MULTI && X.depCnt != nullptr) ctrO = (has && moving) ? X.rankOf[other] : 0;   /* (early: the signal behind the publish must not wait for it) */
         if (MULTI && it > 0) {
             /* a later task of a body that has been parked: ONE contiguous record per entry for what its tasks change (64 B: normal +
              * tangent memo, lambda, penalty, stick), one for what they do not (80 B: anchors, bias terms, friction, the partner's inverse
@@ -631,7 +656,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         /* arrivals at the earlier-created partners (their task `it` reads this pose and the visit record, both on their way): as early as possible,
          * the hop from a publish to the consumer's examination is what the launch is a chain of */
         if (SHARDK == 0 && MULTI && depSig && has && moving && !owned && (idx & 3) == 0)
-            __hip_atomic_fetch_add(X.depCnt + other, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(X.depCnt + ctrO, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
 #ifdef AVBD_DF_STATS
@@ -651,7 +676,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 xstA(rD, offD, r0); xstA(rD, offD + 16, r1);
                 /* ... and at the later-created partner, whose task it + 1 reads this dual */
                 if (SHARDK == 0 && MULTI && depSig && (idx & 3) == 0 && it + 1 < itStop)
-                    __hip_atomic_fetch_add(X.depCnt + other, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(X.depCnt + ctrO, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         /* ---- the body's last task: final state back to the tables (plain stores; the next kernel of the stream reads them) ---- */
@@ -896,6 +921,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
          * together. ---- */
         int bodyK = -1, eBegK = 0, nEntK = 0, itK = itStop, blkOff = -1;
         int blkPeer = 0;                                              /* EXACT: the window the watched pose record lives in */
+        int ctrK = 0;                                                 /* arrival counters: where lane k's body counts (its class-major rank) */
         /* ARRIVAL COUNTERS (one GPU): instead of watching ONE record of a body that was missing when it was last examined — and finding, after the
          * round trip that fetches records and parked state, that another one is missing too (two examinations out of five ended that way: 1.6 GB of
          * the 4.2 GB a 64 000-cube launch read, and a whole round trip of the wave's pass each) — lane k watches the number of partners that have
@@ -908,13 +934,14 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
          * examination that finds one missing is simply repeated in the next pass. */
         constexpr bool DEPC = SHARDK == 0;
         const bool dep = DEPC && X.depCnt != nullptr && (X.depKeep || !(X.specMode != 2 && rounds <= X.specRounds));   /* (depKeep 0: classes that take a task in hand keep the watched records) */
-        const __amdgpu_buffer_rsrc_t rC = xrsrc(dep ? (void*)X.depCnt : (void*)X.pose, dep ? (unsigned)B.cap * 4u : 16u);
+        const __amdgpu_buffer_rsrc_t rC = xrsrc(dep ? (void*)X.depCnt : (void*)X.pose, dep ? (unsigned)cap * 12u : 16u);   /* three classes of `cap` ranks */
         unsigned depPerIt = 0, depNeed = 0;                           /* lane k: arrivals per iteration, arrivals its body's next task waits for */
         int itEndK = itStop;                                          /* EXACT: + the task that takes the owner's last dual (see the header table) */
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
-            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl);
+            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl, pools);
+            ctrK = cls * cap + group_unit_rank(plan, cls, wl, gBase >> (4 + cls), gl, pools);
             if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
         }
         /* the header table: three dependent loads per entry (incidence word -> pair -> is the partner swept?), four rounds in flight */
@@ -988,7 +1015,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             if (!KEEP) prep = false;
             /* one round trip: what the task in hand still misses, and the watched words of the other bodies */
             if (prep) poll_issue();
-            if (dep) { if (activeK && depNeed != 0u) watchVal = xldw(rC, bodyK * 4); }
+            if (dep) { if (activeK && depNeed != 0u) watchVal = xldw(rC, ctrK * 4); }
             else {
             watch_pose(activeK && blkOff >= 0, blkOff, blkPeer, watchVal);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
@@ -1116,7 +1143,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             grpWaiting = (__ballot(activeK) & gMask) != 0;
             bool candK = activeK;
             if (dep) {
-                if (activeK && depNeed != 0u) { watchVal = xldw(rC, bodyK * 4); candK = watchVal >= depNeed; }
+                if (activeK && depNeed != 0u) { watchVal = xldw(rC, ctrK * 4); candK = watchVal >= depNeed; }
             } else {
             watch_pose(activeK && blkOff >= 0, blkOff, blkPeer, watchVal);
             if (SHARD && activeK && blkOff == -2) watchVal = xldw(rGW, 0);   /* waiting for an all-gather */
@@ -1226,6 +1253,125 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         return true;
         };
         depSig = DEPC && X.depCnt != nullptr;                        /* every task signals, whichever loop its class runs: the partners may be counting */
+        /* ---- POOL LOOP (round 4).  The launch is a chain of ~350 hops, and a third of a hop was a ready task waiting for ITS wave to come out
+         * of the pass it was in for other sub-groups.  In a full class-0 workgroup the 16 sub-groups therefore SHARE their 16 x rounds bodies:
+         * a slot table in LDS holds, per body, its next iteration and the arrivals that task waits for; every wave that starts a pass polls
+         * the arrival counters of ALL the pool's slots (they are neighbours in memory: a few cache lines), takes up to four ready slots —
+         * oldest iteration first, claimed with an LDS compare-and-swap — and its four sub-groups run them.  A task no longer waits for one
+         * particular wave but for the first of four, and a pass fills up: the pool offers its ready tasks to whoever comes.
+         * Nothing else changes: the records carry the dependencies, any order that respects them gives the same bits.
+         * A slot is given back (next iteration, not claimed) one pass later, behind the poll's wait: the loads of that poll return in issue
+         * order behind the stores that parked the body, so whoever claims the slot next finds the parked state in memory. */
+        const bool poolWave = DEPC && pools > 0 && cls == 0 && wl < 4 * pools;
+        auto pool_loop = [&]() __attribute__((always_inline)) -> bool {
+            auto tail = [&](int k) { return reinterpret_cast<int*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes + k * kGrpHdrBytesPerWave + kGrpPoolMaxRounds * 64 * 8); };
+            int* const sBody = tail(0); int* const sE0 = tail(1); int* const sNeed = tail(2); int* const sState = tail(3);
+            const HdrT* const hdr0 = reinterpret_cast<const HdrT*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes);
+            const int S = 16 * rounds, qBase = (wl >> 2) * S;          /* slots of this pool; class-major rank of slot 0 (class 0: ranks start at 0) */
+            /* slot (wave-in-workgroup, sub-group, round) <-> this lane's body: exactly the header table's layout */
+            if (gl < rounds) {
+                const int sl = (wv * 4 + (gBase >> 4)) * rounds + gl;
+                sBody[sl] = bodyK; sE0[sl] = eBegK; sNeed[sl] = (int)depNeed;
+                sState[sl] = (bodyK >= 0 ? 0 : itStop) | (nEntK << 16) | ((int)depPerIt << 24);
+            }
+            __syncthreads();                                           /* (all four waves of a pool workgroup are here: full class-0 workgroups only) */
+            constexpr int kInf = 0x7fffffff;
+            int relSlot = -1, relIt = 0, relNeed = 0;                 /* uniform over a sub-group: the slot it gives back behind the next poll */
+            for (;;) {
+                AVBD_MARK(g_examine);
+                /* ---- poll: every lane looks at up to four slots ---- */
+                int key[4]; unsigned cnt[4]; int st[4], nd[4];
+                bool anyActive = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sl = lane + 64 * i;
+                    st[i] = itStop; nd[i] = 0; cnt[i] = 0u;
+                    if (sl < S) { st[i] = sState[sl]; nd[i] = sNeed[sl]; }
+                    const bool act = (st[i] & 255) < itStop;
+                    anyActive |= act;
+                    if (act && !(st[i] & 256) && nd[i] != 0) cnt[i] = xldw(rC, (qBase + sl) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool act = (st[i] & 255) < itStop && !(st[i] & 256);
+                    key[i] = (act && (nd[i] == 0 || cnt[i] >= (unsigned)nd[i])) ? (((st[i] & 255) << 8) | (lane + 64 * i)) : kInf;
+                }
+                if (__ballot(anyActive) == 0) break;
+                grpWaiting = true;
+                dbgBody = lane < S ? sBody[lane] : -1; dbgIt = (st[0] & 255) | (itStop << 8); dbgOff = -4; dbgStamp = nd[0]; dbgSeen = (int)cnt[0];
+                GS_STAMP(12);
+                /* ---- the slots of the last pass go back to the pool (its stores are in memory: the poll's loads returned behind them) ---- */
+                if (__ballot(relSlot >= 0) != 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* (what the poll's wait amounts to: memory operations complete in issue order) */
+                    if (relSlot >= 0 && gl == 0) { sNeed[relSlot] = relNeed; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); sState[relSlot] = relIt; }
+                }
+                relSlot = -1;
+                /* ---- take up to four ready slots, oldest iteration first ---- */
+                int mine = kInf;                                      /* the key this lane's sub-group runs */
+                int taken = 0;
+                for (int tries = 0; tries < 8 && taken < 4; ++tries) {
+                    int best = key[0] < key[1] ? key[0] : key[1]; { const int b2 = key[2] < key[3] ? key[2] : key[3]; best = b2 < best ? b2 : best; }
+                    int m = best;
+                    for (int o = 1; o < 64; o <<= 1) { const int x2 = __shfl_xor(m, o, 64); m = x2 < m ? x2 : m; }
+                    m = __builtin_amdgcn_readfirstlane(m);
+                    if (m == kInf) break;
+                    bool got = false;
+                    if (best == m) {                                   /* exactly one lane holds a given slot */
+                        const int sl = m & 255;
+                        int was = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (key[i] == m) { was = st[i]; key[i] = kInf; }
+                        got = atomicCAS(&sState[sl], was, was | 256) == was;
+                    }
+                    if (__ballot(got) != 0) { if ((gBase >> 4) == taken) mine = m; ++taken; }
+                }
+                bool sel = mine != kInf;
+                int slot = 0;
+                if (sel) {
+                    slot = mine & 255; it = mine >> 8;
+                    hdrRow = hdr0 + (slot / (4 * rounds)) * (kGrpHdrBytesPerWave / (int)sizeof(HdrT)) + (slot % rounds) * 64 + ((slot / rounds) & 3) * 16;
+                    load_header(sBody[slot], sE0[slot], (sState[slot] >> 16) & 255, 0);
+                    set_needs();
+                    poll_issue();
+                    load_rest();
+                    poll_check();
+                    AVBD_MARK(g_examine2);
+                    if ((__ballot(okP & okV & okD) & gMask) != gMask) {  /* counted, but a record's store is still on its way: back into the pool as it was */
+                        if (gl == 0) sState[slot] = sState[slot] & ~256;
+                        sel = false;
+                    }
+                }
+                GS_STAMP(0);
+#ifdef AVBD_DF_STATS
+                stat[14] += 1;
+                if (__ballot(sel)) { stat[5] += 1; stat[4] += (unsigned long long)__popcll(__ballot(sel && gl == 0)); }
+                unsigned* trecM = reinterpret_cast<unsigned*>(X.privN) + ((size_t)(it < itStop ? it : 0) * B.n + (size_t)(body < 0 ? 0 : body)) * 4;
+                if (sel && gl == 0 && X.privN) trecM[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+                if (sel) prepare_task();
+                GS_STAMP(2);
+                if (sel) {
+                    finish_visit();
+                    finish_accumulate();
+                    finish_solve();
+                    GS_STAMP_ND(13);
+                    GS_STAMP(3);
+                    if (it < itStop - 1) park_body();
+                    GS_STAMP_ND(15);
+                    spins = 0;
+                    { const int wd = sState[slot]; relSlot = slot; relIt = (wd & ~511) | (it + 1); relNeed = sNeed[slot] + ((wd >> 24) & 255); }
+#ifdef AVBD_DF_STATS
+                    if (gl == 0 && X.privN) { trecM[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); trecM[3] = (unsigned)w; }
+#endif
+                }
+                AVBD_MARK(g_pass_end);
+                GS_STAMP(1);
+                if (__ballot(sel) == 0 && !back_off()) return false;
+            }
+            return true;
+        };
+        if (poolWave) { if (!pool_loop()) return; }
+        else
         if (keepMode) { if (!multi_loop(std::true_type{})) return; }
         else if (!multi_loop_plain()) return;
     }

@@ -75,8 +75,11 @@ struct ResidentExchange {
     int specRounds;    /* ... only in classes with at most this many bodies per sub-group */
     int specMode;      /* group schedule, several bodies per sub-group: when a sub-group with nothing ready takes its oldest task in hand (0: when its wave has nothing else to do in the pass, 1: always, 2: never) */
     float4 *parkC, *parkS, *parkB;   /* group schedule, several bodies per sub-group: packed records of a parked body (k_iterate_groups::load_rest) */
+    const int* rankOf; /* [bodyCap] class-major rank of a swept body in this step's plan (k_group_plan): where its arrivals are counted */
+    int poolMode;      /* several bodies per sub-group with arrival counters: the 16 sub-groups of a class-0 workgroup share their bodies (0: every sub-group keeps its own) */
+    int poolMinRounds; /* ... from this many bodies per sub-group on */
     int depKeep;       /* arrival counters also in classes that take a task in hand (which they then pick by the fewest missing arrivals) */
-    unsigned* depCnt;  /* [bodyCap] group schedule, several bodies per sub-group on one GPU: arrivals at a body — every task that ends adds one to each moving
+    unsigned* depCnt;  /* [3 * bodyCap] group schedule, several bodies per sub-group on one GPU: arrivals at a body — every task that ends adds one to each moving
                         * partner whose NEXT task reads what it has just published (k_group_plan zeroes the words of the swept bodies every step); nullptr: off */
     const int* place;  /* one body per wave: body of wave w (-1: none) instead of the sweep order's slot — chains of bodies that hand their pose to each
                         * other share a workgroup and pass it through LDS (k_place_chains); nullptr: slots of the sweep order */
