@@ -247,7 +247,7 @@ struct AvbdContext {
     int groupDepKeep = 1;          /* AVBD_GROUP_DEP_KEEP=0: classes that take a task in hand keep the watched records of round 3 (ResidentExchange::depKeep) */
     int groupDep = 1;              /* several bodies per sub-group on one GPU: arrival counters instead of watched records (AVBD_GROUP_DEP=0: the watched records of round 3) */
     DevArr<unsigned> xDepCnt; DevArr<int> xRankOf;
-    int groupPool = 1, groupPoolMinRounds = 5;   /* ResidentExchange::poolMode / poolMinRounds (classes with fewer bodies per sub-group take a task in hand instead) */
+    int groupPool = 1, groupPoolMinRounds = 3;   /* ResidentExchange::poolMode / poolMinRounds (classes with fewer bodies per sub-group take a task in hand instead) */
     int groupSpecMode = 0, groupSpecRounds = 4;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
     bool turnReleased = false;          /* avbd_destroy has taken this context out of its device's count (turn_begin / turn_end) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */

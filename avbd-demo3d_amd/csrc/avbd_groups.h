@@ -104,21 +104,20 @@ static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "t
  * fill whole workgroups from wave 0 on.  Classes 1 and 2, and the class-0 waves behind the last FULL class-0 workgroup: sub-group j of the wl-th
  * wave serves, in round k, rank r = (k * G + j) * Wc + wl of its class — bodies that follow each other in the sweep go to different waves
  * (other static assignments were measured in round 3 and removed: neighbours of the sweep are ready together, and a wave runs its ready
- * sub-groups one pass at a time).  `pools` > 0: the first `pools` class-0 workgroups each serve a contiguous run of 16 * rounds ranks as a POOL —
- * any of a pool's 16 sub-groups runs any of its bodies (iterate_groups, pool loop) — and the waves behind them share the rest. */
-__device__ __forceinline__ int group_unit_rank(const GroupPlan* plan, int cls, int wl, int j, int round, int pools)
+ * sub-groups one pass at a time).  `pooled`: the class runs as POOLS — every workgroup (a plan with several bodies per sub-group gives each class
+ * whole workgroups) serves a contiguous run of its class's ranks, and any of its sub-groups runs any of those bodies (iterate_groups, pool loop). */
+__device__ __forceinline__ int group_unit_rank(const GroupPlan* plan, int cls, int wl, int j, int round, bool pooled)
 {
     const int Wc = plan->waves[cls], G = 4 >> cls;
-    if (cls == 0 && pools > 0) {
-        const int S = 16 * plan->rounds[0];
-        if (wl < 4 * pools) return (wl >> 2) * S + ((wl & 3) * 4 + j) * plan->rounds[0] + round;      /* slot (wave-in-workgroup, sub-group, round) of pool wl / 4 */
-        return pools * S + (round * G + j) * (Wc - 4 * pools) + (wl - 4 * pools);
+    if (pooled) {                                                      /* slot (wave-in-workgroup, sub-group, round) of pool wl / 4: a contiguous run of the class's ranks */
+        const int R = plan->rounds[cls];
+        return (wl >> 2) * (4 * G * R) + ((wl & 3) * G + j) * R + round;
     }
     return (round * G + j) * Wc + wl;
 }
-__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round, int pools = 0)
+__device__ __forceinline__ int group_unit_body(const GroupPlan* plan, const int* __restrict__ byClass, int cap, int cls, int wl, int j, int round, bool pooled = false)
 {
-    const int r = group_unit_rank(plan, cls, wl, j, round, pools);
+    const int r = group_unit_rank(plan, cls, wl, j, round, pooled);
     return r < plan->nClass[cls] ? byClass[cls * cap + r] : -1;
 }
 
@@ -174,6 +173,8 @@ __global__ __launch_bounds__(1024) void k_group_plan(BodyTable B, const int* __r
              * one wave their share of the lanes gives them would be ten rounds): at least the waves that keep it within maxRounds */
             wv[2] = max(wv[2], (n[2] + maxRounds - 1) / maxRounds);
             wv[1] = max(wv[1], (n[1] + 2 * maxRounds - 1) / (2 * maxRounds));
+            /* whole workgroups per class: a workgroup whose four waves serve one class can share its bodies between them (pool loop) */
+            if ((W & 3) == 0 && W - ((wv[2] + 3) & ~3) - ((wv[1] + 3) & ~3) >= (n[0] ? 4 : 0)) { wv[2] = (wv[2] + 3) & ~3; wv[1] = (wv[1] + 3) & ~3; }
             wv[0] = W - wv[2] - wv[1];
             if (wv[0] < (n[0] ? 1 : 0)) bad = 1;
             for (int c = 0; c < 3; ++c) if (n[c]) { const int per = wv[c] * (4 >> c); rounds[c] = (n[c] + per - 1) / per; }
@@ -318,8 +319,9 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     const int cls = w < W0 ? 0 : (w < W0 + W1 ? 1 : 2);              /* wave-uniform; class 0 first: its waves fill whole workgroups (pools) */
     const int wl = w - (cls == 0 ? 0 : (cls == 1 ? W0 : W0 + W1));    /* which wave of its class */
     const int rounds = __builtin_amdgcn_readfirstlane(plan->rounds[cls]);
-    /* class-0 workgroups that run as pools (several bodies per sub-group, one GPU, arrival counters); the same number for every wave of the launch */
-    const int pools = (MULTI && SHARDK == 0 && X.depCnt != nullptr && X.poolMode != 0 && plan->rounds[0] >= X.poolMinRounds && plan->rounds[0] <= kGrpPoolMaxRounds) ? (W0 >> 2) : 0;
+    /* does this wave's class run as pools (several bodies per sub-group, one GPU, arrival counters, whole workgroups per class)? */
+    const bool pooled = MULTI && SHARDK == 0 && X.depCnt != nullptr && X.poolMode != 0 && rounds >= X.poolMinRounds && rounds <= kGrpPoolMaxRounds &&
+                        (W0 & 3) == 0 && (W1 & 3) == 0 && (W2 & 3) == 0;
     const int gw = 16 << cls, gl = lane & (gw - 1), gBase = lane & ~(gw - 1);
     const unsigned long long gMask = (cls == 2 ? ~0ull : ((1ull << gw) - 1ull)) << gBase;
     float* const J = reinterpret_cast<float*>(sGroups) + wv * kGrpWaveFloats;
@@ -933,15 +935,15 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
          * almost always right, not a proof: the adds are not ordered behind the record stores, so the stamps of the records still decide, and an
          * examination that finds one missing is simply repeated in the next pass. */
         constexpr bool DEPC = SHARDK == 0;
-        const bool dep = DEPC && X.depCnt != nullptr && (X.depKeep || !(X.specMode != 2 && rounds <= X.specRounds));   /* (depKeep 0: classes that take a task in hand keep the watched records) */
+        const bool dep = DEPC && X.depCnt != nullptr && (pooled || X.depKeep || !(X.specMode != 2 && rounds <= X.specRounds));   /* (depKeep 0: classes that take a task in hand keep the watched records) */
         const __amdgpu_buffer_rsrc_t rC = xrsrc(dep ? (void*)X.depCnt : (void*)X.pose, dep ? (unsigned)cap * 12u : 16u);   /* three classes of `cap` ranks */
         unsigned depPerIt = 0, depNeed = 0;                           /* lane k: arrivals per iteration, arrivals its body's next task waits for */
         int itEndK = itStop;                                          /* EXACT: + the task that takes the owner's last dual (see the header table) */
         int reportedM = 0;                                            /* SHARD: iterations this wave has counted in Z.done */
         unsigned blkStamp = 0;
         if (gl < rounds) {
-            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl, pools);
-            ctrK = cls * cap + group_unit_rank(plan, cls, wl, gBase >> (4 + cls), gl, pools);
+            bodyK = group_unit_body(plan, byClass, cap, cls, wl, gBase >> (4 + cls), gl, pooled);
+            ctrK = cls * cap + group_unit_rank(plan, cls, wl, gBase >> (4 + cls), gl, pooled);
             if (bodyK >= 0) { eBegK = incStart[bodyK]; nEntK = incStart[bodyK + 1] - eBegK; itK = 0; }
         }
         /* the header table: three dependent loads per entry (incidence word -> pair -> is the partner swept?), four rounds in flight */
@@ -1254,7 +1256,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         };
         depSig = DEPC && X.depCnt != nullptr;                        /* every task signals, whichever loop its class runs: the partners may be counting */
         /* ---- POOL LOOP (round 4).  The launch is a chain of ~350 hops, and a third of a hop was a ready task waiting for ITS wave to come out
-         * of the pass it was in for other sub-groups.  In a full class-0 workgroup the 16 sub-groups therefore SHARE their 16 x rounds bodies:
+         * of the pass it was in for other sub-groups.  The sub-groups of a workgroup (16, 8 or 4 by class) therefore SHARE their bodies:
          * a slot table in LDS holds, per body, its next iteration and the arrivals that task waits for; every wave that starts a pass polls
          * the arrival counters of ALL the pool's slots (they are neighbours in memory: a few cache lines), takes up to four ready slots —
          * oldest iteration first, claimed with an LDS compare-and-swap — and its four sub-groups run them.  A task no longer waits for one
@@ -1262,19 +1264,20 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
          * Nothing else changes: the records carry the dependencies, any order that respects them gives the same bits.
          * A slot is given back (next iteration, not claimed) one pass later, behind the poll's wait: the loads of that poll return in issue
          * order behind the stores that parked the body, so whoever claims the slot next finds the parked state in memory. */
-        const bool poolWave = DEPC && pools > 0 && cls == 0 && wl < 4 * pools;
+        const bool poolWave = DEPC && pooled;
         auto pool_loop = [&]() __attribute__((always_inline)) -> bool {
             auto tail = [&](int k) { return reinterpret_cast<int*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes + k * kGrpHdrBytesPerWave + kGrpPoolMaxRounds * 64 * 8); };
             int* const sBody = tail(0); int* const sE0 = tail(1); int* const sNeed = tail(2); int* const sState = tail(3);
             const HdrT* const hdr0 = reinterpret_cast<const HdrT*>(reinterpret_cast<char*>(sGroups) + kGrpLdsBytes);
-            const int S = 16 * rounds, qBase = (wl >> 2) * S;          /* slots of this pool; class-major rank of slot 0 (class 0: ranks start at 0) */
+            const int G = 4 >> cls, sg = gBase >> (4 + cls);            /* sub-groups per wave, this lane's */
+            const int S = 4 * G * rounds, qBase = cls * cap + (wl >> 2) * S;   /* slots of this pool; where slot 0 counts its arrivals (its class-major rank) */
             /* slot (wave-in-workgroup, sub-group, round) <-> this lane's body: exactly the header table's layout */
             if (gl < rounds) {
-                const int sl = (wv * 4 + (gBase >> 4)) * rounds + gl;
+                const int sl = (wv * G + sg) * rounds + gl;
                 sBody[sl] = bodyK; sE0[sl] = eBegK; sNeed[sl] = (int)depNeed;
                 sState[sl] = (bodyK >= 0 ? 0 : itStop) | (nEntK << 16) | ((int)depPerIt << 24);
             }
-            __syncthreads();                                           /* (all four waves of a pool workgroup are here: full class-0 workgroups only) */
+            __syncthreads();                                           /* (all four waves of a pool workgroup are here: they serve one class) */
             constexpr int kInf = 0x7fffffff;
             int relSlot = -1, relIt = 0, relNeed = 0;                 /* uniform over a sub-group: the slot it gives back behind the next poll */
             for (;;) {
@@ -1309,7 +1312,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 /* ---- take up to four ready slots, oldest iteration first ---- */
                 int mine = kInf;                                      /* the key this lane's sub-group runs */
                 int taken = 0;
-                for (int tries = 0; tries < 8 && taken < 4; ++tries) {
+                for (int tries = 0; tries < 8 && taken < G; ++tries) {
                     int best = key[0] < key[1] ? key[0] : key[1]; { const int b2 = key[2] < key[3] ? key[2] : key[3]; best = b2 < best ? b2 : best; }
                     int m = best;
                     for (int o = 1; o < 64; o <<= 1) { const int x2 = __shfl_xor(m, o, 64); m = x2 < m ? x2 : m; }
@@ -1323,13 +1326,13 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                         for (int i = 0; i < 4; ++i) if (key[i] == m) { was = st[i]; key[i] = kInf; }
                         got = atomicCAS(&sState[sl], was, was | 256) == was;
                     }
-                    if (__ballot(got) != 0) { if ((gBase >> 4) == taken) mine = m; ++taken; }
+                    if (__ballot(got) != 0) { if (sg == taken) mine = m; ++taken; }
                 }
                 bool sel = mine != kInf;
                 int slot = 0;
                 if (sel) {
                     slot = mine & 255; it = mine >> 8;
-                    hdrRow = hdr0 + (slot / (4 * rounds)) * (kGrpHdrBytesPerWave / (int)sizeof(HdrT)) + (slot % rounds) * 64 + ((slot / rounds) & 3) * 16;
+                    hdrRow = hdr0 + (slot / (G * rounds)) * (kGrpHdrBytesPerWave / (int)sizeof(HdrT)) + (slot % rounds) * 64 + ((slot / rounds) % G) * gw;
                     load_header(sBody[slot], sE0[slot], (sState[slot] >> 16) & 255, 0);
                     set_needs();
                     poll_issue();
