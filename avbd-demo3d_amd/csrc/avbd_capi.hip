@@ -1730,6 +1730,7 @@ void turn_end(AvbdContext* c)
     INT("shard_persistent", shardPersistent, -1, 1) /* all-gather form: 1 one persistent launch per step also across devices, 0 one launch per iteration */ \
     INT("iter_blocks", iterBlocks, 1, 1 << 20)    /* workgroups of the iteration launch (clamped to what is resident on the device) */    \
     INT("iter_mode", iterForceMode, 0, 2)                                                                                                  \
+    INT("iter_sleep", iterSleep, 0, 3)            /* back-off of a wave that found nothing to run: s_sleep 1 / 2 / 4 / 8 */                 \
     BOOL("resident", residentAllowed)             /* the schedules with one launch for the whole loop */                                   \
     BOOL("race_check", raceCheck)                 /* debug race checker before every loop */                                               \
     BOOL("single_kernel", singleKernel)           /* k_iterate_single for scenes with a wave per body */                                   \

@@ -92,7 +92,7 @@ constexpr int kGrpHdrBytesPerWave = kGrpMaxRounds * 64 * 8;
  * of at most kGrpPoolMaxRounds bodies per sub-group leaves free: no LDS of its own. */
 constexpr int kGrpPoolMaxRounds = 12;
 constexpr int kGrpLdsBytesMulti = kGrpLdsBytes + kGrpWavesPerBlock * kGrpHdrBytesPerWave;   /* 79 360 B */
-static_assert((kGrpMaxRounds - kGrpPoolMaxRounds) * 64 * 8 >= 16 * kGrpPoolMaxRounds * 4, "a pool's slot array fits the tail of a header table");
+static_assert((kGrpMaxRounds - kGrpPoolMaxRounds) * 64 * 8 >= 16 * kGrpPoolMaxRounds * 4 && 16 * kGrpPoolMaxRounds <= 3 * 64, "a pool's slot array fits the tail of a header table; three slots per lane");
 static_assert(kGrpWaveFloats % 4 == 0 && 2 * kGrpLdsBytesMulti <= 160 * 1024, "two workgroups of k_iterate_groups share a CU's LDS");
 
 /* ---- plan: classes, waves per class, the bodies of each class in sweep order -----------------------------------------------
@@ -1282,11 +1282,11 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             int relSlot = -1, relIt = 0, relNeed = 0;                 /* uniform over a sub-group: the slot it gives back behind the next poll */
             for (;;) {
                 AVBD_MARK(g_examine);
-                /* ---- poll: every lane looks at up to four slots ---- */
-                int key[4]; unsigned cnt[4]; int st[4], nd[4];
+                /* ---- poll: every lane looks at up to three slots ---- */
+                int key[3]; unsigned cnt[3]; int st[3], nd[3];              /* 16 * kGrpPoolMaxRounds = 192 slots at most */
                 bool anyActive = false;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 3; ++i) {
                     const int sl = lane + 64 * i;
                     st[i] = itStop; nd[i] = 0; cnt[i] = 0u;
                     if (sl < S) { st[i] = sState[sl]; nd[i] = sNeed[sl]; }
@@ -1295,7 +1295,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     if (act && !(st[i] & 256) && nd[i] != 0) cnt[i] = xldw(rC, (qBase + sl) * 4);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 3; ++i) {
                     const bool act = (st[i] & 255) < itStop && !(st[i] & 256);
                     key[i] = (act && (nd[i] == 0 || cnt[i] >= (unsigned)nd[i])) ? (((st[i] & 255) << 8) | (lane + 64 * i)) : kInf;
                 }
@@ -1313,7 +1313,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 int mine = kInf;                                      /* the key this lane's sub-group runs */
                 int taken = 0;
                 for (int tries = 0; tries < 8 && taken < G; ++tries) {
-                    int best = key[0] < key[1] ? key[0] : key[1]; { const int b2 = key[2] < key[3] ? key[2] : key[3]; best = b2 < best ? b2 : best; }
+                    int best = key[0] < key[1] ? key[0] : key[1]; best = key[2] < best ? key[2] : best;
                     int m = best;
                     for (int o = 1; o < 64; o <<= 1) { const int x2 = __shfl_xor(m, o, 64); m = x2 < m ? x2 : m; }
                     m = __builtin_amdgcn_readfirstlane(m);
@@ -1323,7 +1323,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                         const int sl = m & 255;
                         int was = 0;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (key[i] == m) { was = st[i]; key[i] = kInf; }
+                        for (int i = 0; i < 3; ++i) if (key[i] == m) { was = st[i]; key[i] = kInf; }
                         got = atomicCAS(&sState[sl], was, was | 256) == was;
                     }
                     if (__ballot(got) != 0) { if (sg == taken) mine = m; ++taken; }
