@@ -90,7 +90,7 @@ def dependency_chain_hops(forces, bodies, total_iterations):
     return longest
 
 
-PMC_SUMMARIES = {"Stress1000": "r3_stress1000_cli_summary.json", "StressN:20": "r3_8k_cli_summary.json", "StressN:40": "r3_64k_cli_summary.json"}
+PMC_SUMMARIES = {"Stress1000": "r4_stress1000_cli_summary.json", "StressN:20": "r4_8k_cli_summary.json", "StressN:40": "r4_64k_cli_summary.json"}
 
 
 def pmc_traffic(scene, fused):
