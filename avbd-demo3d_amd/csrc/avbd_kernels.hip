@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
     }
     __syncthreads();
     int offset = 0;
+    unsigned long long hitMask = 0ull;
     for (int pass = 0; pass < 2; ++pass) {
         int mine = 0;
         if (live && k == 13) {                                        /* pairs with a big body: once per unordered pair */
@@ -213,8 +214,15 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
                 }
             }
         }
-        for (int j = head; j >= 0; j = cellNext[j]) {
-            if (j < i && broadphase_pair_passes(B, i, j, adjStart, adjOther, keepUnsolvedPairs)) {
+        /* (the tests — two position loads, the adjacency search of isConstrainedTo — are made ONCE: the counting pass remembers which of the
+         * bucket's first 64 bodies passed, the writing pass only walks the list again) */
+        int posInList = 0;
+        for (int j = head; j >= 0; j = cellNext[j], ++posInList) {
+            bool hit;
+            if (pass && posInList < 64) hit = (hitMask >> posInList) & 1ull;
+            else hit = j < i && broadphase_pair_passes(B, i, j, adjStart, adjOther, keepUnsolvedPairs);
+            if (!pass && hit && posInList < 64) hitMask |= 1ull << posInList;
+            if (hit) {
                 if (pass) { const int slot = offset + mine; if (slot < candCap) cand[slot] = make_int2(i, j); }
                 ++mine;
             }
