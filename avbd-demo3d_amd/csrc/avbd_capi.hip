@@ -2266,7 +2266,9 @@ static int validate_forces(AvbdContext* c, const AvbdForce* in, int n, int nBodi
     return AVBD_OK;
 }
 
-static int restore_state(AvbdContext* c, const AvbdParams& params, int stepIndex, const AvbdBody* bodies, int nBodies, const AvbdForce* forces, int nForces)
+static int upload_forces_keyed(AvbdContext* c, const AvbdForce* in, int n, const uint64_t* keys);
+static int restore_state(AvbdContext* c, const AvbdParams& params, int stepIndex, const AvbdBody* bodies, int nBodies, const AvbdForce* forces, int nForces,
+                         const uint64_t* keys = nullptr)
 {
     int rc;
     /* validate BEFORE touching the context: a failed restore leaves the old scene in place */
@@ -2298,7 +2300,7 @@ static int restore_state(AvbdContext* c, const AvbdParams& params, int stepIndex
         c->hJ.insert(c->hJ.end(), J9, J9 + 9);
     }
     c->bodiesStale = true; c->adjDirty = true;
-    if ((rc = avbd_upload_forces(c, forces, nForces))) return rc;
+    if ((rc = upload_forces_keyed(c, forces, nForces, keys))) return rc;
     c->stepIndex = stepIndex;
     return AVBD_OK;
 }
@@ -2650,7 +2652,97 @@ int avbd_download_force(AvbdContext* c, int list_index, AvbdForce* out)
     return AVBD_OK;
 }
 
-int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
+/* Re-balanced ownership ("spatial slabs re-balanced every K steps") for the contexts of ONE process.  Ownership decides which
+ * manifolds a rank holds — those that touch a body it sweeps — so changing it after the first step means moving manifolds (contacts, lambda,
+ * penalty, their place in the force lists) between ranks: every rank's forces are downloaded with their creation keys, merged into the one list
+ * the single-GPU run would hold (a manifold that lives on two ranks is taken from the rank that swept its owner, the earlier-created dynamic
+ * endpoint, which ran its last dual), and every rank is rebuilt from the bodies (identical on all ranks after a step) and the part of that list
+ * that touches a body it sweeps under the NEW ownership.  With exact cuts the step after a re-balance continues the single-GPU sweep bit for bit
+ * (tests/test_gpu_exact_cuts.py::test_rebalanced_ownership_...), i.e. it equals a run that was started with the new ownership.  Host-side and
+ * synchronous: meant for every few hundred steps.  (Ranks that are processes would exchange their lists the same way through the caller's
+ * transport; not built.) */
+int avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodies)
+{
+    if (!ctxs || n < 1 || !owner) return AVBD_E_INVALID;
+    for (int r = 0; r < n; ++r) if (!ctxs[r]) return AVBD_E_INVALID;
+    AvbdContext* L = ctxs[0];
+    int rc;
+    for (int r = 0; r < n; ++r) {
+        AvbdContext* c = ctxs[r];
+        if (c->nranks != n || c->rank != r) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: the contexts are not the ranks 0..n-1 of one sharded scene");
+        if ((int)c->hBodies.size() != nbodies) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: owner[] must have one entry per body");
+        if (!c->hostForceG.empty()) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: scenes with user-defined Force subclasses cannot be sharded");
+        if (c->xwAttached) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: ranks that are processes are not supported");
+    }
+    for (int i = 0; i < nbodies; ++i) if (owner[i] >= n) return L->fail(AVBD_E_INVALID, "avbd_group_rebalance: owner index out of range");
+    /* 1. every rank's forces, newest first, with their keys */
+    struct Item { uint64_t key; AvbdForce f; int rank; };
+    std::vector<Item> all;
+    for (int r = 0; r < n; ++r) {
+        AvbdContext* c = ctxs[r];
+        (void)hipSetDevice(c->device);
+        HostManifolds hm; std::vector<ForceRef> refs;
+        if ((rc = sorted_force_refs(c, hm, refs))) return rc;
+        std::vector<AvbdForce> fs(std::max<size_t>(refs.size(), 1));
+        const int got = avbd_download_forces(c, fs.data(), (int)refs.size());
+        if (got < 0) return got;
+        if (got != (int)refs.size()) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: the force list changed under the download");
+        for (int i = 0; i < got; ++i) all.push_back({refs[(size_t)i].key, fs[(size_t)i], r});
+    }
+    /* 2. one copy per force: the one of the rank that swept its owner (old ownership) */
+    const std::vector<int> oldOwner = L->hOwner;
+    auto prefer = [&](const AvbdForce& f) -> int {
+        const int a = f.bodyA, b = f.bodyB;
+        const bool da = a >= 0 && a < nbodies && oldOwner[(size_t)a] >= 0, db = b >= 0 && b < nbodies && oldOwner[(size_t)b] >= 0;
+        const int own = (da && db) ? std::min(a, b) : (da ? a : (db ? b : -1));
+        return own >= 0 ? oldOwner[(size_t)own] : 0;
+    };
+    std::stable_sort(all.begin(), all.end(), [](const Item& x, const Item& y) { return x.key > y.key; });
+    std::vector<AvbdForce> merged;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i, pick = i;
+        const int want = prefer(all[i].f);
+        for (; j < all.size() && all[j].key == all[i].key; ++j) {
+            if (all[j].f.bodyA != all[i].f.bodyA || all[j].f.bodyB != all[i].f.bodyB || all[j].f.kind != all[i].f.kind)
+                return L->fail(AVBD_E_INVALID, "avbd_group_rebalance: two different forces carry one creation key (were the ranks built from the same scene?)");
+            if (all[j].rank == want) pick = j;
+        }
+        merged.push_back(all[pick].f);
+        i = j;
+    }
+    /* the merged list's own keys: position in the ONE list, the same on every rank that gets the force (manifolds created later have step >= 1
+     * in their key and stay newer) */
+    std::vector<uint64_t> mkeys(merged.size());
+    for (size_t i = 0; i < merged.size(); ++i) mkeys[i] = make_host_key(0, (uint64_t)(merged.size() - i));
+    /* 3. the bodies (every rank holds the same state after a step) and every rank rebuilt under the new ownership */
+    std::vector<AvbdBody> bodies((size_t)std::max(nbodies, 1));
+    (void)hipSetDevice(L->device);
+    if (nbodies && (rc = avbd_download_bodies(L, bodies.data(), nbodies)) < 0) return rc;
+    const AvbdParams params = L->params;
+    const int stepIndex = L->stepIndex;
+    for (int r = 0; r < n; ++r) {
+        AvbdContext* c = ctxs[r];
+        (void)hipSetDevice(c->device);
+        std::vector<AvbdForce> mine; std::vector<uint64_t> mineKeys;
+        for (size_t i = 0; i < merged.size(); ++i) {
+            const AvbdForce& f = merged[i];
+            const bool ta = f.bodyA >= 0 && f.bodyA < nbodies && owner[f.bodyA] == r, tb = f.bodyB >= 0 && f.bodyB < nbodies && owner[f.bodyB] == r;
+            if (f.kind != AVBD_FORCE_MANIFOLD || ta || tb) { mine.push_back(f); mineKeys.push_back(mkeys[i]); }
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->hOwner.assign(owner, owner + nbodies);                     /* (before the rebuild: the upload marks the bodies this rank sweeps) */
+        if ((rc = restore_state(c, params, stepIndex, bodies.data(), nbodies, mine.data(), (int)mine.size(), mineKeys.data()))) return rc;
+        c->hOwner.assign(owner, owner + nbodies);
+        c->bodiesStale = true; c->adjDirty = true;
+    }
+    return AVBD_OK;
+}
+
+static int upload_forces_keyed(AvbdContext* c, const AvbdForce* in, int n, const uint64_t* keys);
+int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n) { return upload_forces_keyed(c, in, n, nullptr); }
+/* `keys` (optional, descending): the creation keys the forces keep — a re-balance gives every rank a part of ONE list, and the same force must
+ * carry the same key on every rank that holds it (the next re-balance merges the ranks' lists by key) */
+static int upload_forces_keyed(AvbdContext* c, const AvbdForce* in, int n, const uint64_t* keys)
 {
     if (!c || (!in && n > 0) || n < 0) return AVBD_E_INVALID;
     (void)hipSetDevice(c->device);
@@ -2672,7 +2764,7 @@ int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
     int m = 0;
     for (int i = 0; i < n; ++i) {
         const AvbdForce& f = in[i];
-        const uint64_t key = make_host_key(0, (uint64_t)(n - i)); /* newest first → descending keys */
+        const uint64_t key = keys ? keys[i] : make_host_key(0, (uint64_t)(n - i)); /* newest first → descending keys */
         if (f.kind == AVBD_FORCE_MANIFOLD) {
             h.pair[m] = make_int2(f.bodyA, f.bodyB); h.key[m] = key; h.nc[m] = f.numContacts; h.fric[m] = f.combinedFriction;
             for (int ci = 0; ci < f.numContacts; ++ci) {
@@ -2708,6 +2800,7 @@ int avbd_upload_forces(AvbdContext* c, const AvbdForce* in, int n)
         }
     }
     c->hostKeyCounter = (uint64_t)n + 1;
+    if (keys && n > 0) c->hostKeyCounter = std::max<uint64_t>(c->hostKeyCounter, (keys[0] & ((1ull << 40) - 1)) + 1);
     ManifoldBuf& b = c->mbuf[c->cur];
     if (nm) {
         HIPCHK(c, hipMemcpy(b.pair.p, h.pair.data(), nm * sizeof(int2), hipMemcpyHostToDevice));

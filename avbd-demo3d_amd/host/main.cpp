@@ -37,7 +37,7 @@ int main(int argc, char** argv)
     int removeBody = -1, removeAt = -1;   /* --remove-body <creation index> --remove-at <step>: `delete body` mid-run */
     int steps = 300; /* main.cpp:192 */
     bool quiet = false, batch = false;
-    int gpus = 1; bool exactCuts = false;
+    int gpus = 1; bool exactCuts = false; int rebalanceEvery = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--nogfx") || !strcmp(argv[i], "--headless")) { /* this build is always headless */ }
         else if ((!strcmp(argv[i], "--scene") || !strcmp(argv[i], "-s")) && i + 1 < argc) requested = argv[++i];
@@ -53,6 +53,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) setenv("AVBD_DEVICE", argv[++i], 1);
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = atoi(argv[++i]); if (gpus < 1) gpus = 1; }
         else if (!strcmp(argv[i], "--cuts") && i + 1 < argc) exactCuts = !strcmp(argv[++i], "exact");
+        else if (!strcmp(argv[i], "--rebalance") && i + 1 < argc) rebalanceEvery = atoi(argv[++i]);   /* --gpus N: new slabs from the current positions every K steps */
     }
 
     if (gpus > 1) { batch = true; quiet = true; }
@@ -89,7 +90,12 @@ int main(int argc, char** argv)
     auto t0 = std::chrono::steady_clock::now();
     if (gpus > 1) {
         for (Solver* s : ranks) s->hostSync = false;
-        Solver::stepGroup(ranks.data(), gpus, steps);
+        if (rebalanceEvery > 0) {
+            for (int done = 0; done < steps; done += rebalanceEvery) {
+                if (done) Solver::rebalance(ranks.data(), gpus, 0);
+                Solver::stepGroup(ranks.data(), gpus, steps - done < rebalanceEvery ? steps - done : rebalanceEvery);
+            }
+        } else Solver::stepGroup(ranks.data(), gpus, steps);
         solver->pull();
     } else if (batch) {
         solver->hostSync = false;

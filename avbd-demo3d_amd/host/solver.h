@@ -191,6 +191,9 @@ struct Solver {
      * exactCuts: results bit-identical to one GPU (avbd_set_shard_mode(ctx, 1)); otherwise one all-gather per iteration. */
     static void shardAcross(Solver** solvers, int n, int axis, bool exactCuts);
     static void stepGroup(Solver** solvers, int n, int steps);
+    /* ownership re-balanced after steps have run (slabs re-balanced every K steps): equal slabs along `axis` from the CURRENT
+     * positions, the manifolds move with the bodies (avbd_group_rebalance); with exact cuts the run continues the single-GPU sweep bit for bit */
+    static void rebalance(Solver** solvers, int n, int axis);
     AvbdContext* context() const { return ctx; }
     int bodyCount() const { return numBodies; }
     Rigid* bodyByIndex(int i) const;

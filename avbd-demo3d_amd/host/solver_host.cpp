@@ -629,6 +629,26 @@ void Solver::shardAcross(Solver** solvers, int n, int axis, bool exactCuts)
     }
 }
 
+void Solver::rebalance(Solver** solvers, int n, int axis)
+{
+    if (!solvers || n < 1) return;
+    Solver* s0 = solvers[0];
+    const int nb = s0->numBodies;
+    std::vector<AvbdBody> hb((size_t)std::max(nb, 1));
+    if (nb) { int rc = avbd_download_bodies(s0->ctx, hb.data(), nb); if (rc < 0) s0->fail("avbd_download_bodies", rc); }
+    std::vector<float> pos((size_t)3 * nb), inv((size_t)nb);
+    for (int i = 0; i < nb; ++i) { pos[3 * i] = hb[i].position[0]; pos[3 * i + 1] = hb[i].position[1]; pos[3 * i + 2] = hb[i].position[2]; inv[i] = hb[i].invMass; }
+    std::vector<int> owner((size_t)std::max(nb, 1), -1);
+    int rc = avbd_partition_by_axis(nb, pos.data(), inv.data(), n, axis, owner.data());
+    if (rc) s0->fail("avbd_partition_by_axis", rc);
+    std::vector<AvbdContext*> ctxs((size_t)n);
+    for (int r = 0; r < n; ++r) ctxs[(size_t)r] = solvers[r]->ctx;
+    if ((rc = avbd_group_rebalance(ctxs.data(), n, owner.data(), nb))) s0->fail("avbd_group_rebalance", rc);
+    for (int r = 0; r < n; ++r) {                                      /* the manifold mirrors refer to list positions of the old tables */
+        for (Manifold* m : solvers[r]->impl->manifolds) m->listIndex = -1;
+    }
+}
+
 void Solver::stepGroup(Solver** solvers, int n, int steps)
 {
     if (!solvers || n < 1) return;

@@ -304,6 +304,10 @@ int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
  * ranks of one avbd_group_step call must share a device.  A step that cannot run them FAILS with AVBD_E_INVALID and the reason in
  * avbd_last_error — a caller that asked for single-GPU bits never gets a Jacobi coupling under that name.
  * 2: exact cuts when the step can run them, the all-gather form otherwise; AvbdStepStats.cutMode tells which one ran. */
+/* Ownership re-balanced AFTER the first step, for the ranks of one avbd_group_step call (slabs re-balanced every K steps):
+ * the manifolds move with the bodies (contacts, lambda, penalty, list order), every rank continues from the state the single-GPU run would hold.
+ * owner[] as for avbd_set_ownership (avbd_partition_by_axis on the current positions gives equal slabs again).  Synchronous, host-side. */
+int  avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodies);
 int  avbd_set_shard_mode(AvbdContext* ctx, int mode);
 /* Exact cuts between ranks that are PROCESSES — one per GPU, or several on one device (how they are validated: N processes on one
  * MI355X reproduce the single-GPU sweep bit for bit, tests/test_gpu_exact_processes.py).  Every rank holds the whole scene and has

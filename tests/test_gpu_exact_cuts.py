@@ -120,7 +120,8 @@ def test_cli_gpus_flag_exact_cuts_give_the_single_gpu_dump(tmp_path):
     #  the visible devices: HIP_VISIBLE_DEVICES=0 keeps this test the same test on an 8-GPU node)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
     want = {"one": '"cuts": "none"', "exact": '"cuts": "exact"', "gather": '"cuts": "all-gather per iteration'}
-    for tag, extra in (("one", []), ("exact", ["--gpus", "2", "--cuts", "exact"]), ("gather", ["--gpus", "2"])):
+    want["rebalanced"] = want["exact"]
+    for tag, extra in (("one", []), ("exact", ["--gpus", "2", "--cuts", "exact"]), ("rebalanced", ["--gpus", "2", "--cuts", "exact", "--rebalance", "50"]), ("gather", ["--gpus", "2"])):
         d = str(tmp_path / (tag + ".bin"))
         r = subprocess.run([exe, "--nogfx", "--scene", "Stress1000", "--steps", "170", "--batch", "--device", "0", "--dump", d] + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
@@ -128,6 +129,7 @@ def test_cli_gpus_flag_exact_cuts_give_the_single_gpu_dump(tmp_path):
         assert want[tag] in r.stdout, r.stdout[-400:]          # the CLI prints the coupling that RAN (AvbdStepStats.cutMode)
         dumps[tag] = np.fromfile(d, dtype=H.load_product().BODY_DT)
     assert dumps["exact"].tobytes() == dumps["one"].tobytes()
+    assert dumps["rebalanced"].tobytes() == dumps["one"].tobytes()      # new slabs from the current positions every 50 steps: still the single-GPU bytes
     assert dumps["gather"].tobytes() != dumps["one"].tobytes()
     assert np.isfinite(dumps["gather"]["position"]).all() and float(dumps["gather"]["position"][1:, 1].min()) > 0.3   # (forty steps into a tumbling landing the Jacobi coupling of the cut has long diverged from the exact sweep: only sanity is asserted)
 
@@ -155,3 +157,61 @@ def test_a_declined_exact_step_is_an_error_and_mode_2_reports_the_fall_back():
     assert all(int(w.w.stats()["cutMode"]) == 3 for w in ws)
     one = H.HipWorld(); one.scene("PackedGrid:4,4,4"); one.step(3)
     assert int(one.w.stats()["cutMode"]) == 0
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_rebalanced_ownership_continues_the_single_gpu_sweep(monkeypatch, nranks):
+    """SURVEY.md §8e "spatial slabs re-balanced every K steps" (missing #2): ownership changed AFTER steps have run —
+    avbd_group_rebalance moves the manifolds with the bodies (contacts, lambda, penalty, list order).  With exact cuts every leg is the
+    single-GPU sweep, so the re-balanced run equals a run that was started with the new ownership: bodies and force lists bit for bit,
+    slabs along z, then along x from the CURRENT positions, then along z again."""
+    monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+    scene = "PackedGrid:4,4,8"
+    pkg, worlds, owner = _ranks(scene, nranks, 2)
+    monkeypatch.delenv("AVBD_SHARD_EXACT")
+    single = H.HipWorld(); single.scene(scene)
+    done = 0
+    for leg, axis in enumerate((2, 0, 2)):
+        if leg:
+            b = worlds[0].bodies()
+            owner = pkg.partition_by_axis(b["pos"], b["invMass"], nranks, axis=axis)
+            pkg.group_rebalance([w.w for w in worlds], owner)
+        for s in range(3):
+            pkg.group_step([w.w for w in worlds], 4); single.step(4); done += 4
+            bs, fs = single.bodies(), single.forces()
+            for r, w in enumerate(worlds):
+                assert int(w.w.stats()["cutMode"]) == 3
+                assert H.same_bits(bs, w.bodies()), f"rank {r}: body state differs from the single-GPU sweep after {done} steps (leg {leg})"
+                _same_forces(fs, w.forces(), owner, r, f"after {done} steps (leg {leg})")
+    assert int(single.w.stats()["numManifolds"]) > 50
+
+
+def test_rebalance_on_a_falling_pile_and_in_the_all_gather_form(monkeypatch):
+    """a pile that lands while its slabs are re-cut every 20 steps: exact cuts stay bit-identical to one GPU; the all-gather form (Jacobi across
+    the cuts) keeps all ranks' gathered state identical and the pile sane"""
+    scene, nranks = "StressN:10", 2
+    monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+    pkg, worlds, owner = _ranks(scene, nranks, 0)
+    monkeypatch.delenv("AVBD_SHARD_EXACT")
+    single = H.HipWorld(); single.scene(scene)
+    pkg.group_step([w.w for w in worlds], 125); single.step(125)
+    for leg in range(3):
+        b = worlds[0].bodies()
+        owner = pkg.partition_by_axis(b["pos"], b["invMass"], nranks, axis=(2, 0, 2)[leg])
+        pkg.group_rebalance([w.w for w in worlds], owner)
+        pkg.group_step([w.w for w in worlds], 20); single.step(20)
+        for r, w in enumerate(worlds):
+            assert H.same_bits(single.bodies(), w.bodies()), f"rank {r} after leg {leg}"
+    assert int(single.w.stats()["numManifolds"]) > 300
+    # all-gather form
+    pkg, worlds, owner = _ranks(scene, nranks, 0)
+    pkg.group_step([w.w for w in worlds], 140)
+    b = worlds[0].bodies()
+    owner = pkg.partition_by_axis(b["pos"], b["invMass"], nranks, axis=2)
+    pkg.group_rebalance([w.w for w in worlds], owner)
+    pkg.group_step([w.w for w in worlds], 30)
+    b0, b1 = worlds[0].bodies(), worlds[1].bodies()
+    for f in ("pos", "quat", "linVel", "angVel"):
+        assert H.same_bits(b0[f], b1[f]), f
+    assert int(worlds[0].w.stats()["cutMode"]) in (1, 2)
+    assert np.isfinite(b0["pos"]).all() and float(b0["pos"][1:, 1].min()) > 0.3

@@ -146,3 +146,17 @@ def test_config3_in_its_stated_form_eight_process_ranks_64000_cubes(tmp_path):
             rb = np.load(os.path.join(str(tmp_path), f"bodies_{done}_{r}.npy"))
             assert H.same_bits(bs, rb), f"rank {r}: body state differs from the single-GPU sweep after {done} steps"
     assert int(single.w.stats()["numManifolds"]) > 3000
+
+
+def test_bench_multi_process_path_on_one_device(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (python -m torch.distributed.run, one process per rank), with both ranks on device 0
+    (AVBD_BENCH_ONE_DEVICE=1: rendezvous over gloo, exact cuts through hipIpc windows — the only form that needs no collective): the JSON line
+    says which coupling ran, and the timed window is finite."""
+    import json
+    env = dict(os.environ, AVBD_BENCH_ONE_DEVICE="1", HIP_VISIBLE_DEVICES="0")
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--scene", "StressN:16", "--presim", "380"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["shard_form"].startswith("exact cuts") and "bit-identical" in line["config"]["mode"]

@@ -132,3 +132,41 @@ def test_out_of_order_sweep_in_the_per_iteration_launches_of_a_sharded_run(monke
             o.step(); g.step()
             H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
         assert int(g.w.stats()["schedule"]) == 3
+
+
+def build_contacts_only(w, seed):
+    """random boxes, contacts only (what the group schedule runs), dense enough that bodies get many partners"""
+    r = np.random.default_rng(seed)
+    n = int(r.integers(40, 400))
+    w.add_body((float(r.uniform(10, 30)), 1.0, float(r.uniform(10, 30))), 0.0, float(r.uniform(0.1, 1.0)), (0, -0.5, 0))
+    span = float(r.uniform(1.5, 4.0))
+    for k in range(n):
+        size = tuple(float(x) for x in r.uniform(0.4, 1.5, 3))
+        pos = (float(r.uniform(-span, span)), float(r.uniform(0.4, 6)), float(r.uniform(-span, span)))
+        q = r.normal(size=4); q = tuple(float(x) for x in q / np.linalg.norm(q))
+        w.add_body(size, float(r.uniform(0.3, 4.0)), float(r.uniform(0.0, 1.0)), pos, q, tuple(float(x) for x in r.uniform(-2, 2, 3)), tuple(float(x) for x in r.uniform(-3, 3, 3)))
+    w.set_params(iterations=int(r.integers(1, 25)), alpha=float(r.uniform(0.5, 1.0)), beta=float(r.uniform(1e3, 2e5)), gamma=float(r.uniform(0.9, 1.0)),
+                 postStabilize=int(r.integers(0, 2)))
+    return n
+
+
+@pytest.mark.parametrize("first", [300, 312, 324])
+def test_random_piles_in_the_several_bodies_loops_of_the_group_schedule(first):
+    """The loops of k_iterate_groups<true, 0> — pools (round 4), the task in hand, the plain loop, with and without arrival counters — on random
+    piles: a handful of waves (`groups_waves`) makes a small scene a several-bodies-per-sub-group scene; wide boxes bring the 32- and 64-lane classes."""
+    variants = [dict(groups_waves=8), dict(groups_waves=8, group_pool=0), dict(groups_waves=16, group_pool=0, group_dep=0), dict(groups_waves=4, group_pool_min_rounds=2),
+                dict(groups_waves=12, group_spec=1, group_spec_rounds=16, group_pool=0), dict(groups_waves=8, groups_rounds=16)]
+    ran4 = 0
+    for seed in range(first, first + 12):
+        opt = variants[seed % len(variants)]
+        o, g = H.CpuWorld("orc"), H.HipWorld()
+        for w in (o, g):
+            build_contacts_only(w, seed)
+        g.w.set_option("groups", 1)
+        for k, v in opt.items():
+            g.w.set_option(k, v)
+        for s in range(14):
+            o.step(); g.step()
+            H.assert_same_world(o, g, f"seed {seed} step {s + 1} with {opt}")
+            ran4 += int(g.w.stats()["schedule"]) == 4
+    assert ran4 >= 100, ran4          # (a few waves decline the densest piles — more than 16 bodies per sub-group: those steps take the resident schedule)
