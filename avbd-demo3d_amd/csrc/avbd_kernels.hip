@@ -638,23 +638,46 @@ __global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc
     }
 }
 
+/* A position in a body's adjacency list.  Bodies this context sweeps have a handful of forces each: one returning atomic per entry.  A body that
+ * is not swept — the ground under a 64 000-cube pile carries 6 400 manifolds — would serialise thousands of returning atomics on ONE word
+ * (13 ns each: 68 of the launch's 68 us): the lanes of a wave that target the same such body take their positions from one atomic. */
+__device__ __forceinline__ int adj_position(int body, bool want, const int* __restrict__ solved, const int* __restrict__ adjStart, int* cursor)
+{
+    const int lane = threadIdx.x & 63;
+    const bool shared = want && !solved[body];
+    int pos = -1;
+    if (want && !shared) pos = adjStart[body] + atomicAdd(&cursor[body], 1);
+    unsigned long long m = __ballot(shared);
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        const int v = __shfl(body, l, 64);
+        const unsigned long long same = __ballot(shared && body == v);
+        int base = 0;
+        if (lane == l) base = atomicAdd(&cursor[v], (int)__popcll(same));
+        base = __shfl(base, l, 64);
+        if (shared && body == v) pos = adjStart[v] + base + (int)__popcll(same & ((1ull << lane) - 1ull));
+        m &= ~same;
+    }
+    return pos;
+}
+
 __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* gf, int ng, const int* adjStart, int* cursor,
-                           int* adjRef, int* adjOther, uint64_t* adjKey)
+                           int* adjRef, int* adjOther, uint64_t* adjKey, const int* __restrict__ solved)
 {
     const int nm = cnt->numManifolds;
     const int total = nm + ng;
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-        int a, b, kind, index; uint64_t key;
-        if (item < nm) { int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; }
-        else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = gforce_ref_kind(f.kind); index = item - nm; key = f.key; }
-        if (a >= 0) {
-            int pos = adjStart[a] + atomicAdd(&cursor[a], 1);
-            adjRef[pos] = make_inc(1, kind, index); adjOther[pos] = b; adjKey[pos] = key;
+    const int stride = gridDim.x * blockDim.x;
+    for (int base = blockIdx.x * blockDim.x; base < total; base += stride) {      /* (whole waves stay in the loop: adj_position uses wave-wide votes) */
+        const int item = base + (int)threadIdx.x;
+        int a = -1, b = -1, kind = 0, index = 0; uint64_t key = 0;
+        if (item < total) {
+            if (item < nm) { int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; }
+            else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = gforce_ref_kind(f.kind); index = item - nm; key = f.key; }
         }
-        if (b >= 0) {
-            int pos = adjStart[b] + atomicAdd(&cursor[b], 1);
-            adjRef[pos] = make_inc(0, kind, index); adjOther[pos] = a; adjKey[pos] = key;
-        }
+        const int pa = adj_position(a, a >= 0, solved, adjStart, cursor);
+        if (a >= 0) { adjRef[pa] = make_inc(1, kind, index); adjOther[pa] = b; adjKey[pa] = key; }
+        const int pb = adj_position(b, b >= 0, solved, adjStart, cursor);
+        if (b >= 0) { adjRef[pb] = make_inc(0, kind, index); adjOther[pb] = a; adjKey[pb] = key; }
     }
 }
 
