@@ -241,6 +241,7 @@ struct AvbdContext {
     /* exact cuts between processes: this rank's window, the peers' windows as this process sees them (own window at [rank]) */
     float4* xwOwn = nullptr; float4* xwPeer[kMaxExactRanks] = {}; bool xwAttached = false; bool xwSharedDevice = false; unsigned xwSerial = 0; int xwBodyCap = 0, xwMCap = 0, xwRanks = 0;
     int cutRanks = 0;
+    int diagBlocksCap = 256;       /* workgroups of the contact diagnostics: each ends with five atomics on ONE line, 13 ns apiece whoever issues them (64 000 cubes: 1024 -> 50 us, 256 -> 28 us, 128 -> 34 us) */
     bool debugSharedMulti = false;
     int iterBlocksMax = 0;         /* what the occupancy query allows (avbd_create) */
     bool exactAllowed = true;      /* the exact-cut kernels fit two workgroups per CU on this device / this build */
@@ -1115,7 +1116,7 @@ int step_end(AvbdContext* c, bool haveCounts)
     {
         SpanGuard g(c, F_VELOCITY);
         const int velBlocks = grid_for(n, 256, 1 << 20);
-        const int diagBlocks = contactSlots > 0 ? grid_for(contactSlots, 256, 1024) : 1;   /* (grid-stride; every workgroup ends with five atomics on one line) */
+        const int diagBlocks = contactSlots > 0 ? grid_for(contactSlots, 256, c->diagBlocksCap) : 1;   /* (grid-stride; every workgroup ends with five atomics on one line) */
         hipLaunchKernelGGL(k_tail, dim3(velBlocks + diagBlocks), dim3(256), 0, c->stream, B, M, P, c->dCnt.p, c->dDiag.p, velBlocks);
     }
     HIPCHK(c, hipGetLastError());
@@ -1755,6 +1756,7 @@ void turn_end(AvbdContext* c)
     BOOL("order_by_index", orderByIndex)          /* 0: sweep order by dependency level */                                                 \
     BOOL("fused_topology", fusedTopology)                                                                                                  \
     BOOL("fused_front", fusedFront)                                                                                                        \
+    INT("diag_blocks", diagBlocksCap, 1, 4096)                                                                                            \
     BOOL("debug_shared_multi", debugSharedMulti)  /* debug: more than two contexts of one device in the persistent several-bodies all-gather form (see avbd_group_step) */
 
 static int option_access(AvbdContext* c, const char* key, int* v, bool set)
