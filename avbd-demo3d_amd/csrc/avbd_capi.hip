@@ -727,6 +727,12 @@ int refresh_stats(AvbdContext* c, bool withLevels)
         std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
         return c->fail(AVBD_E_CAPACITY, buf);
     }
+    if (iterError == 2 || iterError == 3) {
+        (void)hipMemsetAsync(c->dFlags.p + 2 * (size_t)c->bodyCap, 0, 16 * sizeof(int), c->stream);
+        return c->fail(iterError == 2 ? AVBD_E_INVALID : AVBD_E_CAPACITY, iterError == 2 ?
+            "exact cuts between processes: the plan of a step did not fit this rank's share of the device (a body with more than 64 contacts, or more than 8 bodies per sub-group): that step was not iterated" :
+            "exact cuts: more manifolds across the cuts than the cut tables hold (16 384 per pair of ranks): the records of some cut contacts shared a slot, the results are not the single-GPU sweep's");
+    }
     if (iterError) {
         int why[16] = {0};
         (void)hipMemcpy(why, c->dFlags.p + 2 * (size_t)c->bodyCap, sizeof(why), hipMemcpyDeviceToHost);
@@ -1522,8 +1528,6 @@ int exact_process_step(AvbdContext* c, bool needReadback)
     if (!why && !c->exactAllowed) why = "the exact-cut kernels do not fit two workgroups per CU on this device / this build";
     if (!why && !c->groupsPlanned) why = "the group schedule was not planned (levels mode, more than 60 iterations, or no swept body)";
     if (!why && (c->xwBodyCap != c->bodyCap || c->xwMCap != c->mCap)) why = "the pools have grown since the window was exported: export and attach again";
-    bool ok = false;
-    if (!why) { if ((rc = shard_plan_accepted(c, ok))) return rc; if (!ok) why = "the plan does not fit this rank's share of the device (a body with more than 64 contacts, or more than 8 bodies per sub-group)"; }
     if (why) {
         char msg[384];
         std::snprintf(msg, sizeof(msg), "exact cuts between processes (avbd_exact_window_attach) cannot run this step: %s", why);
@@ -1578,9 +1582,12 @@ int exact_process_step(AvbdContext* c, bool needReadback)
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    auto kern = c->shardMulti ? k_iterate_groups<true, 2> : k_iterate_groups<false, 2>;
+    /* both forms of the loop, one behind the other: the plan says which one runs (the other returns at once); the host never reads it back */
     const int wg = std::max(1, groups_waves(c) / kGrpWavesPerBlock);
-    hipExtLaunchKernelGGL(kern, dim3(wg), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
+    hipLaunchKernelGGL(k_plan_guard, dim3(1), dim3(1), 0, c->stream, (const GroupPlan*)c->dPlan.p, (const CutCounters*)c->dCutCnt.p, S.error);
+    hipExtLaunchKernelGGL((k_iterate_groups<false, 2>), dim3(wg), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P,
+                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
+    hipExtLaunchKernelGGL((k_iterate_groups<true, 2>), dim3(wg), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytesMulti, c->stream, nullptr, e1, 0, B, M, c->incStart.p, c->inc.p, P,
                           S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
     ++c->prof.launches_primal; ++c->prof.launches_total;
     c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true; c->cutModeRan = 3;

@@ -94,6 +94,14 @@ __global__ void k_unpack_records(BodyTable B, const int* __restrict__ owner, int
  * in its window" — and the kernel that copies the other ranks' final poses waits for that word of every peer first (k_wait_peers; bounded, the
  * error word of the context is raised on a time-out).  Besides the final poses this is what makes the windows reusable: no rank starts the
  * records of step s + 1 while a peer can still read those of step s (the last read is the owner's last dual, final_store). */
+/* Ranks that are processes queue both forms of the loop kernel behind the plan and never read it back (a host synchronisation per step is a
+ * pipeline bubble per step on every rank): a plan the device declined, or cut tables that overflowed, raise the context's error word instead —
+ * errWord[0] = 2 / 3, decoded by the next call that looks (the peers' waves, which wait for records that will never come, time out). */
+__global__ void k_plan_guard(const GroupPlan* __restrict__ plan, const CutCounters* __restrict__ cc, int* errWord)
+{
+    if (plan->bad) { __hip_atomic_store(errWord, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (cc->overflow) __hip_atomic_store(errWord, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void k_step_done(volatile unsigned* head, int word, unsigned serial)
 {
     __hip_atomic_store(const_cast<unsigned*>(head) + word, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
