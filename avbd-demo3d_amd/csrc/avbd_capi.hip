@@ -753,850 +753,13 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     return AVBD_OK;
 }
 
-/* ---- one Solver::step() split into phases so that several contexts (GPUs) can be driven in lock-step ---- */
+#include "avbd_capi_step.inc"
 
-constexpr int kShardFreeSlots = 4;    /* workgroup slots a persistent sharded launch leaves to the collective's kernel (avbd_comm_init caps its channels at 4);
-                                       * more would push a rank of 8 000 bodies — an eighth of the 64 000-cube scene — out of the one-body-per-sub-group form */
-int groups_waves(const AvbdContext* c)
-{
-    int all = 2 * c->iterBlocks * kGrpWavesPerBlock;                   /* two workgroups of four waves per CU */
-    if (c->nranks > 1 || c->forceSharded) {
-        /* a sharded step: contexts that share this device split the waves (avbd_group_step sets shardWaves); with a real
-         * collective its kernel needs room beside the persistent launch: kShardFreeSlots workgroup slots stay free */
-        /* (avbd_group_step's device copies are kernels too: every context leaves a few slots of its share free as well — a plan with
-         * several bodies per sub-group uses every wave it is given) */
-        if (c->shardWaves > 0 && c->shardExact && c->nranks > 1) all = std::max(kGrpWavesPerBlock, std::min(all, c->shardWaves));   /* exact cuts: no copies beside the launches */
-        else if (c->shardWaves > 0) all = std::max(kGrpWavesPerBlock, std::min(all, c->shardWaves) - 4 * kGrpWavesPerBlock);
-        else if (c->comm) all -= kShardFreeSlots * kGrpWavesPerBlock;
-    }
-    return c->groupsWaves > 0 ? std::min(c->groupsWaves, all) : all;
-}
+#include "avbd_capi_shard.inc"
 
-/* Can this step's iteration loop be offered to the group schedule?  Host-side prerequisites only (one GPU, contacts and
- * ignore markers only, stamps fit); the device declines on its own if a body has too many entries (GroupPlan.bad). */
-bool groups_eligible(const AvbdContext* c)
-{
-    if (c->groupsMode == 0 || c->mode == 0 || !c->residentAllowed || !c->dPlan.p) return false;
-    const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
-    if (totalIt <= 0 || totalIt > 60) return false;
-    for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) return false;
-    if (c->nranks > 1 && c->shardExact) return true;                   /* exact cuts: the group schedule over the bodies this rank sweeps */
-    if (c->nranks > 1 || c->forceSharded)                              /* sharded: the persistent launch IS the group schedule */
-        return c->shardPersistent != 0 && (c->shardPersistent == 1 || c->comm == nullptr || c->nranks == 1) &&
-               c->canWaitValue && c->sigDone && c->sigGather && c->stream2;
-    const int dyn = (int)c->hBodies.size() - c->numStatic;
-    return c->groupsMode == 1 || dyn > c->iterBlocks * kIterWaves;
-}
+#include "avbd_capi_hostrows.inc"
 
-/* phases 1-3 of solver.cpp:255-337 + the topology rebuild; leaves the stream ready for the iteration loop */
-int step_begin(AvbdContext* c)
-{
-    int rc;
-    if ((rc = upload_bodies_if_stale(c))) return rc;
-    if ((rc = upload_gforces_if_stale(c))) return rc;
-    BodyTable B = body_table(c);
-    const int n = B.n;
-    SolverParams P = solver_params(c);
-    if (c->adjDirty && (rc = launch_topology(c, false))) return rc;
-
-    ++c->stepIndex;
-    {
-        /* (the grid broadphase's bucket heads are cleared by the same launch) */
-        const bool grid = !(c->fusedFront && n > 1 && n <= 4096) && !(n > 1 && n <= 4096) && n > 1 && c->gridBuckets > 0 && c->nBig <= 64;
-        if (grid) hipLaunchKernelGGL(k_begin_step, dim3(grid_for(c->gridBuckets, 256, 1024)), dim3(256), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p, c->dCellHead.p, c->gridBuckets);
-        else hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(1), 0, c->stream, c->dCnt.p, c->dDiag.p, c->dNext.p, (int*)nullptr, 0);
-    }
-    if (c->fusedFront && n > 1 && n <= 4096) {
-        /* small scene: persistent manifolds and the broadphase (+ its own candidates) side by side in one launch */
-        SpanGuard g(c, F_NARROW);
-        ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
-        const int slices = (n + kFrontSlice - 1) / kFrontSlice;
-        const int ppw = kFrontPairs;                                  /* sixteen lanes per pair */
-        const int persistBlocks = std::max(1, std::min(16384, (c->stats.numManifolds + c->stats.numCandidates + n + ppw - 1) / ppw));
-        const int broadBlocks = (int)(((long long)n * slices + kFrontThreads - 1) / kFrontThreads);
-        hipLaunchKernelGGL(k_front_small, dim3(persistBlocks + broadBlocks), dim3(kFrontThreads), 0, c->stream, B, src, dst, c->adjStart.p, c->adjOther.p, c->dCnt.p,
-                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex, persistBlocks, c->rank == 0 ? 1 : 0, slices);
-        c->cur ^= 1;
-    } else {
-    {
-        SpanGuard g(c, F_BROAD);
-        if (n > 1 && n <= 4096) {
-            const int slices = (n + 31) / 32;
-            hipLaunchKernelGGL(k_broadphase_small, dim3(grid_for((long long)n * slices, 256, 1 << 24)), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p,
-                               c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0, slices);
-        } else if (n > 1 && c->gridBuckets > 0 && c->nBig <= 64) {
-            const float invCell = 1.0f / c->gridCell;
-            const unsigned mask = (unsigned)c->gridBuckets - 1u;
-            hipLaunchKernelGGL(k_grid_build, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0, c->stream, B, c->dIsBig.p, invCell, mask, c->dCellHead.p, c->dCellNext.p);
-            hipLaunchKernelGGL(k_grid_pairs, dim3(grid_for((long long)n * 27, 256, 1 << 24)), dim3(256), 0, c->stream, B, c->dIsBig.p, c->dBigList.p, c->nBig, invCell, mask,
-                               c->dCellHead.p, c->dCellNext.p, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
-        } else if (n > 1) {
-            const int T = (n + 255) / 256;
-            hipLaunchKernelGGL(k_broadphase, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, B, c->adjStart.p, c->adjOther.p, c->cand.p, c->candCap, c->dCnt.p, c->rank == 0 ? 1 : 0);
-        }
-    }
-    {
-        SpanGuard g(c, F_NARROW);
-        ManifoldTable src = c->mbuf[c->cur].view(), dst = c->mbuf[c->cur ^ 1].view();
-        long long est = (long long)c->stats.numManifolds + std::max(c->stats.numCandidates, n) + 4096;
-        hipLaunchKernelGGL(k_narrowphase, dim3(grid_for(est * 2, 32, 32768)), dim3(32), 0, c->stream, B, src, dst, c->cand.p, c->candCap, c->dCnt.p,
-                           c->dNext.p, c->degForce.p, c->degInc.p, P, c->stepIndex);
-        c->cur ^= 1;
-    }
-    }
-    {
-        SpanGuard g(c, F_TOPO);
-        if ((rc = launch_topology(c, true))) return rc;
-    }
-    if (!c->topologyDidPredict) {
-        {
-            SpanGuard g(c, F_PREDICT);
-            /* (with the done-counters of the task schedule; the error word behind them is sticky) */
-            hipLaunchKernelGGL(k_predict, dim3(grid_for(n, 128, 1 << 20)), dim3(128), 0, c->stream, B, P, c->dCnt.p, c->mode != 0 ? c->dFlags.p : (int*)nullptr);
-        }
-    }
-    if (c->raceCheck && n > 0) {
-        if (c->dSlotOf.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dSlotOf.alloc((size_t)c->bodyCap)); }
-        HIPCHK(c, hipMemsetAsync(c->dSlotOf.p, 0xff, (size_t)c->bodyCap * sizeof(int), c->stream));
-        const bool byLevel = c->mode == 0 || !c->orderByIndex;
-        for (int pass = 0; pass < 2; ++pass)
-            hipLaunchKernelGGL(k_race_check, dim3(grid_for(n, 256, 1024)), dim3(256), 0, c->stream, B, c->mbuf[c->cur].view(), c->dG.p, c->dCnt.p, c->dCnt.p, c->adjStart.p, c->adjRef.p,
-                               c->adjOther.p, c->incStart.p, c->inc.p, c->level.p, c->order.p, c->lvlStart.p, c->dSlotOf.p, byLevel ? 1 : 0, pass);
-    }
-    c->groupsPlanned = false;
-    if (groups_eligible(c)) {
-        const int W = groups_waves(c);
-        const int needUnits = 3 * c->bodyCap;                          /* the bodies of each of the three classes in sweep order */
-        if (c->unitCap < needUnits) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, c->dUnit.alloc((size_t)needUnits)); c->unitCap = needUnits;
-        }
-        {   /* state parked between a body's tasks when a sub-group serves several bodies */
-            const size_t needN = (size_t)3 * c->incCap, needP = (size_t)2 * c->bodyCap;
-            if (c->privNCap < needN) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivN.alloc(needN)); c->privNCap = needN; }
-            if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
-            if (c->probeCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap; }
-            if (c->parkCap < (size_t)c->incCap || c->parkBodyCap < (size_t)c->bodyCap) {
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                HIPCHK(c, c->xParkC.alloc((size_t)5 * c->incCap)); HIPCHK(c, c->xParkS.alloc((size_t)4 * c->incCap)); HIPCHK(c, c->xParkB.alloc((size_t)10 * c->bodyCap));
-                c->parkCap = (size_t)c->incCap; c->parkBodyCap = (size_t)c->bodyCap;
-            }
-            if (c->xDepCnt.n < (size_t)3 * c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xDepCnt.alloc((size_t)3 * c->bodyCap)); HIPCHK(c, c->xRankOf.alloc((size_t)c->bodyCap)); }
-        }
-        hipLaunchKernelGGL(k_group_plan, dim3(std::max(1, (c->numSolved + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, B, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p,
-                           c->dPlan.p, c->dUnit.p, c->bodyCap, W, std::min((c->nranks > 1 && c->shardExact) ? kGrpMaxRounds / 2 : kGrpMaxRounds, c->groupsMaxRounds), c->dTileAgg.p, ++c->tileStamp,
-                           (c->groupDep && c->nranks == 1 && !c->forceSharded) ? c->xDepCnt.p : (unsigned*)nullptr, c->xRankOf.p);
-        c->groupsPlanned = true;
-    }
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-/* iterations [itBegin, itEnd) of solver.cpp:340-431 as one persistent data-flow launch */
-int step_iterate(AvbdContext* c, int itBegin, int itEnd)
-{
-    BodyTable B = body_table(c);
-    SolverParams P = solver_params(c);
-    ManifoldTable M = c->mbuf[c->cur].view();
-    IterateState S;
-    S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
-    long long tasks = (long long)B.n * (itEnd - itBegin);
-    int blocks = (int)std::min<long long>(c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
-    if (blocks < 1) blocks = 1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    /* latency mode (one workgroup per CU) unless every wave would have to run hundreds of tasks: then two workgroups per CU */
-    /* resident schedule (one wave per body for the whole loop): whole loop in one launch on one GPU, contacts only, stamps fit */
-    ResidentExchange X{};
-    X.pose = c->xPose.p; X.visit = c->xVisit.p; X.dual = c->xDual.p;
-    /* dual records: two per contact slot, then two per joint half */
-    const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes + (size_t)4 * c->gCap * sizeof(float4), poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
-    if (c->xDual.n * sizeof(float4) < dualBytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, c->xDual.alloc(dualBytes / sizeof(float4)));
-        HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
-        X.dual = c->xDual.p;
-    }
-    X.jointRecBase = 4 * c->mCap;
-    bool noSprings = true, anyJoint = false;
-    for (const GForce& g : c->hG) { noSprings &= g.kind != FK_SPRING; anyJoint |= g.kind == FK_JOINT; }
-    X.joints = anyJoint ? 1 : 0;
-    X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
-    X.maxWaves = c->iterBlocks * kIterWaves;
-    X.quietPermille = c->residentQuiet;
-    X.prStride = kResStride;
-    X.spread = c->residentSpread ? 1 : 0;
-    const int totalItAll = P.iterations + (P.postStabilize ? 1 : 0);
-    const bool wholeLoop = itBegin == 0 && itEnd >= totalItAll && c->nranks == 1 && !c->forceSharded;
-    const bool sharded = c->nranks > 1 || c->forceSharded;
-    const int dynBodies = sharded ? c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank] : B.n - c->numStatic;
-    const bool fitsOne = wholeLoop && dynBodies <= X.maxWaves && !c->residentForceLite;
-    const bool fitsMulti = c->residentMultiAllowed && dynBodies <= c->residentMultiMax * X.maxWaves;   /* beyond: throughput-bound, task schedule with two workgroups per CU */
-    X.enabled = (c->residentAllowed && c->iterForceMode != 2 && c->iterLdsPad >= kIterWaves * kResProductBytesPerWave &&
-                 (wholeLoop || (sharded && c->residentSharded)) && noSprings &&
-                 totalItAll <= 60 && totalItAll > 0 && (fitsOne || fitsMulti) && dualBytes < (1ull << 31) && poseBytes < (1ull << 31)) ? 1 : 0;
-    X.multi = 0; X.forceMulti = 0; X.planesAlways = 0;
-    if (X.enabled && !fitsOne) {
-        const size_t needN = (size_t)3 * c->incCap, needP = (size_t)2 * c->bodyCap;
-        if (c->privNCap < needN) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivN.alloc(needN)); c->privNCap = needN; }
-        if (c->privPoseCap < needP) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xPrivPose.alloc(needP)); c->privPoseCap = needP; }
-        X.multi = 1;
-        if (!wholeLoop) { X.forceMulti = 1; X.planesAlways = 1; }
-    }
-    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p;
-    X.depCnt = (c->groupDep && !sharded && c->groupsPlanned) ? c->xDepCnt.p : nullptr;
-    X.depKeep = c->groupDepKeep; X.rankOf = c->xRankOf.p; X.poolMode = c->groupPool; X.poolMinRounds = c->groupPoolMinRounds;
-    X.send = (sharded && c->dSend.p && c->dSendSlot.p) ? c->dSend.p : nullptr; X.sendSlot = c->dSendSlot.p;
-    c->residentMultiLaunched = X.multi != 0;
-    c->packFused = X.send != nullptr;
-    c->residentLaunched = X.enabled != 0;
-    if (X.enabled) {
-        if (itBegin == 0 && c->xSerial >= (1u << 24) - 2u) {      /* stamps are about to wrap: forget every old record */
-            HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, visitBytes, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
-            c->xSerial = 0;
-        }
-        if (itBegin == 0) ++c->xSerial;                                /* one stamp window per step, shared by its launches */
-        X.base = c->xSerial * 64u;
-        blocks = c->iterBlocks;                                        /* every swept body needs its wave resident */
-    }
-    /* several bodies per wave and more than residentLiteFrom of them: two workgroups per CU (twice the waves, short product lines) */
-    const bool lite = X.enabled && X.multi && (c->residentForceLite || (c->residentLiteFrom > 0 && dynBodies > c->residentLiteFrom * X.maxWaves));
-    if (lite) { X.prStride = kResStrideLite; X.maxWaves *= 2; }
-    /* out-of-order sweep of a wave's bodies: pays once a wave owns many bodies (measured ms/step in order / out of order over
-     * bench.py's 200-step steady window: 4 096 cubes, 2 per wave, 1.31 / 1.89; 8 000 cubes, 4 per wave, 2.45 / 2.69;
-     * 22 000 cubes, 11 per wave, 5.58 / 4.94; 64 000 cubes, 31 per wave, 12.3 / 9.9) */
-    X.outOfOrder = (X.enabled && X.multi && (c->residentOutOfOrder == 1 || (c->residentOutOfOrder < 0 && dynBodies > 7 * X.maxWaves))) ? 1 : 0;
-    if (X.outOfOrder && c->probeCap < (size_t)c->incCap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->xProbe.alloc((size_t)c->incCap)); c->probeCap = (size_t)c->incCap;
-    }
-    X.probe = c->xProbe.p;
-    X.patience = c->residentPatience;
-    const bool throughput = lite || (!X.enabled && c->liteResident && (c->iterForceMode == 2 || (c->iterForceMode == 0 && (long long)B.n * (P.iterations + (P.postStabilize ? 1 : 0)) > 32ll * c->iterBlocks * kIterWaves)));
-    /* group schedule first; the launch below then runs only if the device declined (runIf) */
-    const int* runIf = nullptr;
-    c->groupsLaunched = false;
-    if (c->groupsPlanned && X.enabled && wholeLoop && !X.joints && !sharded) {
-        hipExtLaunchKernelGGL((k_iterate_groups<false, 0>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
-                              X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
-        if (c->groupsMaxRounds > 1)
-            hipLaunchKernelGGL((k_iterate_groups<true, 0>), dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytesMulti, c->stream, B, M, c->incStart.p, c->inc.p, P, S.error, c->dCnt.p,
-                               X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, ShardExchange{});
-        runIf = &c->dPlan.p->bad;
-        c->groupsLaunched = true;
-        e0 = nullptr;                                                  /* the profiling span covers both launches (the second one is empty unless the device declined) */
-    }
-    if (throughput) {
-        int blocks2 = (int)std::min<long long>(2ll * c->iterBlocks, (tasks + kIterWaves - 1) / kIterWaves);
-        if (blocks2 < 1) blocks2 = 1;
-        if (lite) blocks2 = 2 * c->iterBlocks;
-        auto kern = X.joints ? k_iterate<2, true> : k_iterate<2, false>;
-        hipExtLaunchKernelGGL(kern, dim3(blocks2), dim3(64 * kIterWaves), kIterWaves * kResProductBytesPerWaveLite, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X, runIf);
-    } else {
-        if (c->singleKernel && X.enabled && !X.multi && !X.forceMulti && wholeLoop && !runIf) {
-            /* every swept body has a resident wave: the kernel that holds nothing but that schedule; the launch below runs if the
-             * device vetoed it */
-            auto single = X.joints ? k_iterate_single<true> : k_iterate_single<false>;
-            X.crit = c->dCrit.p;
-            if (c->placeChains && blocks * kIterWaves <= 1024 && c->placeQueued && blocks == c->iterBlocks) X.place = c->dPlace.p;   /* k_topology_small built the table */
-            else if (c->placeChains && blocks * kIterWaves <= 1024) {
-                /* this step's table from the last launch's report, on this step's sweep order */
-                hipLaunchKernelGGL(k_place_chains, dim3(1), dim3(1024), 0, c->stream, c->order.p, c->lvlStart.p, c->dCnt.p, c->dCrit.p, c->dTail.p, c->dPlaceSlot.p,
-                                   c->bodyCap, blocks * kIterWaves, c->dPlace.p, c->dPlaceInfo.p);
-                X.place = c->dPlace.p;
-            }
-            hipExtLaunchKernelGGL(single, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, nullptr, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                                  c->incStart.p, c->inc.p, P, S.error, c->dCnt.p, c->iterSleep, itEnd, X);
-            runIf = &c->dCnt.p->residentBad;
-            e0 = nullptr;
-        }
-        auto kern = X.joints ? k_iterate<1, true> : k_iterate<1, false>;
-        hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kIterWaves), c->iterLdsPad, c->stream, e0, e1, 0, B, M, c->dG.p, c->order.p, c->lvlStart.p, c->dCnt.p,
-                              c->adjStart.p, c->adjRef.p, c->adjOther.p, c->incStart.p, c->inc.p, P, S, c->dCnt.p, c->iterSleep, itBegin, itEnd, X, runIf);
-    }
-    ++c->prof.launches_primal; ++c->prof.launches_total;
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-/* level mode (AVBD_MODE=levels): one k_primal launch per Gauss-Seidel level, needs the schedule on the host */
-int step_iterate_levels(AvbdContext* c)
-{
-    BodyTable B = body_table(c);
-    SolverParams P = solver_params(c);
-    ManifoldTable M = c->mbuf[c->cur].view();
-    const int ng = (int)c->hG.size();
-    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
-    const Counters& cnt = c->hRb->cnt;
-    const long long contactSlots = (long long)cnt.numManifolds * 4;
-    const int L = cnt.numLevels;
-    std::vector<int> lvl;
-    const int* lvlStart = c->hRb->lvlStart;
-    if (L > kReadbackLevels) {
-        lvl.resize(L + 1);
-        HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost));
-        lvlStart = lvl.data();
-    }
-    for (int it = 0; it < totalIt; ++it) {
-        const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
-        const int writeRows = it >= P.iterations ? 1 : 0;
-        for (int l = 0; l < L; ++l) {
-            const int count = lvlStart[l + 1] - lvlStart[l];
-            if (count <= 0) continue;
-            /* profiling: per-launch start/stop events (kernel begin → end, like a kernel trace) */
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-            hipExtLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, e0, e1, 0, B, M,
-                                  c->dG.p, c->order.p, c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p, it, c->dHostRows.p);
-            ++c->prof.launches_primal; ++c->prof.launches_total;
-        }
-        if (it < P.iterations) {
-            if (contactSlots > 0) {
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_DUAL, i0, i0 + 1}); }
-                hipExtLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, e0, e1, 0, B, M, c->dCnt.p, P, alphaCur);
-                ++c->prof.launches_dual; ++c->prof.launches_total;
-            }
-            if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
-        }
-    }
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-/* sharded runs: this rank's solved bodies → contiguous send rows / gathered rows → the other ranks' bodies */
-int step_pack(AvbdContext* c)
-{
-    const int first = c->hRankStart[(size_t)c->rank], count = c->hRankStart[(size_t)c->rank + 1] - first;
-    if (c->packFused) return AVBD_OK;                                   /* k_iterate wrote the rows when it published each pose */
-    if (count > 0)
-        hipLaunchKernelGGL(k_pack_poses, dim3(grid_for(count, 128, 1 << 20)), dim3(128), 0, c->stream, body_table(c), c->dPerm.p, first, count, c->dSend.p);
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-int step_unpack(AvbdContext* c)
-{
-    if (c->maxCount > 0)
-        hipLaunchKernelGGL(k_unpack_poses, dim3(grid_for(c->maxCount, 128, 1 << 20), c->nranks), dim3(128), 0, c->stream, body_table(c), c->dPerm.p,
-                           c->dRankStart.p, c->nranks, c->rank, c->maxCount, c->dRecv.p);
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-/* 13-float exchange: the velocity half, once per step after k_tail (the rows reuse the pose buffers) */
-int step_pack_velocities(AvbdContext* c)
-{
-    const int first = c->hRankStart[(size_t)c->rank], count = c->hRankStart[(size_t)c->rank + 1] - first;
-    if (count > 0)
-        hipLaunchKernelGGL(k_pack_velocities, dim3(grid_for(count, 128, 1 << 20)), dim3(128), 0, c->stream, body_table(c), c->dPerm.p, first, count, c->dSend.p);
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-int step_unpack_velocities(AvbdContext* c)
-{
-    if (!c->dXchMismatch.p) { HIPCHK(c, c->dXchMismatch.alloc(2)); HIPCHK(c, hipMemsetAsync(c->dXchMismatch.p, 0, 2 * sizeof(unsigned), c->stream)); }
-    if (c->maxCount > 0)
-        hipLaunchKernelGGL(k_unpack_velocities, dim3(grid_for(c->maxCount, 128, 1 << 20), c->nranks), dim3(128), 0, c->stream, body_table(c), c->dPerm.p,
-                           c->dRankStart.p, c->nranks, c->rank, c->maxCount, c->dRecv.p, c->dXchMismatch.p);
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-/* phases 5-6 of solver.cpp:434-497 */
-int step_end(AvbdContext* c, bool haveCounts)
-{
-    BodyTable B = body_table(c);
-    const int n = B.n;
-    const int ng = (int)c->hG.size();
-    SolverParams P = solver_params(c);
-    ManifoldTable M = c->mbuf[c->cur].view();
-    const Counters& cnt = c->hRb->cnt;
-    /* without a readback the grid sizes come from the last known counts (all kernels grid-stride) */
-    const long long contactSlots = haveCounts ? (long long)cnt.numManifolds * 4 : (long long)std::max(c->stats.numManifolds + c->stats.numCandidates, n) * 4 + 4096;
-    if (c->mode != 0 && (c->numStatic > 1 || ng > 0))
-        hipLaunchKernelGGL(k_dual_static, dim3(grid_for(contactSlots + ng, 128, 4096)), dim3(128), 0, c->stream, B, M, c->dCnt.p, c->dG.p, ng, P);
-    {
-        SpanGuard g(c, F_VELOCITY);
-        const int velBlocks = grid_for(n, 256, 1 << 20);
-        const int diagBlocks = contactSlots > 0 ? grid_for(contactSlots, 256, c->diagBlocksCap) : 1;   /* (grid-stride; every workgroup ends with five atomics on one line) */
-        hipLaunchKernelGGL(k_tail, dim3(velBlocks + diagBlocks), dim3(256), 0, c->stream, B, M, P, c->dCnt.p, c->dDiag.p, velBlocks);
-    }
-    HIPCHK(c, hipGetLastError());
-    c->deviceAhead = true;
-    if (ng) c->gDeviceAhead = true;
-    if (haveCounts) {
-        /* algorithmic bytes of this step's iteration loop */
-        const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
-        const double nbDyn = c->stats.numDynamic, ninc = cnt.numIncidences, ncon = cnt.numContacts;
-        if (c->mode == 0) {
-            c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc);
-            c->prof.algorithmic_bytes_dual += (double)P.iterations * (160.0 * ncon);
-        } else {
-            c->prof.algorithmic_bytes_primal += (double)totalIt * (100.0 * nbDyn + 124.0 * ninc) + (double)P.iterations * (160.0 * ncon);
-        }
-    }
-    ++c->prof.steps;
-    collect_spans(c);
-    return AVBD_OK;
-}
-
-int rccl_allgather(AvbdContext* c); /* below, next to the communicator set-up */
-int rccl_exchange_velocities(AvbdContext* c);
-int rccl_allgather_inplace(AvbdContext* c, float4* buffer, hipStream_t stream);
-
-/* Exchange stream without hipStreamWaitValue32 / WriteValue32 (AVBD_SHARD_GATE=kernel): a one-wave kernel that waits until a
- * rank's signal word says all its bodies are past iteration `it` (raised by the wave that completes the count, after the rows
- * have reached memory) — or until the launch is being abandoned —, optionally copies that rank's rows (avbd_group_step), and a one-thread
- * kernel that publishes "all-gather it has landed" to the word the waves poll. */
-__global__ void k_exchange_gate(const unsigned* signal, unsigned target, const int* errWord, float4* dst, const float4* src, int rows)
-{
-    if (threadIdx.x == 0) {
-        /* (the signal word is a stamp that only grows: base + iterations completed — nothing to reset between steps) */
-        while ((int)(__hip_atomic_load(signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0 &&
-               __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(32);
-    }
-    __syncthreads();
-    if (dst) {
-        const tile_v4u* s4 = reinterpret_cast<const tile_v4u*>(src);
-        tile_v4u* d4 = reinterpret_cast<tile_v4u*>(dst);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)s4, 0, rows * 16, 0x00020000), rd = __builtin_amdgcn_make_buffer_rsrc((void*)d4, 0, rows * 16, 0x00020000);
-        for (int i = threadIdx.x; i < rows; i += blockDim.x)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16), rd, i * 16, 0, 16);
-    }
-}
-__global__ void k_exchange_publish(unsigned* word, unsigned value)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-/* the stamp window wraps: the exchange stream's two words start from zero again (queued on the solver stream, before evBegin) */
-__global__ void k_reset_exchange_words(unsigned* sigDone, unsigned* sigGather)
-{
-    if (sigDone) __hip_atomic_store(sigDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (sigGather) __hip_atomic_store(sigGather, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-/* debug (AVBD_DEBUG_COPY_KERNEL): the device copy of avbd_group_step's exchange as a two-workgroup kernel of this library */
-__global__ void k_copy_rows(float4* dst, const float4* src, int n)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
-/* Sharded step, persistent form: has the device accepted the plan (every owned body in a sub-group of its own)?  One small
- * readback; the per-iteration schedule is the fallback. */
-int shard_plan_accepted(AvbdContext* c, bool& ok)
-{
-    ok = false;
-    if (!c->groupsPlanned) return AVBD_OK;
-    HIPCHK(c, hipMemcpyAsync(&c->hRb->plan, c->dPlan.p, sizeof(GroupPlan), hipMemcpyDeviceToHost, c->stream));
-    CutCounters cc{};                                                  /* exact cuts: the cut tables of the PREVIOUS step (this step's are built after this readback) */
-    if (c->dCutCnt.p && c->cutRanks > 0) HIPCHK(c, hipMemcpyAsync(&cc, c->dCutCnt.p, sizeof(CutCounters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (cc.overflow)
-        return c->fail(AVBD_E_CAPACITY, "exact cuts: more manifolds across the cuts than the cut tables hold (16 384 per pair of ranks, ranks x 16 384 in all): the previous step's "
-                                        "records of some cut contacts shared a slot, its results are not the single-GPU sweep's");
-    const GroupPlan& p = c->hRb->plan;
-    ok = p.bad == 0;
-    if (std::getenv("AVBD_DEBUG_PLAN"))
-        std::fprintf(stderr, "[avbd rank %d step %d] plan: classes %d/%d/%d waves %d/%d/%d rounds %d/%d/%d bad %d nd %d (W %d)\n", c->rank, c->stepIndex, p.nClass[0], p.nClass[1], p.nClass[2],
-                     p.waves[0], p.waves[1], p.waves[2], p.rounds[0], p.rounds[1], p.rounds[2], p.bad, p.nd, groups_waves(c));
-    c->shardMulti = p.rounds[0] > 1 || p.rounds[1] > 1 || p.rounds[2] > 1;     /* several bodies per sub-group: k_iterate_groups<true, 1> */
-    return AVBD_OK;
-}
-
-/* (re)size the exchange buffers of the persistent sharded step and upload the row of every body */
-int shard_prepare_buffers(AvbdContext* c)
-{
-    const size_t rows = (size_t)std::max(1, c->maxCount) * (size_t)c->nranks;
-    if (c->gatherRows < rows || !c->dDone.p) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, c->dGather[0].alloc(2 * rows)); HIPCHK(c, c->dGather[1].alloc(2 * rows));
-        HIPCHK(c, hipMemsetAsync(c->dGather[0].p, 0, 2 * rows * sizeof(float4), c->stream)); HIPCHK(c, hipMemsetAsync(c->dGather[1].p, 0, 2 * rows * sizeof(float4), c->stream));
-        HIPCHK(c, c->dDone.alloc(64));
-        c->gatherRows = rows;
-    }
-    if (c->dRow.n < (size_t)c->bodyCap || c->rowsStale) {
-        if (c->dRow.n < (size_t)c->bodyCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRow.alloc((size_t)c->bodyCap)); }
-        const int n = (int)c->hBodies.size();
-        if (n) HIPCHK(c, hipMemcpy(c->dRow.p, c->hRow.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        c->rowsStale = false;
-    }
-    return AVBD_OK;
-}
-
-/* Queue the persistent launch of a sharded step on the solver stream.  The caller queues the exchange (one wait -> gather ->
- * release per iteration) on c->stream2 and the final unpack. */
-int shard_launch_persistent(AvbdContext* c)
-{
-    int rc;
-    if ((rc = shard_prepare_buffers(c))) return rc;
-    BodyTable B = body_table(c);
-    SolverParams P = solver_params(c);
-    ManifoldTable M = c->mbuf[c->cur].view();
-    IterateState S;
-    S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
-    ResidentExchange X{};
-    X.pose = c->xPose.p; X.visit = c->xVisit.p; X.dual = c->xDual.p;
-    const size_t visitBytes = (size_t)4 * c->mCap * sizeof(float4), dualBytes = 2 * visitBytes + (size_t)4 * c->gCap * sizeof(float4), poseBytes = (size_t)3 * c->bodyCap * sizeof(float4);
-    if (c->xDual.n * sizeof(float4) < dualBytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, c->xDual.alloc(dualBytes / sizeof(float4)));
-        HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
-        X.dual = c->xDual.p;
-    }
-    X.poseBytes = (unsigned)poseBytes; X.visitBytes = (unsigned)visitBytes; X.dualBytes = (unsigned)dualBytes;
-    X.enabled = 1;
-    if (c->xSerial >= (1u << 24) - 2u) {
-        /* the stamps wrap: forget every old record AND the two words the exchange stream and the waves compare with stamps — left
-         * at ~2^30 they would satisfy every wait of the new window at once (the all-gathers would run ahead of the kernel) */
-        HIPCHK(c, hipMemsetAsync(c->xPose.p, 0, poseBytes, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->xVisit.p, 0, visitBytes, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->xDual.p, 0, dualBytes, c->stream));
-        hipLaunchKernelGGL(k_reset_exchange_words, dim3(1), dim3(1), 0, c->stream, c->sigDone, c->sigGather);
-        c->xSerial = 0;
-    }
-    ++c->xSerial;
-    X.base = c->xSerial * 64u;
-    ShardExchange Z{};
-    Z.gather[0] = c->dGather[0].p; Z.gather[1] = c->dGather[1].p;
-    Z.gatherBytes = (unsigned)(2 * c->gatherRows * sizeof(float4));
-    Z.row = c->dRow.p; Z.done = c->dDone.p; Z.doneSignal = c->sigDone; Z.gatherWord = c->sigGather;
-    Z.nOwned = c->hRankStart[(size_t)c->rank + 1] - c->hRankStart[(size_t)c->rank];
-    Z.keepExchangeWaiting = std::getenv("AVBD_DEBUG_KEEP_EXCHANGE_WAITING") ? 1 : 0;
-    HIPCHK(c, hipMemsetAsync(c->dDone.p, 0, 64 * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipEventRecord(c->evBegin, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evBegin, 0));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;      /* parked state of a sub-group's bodies (several rounds) */
-    auto kern = c->shardMulti ? k_iterate_groups<true, 1> : k_iterate_groups<false, 1>;
-    hipExtLaunchKernelGGL(kern, dim3(2 * c->iterBlocks), dim3(64 * kGrpWavesPerBlock), c->shardMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, c->stream, e0, e1, 0, B, M, c->incStart.p, c->inc.p, P,
-                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
-    ++c->prof.launches_primal; ++c->prof.launches_total;
-    HIPCHK(c, hipGetLastError());
-    c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false;
-    c->shardRanPersistent = true;
-    return AVBD_OK;
-}
-
-/* after the last all-gather: the other ranks' final poses into the body table, on the solver stream */
-int shard_finish_persistent(AvbdContext* c, int totalIt)
-{
-    HIPCHK(c, hipEventRecord(c->evGathered, c->stream2));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evGathered, 0));
-    if (c->maxCount > 0)
-        hipLaunchKernelGGL(k_unpack_poses, dim3(grid_for(c->maxCount, 128, 1 << 20), c->nranks), dim3(128), 0, c->stream, body_table(c), c->dPerm.p,
-                           c->dRankStart.p, c->nranks, c->rank, c->maxCount, c->dGather[(totalIt - 1) & 1].p);
-    HIPCHK(c, hipGetLastError());
-    return AVBD_OK;
-}
-
-/* ---- steps of a scene that contains user-defined Force subclasses (avbd_add_host_force) --------------------------------------
- * Their virtuals are the caller's code, so the rows of every visit are fetched from the host right before the launch that reads
- * them: one k_primal launch per Gauss-Seidel level (the level schedule is exact: bodies of a level share no force), host in
- * the loop for the levels that visit an endpoint of such a force and for the dual pass.  Slow by construction, exact by
- * construction: the subclass sees the same sequence of initialize / computeConstraint / computeDerivatives calls, with the same
- * body poses, as inside the reference's Solver::step (solver.cpp:273-296, 371-399, 411-430). */
-int host_current_pose(AvbdContext* c, int body, float out[7])
-{
-    float4 pq[2];
-    HIPCHK(c, hipMemcpyAsync(&pq[0], c->dPlanes.p + (size_t)BP_POSR * c->bodyCap + body, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&pq[1], c->dPlanes.p + (size_t)BP_QUAT * c->bodyCap + body, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    out[0] = pq[0].x; out[1] = pq[0].y; out[2] = pq[0].z; out[3] = pq[1].x; out[4] = pq[1].y; out[5] = pq[1].z; out[6] = pq[1].w;
-    return AVBD_OK;
-}
-
-int host_force_call(AvbdContext* c, int ord, int phase, float alpha, int body, bool fromDevice, AvbdHostRows& R)
-{
-    const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)ord]];
-    float pa[7], pb[7];
-    int rc;
-    for (int e = 0; e < 2; ++e) {
-        const int b = e == 0 ? g.bodyA : g.bodyB;
-        float* o = e == 0 ? pa : pb;
-        if (b < 0) continue;
-        if (fromDevice) { if ((rc = host_current_pose(c, b, o))) return rc; }
-        else { const AvbdBody& hb = c->hBodies[(size_t)b]; for (int k = 0; k < 3; ++k) o[k] = hb.position[k]; for (int k = 0; k < 4; ++k) o[3 + k] = hb.orientation[k]; }
-    }
-    if (c->hostFn(c->hostUser, ord, phase, alpha, body, g.bodyA >= 0 ? pa : nullptr, pb, &R) != 0)
-        return c->fail(AVBD_E_INVALID, "the host force callback reported an error");
-    if (R.rows == -1 && phase == AVBD_HOST_INITIALIZE) return AVBD_OK;  /* initialize() failed: the caller deletes the force */
-    if (R.rows < 0 || R.rows > 12) return c->fail(AVBD_E_INVALID, "host force: row count out of range (0..12)");
-    return AVBD_OK;
-}
-
-void host_rows_to_record(const AvbdHostRows& R, HostRowsDev& h, bool sideA, bool sideB)
-{
-    h.rows = R.rows;
-    for (int r = 0; r < 12; ++r) {
-        h.C[r] = R.C[r]; h.fmin[r] = R.fmin[r]; h.fmax[r] = R.fmax[r]; h.lambda[r] = R.lambda[r]; h.penalty[r] = R.penalty[r];
-        h.stiffness[r] = R.stiffness[r]; h.motor[r] = R.motor[r];
-        for (int k = 0; k < 3; ++k) {
-            if (sideA) { h.JlA[r][k] = R.JlA[r][k]; h.JaA[r][k] = R.JaA[r][k]; }
-            if (sideB) { h.JlB[r][k] = R.JlB[r][k]; h.JaB[r][k] = R.JaB[r][k]; }
-        }
-    }
-}
-
-int step_with_host_rows(AvbdContext* c)
-{
-    if (!c->hostFn) return c->fail(AVBD_E_INVALID, "a user-defined Force is registered (avbd_add_host_force) but no callback (avbd_set_host_force_callback)");
-    if (c->nranks > 1 || c->forceSharded) return c->fail(AVBD_E_INVALID, "user-defined Force subclasses are not supported in sharded runs");
-    int nh = (int)c->hostForceG.size();
-    const SolverParams P = solver_params(c);
-    int rc;
-    struct ModeGuard { AvbdContext* c; int saved; ~ModeGuard() { c->mode = saved; } } guard{c, c->mode};
-    c->mode = 0;                                                       /* level launches + level readback for this step */
-
-    /* ---- 2. initialize + warm start (solver.cpp:273-296) ---- */
-    if ((rc = download_bodies_to_host(c))) return rc;
-    if ((rc = gforces_to_host(c))) return rc;
-    std::vector<AvbdHostRows> R((size_t)nh);
-    std::vector<decltype(GForce::key)> dead;                           /* forces deleted by this step (their initialize() failed) */
-    for (int ord = 0; ord < nh; ++ord) {
-        std::memset(&R[(size_t)ord], 0, sizeof(AvbdHostRows));
-        if ((rc = host_force_call(c, ord, AVBD_HOST_INITIALIZE, P.alpha, -1, false, R[(size_t)ord]))) return rc;
-        AvbdHostRows& h = R[(size_t)ord];
-        if (h.rows < 0) {
-            /* its initialize() returned false: deleted (solver.cpp:274-279).  The caller has dropped ordinal `ord` too; the ordinals
-             * behind it move up by one on both sides, so the next force to initialise is `ord` again.  The reference deletes it
-             * AFTER this step's broadphase, which therefore still saw the pair as constrained: the record stays for this step as an
-             * ignore-collision marker (no rows) and leaves the list at the end of the step. */
-            const int gi = c->hostForceG[(size_t)ord];
-            c->hG[(size_t)gi].kind = FK_IGNORE; c->hG[(size_t)gi].pad = 0;
-            dead.push_back(c->hG[(size_t)gi].key);
-            c->hostForceG.erase(c->hostForceG.begin() + ord);
-            c->hHostRows.erase(c->hHostRows.begin() + ord);
-            R.erase(R.begin() + ord);
-            for (size_t o = (size_t)ord; o < c->hostForceG.size(); ++o) {
-                GForce& g = c->hG[(size_t)c->hostForceG[o]];
-                g.pad = (int)o | (int)((unsigned)g.pad & 0xFF000000u);
-            }
-            c->gStale = true; c->adjDirty = true;
-            --nh; --ord;
-            continue;
-        }
-        for (int i = 0; i < h.rows; ++i) {
-            if (!P.postStabilize) h.lambda[i] *= P.alpha * P.gamma;
-            h.penalty[i] = rclamp(h.penalty[i] * P.gamma, kPenaltyMin, kPenaltyMax);
-            if (h.stiffness[i] > 0.0f && h.stiffness[i] < FLT_MAX) h.penalty[i] = rmin(h.penalty[i], h.stiffness[i]);
-        }
-        if ((rc = host_force_call(c, ord, AVBD_HOST_STORE, P.alpha, -1, false, h))) return rc;
-        GForce& g = c->hG[(size_t)c->hostForceG[(size_t)ord]];
-        if (g.pad != (ord | (h.rows << 24))) { g.pad = ord | (h.rows << 24); c->gStale = true; }
-        host_rows_to_record(h, c->hHostRows[(size_t)ord], false, false);
-    }
-    if (c->dHostRows.n < (size_t)nh) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dHostRows.alloc((size_t)std::max(nh, 16))); }
-
-    if ((rc = step_begin(c))) return rc;
-    if ((rc = refresh_stats(c, true))) return rc;                      /* the level schedule of this step */
-    const Counters& cnt = c->hRb->cnt;
-    const int L = cnt.numLevels;
-    std::vector<int> lvl;
-    const int* lvlStart = c->hRb->lvlStart;
-    if (L > kReadbackLevels) {
-        lvl.resize((size_t)L + 1);
-        HIPCHK(c, hipMemcpy(lvl.data(), c->lvlStart.p, sizeof(int) * ((size_t)L + 1), hipMemcpyDeviceToHost));
-        lvlStart = lvl.data();
-    }
-    /* which level visits which endpoint: the level of a swept body */
-    std::vector<std::vector<std::pair<int, int>>> visits((size_t)std::max(L, 1));   /* per level: (body, host force), newest body first, newest force first */
-    {
-        std::vector<int> level((size_t)c->hBodies.size());
-        if (!level.empty()) HIPCHK(c, hipMemcpy(level.data(), c->level.p, level.size() * sizeof(int), hipMemcpyDeviceToHost));
-        std::vector<std::pair<uint64_t, int>> byKey;
-        for (int ord = 0; ord < nh; ++ord) byKey.push_back({c->hG[(size_t)c->hostForceG[(size_t)ord]].key, ord});
-        std::sort(byKey.begin(), byKey.end(), [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return a.first > b.first; });
-        for (const auto& kv : byKey) {
-            const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)kv.second]];
-            if (host_force_rows(g) == 0) continue;
-            for (int e = 0; e < 2; ++e) {
-                const int b = e == 0 ? g.bodyA : g.bodyB;
-                if (b < 0 || !(c->hBodies[(size_t)b].invMass > 0.0f)) continue;
-                const int lv = level[(size_t)b] - 1;                 /* k_levels numbers the levels from 1; launch l sweeps level l + 1 */
-                if (lv >= 0 && lv < L) visits[(size_t)lv].push_back({b, kv.second});
-            }
-        }
-        for (auto& v : visits) std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
-    }
-
-    BodyTable B = body_table(c);
-    ManifoldTable M = c->mbuf[c->cur].view();
-    const int ng = (int)c->hG.size();
-    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
-    const long long contactSlots = (long long)cnt.numManifolds * 4;
-    for (int it = 0; it < totalIt; ++it) {
-        const float alphaCur = P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha;
-        const int writeRows = it >= P.iterations ? 1 : 0;
-        for (int l = 0; l < L; ++l) {
-            const int count = lvlStart[l + 1] - lvlStart[l];
-            if (count <= 0) continue;
-            for (const auto& v : visits[(size_t)l]) {
-                /* the visit of body v.first calls computeConstraint + computeDerivatives of host force v.second (solver.cpp:371-376) */
-                AvbdHostRows& h = R[(size_t)v.second];
-                if ((rc = host_force_call(c, v.second, AVBD_HOST_PRIMAL, alphaCur, v.first, true, h))) return rc;
-                const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)v.second]];
-                h.rows = std::min(h.rows, host_force_rows(g));          /* the entries of this step were laid out for that many rows */
-                host_rows_to_record(h, c->hHostRows[(size_t)v.second], v.first == g.bodyA, v.first == g.bodyB);
-                HIPCHK(c, hipMemcpyAsync(c->dHostRows.p + v.second, &c->hHostRows[(size_t)v.second], sizeof(HostRowsDev), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));            /* (the source is reused by the next visit) */
-            }
-            hipLaunchKernelGGL(k_primal, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, c->stream, B, M, c->dG.p, c->order.p,
-                               c->lvlStart.p, l, c->incStart.p, c->inc.p, P, alphaCur, writeRows, c->dCnt.p, it, c->dHostRows.p);
-            ++c->prof.launches_primal; ++c->prof.launches_total;
-        }
-        if (it < P.iterations) {
-            if (contactSlots > 0) hipLaunchKernelGGL(k_dual, dim3(grid_for(contactSlots, 128, 1 << 20)), dim3(128), 0, c->stream, B, M, c->dCnt.p, P, alphaCur);
-            if (ng) hipLaunchKernelGGL(k_dual_gforce, dim3(grid_for(ng, 128)), dim3(128), 0, c->stream, B, c->dG.p, ng, P);
-            for (int ord = 0; ord < nh; ++ord) {
-                /* solver.cpp:411-430 for a host force: computeConstraint, then the row update with rowPenaltyGain (solver.cpp:94-125) */
-                AvbdHostRows& h = R[(size_t)ord];
-                const GForce& g = c->hG[(size_t)c->hostForceG[(size_t)ord]];
-                if (host_force_rows(g) == 0) continue;
-                if ((rc = host_force_call(c, ord, AVBD_HOST_DUAL, alphaCur, -1, true, h))) return rc;
-                h.rows = std::min(h.rows, host_force_rows(g));
-                for (int row = 0; row < h.rows; ++row) {
-                    if (h.stiffness[row] != FLT_MAX) continue;
-                    const float lu = rclamp(h.penalty[row] * h.C[row] + h.lambda[row], h.fmin[row], h.fmax[row]);
-                    const bool active = lu > h.fmin[row] && lu < h.fmax[row];
-                    h.lambda[row] = lu;
-                    if (active) {
-                        float lw = 0.0f, aw = 0.0f;
-                        if (g.bodyA >= 0) { lw += lensq3(mk3(h.JlA[row][0], h.JlA[row][1], h.JlA[row][2])); aw += lensq3(mk3(h.JaA[row][0], h.JaA[row][1], h.JaA[row][2])); }
-                        lw += lensq3(mk3(h.JlB[row][0], h.JlB[row][1], h.JlB[row][2])); aw += lensq3(mk3(h.JaB[row][0], h.JaB[row][1], h.JaB[row][2]));
-                        const float betaRow = row_penalty_gain(lw, aw, P.beta);
-                        h.penalty[row] = rmin(h.penalty[row] + betaRow * fabsf(h.C[row]), kPenaltyMax);
-                    }
-                }
-                if ((rc = host_force_call(c, ord, AVBD_HOST_STORE, alphaCur, -1, true, h))) return rc;
-            }
-        }
-    }
-    HIPCHK(c, hipGetLastError());
-    if ((rc = step_end(c, true))) return rc;
-    if (!dead.empty()) {
-        if ((rc = gforces_to_host(c))) return rc;
-        for (const auto key : dead)
-            for (size_t gi = 0; gi < c->hG.size(); ++gi)
-                if (c->hG[gi].key == key && c->hG[gi].kind == FK_IGNORE) {
-                    c->hG.erase(c->hG.begin() + (long)gi);
-                    for (int& x : c->hostForceG) if (x > (int)gi) --x;
-                    break;
-                }
-        c->gStale = true; c->adjDirty = true;
-    }
-    return AVBD_OK;
-}
-
-/* per-step tables of the exact cuts (avbd_cuts.h), sized by the manifold pool AND the number of ranks */
-int exact_cut_buffers(AvbdContext* c, int n, int cutManifolds)
-{
-    if (c->cutOfCap < (size_t)c->mCap || c->cutRanks != n) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, c->dCutOf.alloc((size_t)c->mCap)); HIPCHK(c, c->dCutMan.alloc((size_t)n * cutManifolds)); HIPCHK(c, c->dCutKeys.alloc((size_t)n * cutManifolds));
-        HIPCHK(c, c->dCutCnt.alloc(1));
-        HIPCHK(c, hipMemsetAsync(c->dCutCnt.p, 0, sizeof(CutCounters), c->stream));
-        c->cutOfCap = (size_t)c->mCap; c->cutRanks = n;
-    }
-    return AVBD_OK;
-}
-
-/* ---- exact cuts between ranks that are PROCESSES (avbd_exact_window_export / _attach) -------------------------------------------
- * Window of a rank = one hipMalloc'ed block, the same layout on every rank:
- *   [ head: 64 words, word 0 = last step whose records are complete ][ pose: 2 sets of 3 per body ][ visit: L + cuts ][ dual: 2 * (L + cuts) ]
- * with L = 4 * manifold capacity local record slots and n * n * kExactCutManifolds * 4 slots for the contacts across cuts, at the index
- * k_cut_fill gives both ranks of a cut alike.  A rank writes into its own window and reads a partner's records from the window of the
- * rank that sweeps the partner (ShardExchange::peerPose / peerVisit / peerDual). */
-constexpr int kExactCutManifolds = 16384;
-constexpr size_t kWindowHeadFloat4 = 16;
-size_t exact_window_slots(const AvbdContext* c, int n) { return (size_t)4 * c->mCap + (size_t)n * n * kExactCutManifolds * 4; }
-size_t exact_window_float4(const AvbdContext* c, int n) { return kWindowHeadFloat4 + (size_t)6 * c->bodyCap + 3 * exact_window_slots(c, n); }
-
-int exact_process_step(AvbdContext* c, bool needReadback)
-{
-    int rc;
-    const int n = c->nranks;
-    const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
-    const char* why = nullptr;
-    for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) why = "the scene has joints or springs (exact cuts carry contacts only)";
-    if (!why && !c->exactAllowed) why = "the exact-cut kernels do not fit two workgroups per CU on this device / this build";
-    if (!why && !c->groupsPlanned) why = "the group schedule was not planned (levels mode, more than 60 iterations, or no swept body)";
-    if (!why && (c->xwBodyCap != c->bodyCap || c->xwMCap != c->mCap)) why = "the pools have grown since the window was exported: export and attach again";
-    if (why) {
-        char msg[384];
-        std::snprintf(msg, sizeof(msg), "exact cuts between processes (avbd_exact_window_attach) cannot run this step: %s", why);
-        return c->fail(AVBD_E_INVALID, msg);
-    }
-    const size_t localSlots = (size_t)4 * c->mCap, total = exact_window_slots(c, n);
-    if ((rc = exact_cut_buffers(c, n, kExactCutManifolds))) return rc;
-    if (c->recIdxCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRecIdx.alloc((size_t)c->incCap)); c->recIdxCap = (size_t)c->incCap; }
-    BodyTable B = body_table(c);
-    SolverParams P = solver_params(c);
-    ManifoldTable M = c->mbuf[c->cur].view();
-    const int cutCap = n * kExactCutManifolds;
-    HIPCHK(c, hipMemsetAsync(c->dCutCnt.p, 0, sizeof(CutCounters), c->stream));
-    hipLaunchKernelGGL(k_cut_list, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, M, c->dCnt.p, c->dOwner.p, n, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p);
-    hipLaunchKernelGGL(k_cut_rank, dim3(grid_for(cutCap, 128, 1024)), dim3(128), 0, c->stream, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p, kExactCutManifolds);
-    hipLaunchKernelGGL(k_cut_fill, dim3(grid_for(std::max(1, c->numSolved), 128, 4096)), dim3(128), 0, c->stream, B, M, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->inc.p,
-                       c->dOwner.p, n, c->rank, c->dCutOf.p, 0, (int)localSlots, kExactCutManifolds, c->dRecIdx.p);
-    /* stamps: 64 per step, the same on every rank (all ranks step together from the attach on).  A window is never cleared once attached —
-     * a peer may be reading it — so the stamps must not wrap: 2^26 steps, then the ranks must attach fresh windows. */
-    if (c->xwSerial >= (1u << 26) - 2u) return c->fail(AVBD_E_INVALID, "exact cuts between processes: the stamps of this window are used up (2^26 steps): export and attach fresh windows");
-    ++c->xwSerial;
-    IterateState S;
-    S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
-    /* TWO sets of pose records, by the parity of the step: a peer copies this rank's final poses of step s (k_unpack_records, behind its wait
-     * for this rank's "step s complete") while this rank may already be publishing the poses of step s + 1 — it cannot be two steps ahead, its
-     * own wait for the peer's "step s + 1 complete" stands in between.  Visit / dual records are only read inside the peers' loop kernels. */
-    const size_t poseSet = (size_t)(c->xwSerial & 1u) * 3 * c->bodyCap;
-    auto posePtr = [&](float4* w) { return w + kWindowHeadFloat4 + poseSet; };
-    auto visitPtr = [&](float4* w) { return w + kWindowHeadFloat4 + (size_t)6 * c->bodyCap; };
-    auto dualPtr = [&](float4* w) { return w + kWindowHeadFloat4 + (size_t)6 * c->bodyCap + total; };
-    ResidentExchange X{};
-    X.pose = posePtr(c->xwPeer[c->rank]); X.visit = visitPtr(c->xwPeer[c->rank]); X.dual = dualPtr(c->xwPeer[c->rank]);
-    X.poseBytes = (unsigned)((size_t)3 * c->bodyCap * sizeof(float4)); X.visitBytes = (unsigned)(total * sizeof(float4)); X.dualBytes = (unsigned)(2 * total * sizeof(float4));
-    X.enabled = 1; X.base = c->xwSerial * 64u;
-    X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;
-    ShardExchange Z{};
-    Z.xPose = X.pose; Z.xVisit = X.visit; Z.xDual = X.dual;
-    Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;
-    Z.recIdx = c->dRecIdx.p; Z.nPeers = n; Z.owner = c->dOwner.p;
-    PeerWindows PW{}; PW.n = n;
-    for (int q = 0; q < n; ++q) {
-        Z.peerPose[q] = posePtr(c->xwPeer[q]); Z.peerVisit[q] = visitPtr(c->xwPeer[q]); Z.peerDual[q] = dualPtr(c->xwPeer[q]);
-        PW.pose[q] = Z.peerPose[q]; PW.head[q] = reinterpret_cast<volatile unsigned*>(c->xwPeer[q]);
-    }
-    if (c->xwSharedDevice) {
-        /* Ranks that share a device: no loop kernel starts before EVERY rank's front end has run.  The loop kernels of the other ranks leave
-         * 256 free registers on every SIMD they sit on, k_narrowphase needs 278: a rank whose front end is still queued when the others' loops
-         * are resident never gets to run it, and they wait for its records (one run in three of the four-process test ended in that time-out).
-         * Word 1 of the window heads: "the tables of step s are built".  One rank per device has the device to itself and skips this. */
-        hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, c->stream, PW.head[c->rank], 1, c->xwSerial);
-        hipLaunchKernelGGL(k_wait_peers, dim3(1), dim3(64), 0, c->stream, PW, c->rank, 1, c->xwSerial, S.error, (unsigned long long)kSpinTimeoutTicks * 2ull);
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling) { size_t i0 = c->evUsed; e0 = next_event(c); e1 = next_event(c); c->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-    /* both forms of the loop, one behind the other: the plan says which one runs (the other returns at once); the host never reads it back */
-    const int wg = std::max(1, groups_waves(c) / kGrpWavesPerBlock);
-    hipLaunchKernelGGL(k_plan_guard, dim3(1), dim3(1), 0, c->stream, (const GroupPlan*)c->dPlan.p, (const CutCounters*)c->dCutCnt.p, S.error);
-    hipExtLaunchKernelGGL((k_iterate_groups<false, 2>), dim3(wg), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytes, c->stream, e0, nullptr, 0, B, M, c->incStart.p, c->inc.p, P,
-                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
-    hipExtLaunchKernelGGL((k_iterate_groups<true, 2>), dim3(wg), dim3(64 * kGrpWavesPerBlock), kGrpLdsBytesMulti, c->stream, nullptr, e1, 0, B, M, c->incStart.p, c->inc.p, P,
-                          S.error, c->dCnt.p, X, c->dPlan.p, c->dUnit.p, c->bodyCap, c->iterSleep, Z);
-    ++c->prof.launches_primal; ++c->prof.launches_total;
-    c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true; c->cutModeRan = 3;
-    hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, c->stream, PW.head[c->rank], 0, c->xwSerial);
-    hipLaunchKernelGGL(k_wait_peers, dim3(1), dim3(64), 0, c->stream, PW, c->rank, 0, c->xwSerial, S.error, (unsigned long long)kSpinTimeoutTicks * 2ull);
-    hipLaunchKernelGGL(k_unpack_records, dim3(grid_for((int)c->hBodies.size(), 256, 1024)), dim3(256), 0, c->stream, B, c->dOwner.p, c->rank, PW);
-    HIPCHK(c, hipGetLastError());
-    return step_end(c, needReadback);
-}
+#include "avbd_capi_exact.inc"
 
 int step_once(AvbdContext* c)
 {
@@ -1727,87 +890,7 @@ void turn_end(AvbdContext* c)
 }
 } // namespace
 
-/* ---- schedule options ------------------------------------------------------------------------------------------------------------
- * ONE entry point, avbd_set_option(ctx, key, value), for everything that selects a schedule or a form of a kernel (VERDICT round 3:
- * "a library that changes schedule on process environment is not an API").  Every option leaves the results bit-identical — they
- * choose HOW the reference's sweep is run, tests/test_gpu_options.py runs each of them against the oracle.  The environment
- * variables AVBD_<KEY IN CAPITALS> remain as a debug override, read once when a context is created. */
-#define AVBD_OPTION_LIST(INT, BOOL)                                                                                                      \
-    INT("mode", mode, 0, 1)                       /* 0: one launch per Gauss-Seidel level, 1: data-flow schedules (default) */             \
-    BOOL("force_sharded", forceSharded)           /* one rank, but the sharded schedule */                                                 \
-    INT("shard_persistent", shardPersistent, -1, 1) /* all-gather form: 1 one persistent launch per step also across devices, 0 one launch per iteration */ \
-    INT("iter_blocks", iterBlocks, 1, 1 << 20)    /* workgroups of the iteration launch (clamped to what is resident on the device) */    \
-    INT("iter_mode", iterForceMode, 0, 2)                                                                                                  \
-    INT("iter_sleep", iterSleep, 0, 3)            /* back-off of a wave that found nothing to run: s_sleep 1 / 2 / 4 / 8 */                 \
-    BOOL("resident", residentAllowed)             /* the schedules with one launch for the whole loop */                                   \
-    BOOL("race_check", raceCheck)                 /* debug race checker before every loop */                                               \
-    BOOL("single_kernel", singleKernel)           /* k_iterate_single for scenes with a wave per body */                                   \
-    BOOL("place", placeChains)                    /* chains of hand-offs share a workgroup */                                              \
-    INT("group_spec", groupSpecMode, 0, 2)        /* several bodies per sub-group: a task in hand 0 when the wave is idle, 1 always, 2 never */ \
-    INT("group_spec_rounds", groupSpecRounds, 0, 64)                                                                                       \
-    BOOL("group_dep", groupDep)                   /* arrival counters */                                                                   \
-    BOOL("group_dep_keep", groupDepKeep)                                                                                                   \
-    BOOL("group_pool", groupPool)                 /* several bodies per sub-group: the sub-groups of a class-0 workgroup share their bodies */  \
-    INT("group_pool_min_rounds", groupPoolMinRounds, 2, 16)                                                                                \
-    BOOL("shard_gate_kernel", shardGateKernel)                                                                                             \
-    INT("groups", groupsMode, -1, 1)              /* 1: the group schedule for every scene it can run, 0: never, -1: by size */            \
-    INT("groups_rounds", groupsMaxRounds, 1, 16)                                                                                           \
-    INT("groups_waves", groupsWaves, 0, 1 << 20)                                                                                           \
-    BOOL("resident_multi", residentMultiAllowed)                                                                                           \
-    BOOL("resident_force_lite", residentForceLite)                                                                                         \
-    INT("resident_lite_from", residentLiteFrom, 0, 1 << 20)                                                                                \
-    INT("resident_ooo", residentOutOfOrder, -1, 1)                                                                                         \
-    INT("resident_patience", residentPatience, 0, 1 << 30)                                                                                 \
-    INT("resident_quiet", residentQuiet, 0, 1000)                                                                                          \
-    BOOL("grid_broadphase", gridBroadphase)       /* 0: the n^2 tile kernel (SURVEY section 8 f1's parity reference) */                     \
-    BOOL("order_by_index", orderByIndex)          /* 0: sweep order by dependency level */                                                 \
-    BOOL("fused_topology", fusedTopology)                                                                                                  \
-    BOOL("fused_front", fusedFront)                                                                                                        \
-    INT("diag_blocks", diagBlocksCap, 1, 4096)                                                                                            \
-    BOOL("debug_shared_multi", debugSharedMulti)  /* debug: more than two contexts of one device in the persistent several-bodies all-gather form (see avbd_group_step) */
-
-static int option_access(AvbdContext* c, const char* key, int* v, bool set)
-{
-#define OPT_INT(name, field, lo, hi) if (!std::strcmp(key, name)) { if (set) c->field = std::max(lo, std::min(hi, *v)); else *v = (int)c->field; return AVBD_OK; }
-#define OPT_BOOL(name, field) if (!std::strcmp(key, name)) { if (set) c->field = *v != 0; else *v = c->field ? 1 : 0; return AVBD_OK; }
-    AVBD_OPTION_LIST(OPT_INT, OPT_BOOL)
-#undef OPT_INT
-#undef OPT_BOOL
-    if (!std::strcmp(key, "shard_exact")) {                            /* = avbd_set_shard_mode */
-        if (set) { if (*v < 0 || *v > 2) return AVBD_E_INVALID; c->shardExact = *v != 0; c->shardExactStrict = *v != 2; }
-        else *v = c->shardExact ? (c->shardExactStrict ? 1 : 2) : 0;
-        return AVBD_OK;
-    }
-    if (!std::strcmp(key, "resident_serial")) {                        /* tests: start near the wrap of the stamps */
-        if (set) c->xSerial = (unsigned)*v; else *v = (int)c->xSerial;
-        return AVBD_OK;
-    }
-    return AVBD_E_INVALID;
-}
-static const char* const kOptionKeys[] = {
-#define OPT_KEY(name, ...) name,
-    AVBD_OPTION_LIST(OPT_KEY, OPT_KEY)
-#undef OPT_KEY
-    "shard_exact", "resident_serial"};
-
-static void apply_env_options(AvbdContext* c)
-{
-    for (const char* key : kOptionKeys) {
-        char env[96] = "AVBD_";
-        size_t n = 5;
-        for (const char* p = key; *p && n + 1 < sizeof(env); ++p) env[n++] = (char)std::toupper((unsigned char)*p);
-        env[n] = 0;
-        const char* e = std::getenv(env);
-        if (!e) continue;
-        int v = std::atoi(e);
-        if (!std::strcmp(key, "mode")) v = (std::strcmp(e, "levels") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
-        (void)option_access(c, key, &v, true);
-    }
-    /* the spellings older tools use */
-    if (const char* e = std::getenv("AVBD_BROADPHASE")) c->gridBroadphase = std::strcmp(e, "n2") != 0;
-    if (const char* e = std::getenv("AVBD_ORDER")) c->orderByIndex = std::strcmp(e, "levels") != 0;
-    if (const char* e = std::getenv("AVBD_SHARD_GATE")) c->shardGateKernel = std::strcmp(e, "kernel") == 0;
-}
+#include "avbd_capi_options.inc"
 
 int avbd_create(int device, AvbdContext** out)
 {
@@ -2253,166 +1336,7 @@ namespace {
 struct SnapshotHeader { char magic[8]; int bodyBytes, forceBytes, nBodies, nForces, stepIndex, reserved; AvbdParams params; };
 }
 
-/* Every record that reaches the device tables comes through here first (uploads, snapshots from a file, removals): a bad
- * index or count must never become an out-of-bounds access in a kernel or in the host packing loops. */
-static int validate_forces(AvbdContext* c, const AvbdForce* in, int n, int nBodies)
-{
-    char why[160];
-    for (int i = 0; i < n; ++i) {
-        const AvbdForce& f = in[i];
-        const char* bad = nullptr;
-        if (f.kind != AVBD_FORCE_MANIFOLD && f.kind != AVBD_FORCE_JOINT && f.kind != AVBD_FORCE_SPRING && f.kind != AVBD_FORCE_IGNORE) bad = f.kind == AVBD_FORCE_HOST ? "a user-defined Force cannot be restored from a record (its state lives in the caller's object)" : "unknown kind";
-        else if (f.bodyB < 0 || f.bodyB >= nBodies || f.bodyA < -1 || f.bodyA >= nBodies) bad = "body index out of range";
-        else if (f.kind != AVBD_FORCE_JOINT && f.bodyA < 0) bad = "only a Joint may be anchored to the world";
-        else if (f.rows < 0 || f.rows > 12) bad = "row count out of range";
-        else if (f.kind == AVBD_FORCE_MANIFOLD && (f.numContacts < 0 || f.numContacts > 4)) bad = "numContacts out of range";
-        else if (f.kind == AVBD_FORCE_MANIFOLD && f.bodyA == f.bodyB) bad = "manifold between a body and itself";
-        if (bad) {
-            std::snprintf(why, sizeof(why), "force record %d: %s (kind %d, bodies %d/%d, rows %d, contacts %d)", i, bad, f.kind, f.bodyA, f.bodyB, f.rows, f.numContacts);
-            return c->fail(AVBD_E_INVALID, why);
-        }
-    }
-    return AVBD_OK;
-}
-
-static int upload_forces_keyed(AvbdContext* c, const AvbdForce* in, int n, const uint64_t* keys);
-static int restore_state(AvbdContext* c, const AvbdParams& params, int stepIndex, const AvbdBody* bodies, int nBodies, const AvbdForce* forces, int nForces,
-                         const uint64_t* keys = nullptr)
-{
-    int rc;
-    /* validate BEFORE touching the context: a failed restore leaves the old scene in place */
-    if (nBodies < 0 || nForces < 0 || nBodies > (1 << 20) - 2 || stepIndex < 0) return c->fail(AVBD_E_INVALID, "restore: counts out of range");
-    if (!(params.iterations >= 0 && params.iterations <= 100000) || !(params.dt == params.dt)) return c->fail(AVBD_E_INVALID, "restore: parameters out of range");
-    if ((rc = validate_forces(c, forces, nForces, nBodies))) return rc;
-    {
-        int nm = 0;
-        for (int i = 0; i < nForces; ++i) nm += forces[i].kind == AVBD_FORCE_MANIFOLD;
-        int cap = std::max(1024, c->bodyCap);                         /* what ensure_capacity will size the manifold pool to */
-        while (cap < nBodies) cap *= 2;
-        if (nm > std::max(std::max(8192, cap * 16), c->mCap)) return c->fail(AVBD_E_CAPACITY, "restore: more manifolds than the pool of this many bodies can hold");
-    }
-    if ((rc = avbd_clear(c))) return rc;
-    if ((rc = avbd_set_params(c, &params))) return rc;
-    for (int i = 0; i < nBodies; ++i) {
-        const AvbdBody& b = bodies[(size_t)i];
-        float I9[9], J9[9];
-        for (int k = 0; k < 9; ++k) { I9[k] = 0.0f; J9[k] = 0.0f; }
-        if (b.invMass > 0.0f) {                                       /* rigid.cpp:31-40 from the stored mass: same bits as at creation */
-            const float Ixx = (1.0f / 12.0f) * b.mass * (b.size[1] * b.size[1] + b.size[2] * b.size[2]);
-            const float Iyy = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[2] * b.size[2]);
-            const float Izz = (1.0f / 12.0f) * b.mass * (b.size[0] * b.size[0] + b.size[1] * b.size[1]);
-            I9[0] = Ixx; I9[4] = Iyy; I9[8] = Izz;
-            J9[0] = 1.0f / Ixx; J9[4] = 1.0f / Iyy; J9[8] = 1.0f / Izz;
-        } else ++c->numStatic;
-        c->hBodies.push_back(b);
-        c->hI.insert(c->hI.end(), I9, I9 + 9);
-        c->hJ.insert(c->hJ.end(), J9, J9 + 9);
-    }
-    c->bodiesStale = true; c->adjDirty = true;
-    if ((rc = upload_forces_keyed(c, forces, nForces, keys))) return rc;
-    c->stepIndex = stepIndex;
-    return AVBD_OK;
-}
-
-int avbd_set_step_index(AvbdContext* c, int stepIndex)
-{
-    if (!c || stepIndex < 0) return AVBD_E_INVALID;
-    c->stepIndex = stepIndex;
-    return AVBD_OK;
-}
-
-int avbd_save_snapshot(AvbdContext* c, const char* path)
-{
-    if (!c || !path) return AVBD_E_INVALID;
-    const int nb = avbd_num_bodies(c), nf = avbd_num_forces(c);
-    if (nb < 0 || nf < 0) return c->fail(AVBD_E_INVALID, "avbd_save_snapshot: cannot count the state");
-    std::vector<AvbdBody> bodies((size_t)std::max(nb, 1));
-    std::vector<AvbdForce> forces((size_t)std::max(nf, 1));
-    int rc;
-    if (nb && (rc = avbd_download_bodies(c, bodies.data(), nb)) < 0) return rc;
-    if (nf && (rc = avbd_download_forces(c, forces.data(), nf)) < 0) return rc;
-    SnapshotHeader h;
-    std::memset(&h, 0, sizeof(h));
-    std::memcpy(h.magic, "AVBDSNP1", 8);
-    h.bodyBytes = (int)sizeof(AvbdBody); h.forceBytes = (int)sizeof(AvbdForce); h.nBodies = nb; h.nForces = nf; h.stepIndex = c->stepIndex; h.params = c->params;
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return c->fail(AVBD_E_INVALID, "avbd_save_snapshot: cannot open the file for writing");
-    bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1;
-    if (ok && nb) ok = std::fwrite(bodies.data(), sizeof(AvbdBody), (size_t)nb, f) == (size_t)nb;
-    if (ok && nf) ok = std::fwrite(forces.data(), sizeof(AvbdForce), (size_t)nf, f) == (size_t)nf;
-    ok = (std::fclose(f) == 0) && ok;
-    return ok ? AVBD_OK : c->fail(AVBD_E_INVALID, "avbd_save_snapshot: short write");
-}
-
-int avbd_load_snapshot(AvbdContext* c, const char* path)
-{
-    if (!c || !path) return AVBD_E_INVALID;
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return c->fail(AVBD_E_INVALID, "avbd_load_snapshot: cannot open the file");
-    SnapshotHeader h;
-    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "AVBDSNP1", 8) == 0 && h.bodyBytes == (int)sizeof(AvbdBody) &&
-              h.forceBytes == (int)sizeof(AvbdForce) && h.nBodies >= 0 && h.nForces >= 0 && h.nBodies <= (1 << 20) - 2;
-    std::vector<AvbdBody> bodies; std::vector<AvbdForce> forces;
-    if (ok) {
-        /* the counts must agree with the size of the file before anything is allocated from them */
-        long here = std::ftell(f), end = -1;
-        if (here >= 0 && std::fseek(f, 0, SEEK_END) == 0) { end = std::ftell(f); (void)std::fseek(f, here, SEEK_SET); }
-        const long long need = (long long)h.nBodies * (long long)sizeof(AvbdBody) + (long long)h.nForces * (long long)sizeof(AvbdForce);
-        ok = here >= 0 && end >= here && (long long)(end - here) == need;
-    }
-    if (ok) {
-        try {
-            bodies.resize((size_t)std::max(h.nBodies, 1)); forces.resize((size_t)std::max(h.nForces, 1));
-        } catch (...) { std::fclose(f); return c->fail(AVBD_E_CAPACITY, "avbd_load_snapshot: out of host memory"); }
-        if (h.nBodies) ok = std::fread(bodies.data(), sizeof(AvbdBody), (size_t)h.nBodies, f) == (size_t)h.nBodies;
-        if (ok && h.nForces) ok = std::fread(forces.data(), sizeof(AvbdForce), (size_t)h.nForces, f) == (size_t)h.nForces;
-    }
-    std::fclose(f);
-    if (!ok) return c->fail(AVBD_E_INVALID, "avbd_load_snapshot: not a snapshot of this ABI version, or truncated");
-    return restore_state(c, h.params, h.stepIndex, bodies.data(), h.nBodies, forces.data(), h.nForces);
-}
-
-/* Removal (`delete body` / `delete force` in the reference, rigid.cpp:43-49, force.cpp:31-69): the device state is compact and
- * indexed by creation order, so a removal rebuilds it from its own snapshot with the element left out.  Removing a body also
- * removes every force attached to it (the reference leaves them dangling — undefined behaviour there).  Bodies created after
- * the removed one move down by one index; relative order, hence every result-relevant order, is preserved. */
-int avbd_remove_body(AvbdContext* c, int index)
-{
-    if (!c) return AVBD_E_INVALID;
-    const int nb = avbd_num_bodies(c), nf = avbd_num_forces(c);
-    if (index < 0 || index >= nb) return c->fail(AVBD_E_INVALID, "avbd_remove_body: index out of range");
-    std::vector<AvbdBody> bodies((size_t)nb);
-    std::vector<AvbdForce> forces((size_t)std::max(nf, 1));
-    int rc;
-    if ((rc = avbd_download_bodies(c, bodies.data(), nb)) < 0) return rc;
-    if (nf && (rc = avbd_download_forces(c, forces.data(), nf)) < 0) return rc;
-    bodies.erase(bodies.begin() + index);
-    std::vector<AvbdForce> kept;
-    for (int i = 0; i < nf; ++i) {
-        AvbdForce f = forces[(size_t)i];
-        if (f.bodyA == index || f.bodyB == index) continue;
-        if (f.bodyA > index) --f.bodyA;
-        if (f.bodyB > index) --f.bodyB;
-        kept.push_back(f);
-    }
-    const AvbdParams p = c->params;
-    return restore_state(c, p, c->stepIndex, bodies.data(), nb - 1, kept.data(), (int)kept.size());
-}
-
-int avbd_remove_force(AvbdContext* c, int list_index)
-{
-    if (!c) return AVBD_E_INVALID;
-    const int nb = avbd_num_bodies(c), nf = avbd_num_forces(c);
-    if (list_index < 0 || list_index >= nf) return c->fail(AVBD_E_INVALID, "avbd_remove_force: index out of range");
-    std::vector<AvbdBody> bodies((size_t)std::max(nb, 1));
-    std::vector<AvbdForce> forces((size_t)nf);
-    int rc;
-    if (nb && (rc = avbd_download_bodies(c, bodies.data(), nb)) < 0) return rc;
-    if ((rc = avbd_download_forces(c, forces.data(), nf)) < 0) return rc;
-    forces.erase(forces.begin() + list_index);
-    const AvbdParams p = c->params;
-    return restore_state(c, p, c->stepIndex, bodies.data(), nb, forces.data(), nf - 1);
-}
+#include "avbd_capi_state.inc"
 
 int avbd_step(AvbdContext* c, int nsteps)
 {
@@ -2839,222 +1763,8 @@ static int upload_forces_keyed(AvbdContext* c, const AvbdForce* in, int n, const
 
 /* ---- row API on the device ------------------------------------------------------------- */
 namespace {
-__global__ void k_row_api(BodyTable B, ManifoldTable M, GForce* gf, int kind, int index, float alpha, int mode, int body, int row, float* out)
-{
-    /* out: mode 0 → C[12] fmin[12] fmax[12] lambda[12]; mode 1 → Jl[3] Ja[3] */
-    if (threadIdx.x != 0) return;
-    if (kind == FK_MANIFOLD) {
-        const int2 pr = M.pair[index];
-        const f3 posA = ld3(B.plane(BP_POSR), pr.x), posB = ld3(B.plane(BP_POSR), pr.y);
-        const q4 rotA = ldq(B.plane(BP_QUAT), pr.x), rotB = ldq(B.plane(BP_QUAT), pr.y);
-        const float imA = B.plane(BP_MASS)[pr.x].y, imB = B.plane(BP_MASS)[pr.y].y;
-        const int nc = M.nc[index];
-        for (int ci = 0; ci < nc; ++ci) {
-            if (mode == 1 && ci != row / 3) continue;
-            const int s = index * 4 + ci;
-            ContactRows c;
-            load_contact<false>(M, s, c);
-            if (mode == 0) {
-                ContactBasis db;
-                contact_compute_constraint(c, alpha, posA, rotA, imA, posB, rotB, imB, M.fric[index], db);
-                store_contact_mutations<false>(M, s, c, true);
-                for (int k = 0; k < 3; ++k) { out[ci * 3 + k] = c.C[k]; out[12 + ci * 3 + k] = c.fmin[k]; out[24 + ci * 3 + k] = c.fmax[k]; out[36 + ci * 3 + k] = c.lambda[k]; }
-            } else {
-                const bool isA = body == pr.x;
-                f3 Jl[3], Ja[3];
-                contact_compute_derivatives(c, isA, isA ? rotA : rotB, Jl, Ja);
-                const int k = row % 3;
-                out[0] = Jl[k].x; out[1] = Jl[k].y; out[2] = Jl[k].z; out[3] = Ja[k].x; out[4] = Ja[k].y; out[5] = Ja[k].z;
-            }
-        }
-    } else if (kind == FK_JOINT || kind == FK_SPRING) {
-        GForce& f = gf[index];
-        const bool hasA = f.bodyA >= 0;
-        f3 posA = zero3(); q4 rotA = identq();
-        if (hasA) { posA = ld3(B.plane(BP_POSR), f.bodyA); rotA = ldq(B.plane(BP_QUAT), f.bodyA); }
-        f3 posB = ld3(B.plane(BP_POSR), f.bodyB); q4 rotB = ldq(B.plane(BP_QUAT), f.bodyB);
-        const bool isA = body == f.bodyA;
-        if (kind == FK_JOINT) {
-            JointRows j;
-            j.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); j.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); j.q0 = mkq(f.q0[0], f.q0[1], f.q0[2], f.q0[3]);
-            j.fixAngular = (f.pad & 1) != 0;
-            if (mode == 0) {
-                joint_compute_constraint(j, hasA, posA, rotA, posB, rotB);
-                for (int r = 0; r < 6; ++r) { f.C[r] = j.C[r]; f.fmin[r] = -FLT_MAX; f.fmax[r] = FLT_MAX; out[r] = j.C[r]; out[12 + r] = -FLT_MAX; out[24 + r] = FLT_MAX; out[36 + r] = f.lambda[r]; }
-            } else {
-                f3 Jl, Ja;
-                joint_compute_derivatives(j, isA, isA && !hasA, isA ? rotA : rotB, row, Jl, Ja);
-                out[0] = Jl.x; out[1] = Jl.y; out[2] = Jl.z; out[3] = Ja.x; out[4] = Ja.y; out[5] = Ja.z;
-            }
-        } else {
-            SpringRows s;
-            s.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); s.rB = mk3(f.rB[0], f.rB[1], f.rB[2]); s.restLength = f.restLength;
-            if (mode == 0) {
-                spring_compute_constraint(s, hasA, posA, rotA, posB, rotB);
-                f.C[0] = s.C; out[0] = s.C; out[12] = f.fmin[0]; out[24] = f.fmax[0]; out[36] = f.lambda[0];
-            } else {
-                f3 Jl, Ja;
-                spring_compute_derivatives(s, isA, hasA, posA, rotA, posB, rotB, Jl, Ja);
-                out[0] = Jl.x; out[1] = Jl.y; out[2] = Jl.z; out[3] = Ja.x; out[4] = Ja.y; out[5] = Ja.z;
-            }
-        }
-    }
-}
+#include "avbd_capi_rowapi.inc"
 
-int resolve_force(AvbdContext* c, int force_index, ForceRef& ref, HostManifolds& hm)
-{
-    std::vector<ForceRef> refs;
-    int rc = sorted_force_refs(c, hm, refs);
-    if (rc) return rc;
-    if (force_index < 0 || force_index >= (int)refs.size()) return c->fail(AVBD_E_INVALID, "force index out of range");
-    ref = refs[force_index];
-    return AVBD_OK;
-}
-} // namespace
-
-int avbd_force_row_count(AvbdContext* c, int force_index, int* rows)
-{
-    if (!c || !rows) return AVBD_E_INVALID;
-    (void)hipSetDevice(c->device);
-    ForceRef ref; HostManifolds hm;
-    int rc = resolve_force(c, force_index, ref, hm);
-    if (rc) return rc;
-    *rows = force_row_count(ref.kind, ref.kind == FK_MANIFOLD ? hm.nc[ref.index] : 0);
-    return AVBD_OK;
-}
-
-static int run_row_api(AvbdContext* c, int force_index, float alpha, int mode, int body, int row, float* host_out, int nfloats)
-{
-    int rc;
-    if ((rc = upload_bodies_if_stale(c))) return rc;
-    ForceRef ref; HostManifolds hm;
-    if ((rc = resolve_force(c, force_index, ref, hm))) return rc;
-    if ((rc = upload_gforces_if_stale(c))) return rc;
-    DevArr<float> d;
-    HIPCHK(c, d.alloc(48));
-    HIPCHK(c, hipMemsetAsync(d.p, 0, 48 * sizeof(float), c->stream));
-    hipLaunchKernelGGL(k_row_api, dim3(1), dim3(64), 0, c->stream, body_table(c), c->mbuf[c->cur].view(), c->dG.p, ref.kind, ref.index, alpha, mode, body, row, d.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(host_out, d.p, nfloats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    d.release();
-    if (ref.kind != FK_MANIFOLD) c->gDeviceAhead = true;
-    return AVBD_OK;
-}
-
-int avbd_force_compute_constraint(AvbdContext* c, int force_index, float alpha, float* C, float* fmin, float* fmax, float* lambda)
-{
-    if (!c) return AVBD_E_INVALID;
-    (void)hipSetDevice(c->device);
-    float buf[48];
-    int rc = run_row_api(c, force_index, alpha, 0, -1, 0, buf, 48);
-    if (rc) return rc;
-    if (C) std::memcpy(C, buf, 48); if (fmin) std::memcpy(fmin, buf + 12, 48);
-    if (fmax) std::memcpy(fmax, buf + 24, 48); if (lambda) std::memcpy(lambda, buf + 36, 48);
-    return AVBD_OK;
-}
-
-int avbd_force_compute_derivatives(AvbdContext* c, int force_index, int body, int row, float J_linear[3], float J_angular[3])
-{
-    if (!c || !J_linear || !J_angular) return AVBD_E_INVALID;
-    (void)hipSetDevice(c->device);
-    float buf[48];
-    int rc = run_row_api(c, force_index, 0.0f, 1, body, row, buf, 6);
-    if (rc) return rc;
-    std::memcpy(J_linear, buf, 12); std::memcpy(J_angular, buf + 3, 12);
-    return AVBD_OK;
-}
-
-/* ---- known-answer entry points ---------------------------------------------------------- */
-int avbd_pick(AvbdContext* c, int nrays, const float* origins, const float* directions, int* bodies, float* locals)
-{
-    if (!c || nrays < 0 || (nrays && (!origins || !directions || !bodies || !locals))) return AVBD_E_INVALID;
-    if (nrays == 0) return AVBD_OK;
-    (void)hipSetDevice(c->device);
-    int rc = upload_bodies_if_stale(c);
-    if (rc) return rc;
-    DevArr<float> dO, dD, dL; DevArr<int> dB;
-    HIPCHK(c, dO.alloc(3 * nrays)); HIPCHK(c, dD.alloc(3 * nrays)); HIPCHK(c, dL.alloc(3 * nrays)); HIPCHK(c, dB.alloc(nrays));
-    HIPCHK(c, hipMemcpyAsync(dO.p, origins, 12 * (size_t)nrays, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dD.p, directions, 12 * (size_t)nrays, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(dL.p, 0, 12 * (size_t)nrays, c->stream));
-    hipLaunchKernelGGL(k_pick, dim3(nrays), dim3(256), 0, c->stream, body_table(c), nrays, dO.p, dD.p, dB.p, dL.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(bodies, dB.p, 4 * (size_t)nrays, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(locals, dL.p, 12 * (size_t)nrays, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    dO.release(); dD.release(); dL.release(); dB.release();
-    return AVBD_OK;
-}
-
-int avbd_kat_collide(AvbdContext* c, int n, const float* posA, const float* quatA, const float* sizeA, const float* posB, const float* quatB,
-                     const float* sizeB, AvbdContact* out, int* counts)
-{
-    if (!c || n < 0) return AVBD_E_INVALID;
-    (void)hipSetDevice(c->device);
-    DevArr<float> dpA, dqA, dsA, dpB, dqB, dsB; DevArr<KatContact> dout; DevArr<int> dcnt;
-    HIPCHK(c, dpA.alloc(3 * n)); HIPCHK(c, dqA.alloc(4 * n)); HIPCHK(c, dsA.alloc(3 * n));
-    HIPCHK(c, dpB.alloc(3 * n)); HIPCHK(c, dqB.alloc(4 * n)); HIPCHK(c, dsB.alloc(3 * n));
-    HIPCHK(c, dout.alloc(4 * n)); HIPCHK(c, dcnt.alloc(n));
-    HIPCHK(c, hipMemcpy(dpA.p, posA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dqA.p, quatA, 16 * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dsA.p, sizeA, 12 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dpB.p, posB, 12 * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dqB.p, quatB, 16 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dsB.p, sizeB, 12 * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemsetAsync(dout.p, 0, sizeof(KatContact) * 4 * n, c->stream));
-    hipLaunchKernelGGL(k_kat_collide, dim3(grid_for(n, kPairsPerWave, 1 << 20)), dim3(64), 0, c->stream, n, dpA.p, dqA.p, dsA.p, dpB.p, dqB.p, dsB.p, dout.p, dcnt.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    static_assert(sizeof(KatContact) == sizeof(AvbdContact), "contact record layout");
-    HIPCHK(c, hipMemcpy(out, dout.p, sizeof(AvbdContact) * 4 * n, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(counts, dcnt.p, sizeof(int) * n, hipMemcpyDeviceToHost));
-    dpA.release(); dqA.release(); dsA.release(); dpB.release(); dqB.release(); dsB.release(); dout.release(); dcnt.release();
-    return AVBD_OK;
-}
-
-int avbd_kat_solve6(AvbdContext* c, int n, const float* A, const float* b, float* x)
-{
-    if (!c || n < 0) return AVBD_E_INVALID;
-    (void)hipSetDevice(c->device);
-    DevArr<float> dA, db, dx;
-    HIPCHK(c, dA.alloc(36 * n)); HIPCHK(c, db.alloc(6 * n)); HIPCHK(c, dx.alloc(6 * n));
-    HIPCHK(c, hipMemcpy(dA.p, A, 144 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(db.p, b, 24 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_solve6, dim3(grid_for(n, 64, 1 << 20)), dim3(64), 0, c->stream, n, dA.p, db.p, dx.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(x, dx.p, 24 * n, hipMemcpyDeviceToHost));
-    dA.release(); db.release(); dx.release();
-    return AVBD_OK;
-}
-
-int avbd_kat_arith(AvbdContext* c, int n, const float* a, const float* b, float* od, float* os, float* om, float* oa)
-{
-    if (!c || n < 0) return AVBD_E_INVALID;
-    (void)hipSetDevice(c->device);
-    DevArr<float> da, db, d0, d1, d2, d3;
-    HIPCHK(c, da.alloc(n)); HIPCHK(c, db.alloc(n)); HIPCHK(c, d0.alloc(n)); HIPCHK(c, d1.alloc(n)); HIPCHK(c, d2.alloc(n)); HIPCHK(c, d3.alloc(n));
-    HIPCHK(c, hipMemcpy(da.p, a, 4 * n, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(db.p, b, 4 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_arith, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0, c->stream, n, da.p, db.p, d0.p, d1.p, d2.p, d3.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(od, d0.p, 4 * n, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(os, d1.p, 4 * n, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(om, d2.p, 4 * n, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(oa, d3.p, 4 * n, hipMemcpyDeviceToHost));
-    da.release(); db.release(); d0.release(); d1.release(); d2.release(); d3.release();
-    return AVBD_OK;
-}
-
-/* ---- sharding over the GPUs of one node ------------------------------------------------------------------ */
-} // extern "C"  (reopened below)
-struct Id128 { char b[128]; }; /* ncclUniqueId, passed by value */
-namespace {
-/* RCCL is loaded lazily so that single-GPU users (and symbol checks on machines without a GPU) never need it */
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-};
-Rccl g_rccl;
 bool load_rccl()
 {
     if (g_rccl.lib) return true;
@@ -3184,330 +1894,7 @@ int avbd_comm_init(AvbdContext* c, int nranks, int rank, const char id[128])
     return AVBD_OK;
 }
 
-/* One step of all ranks with exact cuts (avbd_cuts.h): step_begin has run on every context.  Returns 1 when the step was queued,
- * 0 when the prerequisites do not hold (the caller falls back to the all-gather forms), < 0 on errors. */
-static int group_step_exact(AvbdContext** ctxs, int n, const char** why)
-{
-    AvbdContext* L = ctxs[0];
-    for (int r = 0; r < n; ++r) {
-        AvbdContext* c = ctxs[r];
-        if (!c->shardExact) { *why = "not every rank was put into shard mode 1 / 2"; return 0; }
-        if (!c->exactAllowed) { *why = "the exact-cut kernels do not fit two workgroups per CU on this device / this build"; return 0; }
-        if (c->device != L->device) { *why = "the ranks' contexts live on different devices (the in-process record space is one allocation of one device)"; return 0; }
-        for (const GForce& g : c->hG) if (g.kind != FK_IGNORE) { *why = "the scene has joints or springs (exact cuts carry contacts only)"; return 0; }
-        if (!c->groupsPlanned) { *why = "a rank did not plan the group schedule (levels mode, more than 60 iterations, or no swept body)"; return 0; }
-        if (c->mCap != L->mCap || c->bodyCap != L->bodyCap) { *why = "the ranks' pools differ in size (every rank must hold the same scene)"; return 0; }
-    }
-    int rc;
-    (void)hipSetDevice(L->device);
-    const int totalIt = L->params.iterations + (L->params.postStabilize ? 1 : 0);
-    if (totalIt <= 0 || totalIt > 60) { *why = "more than 60 iterations"; return 0; }
-    constexpr int kCutManifolds = 16384;                                /* manifolds one cut (pair of ranks) may hold */
-    const size_t localSlots = (size_t)4 * L->mCap, total = (size_t)n * localSlots + (size_t)n * n * kCutManifolds * 4;
-    if (total * 32 >= (1ull << 31)) { *why = "the record space of all ranks exceeds 32-bit offsets"; return 0; }   /* 32-bit record offsets */
-    if (L->xsRanks != n || L->xsLocalSlots != localSlots || L->xsPose.n < (size_t)3 * L->bodyCap) {
-        for (int r = 0; r < n; ++r) HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
-        HIPCHK(L, L->xsPose.alloc((size_t)3 * L->bodyCap)); HIPCHK(L, L->xsVisit.alloc(total)); HIPCHK(L, L->xsDual.alloc(2 * total));
-        HIPCHK(L, hipMemsetAsync(L->xsPose.p, 0, (size_t)3 * L->bodyCap * sizeof(float4), L->stream));
-        HIPCHK(L, hipMemsetAsync(L->xsVisit.p, 0, total * sizeof(float4), L->stream));
-        HIPCHK(L, hipMemsetAsync(L->xsDual.p, 0, 2 * total * sizeof(float4), L->stream));
-        HIPCHK(L, hipStreamSynchronize(L->stream));
-        L->xsRanks = n; L->xsLocalSlots = localSlots; L->xsTotalSlots = total; L->xsSerial = 0;
-    }
-    if (L->xsSerial >= (1u << 24) - 2u) {                               /* the stamps wrap: forget every old record (nothing is in flight between steps) */
-        for (int r = 0; r < n; ++r) HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
-        HIPCHK(L, hipMemsetAsync(L->xsPose.p, 0, (size_t)3 * L->bodyCap * sizeof(float4), L->stream));
-        HIPCHK(L, hipMemsetAsync(L->xsVisit.p, 0, total * sizeof(float4), L->stream));
-        HIPCHK(L, hipMemsetAsync(L->xsDual.p, 0, 2 * total * sizeof(float4), L->stream));
-        HIPCHK(L, hipStreamSynchronize(L->stream));
-        L->xsSerial = 0;
-    }
-    /* every rank's plan must fit its share of the device: all launches are resident together and wait for each other's records */
-    for (int r = 0; r < n; ++r) {
-        bool ok = false;
-        if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
-        if (!ok) { *why = "a rank's plan does not fit its share of the device (a body with more than 64 contacts, or more than 8 bodies per sub-group)"; return 0; }
-    }
-    ++L->xsSerial;
-    if (L->hExactArgs.size() != (size_t)n) { L->hExactArgs.assign((size_t)n, ExactRankArgs{}); HIPCHK(L, L->dExactArgs.alloc((size_t)n)); }
-    int wgPerRank = 1; bool anyMulti = false;
-    for (int r = 0; r < n; ++r) {
-        AvbdContext* c = ctxs[r];
-        if ((rc = exact_cut_buffers(c, n, kCutManifolds))) return rc;
-        if (c->recIdxCap < (size_t)c->incCap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, c->dRecIdx.alloc((size_t)c->incCap)); c->recIdxCap = (size_t)c->incCap; }
-        if (!c->evLoop) HIPCHK(c, hipEventCreateWithFlags(&c->evLoop, hipEventDisableTiming));
-        BodyTable B = body_table(c);
-        SolverParams P = solver_params(c);
-        ManifoldTable M = c->mbuf[c->cur].view();
-        const int cutCap = n * kCutManifolds;
-        HIPCHK(c, hipMemsetAsync(c->dCutCnt.p, 0, sizeof(CutCounters), c->stream));
-        hipLaunchKernelGGL(k_cut_list, dim3(grid_for(c->mCap, 256, 1024)), dim3(256), 0, c->stream, M, c->dCnt.p, c->dOwner.p, n, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p);
-        hipLaunchKernelGGL(k_cut_rank, dim3(grid_for(cutCap, 128, 1024)), dim3(128), 0, c->stream, c->dCutKeys.p, c->dCutMan.p, cutCap, c->dCutOf.p, c->dCutCnt.p, kCutManifolds);
-        hipLaunchKernelGGL(k_cut_fill, dim3(grid_for(std::max(1, c->numSolved), 128, 4096)), dim3(128), 0, c->stream, B, M, c->order.p, c->lvlStart.p, c->dCnt.p, c->incStart.p, c->inc.p,
-                           c->dOwner.p, n, c->rank, c->dCutOf.p, c->rank * (int)localSlots, n * (int)localSlots, kCutManifolds, c->dRecIdx.p);
-        IterateState S;
-        S.primalDone = c->dFlags.p; S.dualDone = c->dFlags.p + c->bodyCap; S.error = c->dFlags.p + 2 * (size_t)c->bodyCap;
-        ResidentExchange X{};
-        X.pose = L->xsPose.p; X.visit = L->xsVisit.p; X.dual = L->xsDual.p;
-        X.poseBytes = (unsigned)((size_t)3 * L->bodyCap * sizeof(float4)); X.visitBytes = (unsigned)(total * sizeof(float4)); X.dualBytes = (unsigned)(2 * total * sizeof(float4));
-        X.enabled = 1; X.base = L->xsSerial * 64u;
-        X.specMode = c->groupSpecMode; X.specRounds = c->groupSpecRounds; X.privN = c->xPrivN.p; X.privPose = c->xPrivPose.p; X.parkC = c->xParkC.p; X.parkS = c->xParkS.p; X.parkB = c->xParkB.p; X.probe = c->xProbe.p;
-        ShardExchange Z{};
-        Z.xPose = L->xsPose.p; Z.xVisit = L->xsVisit.p; Z.xDual = L->xsDual.p;
-        Z.xPoseBytes = X.poseBytes; Z.xVisitBytes = X.visitBytes; Z.xDualBytes = X.dualBytes;
-        Z.recIdx = c->dRecIdx.p; Z.nPeers = 1; Z.owner = c->dOwner.p;
-        ExactRankArgs& A = L->hExactArgs[(size_t)r];
-        A.B = B; A.M = M; A.incStart = c->incStart.p; A.inc = c->inc.p; A.P = P; A.errWord = S.error; A.cntW = c->dCnt.p; A.X = X; A.plan = c->dPlan.p; A.byClass = c->dUnit.p;
-        A.cap = c->bodyCap; A.sleepSel = c->iterSleep; A.Z = Z; A.multi = c->shardMulti ? 1 : 0;
-        wgPerRank = std::max(wgPerRank, std::max(1, groups_waves(c) / kGrpWavesPerBlock));
-        anyMulti |= c->shardMulti;
-        HIPCHK(c, hipEventRecord(c->evLoop, c->stream));              /* this rank's tables are ready */
-        c->groupsLaunched = true; c->residentLaunched = true; c->residentMultiLaunched = false; c->shardRanPersistent = true; c->cutModeRan = 3;
-    }
-    {   /* ONE launch for all ranks, on the first context's stream (k_iterate_groups_exact) */
-        for (int q = 1; q < n; ++q) HIPCHK(L, hipStreamWaitEvent(L->stream, ctxs[q]->evLoop, 0));
-        HIPCHK(L, hipMemcpyAsync(L->dExactArgs.p, L->hExactArgs.data(), (size_t)n * sizeof(ExactRankArgs), hipMemcpyHostToDevice, L->stream));
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (L->profiling) { size_t i0 = L->evUsed; e0 = next_event(L); e1 = next_event(L); L->spans.push_back({F_PRIMAL, i0, i0 + 1}); }
-        hipExtLaunchKernelGGL(k_iterate_groups_exact, dim3(n * wgPerRank), dim3(64 * kGrpWavesPerBlock), anyMulti ? kGrpLdsBytesMulti : kGrpLdsBytes, L->stream, e0, e1, 0,
-                              (const ExactRankArgs*)L->dExactArgs.p, wgPerRank);
-        ++L->prof.launches_primal; ++L->prof.launches_total;
-        HIPCHK(L, hipGetLastError());
-        HIPCHK(L, hipStreamSynchronize(L->stream));                   /* (the host copy of the arguments is rewritten next step) */
-        if (!L->evExact) HIPCHK(L, hipEventCreateWithFlags(&L->evExact, hipEventDisableTiming));
-        HIPCHK(L, hipEventRecord(L->evExact, L->stream));
-    }
-    for (int r = 0; r < n; ++r) {
-        AvbdContext* c = ctxs[r];
-        HIPCHK(c, hipStreamWaitEvent(c->stream, L->evExact, 0));
-        PeerWindows PW{}; PW.n = 1; PW.pose[0] = L->xsPose.p;
-        hipLaunchKernelGGL(k_unpack_records, dim3(grid_for((int)c->hBodies.size(), 256, 1024)), dim3(256), 0, c->stream, body_table(c), c->dOwner.p, c->rank, PW);
-        HIPCHK(c, hipGetLastError());
-        if ((rc = step_end(c, false))) return rc;
-    }
-    return 1;
-}
-
-static int group_exchange_velocities(AvbdContext** ctxs, int n);
-/* hardware queues the HIP runtime maps this process's streams onto (its GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise) */
-static int hw_queues() { const char* e = std::getenv("GPU_MAX_HW_QUEUES"); const int q = e ? std::atoi(e) : 4; return q > 0 ? q : 4; }
-
-/* one step of avbd_group_step */
-static int group_step_one(AvbdContext** ctxs, int n)
-{
-    {
-        int rc;
-        for (int r = 0; r < n; ++r) {
-            AvbdContext* c = ctxs[r];
-            if (!c || c->nranks != n || c->rank != r || c->mode == 0) return AVBD_E_INVALID;
-            (void)hipSetDevice(c->device);
-            {   /* this context's share of its device's resident waves */
-                int sharing = 0;
-                for (int q = 0; q < n; ++q) sharing += ctxs[q] && ctxs[q]->device == c->device;
-                /* contexts that share a device keep a fifth of it free between them: with persistent launches in every workgroup slot
-                 * the exchange streams' waits / copies / writes were starved for seconds (two launches of 1 008 waves each timed out,
-                 * 800 each went through — DESIGN.md §7) */
-                const int usable = (sharing > 1 && !c->shardExact) ? (2 * c->iterBlocks * kGrpWavesPerBlock * 4) / 5 : 2 * c->iterBlocks * kGrpWavesPerBlock;
-                c->shardWaves = std::max(kGrpWavesPerBlock, (usable / std::max(1, sharing)) / kGrpWavesPerBlock * kGrpWavesPerBlock);
-            }
-            if ((rc = step_begin(c))) return rc;
-            c->statsFresh = false;
-        }
-        for (int r = 0; r < n; ++r) {
-            /* Contexts that share a device (several ranks emulated on one GPU): the front ends of ALL of them have finished before the first
-             * iteration launch is queued.  Rank 0's first launch used to start beside the other contexts' broad / narrow phase and topology
-             * kernels — it needs every workgroup resident and spins until it is, some of those kernels wait for earlier workgroups of their own
-             * (decoupled look-back): one run in five of the eight-context tests ended in a dependency time-out in iteration 0 of rank 0
-             * (0 of 40 with this; tests/test_gpu_sharded_full_size.py).  One context per device: no wait. */
-            bool shares = false;
-            for (int q = 0; q < n; ++q) shares |= q != r && ctxs[q]->device == ctxs[r]->device;
-            if (shares) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
-        }
-        if (n > 1 && ctxs[0]->shardExact) {
-            /* exact cuts: no exchange during the loop, results identical to the single-GPU sweep (avbd_cuts.h) */
-            const char* why = "";
-            rc = group_step_exact(ctxs, n, &why);
-            if (rc < 0) return rc;
-            if (rc == 1) return AVBD_OK;
-            /* declined: with mode 1 that is an error — the caller asked for results bit-identical to one GPU and must not get a Jacobi
-             * coupling under that name; mode 2 takes the all-gather form and AvbdStepStats.cutMode reports it */
-            if (ctxs[0]->shardExactStrict) {
-                char msg[384];
-                snprintf(msg, sizeof(msg), "exact cuts were requested (avbd_set_shard_mode 1) and this step cannot run them: %s; mode 2 would fall back to the all-gather form", why);
-                return ctxs[0]->fail(AVBD_E_INVALID, msg);
-            }
-        }
-        const int totalIt = ctxs[0]->params.iterations + (ctxs[0]->params.postStabilize ? 1 : 0);
-        {   /* persistent form (one launch per rank and step, exchange on the second streams) when every rank's plan fits its share
-             * of the device: the launches of contexts that share a device must ALL be resident at the same time */
-            bool all = true;
-            {   /* more than four contexts on one device: their 2 x n streams share the device's few hardware queues, and a queue
-                 * that waits for a signal word holds up whatever else is mapped to it — another context's launch, for one.  One
-                 * context per device (the real layout) has two streams. */
-                for (int r = 0; r < n; ++r) {
-                    int sharing = 0;
-                    for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
-                    if (sharing > 4 && 2 * sharing > hw_queues()) all = false;
-                    /* contexts on different devices: every exchange stream would wait on, and copy from, memory of another device —
-                     * never validated on a multi-GPU box, so only on explicit request, and only with peer access in place */
-                    if (sharing != n) {
-                        if (ctxs[r]->shardPersistent != 1) all = false;
-                        for (int q = 0; q < n && all; ++q) {
-                            if (ctxs[q]->device == ctxs[r]->device) continue;
-                            int can = 0;
-                            if (hipDeviceCanAccessPeer(&can, ctxs[r]->device, ctxs[q]->device) != hipSuccess || !can) { all = false; break; }
-                            (void)hipSetDevice(ctxs[r]->device);
-                            const hipError_t pe = hipDeviceEnablePeerAccess(ctxs[q]->device, 0);
-                            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) all = false;
-                            (void)hipGetLastError();
-                        }
-                    }
-                }
-            }
-            for (int r = 0; r < n && all; ++r) {
-                bool ok = false;
-                (void)hipSetDevice(ctxs[r]->device);
-                if ((rc = shard_plan_accepted(ctxs[r], ok))) return rc;
-                all = ok;
-                /* Several bodies per sub-group with more than two contexts on one device: four contexts of 16 000 bodies each stopped making
-                 * progress on the step the first layer lands — waves that serve ground contacts waited for an all-gather that never landed.
-                 * Explained in round 4 (tools/stall_4x16000.py): four contexts have EIGHT streams (a persistent launch and an exchange
-                 * stream each) and a HIP process maps its streams onto GPU_MAX_HW_QUEUES = 4 hardware queues; an exchange stream that
-                 * shares a queue with another context's persistent launch sits behind a kernel that waits for that very exchange.  With
-                 * GPU_MAX_HW_QUEUES=16 the same run goes through (test_four_contexts_persistent_with_a_hardware_queue_per_stream).  So:
-                 * without a hardware queue per stream that combination takes one launch per iteration. */
-                if (ok && ctxs[r]->shardMulti) {
-                    int sharing = 0;
-                    for (int q = 0; q < n; ++q) sharing += ctxs[q]->device == ctxs[r]->device;
-                    if (sharing > 2 && 2 * sharing > hw_queues() && !ctxs[r]->debugSharedMulti) all = false;
-                }
-            }
-            for (int r = 0; r < n; ++r) ctxs[r]->shardRanPersistent = false;
-            if (all) {
-                for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = shard_launch_persistent(ctxs[r]))) return rc; ctxs[r]->cutModeRan = 2; }
-                /* Iteration-major: exchange streams of contexts on one device may be mapped to the SAME hardware queue, which runs its
-                 * packets in order.  Queued rank by rank, rank 1's deliveries of iteration 0 could sit behind rank 0's wait for
-                 * iteration 1 — which needs rank 1 past iteration 1, which needs that delivery.  In this order every wait is preceded,
-                 * in any in-order merge of the streams, by everything it depends on.  (It does not cure the stall of two launches
-                 * that fill the device) */
-                for (int it = 0; it < totalIt; ++it) {
-                    for (int dst = 0; dst < n; ++dst) {
-                        AvbdContext* d = ctxs[dst];
-                        (void)hipSetDevice(d->device);
-                        const size_t rows = (size_t)2 * std::max(1, d->maxCount);
-                        for (int src = 0; src < n; ++src) {
-                            if (src == dst) continue;
-                            AvbdContext* q = ctxs[src];
-                            if (d->shardGateKernel) {
-                                hipLaunchKernelGGL(k_exchange_gate, dim3(1), dim3(256), 0, d->stream2, q->sigDone, q->xSerial * 64u + (unsigned)it + 1u, q->dFlags.p + 2 * (size_t)q->bodyCap,
-                                                   d->dGather[it & 1].p + rows * src, (const float4*)(q->dGather[it & 1].p + rows * src), (int)rows);
-                                continue;
-                            }
-                            HIPCHK(d, hipStreamWaitValue32(d->stream2, q->sigDone, q->xSerial * 64u + (unsigned)it + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
-                            if (std::getenv("AVBD_DEBUG_COPY_KERNEL"))
-                                hipLaunchKernelGGL(k_copy_rows, dim3(2), dim3(256), 0, d->stream2, d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, (int)rows);
-                            else
-                            HIPCHK(d, hipMemcpyAsync(d->dGather[it & 1].p + rows * src, q->dGather[it & 1].p + rows * src, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream2));
-                        }
-                        if (d->shardGateKernel) hipLaunchKernelGGL(k_exchange_publish, dim3(1), dim3(1), 0, d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u);
-                        else HIPCHK(d, hipStreamWriteValue32(d->stream2, d->sigGather, d->xSerial * 64u + (unsigned)it + 1u, 0));
-                    }
-                }
-                for (int r = 0; r < n; ++r) {
-                    (void)hipSetDevice(ctxs[r]->device);
-                    if ((rc = shard_finish_persistent(ctxs[r], totalIt))) return rc;
-                    if ((rc = step_end(ctxs[r], false))) return rc;
-                }
-                return group_exchange_velocities(ctxs, n);
-            }
-        }
-        for (int r = 0; r < n; ++r) ctxs[r]->cutModeRan = 1;
-        for (int it = 0; it < totalIt; ++it) {
-            for (int r = 0; r < n; ++r) {
-                AvbdContext* c = ctxs[r];
-                (void)hipSetDevice(c->device);
-                /* k_iterate needs ALL its workgroups resident: two such launches must never be dispatched onto one device at
-                 * the same time (each could end up with half of its workgroups on the chip, waiting for the rest).  Contexts that
-                 * share a device run their iteration kernels one after the other. */
-                for (int q = 0; q < r; ++q)
-                    if (ctxs[q]->device == c->device) {
-                        if (!ctxs[q]->iterDone) HIPCHK(c, hipEventCreateWithFlags(&ctxs[q]->iterDone, hipEventDisableTiming));
-                        HIPCHK(c, hipStreamWaitEvent(c->stream, ctxs[q]->iterDone, 0));
-                    }
-                if ((rc = step_iterate(c, it, it + 1))) return rc;
-                if (!c->iterDone) HIPCHK(c, hipEventCreateWithFlags(&c->iterDone, hipEventDisableTiming));
-                HIPCHK(c, hipEventRecord(c->iterDone, c->stream));
-                if ((rc = step_pack(c))) return rc;
-            }
-            for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
-            for (int dst = 0; dst < n; ++dst) {
-                AvbdContext* d = ctxs[dst];
-                (void)hipSetDevice(d->device);
-                for (int src = 0; src < n; ++src) {
-                    if (src == dst) continue;
-                    const size_t rows = (size_t)2 * std::max(1, d->maxCount);
-                    HIPCHK(d, hipMemcpyAsync(d->dRecv.p + rows * src, ctxs[src]->dSend.p, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream));
-                }
-                if ((rc = step_unpack(d))) return rc;
-            }
-        }
-        for (int r = 0; r < n; ++r) {
-            (void)hipSetDevice(ctxs[r]->device);
-            if ((rc = step_end(ctxs[r], false))) return rc;
-        }
-    }
-    return group_exchange_velocities(ctxs, n);
-}
-
-/* avbd_set_exchange_floats(13): the once-per-step gather of the velocities (pos3 + quat4 travel every iteration,
- * linVel3 + angVel3 once per step).  Every rank has ALREADY re-derived every body's velocities from the gathered poses
- * (k_tail runs over all bodies, solver.cpp:434-469), so the rows that arrive must equal what is there bit for bit:
- * k_unpack_velocities counts the words that differ (avbd_debug_exchange_mismatches) before it stores them. */
-static int group_exchange_velocities(AvbdContext** ctxs, int n)
-{
-    if (n < 2 || ctxs[0]->exchangeFloats != 13) return AVBD_OK;
-    int rc;
-    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); if ((rc = step_pack_velocities(ctxs[r]))) return rc; }
-    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
-    for (int dst = 0; dst < n; ++dst) {
-        AvbdContext* d = ctxs[dst];
-        (void)hipSetDevice(d->device);
-        const size_t rows = (size_t)2 * std::max(1, d->maxCount);
-        for (int src = 0; src < n; ++src)
-            if (src != dst) HIPCHK(d, hipMemcpyAsync(d->dRecv.p + rows * src, ctxs[src]->dSend.p, rows * sizeof(float4), hipMemcpyDeviceToDevice, d->stream));
-        if ((rc = step_unpack_velocities(d))) return rc;
-    }
-    /* dSend is the next step's pose rows: nobody may still be reading it */
-    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream)); }
-    return AVBD_OK;
-}
-
-int avbd_group_step(AvbdContext** ctxs, int n, int nsteps)
-{
-    /* Several contexts (one per shard, on one or several devices of this process) stepped in lock-step by one host
-     * thread; the per-iteration pose exchange is done with device-to-device copies instead of RCCL.  Same schedule
-     * and same results as the one-process-per-GPU RCCL path. */
-    if (!ctxs || n < 1 || nsteps < 0) return AVBD_E_INVALID;
-    for (int r = 0; r < n; ++r) if (!ctxs[r]) return AVBD_E_INVALID;
-    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); turn_begin(ctxs[r], ctxs, n); }
-    int rc = AVBD_OK;
-    for (int s = 0; s < nsteps && !rc; ++s) rc = group_step_one(ctxs, n);
-    /* the end of the call on a device: its first context's stream, behind the streams of the others */
-    for (int r = 0; r < n; ++r) {
-        bool first = true;
-        for (int q = 0; q < r; ++q) first &= ctxs[q]->device != ctxs[r]->device;
-        if (!first) continue;
-        (void)hipSetDevice(ctxs[r]->device);
-        for (int q = r + 1; q < n; ++q)
-            if (ctxs[q]->device == ctxs[r]->device) {
-                if (!ctxs[q]->iterDone && hipEventCreateWithFlags(&ctxs[q]->iterDone, hipEventDisableTiming) != hipSuccess) continue;
-                (void)hipEventRecord(ctxs[q]->iterDone, ctxs[q]->stream);
-                (void)hipStreamWaitEvent(ctxs[r]->stream, ctxs[q]->iterDone, 0);
-            }
-        turn_end(ctxs[r]);
-    }
-    return rc;
-}
+#include "avbd_capi_group.inc"
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* debug: per-wave time breakdown of the last k_iterate launch (only in -DAVBD_DF_STATS builds) */
