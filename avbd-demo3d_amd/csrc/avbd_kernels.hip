@@ -317,8 +317,7 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
         int inc = 0;
         if (B.solved[a]) { atomicAdd(&degInc[a], nc); inc += nc; }
         if (B.solved[b]) { atomicAdd(&degInc[b], nc); inc += nc; }
-        atomicAdd(&cnt->numContacts, nc);
-        atomicAdd(&cnt->numIncidences, inc);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&cnt->numContacts), ((unsigned long long)(unsigned)inc << 32) | (unsigned long long)(unsigned)nc);
     }
     if (gl < nc) {
         const int s = slot * 4 + gl;
@@ -417,8 +416,10 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
     int inc = 0;
     if (B.solved[a]) { atomicAdd(&degInc[a], mi.numContacts); inc += mi.numContacts; }
     if (B.solved[b]) { atomicAdd(&degInc[b], mi.numContacts); inc += mi.numContacts; }
-    atomicAdd(&cnt->numContacts, mi.numContacts);
-    atomicAdd(&cnt->numIncidences, inc);
+    /* numContacts and numIncidences are neighbours (an aligned 8 bytes): ONE atomic for both — atomics on one cache line retire one after the other,
+     * about 13 ns each whoever issues them, and a wave's worth of survivors brings one per word (5 300 waves at 64 000 cubes: 69 us per word) */
+    static_assert(offsetof(Counters, numContacts) % 8 == 0 && offsetof(Counters, numIncidences) == offsetof(Counters, numContacts) + 4, "one 64-bit add for both counts");
+    atomicAdd(reinterpret_cast<unsigned long long*>(&cnt->numContacts), ((unsigned long long)(unsigned)inc << 32) | (unsigned long long)(unsigned)mi.numContacts);
 #ifdef AVBD_DF_STATS
     if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
 #endif
