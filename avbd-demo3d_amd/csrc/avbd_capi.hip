@@ -241,6 +241,7 @@ struct AvbdContext {
     /* exact cuts between processes: this rank's window, the peers' windows as this process sees them (own window at [rank]) */
     float4* xwOwn = nullptr; float4* xwPeer[kMaxExactRanks] = {}; bool xwAttached = false; bool xwSharedDevice = false; unsigned xwSerial = 0; int xwBodyCap = 0, xwMCap = 0, xwRanks = 0;
     int cutRanks = 0;
+    int narrowLanes = 0;           /* narrow_lanes option: 32 / 64 lanes per workgroup of k_narrowphase, 0: by the number of pairs */
     int diagBlocksCap = 256;       /* workgroups of the contact diagnostics: each ends with five atomics on ONE line, 13 ns apiece whoever issues them (64 000 cubes: 1024 -> 50 us, 256 -> 28 us, 128 -> 34 us) */
     bool debugSharedMulti = false;
     int iterBlocksMax = 0;         /* what the occupancy query allows (avbd_create) */
@@ -722,6 +723,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
     c->statsFresh = true;
     if (cnt.overflow & 32) return c->fail(AVBD_E_HIP, "race checker: the schedule of this step is not race-free (two bodies of one launch share a force, or the sweep order is not a linear extension of the dependencies)");
+    if (cnt.overflow & 64) return c->fail(AVBD_E_CAPACITY, "narrow phase: a clipped contact polygon had more than eight vertices (the reference's buffers hold sixteen; a quad clipped against four planes cannot have more than eight): the step's manifolds are not the reference's");
     if (cnt.overflow) {
         char buf[160];
         std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);

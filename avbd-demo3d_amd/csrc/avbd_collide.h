@@ -81,7 +81,12 @@ AVBD_HD bool sat_test_axis(const Obb& a, const Obb& b, f3 delta, f3 axis, int ty
 }
 
 /* collision.cpp:136-174 — Sutherland–Hodgman clip of a convex polygon against one plane. */
-AVBD_HD int clip_polygon(const f3* in, int n, f3 pn, float po, f3* out)
+/* `cap`: vertices the output holds.  The reference's buffers hold kMaxPolyVerts = 16 and are never full: a quad clipped against four half-planes has
+ * at most eight vertices (each clip of a convex polygon adds at most one).  The one-lane-per-pair narrow phase keeps buffers of kLanePolyVerts = 8 in
+ * LDS (it is what bounds how many pairs a CU holds); should rounding ever produce a ninth vertex, `over` is raised — the step then fails with a capacity
+ * error instead of silently dropping a vertex the reference would have kept. */
+constexpr int kLanePolyVerts = 8;
+AVBD_HD int clip_polygon(const f3* in, int n, f3 pn, float po, f3* out, int cap, int& over)
 {
     if (n <= 0) return 0;
     int m = 0;
@@ -96,9 +101,9 @@ AVBD_HD int clip_polygon(const f3* in, int n, f3 pn, float po, f3* out)
             float t = 0.0f;
             float denom = da - db;
             if (fabsf(denom) > kSatAxisEps) t = rclamp(da / denom, 0.0f, 1.0f);
-            if (m < kMaxPolyVerts) out[m++] = a + (b - a) * t;
+            if (m < cap) out[m++] = a + (b - a) * t; else if (m < kMaxPolyVerts) over = 1;
         }
-        if (bIn && m < kMaxPolyVerts) out[m++] = b;
+        if (bIn) { if (m < cap) out[m++] = b; else if (m < kMaxPolyVerts) over = 1; }
         a = b; da = db;
     }
     return m;
@@ -125,7 +130,7 @@ AVBD_HD bool add_contact(const BoxPose& A, const BoxPose& B, RawContact* cs, int
 }
 
 /* working storage of the manifold builders: indexed dynamically, so a kernel keeps it in LDS (scratch otherwise) */
-struct CollideScratch { f3 clip0[kMaxPolyVerts], clip1[kMaxPolyVerts]; f3 mids[kMaxContacts]; };
+struct CollideScratch { f3 clip0[kLanePolyVerts], clip1[kLanePolyVerts]; f3 mids[kMaxContacts]; int overflow; };
 
 /* collision.cpp:313-394 — reference-face clipping manifold. */
 AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& boxA, const Obb& boxB, bool refIsA,
@@ -169,13 +174,13 @@ AVBD_HD int build_face_manifold(const BoxPose& A, const BoxPose& B, const Obb& b
     }
     int count = 4;
     f3 n0 = fU;   float o0 = dot3(n0, fC) + eU;
-    count = clip_polygon(clip0, count, n0, o0, clip1); if (!count) return 0;
+    count = clip_polygon(clip0, count, n0, o0, clip1, kLanePolyVerts, ws.overflow); if (!count) return 0;
     f3 n1 = -fU;  float o1 = dot3(n1, fC) + eU;
-    count = clip_polygon(clip1, count, n1, o1, clip0); if (!count) return 0;
+    count = clip_polygon(clip1, count, n1, o1, clip0, kLanePolyVerts, ws.overflow); if (!count) return 0;
     f3 n2 = fV;   float o2 = dot3(n2, fC) + eV;
-    count = clip_polygon(clip0, count, n2, o2, clip1); if (!count) return 0;
+    count = clip_polygon(clip0, count, n2, o2, clip1, kLanePolyVerts, ws.overflow); if (!count) return 0;
     f3 n3 = -fV;  float o3 = dot3(n3, fC) + eV;
-    count = clip_polygon(clip1, count, n3, o3, clip0); if (!count) return 0;
+    count = clip_polygon(clip1, count, n3, o3, clip0, kLanePolyVerts, ws.overflow); if (!count) return 0;
 
     int cc = 0;
     f3* mids = ws.mids;
@@ -258,6 +263,7 @@ AVBD_HD int build_edge_contact(const BoxPose& A, const BoxPose& B, const Obb& bo
 /* Manifold::collide, collision.cpp:420-489 with flip=false. */
 AVBD_HD int collide_boxes(const BoxPose& A, const BoxPose& B, RawContact* cs, CollideScratch& ws)
 {
+    ws.overflow = 0;
     Obb boxA = make_obb(A), boxB = make_obb(B);
     f3 delta = boxB.center - boxA.center;
     SatBest bestFace; bestFace.sep = -FLT_MAX; bestFace.valid = false; bestFace.type = 0; bestFace.iA = 0; bestFace.iB = 0; bestFace.nAB = zero3();

@@ -373,6 +373,7 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
     if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A.pos.x == 12345.0f);
 #endif
     const bool alive = manifold_initialize(mi, old, A, fa, Bp, fb);
+    if (old.ws.overflow) atomicOr(&cnt->overflow, 64);                 /* a clipped polygon with more than eight vertices (clip_polygon) */
 #ifdef AVBD_DF_STATS
     if (dbg) { dbg[2] = __builtin_amdgcn_s_memrealtime(); if (!alive) dbg[3] = dbg[2]; }
 #endif
@@ -427,15 +428,19 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
 
 /* (one wave per SIMD: capped at 256 registers for two, the kernel spills 23 and runs at the same speed — 240 us at 64 000 cubes either way: it is
  * bound by instruction issue, not by latency; sixteen lanes per pair, the small scenes' form, is 2.4x slower here) */
-__global__ __launch_bounds__(32) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
+/* LANES = 32: with a few thousand pairs and 1024 SIMDs a half-filled wavefront costs nothing and halves the branch divergence.  LANES = 64 (round 4) once
+ * the pairs outnumber the lanes of the machine several times: the per-pair LDS (584 B since the clip buffers hold the eight vertices a clipped quad can have and
+ * last step's lambda / penalty stay in registers; 872 B before) lets four 64-lane workgroups share a CU — one wave per SIMD, full waves. */
+template <int LANES>
+__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
                                                       int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
 {
     const int nOld = cnt->numManifolds;
     int nCand = cnt->numCandidates; if (nCand > candCap) nCand = candCap;
     const int total = nOld + nCand;
-    /* 32 pairs per workgroup: with ~5000 pairs and 1024 SIMDs a half-filled wavefront costs nothing and halves the branch
-     * divergence; the dynamically indexed per-pair state lives in LDS instead of scratch */
-    __shared__ ManifoldOld sOld[32];
+    /* the dynamically indexed per-pair state lives in LDS instead of scratch */
+    static_assert(sizeof(ManifoldOld) * 64 * 4 <= 160 * 1024, "four 64-lane workgroups of k_narrowphase share a CU's LDS");
+    __shared__ ManifoldOld sOld[LANES];
     ManifoldInit miPriv;
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         int a = 0, b = 0;

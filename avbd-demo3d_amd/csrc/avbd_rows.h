@@ -226,7 +226,7 @@ struct ManifoldOld {
     int   feature[4];
     f3    rA[4], rB[4], normal[4];
     bool  stick[4], used[4];
-    float lambda[12], penalty[12];
+    /* (last step's lambda / penalty stay in registers while the pair is re-collided — manifold_initialize — : 96 B of LDS per pair less) */
 };
 
 /* `m` holds the previous step's contacts on entry (numContacts = 0 for a fresh manifold) and the
@@ -237,16 +237,18 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, ManifoldOld& old, const BoxPos
 
     int   oldN = m.numContacts;
     int* oldFeature = old.feature; f3* oldRA = old.rA; f3* oldRB = old.rB; f3* oldNormal = old.normal; bool* oldStick = old.stick;
-    float* oldLambda = old.lambda; float* oldPenalty = old.penalty;
+    float oldLambda[12], oldPenalty[12];                               /* registers: read through sel4 below, never indexed dynamically */
     bool* oldUsed = old.used;
     for (int i = 0; i < 4; ++i) oldUsed[i] = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i < oldN) {
             oldFeature[i] = m.feature[i]; oldRA[i] = m.rA[i]; oldRB[i] = m.rB[i]; oldNormal[i] = m.normal[i]; oldStick[i] = m.stick[i];
-            for (int k = 0; k < 3; ++k) { oldLambda[i * 3 + k] = m.lambda[i * 3 + k]; oldPenalty[i * 3 + k] = m.penalty[i * 3 + k]; }
         }
     }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) { oldLambda[r] = m.lambda[r]; oldPenalty[r] = m.penalty[r]; }
+    auto sel4 = [](int j, float a, float b, float c, float d) { return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)); };
 
     RawContact* raw = old.raw;
     m.numContacts = collide_boxes(A, B, raw, old.ws);
@@ -276,9 +278,10 @@ AVBD_HD bool manifold_initialize(ManifoldInit& m, ManifoldOld& old, const BoxPos
             float driftSq = lensq3(newMid - oldMid);
             bool valid = (nd >= kWarmMinDot) && (driftSq <= kWarmMaxDrift * kWarmMaxDrift);
             if (valid) {
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    m.lambda[base + k] = oldLambda[best * 3 + k];
-                    m.penalty[base + k] = rclamp(oldPenalty[best * 3 + k], kPenaltyMin, kManifoldPenaltyCap);
+                    m.lambda[base + k] = sel4(best, oldLambda[k], oldLambda[3 + k], oldLambda[6 + k], oldLambda[9 + k]);
+                    m.penalty[base + k] = rclamp(sel4(best, oldPenalty[k], oldPenalty[3 + k], oldPenalty[6 + k], oldPenalty[9 + k]), kPenaltyMin, kManifoldPenaltyCap);
                 }
             }
             bool reuse = false;
