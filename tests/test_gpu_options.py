@@ -97,3 +97,18 @@ def test_group_schedule_options_on_a_falling_pile():
             o.step(15); g.step(15)
             H.assert_same_world_fast(o, g, f"StressN:8 step {140 + 15 * s} with {options}", check_rows=True)
         assert int(g.w.stats()["schedule"]) == 4 and int(g.w.stats()["numManifolds"]) > 200
+
+
+@pytest.mark.parametrize("lanes", [32, 64])
+def test_narrow_phase_lanes_on_a_grid_scene(lanes):
+    """k_narrowphase<32> / <64> (scenes beyond 4096 bodies; 64 lanes by default from 16 000 bodies on): 4 913 falling cubes into their landing, both forms
+    against the oracle — manifolds, contacts and warm-started rows bit for bit (the 64-lane form keeps last step's lambda / penalty in registers and clips
+    into eight-vertex buffers)."""
+    o = H.CpuWorld("orc"); o.scene("StressN:17"); o.step(128)
+    g = H.HipWorld(); g.scene("StressN:17")
+    g.w.set_option("narrow_lanes", lanes)
+    g.step(128)
+    for s in range(4):
+        o.step(6); g.step(6)
+        H.assert_same_world_fast(o, g, f"StressN:17 step {134 + 6 * s} with {lanes} lanes", check_rows=True)
+    assert int(g.w.stats()["numManifolds"]) > 1500
