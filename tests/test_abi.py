@@ -102,3 +102,17 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu_before_touching_the_gpu():
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "3"] and cmd[-7].endswith("bench.py")
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="4", RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_option_keys_are_enumerable_without_a_device(lib):
+    """avbd_option_count / avbd_option_key need no GPU; every key is documented in DESIGN.md's option table (section 7b) or in the README"""
+    lib.avbd_option_key.restype = C.c_char_p
+    lib.avbd_option_key.argtypes = [C.c_int]
+    n = lib.avbd_option_count()
+    keys = [lib.avbd_option_key(i).decode() for i in range(n)]
+    assert n >= 30 and len(set(keys)) == n and lib.avbd_option_key(n) is None and lib.avbd_option_key(-1) is None
+    text = open(os.path.join(H.ROOT, "DESIGN.md")).read()
+    missing = [k for k in keys if ("`" + k + "`") not in text]
+    assert not missing, f"options without an entry in DESIGN.md's option table: {missing}"
+    # without a context the setters fail cleanly
+    assert lib.avbd_set_option(None, b"place", 1) < 0
