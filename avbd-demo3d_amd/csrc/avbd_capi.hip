@@ -251,6 +251,7 @@ struct AvbdContext {
     DevArr<unsigned> xDepCnt; DevArr<int> xRankOf;
     int groupPool = 1, groupPoolMinRounds = 3;   /* ResidentExchange::poolMode / poolMinRounds (classes with fewer bodies per sub-group take a task in hand instead) */
     int groupSpecMode = 0, groupSpecRounds = 4;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
+    int liveAtCreation = 1;             /* contexts of this process alive on the device when this one made its streams, itself included (hardware queues: avbd_group_step) */
     bool turnReleased = false;          /* avbd_destroy has taken this context out of its device's count (turn_begin / turn_end) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
     DevArr<unsigned> dXchMismatch;      /* words of gathered velocities that differed from the re-derived ones (must stay 0) */
@@ -910,7 +911,18 @@ int avbd_create(int device, AvbdContext** out)
     {   /* second stream + signal words of the persistent sharded step; without them sharded runs launch once per iteration */
         int can = 0;
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
-        if (can && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+        /* The exchange stream gets the HIGHEST priority: HIP maps the streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES = 4) PER PRIORITY, and an
+         * exchange stream that lands on the queue of a persistent launch — its own context's or another's — sits behind the kernel that waits for that very
+         * exchange (the 4 x 16 000 stall of round 3; a 3-in-10 time-out of a test that built its ranks while five other contexts were alive).  With a priority of
+         * their own, exchange streams only ever share queues with each other. */
+        int prLeast = 0, prGreatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest) != hipSuccess) { (void)hipGetLastError(); prLeast = prGreatest = 0; }
+        auto make_stream2 = [&]() {
+            if (prGreatest != prLeast && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prGreatest) == hipSuccess) return true;
+            (void)hipGetLastError();
+            return hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+        };
+        if (can && make_stream2() &&
             hipEventCreateWithFlags(&c->evBegin, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->evGathered, hipEventDisableTiming) == hipSuccess &&
             hipExtMallocWithFlags((void**)&c->sigDone, 8, hipMallocSignalMemory) == hipSuccess && hipExtMallocWithFlags((void**)&c->sigGather, 256, hipDeviceMallocUncached) == hipSuccess) {
             (void)hipMemsetAsync(c->sigDone, 0, 8, c->stream); (void)hipMemsetAsync(c->sigGather, 0, 8, c->stream);
@@ -982,7 +994,7 @@ int avbd_create(int device, AvbdContext** out)
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_levels, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
     }
-    if (device < kMaxDevices) { std::lock_guard<std::mutex> lk(g_turnMu); ++g_turnLive[device]; }
+    if (device < kMaxDevices) { std::lock_guard<std::mutex> lk(g_turnMu); c->liveAtCreation = ++g_turnLive[device]; }
     *out = c;
     return AVBD_OK;
 }

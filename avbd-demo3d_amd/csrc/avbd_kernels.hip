@@ -155,14 +155,17 @@ __global__ void k_grid_build(BodyTable B, const unsigned char* __restrict__ isBi
 }
 
 /* the pair test of solver.cpp:262-270 + Rigid::isConstrainedTo (rigid.cpp:61-69) for one ordered pair i > j */
+template <bool SPHERES_TESTED = false>
 __device__ __forceinline__ bool broadphase_pair_passes(const BodyTable& B, int i, int j, const int* __restrict__ adjStart, const int* __restrict__ adjOther,
                                                        int keepUnsolvedPairs)
 {
-    const float4* posr = B.plane(BP_POSR);
-    const float4 a = posr[i], b = posr[j];
-    const f3 dp = mk3(a.x, a.y, a.z) - mk3(b.x, b.y, b.z);
-    const float r = a.w + b.w;
-    if (!(dot3(dp, dp) <= r * r)) return false;
+    if (!SPHERES_TESTED) {
+        const float4* posr = B.plane(BP_POSR);
+        const float4 a = posr[i], b = posr[j];
+        const f3 dp = mk3(a.x, a.y, a.z) - mk3(b.x, b.y, b.z);
+        const float r = a.w + b.w;
+        if (!(dot3(dp, dp) <= r * r)) return false;
+    }
     if (!B.solved[i] && !B.solved[j]) {
         const bool bothStatic = !(B.plane(BP_MASS)[i].y > 0.0f) && !(B.plane(BP_MASS)[j].y > 0.0f);
         if (!(keepUnsolvedPairs && bothStatic)) return false;
@@ -176,8 +179,10 @@ __device__ __forceinline__ bool broadphase_pair_passes(const BodyTable& B, int i
 
 /* one thread per (body, one of the 27 cells around it): the centre thread also takes the body's pairs with the big bodies.
  * Appending is what bounds a broadphase here (a falling 64 000-cube grid yields 250 000 candidates per step, and atomics on
- * one word retire at ~10 ns each): every thread first COUNTS its candidates, the workgroup reserves its range with ONE atomic,
- * then the threads run their (cheap, cache-resident) tests again and write. */
+ * one word retire at ~10 ns each): every thread first COUNTS its candidates — keeping the first three in registers — the workgroup
+ * reserves its range with ONE atomic, then the threads write (a thread with more than three walks its list a second time).
+ * Different cells may share a bucket of the hash table: a body of the bucket counts for the thread whose cell it really lies in
+ * (its centre is in the thread's hand for the sphere test anyway), so no thread has to know which buckets its 26 siblings scan. */
 __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned char* __restrict__ isBig, const int* __restrict__ bigList, int nBig, float invCell, unsigned mask,
                              const int* __restrict__ cellHead, const int* __restrict__ cellNext, const int* __restrict__ adjStart,
                              const int* __restrict__ adjOther, int2* cand, int candCap, Counters* cnt, int keepUnsolvedPairs)
@@ -188,57 +193,66 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
     const bool live = i < B.n;
     const bool big = live && isBig[i];
     if (threadIdx.x == 0) sCount = 0;
-    int head = -1;
+    int head = -1, tx = 0, ty = 0, tz = 0;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live && !big) {
-        const float4 p = B.plane(BP_POSR)[i];
-        const int cx = grid_coord(p.x, invCell), cy = grid_coord(p.y, invCell), cz = grid_coord(p.z, invCell);
-        const unsigned h = grid_bucket(cx + (k % 3) - 1, cy + ((k / 3) % 3) - 1, cz + (k / 9) - 1, mask);
-        /* different cells may share a bucket: the bucket is scanned by the first of the 27 threads that maps to it */
-        bool first = true;
-        for (int q = 0; q < k; ++q) first &= grid_bucket(cx + (q % 3) - 1, cy + ((q / 3) % 3) - 1, cz + (q / 9) - 1, mask) != h;
-        if (first) head = cellHead[h];
+        pi = B.plane(BP_POSR)[i];
+        tx = grid_coord(pi.x, invCell) + (k % 3) - 1; ty = grid_coord(pi.y, invCell) + ((k / 3) % 3) - 1; tz = grid_coord(pi.z, invCell) + (k / 9) - 1;
+        head = cellHead[grid_bucket(tx, ty, tz, mask)];
     }
     __syncthreads();
-    int offset = 0;
-    unsigned long long hitMask = 0ull;
-    for (int pass = 0; pass < 2; ++pass) {
-        int mine = 0;
-        if (live && k == 13) {                                        /* pairs with a big body: once per unordered pair */
-            for (int g = 0; g < nBig; ++g) {
-                const int o = bigList[g];
-                if (o == i || (big && !(i < o))) continue;
-                const int hi = i > o ? i : o, lo = i > o ? o : i;
-                if (broadphase_pair_passes(B, hi, lo, adjStart, adjOther, keepUnsolvedPairs)) {
-                    if (pass) { const int slot = offset + mine; if (slot < candCap) cand[slot] = make_int2(hi, lo); }
-                    ++mine;
-                }
-            }
+    /* the pair test for a body j of the thread's bucket: in the thread's cell, earlier-created, spheres overlap, no force between them */
+    auto cell_pair_passes = [&](int j) -> bool {
+        if (!(j < i)) return false;
+        const float4 b = B.plane(BP_POSR)[j];
+        const f3 dp = mk3(pi.x, pi.y, pi.z) - mk3(b.x, b.y, b.z);
+        const float r = pi.w + b.w;
+        if (!(dot3(dp, dp) <= r * r)) return false;
+        if (grid_coord(b.x, invCell) != tx || grid_coord(b.y, invCell) != ty || grid_coord(b.z, invCell) != tz) return false;   /* another cell of this bucket */
+        return broadphase_pair_passes<true>(B, i, j, adjStart, adjOther, keepUnsolvedPairs);
+    };
+    int mine = 0;
+    int2 h0 = make_int2(0, 0), h1 = h0, h2 = h0;
+    auto note = [&](int hi, int lo) { if (mine == 0) h0 = make_int2(hi, lo); else if (mine == 1) h1 = make_int2(hi, lo); else if (mine == 2) h2 = make_int2(hi, lo); ++mine; };
+    if (live && k == 13) {                                            /* pairs with a big body: once per unordered pair */
+        for (int g = 0; g < nBig; ++g) {
+            const int o = bigList[g];
+            if (o == i || (big && !(i < o))) continue;
+            const int hi = i > o ? i : o, lo = i > o ? o : i;
+            if (broadphase_pair_passes(B, hi, lo, adjStart, adjOther, keepUnsolvedPairs)) note(hi, lo);
         }
-        /* (the tests — two position loads, the adjacency search of isConstrainedTo — are made ONCE: the counting pass remembers which of the
-         * bucket's first 64 bodies passed, the writing pass only walks the list again) */
-        int posInList = 0;
-        for (int j = head; j >= 0; j = cellNext[j], ++posInList) {
-            bool hit;
-            if (pass && posInList < 64) hit = (hitMask >> posInList) & 1ull;
-            else hit = j < i && broadphase_pair_passes(B, i, j, adjStart, adjOther, keepUnsolvedPairs);
-            if (!pass && hit && posInList < 64) hitMask |= 1ull << posInList;
-            if (hit) {
-                if (pass) { const int slot = offset + mine; if (slot < candCap) cand[slot] = make_int2(i, j); }
-                ++mine;
-            }
-        }
-        if (pass) break;
-        offset = mine ? atomicAdd(&sCount, mine) : 0;                 /* LDS: position inside the workgroup's range */
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int total = sCount;
-            const int base = total ? atomicAdd(&cnt->numCandidates, total) : 0;
-            if (base + total > candCap) atomicOr(&cnt->overflow, 1);
-            sBase = base;
-        }
-        __syncthreads();
-        offset += sBase;
     }
+    for (int j = head; j >= 0; j = cellNext[j])
+        if (cell_pair_passes(j)) note(i, j);
+    int offset = mine ? atomicAdd(&sCount, mine) : 0;                  /* LDS: position inside the workgroup's range */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = sCount;
+        const int base = total ? atomicAdd(&cnt->numCandidates, total) : 0;
+        if (base + total > candCap) atomicOr(&cnt->overflow, 1);
+        sBase = base;
+    }
+    __syncthreads();
+    offset += sBase;
+    if (mine == 0) return;
+    if (mine <= 3) {
+        if (offset < candCap) cand[offset] = h0;
+        if (mine > 1 && offset + 1 < candCap) cand[offset + 1] = h1;
+        if (mine > 2 && offset + 2 < candCap) cand[offset + 2] = h2;
+        return;
+    }
+    int w = 0;                                                         /* (rare) more than three: the same tests again, in the same order */
+    auto put = [&](int hi, int lo) { const int slot = offset + w; if (slot < candCap) cand[slot] = make_int2(hi, lo); ++w; };
+    if (k == 13) {
+        for (int g = 0; g < nBig; ++g) {
+            const int o = bigList[g];
+            if (o == i || (big && !(i < o))) continue;
+            const int hi = i > o ? i : o, lo = i > o ? o : i;
+            if (broadphase_pair_passes(B, hi, lo, adjStart, adjOther, keepUnsolvedPairs)) put(hi, lo);
+        }
+    }
+    for (int j = head; j >= 0; j = cellNext[j])
+        if (cell_pair_passes(j)) put(i, j);
 }
 
 /* ------------------------------------------------------------------------------------------

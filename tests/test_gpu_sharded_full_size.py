@@ -200,14 +200,15 @@ def test_config3_two_ranks_persistent_form_matches_one_launch_per_iteration_thro
     assert out["1"][2] == out["0"][2], "the persistent and the per-iteration form differ (md5 of bodies + forces per rank)"
 
 
-def test_four_contexts_persistent_with_a_hardware_queue_per_stream():
+def test_four_contexts_persistent_several_bodies_per_sub_group():
     """The stall of round 3 ("four contexts of 16 000 bodies in the persistent several-bodies form stop making progress on the step the first
-    layer lands — not understood"), explained: four contexts have eight streams, a HIP process maps them onto GPU_MAX_HW_QUEUES = 4 hardware
-    queues, and an exchange stream that shares a queue with another context's persistent launch waits behind the kernel that waits for it.
-    With a hardware queue per stream the same run goes through the landing (tools/stall_4x16000.py forces the combination; with the default
-    four queues avbd_group_step takes one launch per iteration instead).  A process of its own: the runtime reads the variable once."""
+    layer lands — not understood"), explained and cured in round 4: four contexts have eight streams, a HIP process maps them onto
+    GPU_MAX_HW_QUEUES = 4 hardware queues per stream priority, and an exchange stream that shared a queue with another context's persistent
+    launch waited behind the kernel that waited for it.  The exchange streams now have a priority — and so queues — of their own
+    (avbd_create): the same run goes through the landing with the runtime's default four queues, in the persistent form
+    (tools/stall_4x16000.py).  A process of its own: fresh contexts, nothing else alive on the device."""
     import os, subprocess, sys
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stall_4x16000.py"), "4", "StressN:40", "145"], capture_output=True, text=True, env=env, timeout=280)
     assert r.returncode == 0 and "RESULT: went through" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
     assert "cutMode 2" in r.stdout                                      # the persistent form really ran
