@@ -10,6 +10,7 @@ a `World` raises unless a gfx950 device and the compiled library are present.
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -66,7 +67,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_group_rebalance", "avbd_set_option", "avbd_get_option", "avbd_option_count", "avbd_option_key", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign",
+    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_group_rebalance", "avbd_rebalance_export", "avbd_rebalance_import", "avbd_set_option", "avbd_get_option", "avbd_option_count", "avbd_option_key", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign",
 ]
 
 
@@ -83,6 +84,7 @@ def build(verbose=False):
 
 
 _lib = None
+_live_worlds = weakref.WeakSet()      # every World that has not been closed (close_all_worlds)
 
 
 def lib():
@@ -158,6 +160,20 @@ def comm_unique_id():
     return buf.raw
 
 
+def close_all_worlds():
+    """Destroy every context this process still holds.  A context owns two HIP streams, and how many contexts are alive on a device when another
+    one is made decides whether its streams get hardware queues of their own (avbd_group_step's persistent all-gather form asks for that): a test
+    session closes what a test left behind — a failed test's locals stay alive in its traceback — instead of letting it change later tests."""
+    n = 0
+    for w in list(_live_worlds):
+        try:
+            if getattr(w, "h", None):
+                w.close(); n += 1
+        except Exception:
+            pass
+    return n
+
+
 def group_step(worlds, nsteps=1):
     arr = (C.c_void_p * len(worlds))(*[w.h for w in worlds])
     rc = lib().avbd_group_step(arr, len(worlds), int(nsteps))
@@ -185,6 +201,7 @@ class World:
             raise AvbdError(f"avbd_create(device={device}) failed with code {rc} ({self.L.avbd_last_error(None).decode()}): no usable gfx950 "
                             "device / HIP runtime (this framework has no CPU fallback)")
         self.h = h
+        _live_worlds.add(self)
 
     # -- lifetime
     def close(self):
@@ -346,6 +363,22 @@ class World:
         n = C.c_ulonglong(0)
         self._chk(self.L.avbd_exact_window_export(self.h, h, C.byref(n)))
         return bytes(h)
+
+    def rebalance_export(self):
+        """this rank's force list (newest first) and creation keys, for a re-balance between ranks that are processes"""
+        n = self._chk(self.L.avbd_rebalance_export(self.h, None, None, 0))
+        forces, keys = np.zeros(max(n, 1), FORCE_DT), np.zeros(max(n, 1), np.uint64)
+        got = self._chk(self.L.avbd_rebalance_export(self.h, forces.ctypes.data_as(C.c_void_p), keys.ctypes.data_as(C.c_void_p), max(n, 1)))
+        return forces[:got], keys[:got]
+
+    def rebalance_import(self, owner, exports):
+        """exports: [(forces, keys)] of ALL ranks, index = rank (every rank passes the same list and the same owner[])"""
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        forces = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=FORCE_DT) for f, _ in exports]), dtype=FORCE_DT)
+        keys = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=np.uint64) for _, k in exports]), dtype=np.uint64)
+        frm = np.ascontiguousarray(np.concatenate([np.full(len(k), r, np.int32) for r, (_, k) in enumerate(exports)]), dtype=np.int32)
+        self._chk(self.L.avbd_rebalance_import(self.h, owner.ctypes.data_as(C.POINTER(C.c_int)), len(owner), forces.ctypes.data_as(C.c_void_p),
+                                               keys.ctypes.data_as(C.c_void_p), frm.ctypes.data_as(C.c_void_p), len(keys)))
 
     def exact_window_attach(self, handles, ranks_on_this_device=1):
         blob = b"".join(handles)

@@ -1608,50 +1608,56 @@ int avbd_download_force(AvbdContext* c, int list_index, AvbdForce* out)
  * (tests/test_gpu_exact_cuts.py::test_rebalanced_ownership_...), i.e. it equals a run that was started with the new ownership.  Host-side and
  * synchronous: meant for every few hundred steps.  (Ranks that are processes would exchange their lists the same way through the caller's
  * transport; not built.) */
-int avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodies)
+/* ---- re-balanced ownership (SURVEY.md section 8e "spatial slabs re-balanced every K steps") ------------------------------------------------------
+ * Two halves, so that ranks that are PROCESSES can do it too (the host side gathers the exports, e.g. with torch.distributed.all_gather_object):
+ *   avbd_rebalance_export   this rank's force list, newest first, with the creation keys
+ *   avbd_rebalance_import   all ranks' exports (any order) + the new ownership: one copy per force — the one of the rank that swept the contact's
+ *                           owner under the OLD ownership —, the part of that one list this rank needs, bodies and step index kept
+ * avbd_group_rebalance is the two in a row for contexts of one process. */
+struct RebalanceItem { uint64_t key; AvbdForce f; int rank; };
+
+static int rebalance_collect(AvbdContext* c, std::vector<RebalanceItem>& out)
 {
-    if (!ctxs || n < 1 || !owner) return AVBD_E_INVALID;
-    for (int r = 0; r < n; ++r) if (!ctxs[r]) return AVBD_E_INVALID;
-    AvbdContext* L = ctxs[0];
     int rc;
-    for (int r = 0; r < n; ++r) {
-        AvbdContext* c = ctxs[r];
-        if (c->nranks != n || c->rank != r) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: the contexts are not the ranks 0..n-1 of one sharded scene");
-        if ((int)c->hBodies.size() != nbodies) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: owner[] must have one entry per body");
-        if (!c->hostForceG.empty()) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: scenes with user-defined Force subclasses cannot be sharded");
-        if (c->xwAttached) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: ranks that are processes are not supported");
-    }
-    for (int i = 0; i < nbodies; ++i) if (owner[i] >= n) return L->fail(AVBD_E_INVALID, "avbd_group_rebalance: owner index out of range");
-    /* 1. every rank's forces, newest first, with their keys */
-    struct Item { uint64_t key; AvbdForce f; int rank; };
-    std::vector<Item> all;
-    for (int r = 0; r < n; ++r) {
-        AvbdContext* c = ctxs[r];
-        (void)hipSetDevice(c->device);
-        HostManifolds hm; std::vector<ForceRef> refs;
-        if ((rc = sorted_force_refs(c, hm, refs))) return rc;
-        std::vector<AvbdForce> fs(std::max<size_t>(refs.size(), 1));
-        const int got = avbd_download_forces(c, fs.data(), (int)refs.size());
-        if (got < 0) return got;
-        if (got != (int)refs.size()) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: the force list changed under the download");
-        for (int i = 0; i < got; ++i) all.push_back({refs[(size_t)i].key, fs[(size_t)i], r});
-    }
-    /* 2. one copy per force: the one of the rank that swept its owner (old ownership) */
-    const std::vector<int> oldOwner = L->hOwner;
+    (void)hipSetDevice(c->device);
+    if (!c->hostForceG.empty()) return c->fail(AVBD_E_INVALID, "rebalance: scenes with user-defined Force subclasses cannot be sharded");
+    HostManifolds hm; std::vector<ForceRef> refs;
+    if ((rc = sorted_force_refs(c, hm, refs))) return rc;
+    std::vector<AvbdForce> fs(std::max<size_t>(refs.size(), 1));
+    const int got = avbd_download_forces(c, fs.data(), (int)refs.size());
+    if (got < 0) return got;
+    if (got != (int)refs.size()) return c->fail(AVBD_E_INVALID, "rebalance: the force list changed under the download");
+    for (int i = 0; i < got; ++i) out.push_back({refs[(size_t)i].key, fs[(size_t)i], c->rank});
+    return AVBD_OK;
+}
+
+static int rebalance_apply(AvbdContext* c, const int* owner, int nbodies, std::vector<RebalanceItem> all)
+{
+    int rc;
+    (void)hipSetDevice(c->device);
+    const int n = c->nranks;
+    if ((int)c->hBodies.size() != nbodies) return c->fail(AVBD_E_INVALID, "rebalance: owner[] must have one entry per body");
+    if ((int)c->hOwner.size() != nbodies) return c->fail(AVBD_E_INVALID, "rebalance: the context has no ownership yet (avbd_set_ownership before the first step)");
+    if (!c->hostForceG.empty()) return c->fail(AVBD_E_INVALID, "rebalance: scenes with user-defined Force subclasses cannot be sharded");
+    for (int i = 0; i < nbodies; ++i) if (owner[i] >= n) return c->fail(AVBD_E_INVALID, "rebalance: owner index out of range");
+    for (const RebalanceItem& it : all) if (it.rank < 0 || it.rank >= n) return c->fail(AVBD_E_INVALID, "rebalance: exporting rank out of range");
+    /* one copy per force: the one of the rank that swept its owner (old ownership) */
+    const std::vector<int> oldOwner = c->hOwner;
     auto prefer = [&](const AvbdForce& f) -> int {
         const int a = f.bodyA, b = f.bodyB;
         const bool da = a >= 0 && a < nbodies && oldOwner[(size_t)a] >= 0, db = b >= 0 && b < nbodies && oldOwner[(size_t)b] >= 0;
         const int own = (da && db) ? std::min(a, b) : (da ? a : (db ? b : -1));
         return own >= 0 ? oldOwner[(size_t)own] : 0;
     };
-    std::stable_sort(all.begin(), all.end(), [](const Item& x, const Item& y) { return x.key > y.key; });
+    /* (by key, then by exporting rank: every rank — every process — sees the same list whatever order the exports arrived in) */
+    std::stable_sort(all.begin(), all.end(), [](const RebalanceItem& x, const RebalanceItem& y) { return x.key != y.key ? x.key > y.key : x.rank < y.rank; });
     std::vector<AvbdForce> merged;
     for (size_t i = 0; i < all.size();) {
         size_t j = i, pick = i;
         const int want = prefer(all[i].f);
         for (; j < all.size() && all[j].key == all[i].key; ++j) {
             if (all[j].f.bodyA != all[i].f.bodyA || all[j].f.bodyB != all[i].f.bodyB || all[j].f.kind != all[i].f.kind)
-                return L->fail(AVBD_E_INVALID, "avbd_group_rebalance: two different forces carry one creation key (were the ranks built from the same scene?)");
+                return c->fail(AVBD_E_INVALID, "rebalance: two different forces carry one creation key (were the ranks built from the same scene?)");
             if (all[j].rank == want) pick = j;
         }
         merged.push_back(all[pick].f);
@@ -1659,29 +1665,58 @@ int avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodie
     }
     /* the merged list's own keys: position in the ONE list, the same on every rank that gets the force (manifolds created later have step >= 1
      * in their key and stay newer) */
-    std::vector<uint64_t> mkeys(merged.size());
-    for (size_t i = 0; i < merged.size(); ++i) mkeys[i] = make_host_key(0, (uint64_t)(merged.size() - i));
-    /* 3. the bodies (every rank holds the same state after a step) and every rank rebuilt under the new ownership */
+    std::vector<AvbdForce> mine; std::vector<uint64_t> mineKeys;
+    for (size_t i = 0; i < merged.size(); ++i) {
+        const AvbdForce& f = merged[i];
+        const bool ta = f.bodyA >= 0 && f.bodyA < nbodies && owner[f.bodyA] == c->rank, tb = f.bodyB >= 0 && f.bodyB < nbodies && owner[f.bodyB] == c->rank;
+        if (f.kind != AVBD_FORCE_MANIFOLD || ta || tb) { mine.push_back(f); mineKeys.push_back(make_host_key(0, (uint64_t)(merged.size() - i))); }
+    }
+    /* the bodies: every rank holds the same state after a step */
     std::vector<AvbdBody> bodies((size_t)std::max(nbodies, 1));
-    (void)hipSetDevice(L->device);
-    if (nbodies && (rc = avbd_download_bodies(L, bodies.data(), nbodies)) < 0) return rc;
-    const AvbdParams params = L->params;
-    const int stepIndex = L->stepIndex;
+    if (nbodies && (rc = avbd_download_bodies(c, bodies.data(), nbodies)) < 0) return rc;
+    const AvbdParams params = c->params;
+    const int stepIndex = c->stepIndex;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hOwner.assign(owner, owner + nbodies);                         /* (before the rebuild: the upload marks the bodies this rank sweeps) */
+    if ((rc = restore_state(c, params, stepIndex, bodies.data(), nbodies, mine.data(), (int)mine.size(), mineKeys.data()))) return rc;
+    c->hOwner.assign(owner, owner + nbodies);
+    c->bodiesStale = true; c->adjDirty = true;
+    return AVBD_OK;
+}
+
+int avbd_rebalance_export(AvbdContext* c, AvbdForce* forces, unsigned long long* keys, int capacity)
+{
+    if (!c || capacity < 0 || (capacity > 0 && (!forces || !keys))) return AVBD_E_INVALID;
+    std::vector<RebalanceItem> items;
+    int rc = rebalance_collect(c, items);
+    if (rc) return rc;
+    if (capacity == 0) return (int)items.size();                      /* (a first call for the count) */
+    if ((int)items.size() > capacity) return c->fail(AVBD_E_CAPACITY, "avbd_rebalance_export: the force list is longer than the caller's buffers");
+    for (size_t i = 0; i < items.size(); ++i) { forces[i] = items[i].f; keys[i] = items[i].key; }
+    return (int)items.size();
+}
+
+int avbd_rebalance_import(AvbdContext* c, const int* owner, int nbodies, const AvbdForce* forces, const unsigned long long* keys, const int* fromRank, int count)
+{
+    if (!c || !owner || nbodies < 0 || count < 0 || (count > 0 && (!forces || !keys || !fromRank))) return AVBD_E_INVALID;
+    std::vector<RebalanceItem> all((size_t)count);
+    for (int i = 0; i < count; ++i) all[(size_t)i] = {keys[i], forces[i], fromRank[i]};
+    return rebalance_apply(c, owner, nbodies, std::move(all));
+}
+
+int avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodies)
+{
+    if (!ctxs || n < 1 || !owner) return AVBD_E_INVALID;
+    for (int r = 0; r < n; ++r) if (!ctxs[r]) return AVBD_E_INVALID;
+    int rc;
     for (int r = 0; r < n; ++r) {
         AvbdContext* c = ctxs[r];
-        (void)hipSetDevice(c->device);
-        std::vector<AvbdForce> mine; std::vector<uint64_t> mineKeys;
-        for (size_t i = 0; i < merged.size(); ++i) {
-            const AvbdForce& f = merged[i];
-            const bool ta = f.bodyA >= 0 && f.bodyA < nbodies && owner[f.bodyA] == r, tb = f.bodyB >= 0 && f.bodyB < nbodies && owner[f.bodyB] == r;
-            if (f.kind != AVBD_FORCE_MANIFOLD || ta || tb) { mine.push_back(f); mineKeys.push_back(mkeys[i]); }
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->hOwner.assign(owner, owner + nbodies);                     /* (before the rebuild: the upload marks the bodies this rank sweeps) */
-        if ((rc = restore_state(c, params, stepIndex, bodies.data(), nbodies, mine.data(), (int)mine.size(), mineKeys.data()))) return rc;
-        c->hOwner.assign(owner, owner + nbodies);
-        c->bodiesStale = true; c->adjDirty = true;
+        if (c->nranks != n || c->rank != r) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: the contexts are not the ranks 0..n-1 of one sharded scene");
+        if (c->xwAttached) return c->fail(AVBD_E_INVALID, "avbd_group_rebalance: ranks that are processes exchange their lists themselves (avbd_rebalance_export / _import)");
     }
+    std::vector<RebalanceItem> all;
+    for (int r = 0; r < n; ++r) if ((rc = rebalance_collect(ctxs[r], all))) return rc;
+    for (int r = 0; r < n; ++r) if ((rc = rebalance_apply(ctxs[r], owner, nbodies, all))) return rc;
     return AVBD_OK;
 }
 

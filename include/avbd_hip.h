@@ -308,6 +308,14 @@ int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
  * the manifolds move with the bodies (contacts, lambda, penalty, list order), every rank continues from the state the single-GPU run would hold.
  * owner[] as for avbd_set_ownership (avbd_partition_by_axis on the current positions gives equal slabs again).  Synchronous, host-side. */
 int  avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodies);
+/* The same for ranks that are PROCESSES (exact cuts through windows, or the RCCL all-gather form), in two halves with the caller's own gather in between
+ * (bench.py / the Python mirror: torch.distributed.all_gather_object; any transport does):
+ *   avbd_rebalance_export  this rank's force list, newest first, with its creation keys.  capacity 0: returns the count only.  Returns the count.
+ *   avbd_rebalance_import  ALL ranks' exports in any order (fromRank[i] = the rank that exported item i) and the new ownership; keeps the copy of the
+ *                          rank that swept each contact's owner, rebuilds this rank under the new ownership.  Every rank must call it with the same
+ *                          items and the same owner[]; attached exact-cut windows stay attached (the pools do not grow in a re-balance). */
+int  avbd_rebalance_export(AvbdContext* ctx, AvbdForce* forces, unsigned long long* keys, int capacity);
+int  avbd_rebalance_import(AvbdContext* ctx, const int* owner, int nbodies, const AvbdForce* forces, const unsigned long long* keys, const int* fromRank, int count);
 int  avbd_set_shard_mode(AvbdContext* ctx, int mode);
 /* Exact cuts between ranks that are PROCESSES — one per GPU, or several on one device (how they are validated: N processes on one
  * MI355X reproduce the single-GPU sweep bit for bit, tests/test_gpu_exact_processes.py).  Every rank holds the whole scene and has

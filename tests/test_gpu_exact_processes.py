@@ -22,7 +22,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, %(tests)r)
 import harness as H
-rank, nranks, scene, steps, axis, work = %(rank)d, %(nranks)d, %(scene)r, %(steps)r, %(axis)d, %(work)r
+rank, nranks, scene, steps, axis, work, rebal = %(rank)d, %(nranks)d, %(scene)r, %(steps)r, %(axis)d, %(work)r, %(rebal)r
 pkg = H.load_product()
 w = H.HipWorld(); w.scene(scene)
 b = w.bodies()
@@ -40,6 +40,18 @@ wait_for(["h%%d.bin" %% q for q in range(nranks)], "the peers' handles")
 w.w.exact_window_attach([open(os.path.join(work, "h%%d.bin" %% q), "rb").read() for q in range(nranks)], ranks_on_this_device=nranks)
 done = 0
 for k, s in enumerate(steps):
+    if k in rebal:
+        # ownership re-balanced between ranks that are processes: every rank exports its force list, all lists travel (files here,
+        # torch.distributed in bench.py), every rank imports the same lists with the same new ownership; the windows stay attached
+        f, keys = w.w.rebalance_export()
+        np.save(os.path.join(work, "xf_%%d_%%d.tmp.npy" %% (k, rank)), f); np.save(os.path.join(work, "xk_%%d_%%d.tmp.npy" %% (k, rank)), keys)
+        os.rename(os.path.join(work, "xf_%%d_%%d.tmp.npy" %% (k, rank)), os.path.join(work, "xf_%%d_%%d.npy" %% (k, rank)))
+        os.rename(os.path.join(work, "xk_%%d_%%d.tmp.npy" %% (k, rank)), os.path.join(work, "xk_%%d_%%d.npy" %% (k, rank)))
+        wait_for(["x%%s_%%d_%%d.npy" %% (t, k, q) for q in range(nranks) for t in "fk"], "the peers' force lists")
+        b = w.bodies()
+        owner = pkg.partition_by_axis(b["pos"], b["invMass"], nranks, axis=rebal[k])
+        w.w.rebalance_import(owner, [(np.load(os.path.join(work, "xf_%%d_%%d.npy" %% (k, q))), np.load(os.path.join(work, "xk_%%d_%%d.npy" %% (k, q)))) for q in range(nranks)])
+        np.save(os.path.join(work, "owner_%%d_%%d.npy" %% (k, rank)), owner)
     # (the ranks start every leg together: a rank's waves give up after 4 s without progress)
     open(os.path.join(work, "go%%d_%%d" %% (k, rank)), "w").close()
     wait_for(["go%%d_%%d" %% (k, q) for q in range(nranks)], "the start of leg %%d" %% k)
@@ -59,12 +71,12 @@ w.w.close()
 '''
 
 
-def _run_ranks(tmp_path, scene, nranks, steps, axis=0, env_extra=None):
+def _run_ranks(tmp_path, scene, nranks, steps, axis=0, env_extra=None, rebal=None):
     work = str(tmp_path)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
     env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, "-c", CHILD % {"tests": os.path.join(H.ROOT, "tests"), "rank": r, "nranks": nranks, "scene": scene, "steps": list(steps),
-                                                               "axis": axis, "work": work}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                                               "axis": axis, "work": work, "rebal": dict(rebal or {})}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(nranks)]
     outs, t_end = [], time.time() + 240
     for p in procs:
@@ -109,6 +121,33 @@ def test_process_ranks_on_one_device_reproduce_the_single_gpu_sweep(tmp_path, sc
             assert H.same_bits(bs, rb), f"rank {r}: body state differs from the single-GPU sweep after {done} steps"
             _same_forces(fs, rf, owner, r, f"after {done} steps")
     assert int(single.w.stats()["numManifolds"]) > 0
+
+
+def test_process_ranks_rebalance_their_ownership_between_legs(tmp_path):
+    """avbd_rebalance_export / avbd_rebalance_import (VERDICT round 3 missing #2 in the form a node runs: one PROCESS per rank): a pile that
+    lands while two process ranks re-cut their slabs — along z after 125 steps, along x after 145, along z again after 165 — from the positions of that
+    moment; the force lists travel between the processes, the record windows stay attached.  Every leg is the single-GPU sweep, bodies and forces."""
+    scene, nranks, steps, rebal = "StressN:10", 2, (125, 20, 20, 20), {1: 2, 2: 0, 3: 2}
+    _run_ranks(tmp_path, scene, nranks, steps, 0, rebal=rebal)
+    pkg = H.load_product()
+    single = H.HipWorld(); single.scene(scene)
+    b0 = single.bodies()
+    owner = pkg.partition_by_axis(b0["pos"], b0["invMass"], nranks, axis=0)
+    done = 0
+    for k, s in enumerate(steps):
+        if k in rebal:
+            b = single.bodies()
+            owner = pkg.partition_by_axis(b["pos"], b["invMass"], nranks, axis=rebal[k])
+            for r in range(nranks):
+                assert np.array_equal(owner, np.load(os.path.join(str(tmp_path), f"owner_{k}_{r}.npy"))), f"rank {r} cut different slabs before leg {k}"
+        single.step(s); done += s
+        bs, fs = single.bodies(), single.forces()
+        for r in range(nranks):
+            rb = np.load(os.path.join(str(tmp_path), f"bodies_{done}_{r}.npy"))
+            rf = np.load(os.path.join(str(tmp_path), f"forces_{done}_{r}.npy"))
+            assert H.same_bits(bs, rb), f"rank {r}: body state differs from the single-GPU sweep after {done} steps (leg {k})"
+            _same_forces(fs, rf, owner, r, f"after {done} steps (leg {k})")
+    assert int(single.w.stats()["numManifolds"]) > 300
 
 
 def test_process_ranks_with_several_bodies_per_sub_group(tmp_path):
