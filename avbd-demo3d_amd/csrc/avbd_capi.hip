@@ -134,6 +134,8 @@ struct AvbdContext {
     DevArr<uint64_t> adjKey;
     DevArr<int2> adjTmp;       /* (force reference, other body) in scatter order: k_topology_small */
     DevArr<int2> cand;
+    /* processing order of k_narrowphase (NarrowOrder, avbd_types.h): slots by class and class counters, of the step before and for the step after */
+    DevArr<int> dNarrowPerm[2], dNarrowCnt; int narrowPar = 0; bool narrowOrderValid = false; bool narrowOrder = true;
     /* grid broadphase (scenes above 4096 bodies): radius classes from the host mirror, hashed cell table */
     DevArr<unsigned char> dIsBig; DevArr<int> dBigList, dCellHead, dCellNext;
     int nBig = 0, gridBuckets = 0; float gridCell = 0.0f; bool gridBroadphase = true;   /* AVBD_BROADPHASE=n2: always the O(n^2) tiles */
@@ -354,6 +356,9 @@ int ensure_capacity(AvbdContext* c, int nBodies)
         c->mCap = newMCap;
         c->candCap = newMCap;
         HIPCHK(c, c->cand.alloc(c->candCap));
+        HIPCHK(c, c->dNarrowPerm[0].alloc((size_t)kNarrowClasses * newMCap)); HIPCHK(c, c->dNarrowPerm[1].alloc((size_t)kNarrowClasses * newMCap));
+        if (!c->dNarrowCnt.p) { HIPCHK(c, c->dNarrowCnt.alloc((size_t)2 * kNarrowClasses * kNarrowCntStride)); HIPCHK(c, hipMemsetAsync(c->dNarrowCnt.p, 0, (size_t)2 * kNarrowClasses * kNarrowCntStride * sizeof(int), c->stream)); }
+        c->narrowOrderValid = false;
     }
     HIPCHK(c, c->xPose.alloc((size_t)3 * newCap));
     HIPCHK(c, c->xVisit.alloc((size_t)4 * c->mCap));
@@ -1013,7 +1018,7 @@ int avbd_destroy(AvbdContext* c)
     c->dPlanes.release(); c->mbuf[0].release(); c->mbuf[1].release(); c->dG.release();
     c->adjStart.release(); c->incStart.release(); c->degForce.release(); c->degInc.release(); c->level.release(); c->order.release();
     c->lvlStart.release(); c->lvlCount.release(); c->adjRef.release(); c->adjOther.release(); c->inc.release(); c->adjKey.release();
-    c->cand.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
+    c->cand.release(); c->dNarrowPerm[0].release(); c->dNarrowPerm[1].release(); c->dNarrowCnt.release(); c->dCnt.release(); c->dDiag.release(); c->dNext.release(); c->dFlags.release();
     c->dSolved.release(); c->dPerm.release(); c->dRankStart.release(); c->dSendSlot.release(); c->dSend.release(); c->dRecv.release(); c->dXchMismatch.release();
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
@@ -1784,6 +1789,7 @@ static int upload_forces_keyed(AvbdContext* c, const AvbdForce* in, int n, const
     c->hostKeyCounter = (uint64_t)n + 1;
     if (keys && n > 0) c->hostKeyCounter = std::max<uint64_t>(c->hostKeyCounter, (keys[0] & ((1ull << 40) - 1)) + 1);
     ManifoldBuf& b = c->mbuf[c->cur];
+    c->narrowOrderValid = false;                                       /* (the slots are rewritten: k_narrowphase walks them in slot order once) */
     if (nm) {
         HIPCHK(c, hipMemcpy(b.pair.p, h.pair.data(), nm * sizeof(int2), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(b.key.p, h.key.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice));

@@ -358,7 +358,7 @@ constexpr int kPairsPerWave = 4;       /* sixteen lanes per pair */
  * costs a third of the wave time it costs when sixteen lanes share it): last step's manifold `item` of `src` (item >= 0) or a fresh candidate (a, b); survivors are appended to dst */
 __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const ManifoldTable& src, const ManifoldTable& dst, int item, int a, int b, int step,
                                             ManifoldInit& mi, ManifoldOld& old, Counters* cnt, int* nextCount, int* degForce, int* degInc, const SolverParams& P,
-                                            unsigned long long* dbg = nullptr)
+                                            const NarrowOrder& O, unsigned long long* dbg = nullptr)
 {
     uint64_t key;
     if (item >= 0) {
@@ -405,6 +405,20 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
 
     int slot = atomicAdd(nextCount, 1);
     if (slot >= dst.cap) { atomicOr(&cnt->overflow, 2); return; }
+    if (O.permNext) {                                                 /* next step's processing order: this survivor's slot on the list of its class */
+        const int cls = mi.numContacts >= 3 ? 0 : (mi.numContacts == 2 ? 1 : ((mi.feature[0] >> 24) == 2 ? 3 : 2));
+#pragma unroll
+        for (int k = 0; k < kNarrowClasses; ++k) {
+            const unsigned long long m = __ballot(cls == k);          /* (of the lanes that got here) */
+            if (cls == k) {
+                const int leader = __ffsll((long long)m) - 1, lane = (int)(threadIdx.x & 63);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&O.cntNext[k * kNarrowCntStride], __popcll(m));
+                base = __shfl(base, leader);
+                O.permNext[(size_t)k * O.cap + base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+            }
+        }
+    }
     dst.pair[slot] = make_int2(a, b);
     dst.key[slot] = key;
     dst.nc[slot] = mi.numContacts;
@@ -447,19 +461,30 @@ __device__ __forceinline__ void narrow_pair_lane(const BodyTable& B, const Manif
  * last step's lambda / penalty stay in registers; 872 B before) lets four 64-lane workgroups share a CU — one wave per SIMD, full waves. */
 template <int LANES>
 __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_narrowphase(BodyTable B, ManifoldTable src, ManifoldTable dst, const int2* __restrict__ cand,
-                                                      int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step)
+                                                      int candCap, Counters* cnt, int* nextCount, int* degForce, int* degInc, SolverParams P, int step, NarrowOrder O)
 {
     const int nOld = cnt->numManifolds;
     int nCand = cnt->numCandidates; if (nCand > candCap) nCand = candCap;
     const int total = nOld + nCand;
+    /* last step's manifolds class by class (NarrowOrder): the lists must hold exactly the manifolds of src */
+    int c0 = 0, c1 = 0, c2 = 0;
+    bool ordered = O.permCur != nullptr;
+    if (ordered) {
+        c0 = O.cntCur[0]; c1 = c0 + O.cntCur[kNarrowCntStride]; c2 = c1 + O.cntCur[2 * kNarrowCntStride];
+        ordered = c2 + O.cntCur[3 * kNarrowCntStride] == nOld;
+    }
     /* the dynamically indexed per-pair state lives in LDS instead of scratch */
     static_assert(sizeof(ManifoldOld) * 64 * 4 <= 160 * 1024, "four 64-lane workgroups of k_narrowphase share a CU's LDS");
     __shared__ ManifoldOld sOld[LANES];
     ManifoldInit miPriv;
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-        int a = 0, b = 0;
+        int a = 0, b = 0, slot = -1;
         if (item >= nOld) { int2 pr = cand[item - nOld]; a = pr.x; b = pr.y; }
-        narrow_pair_lane(B, src, dst, item < nOld ? item : -1, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P);
+        else if (ordered) {
+            const int k = item >= c2 ? 3 : (item >= c1 ? 2 : (item >= c0 ? 1 : 0));
+            slot = O.permCur[(size_t)k * O.cap + (item - (k == 3 ? c2 : (k == 2 ? c1 : (k == 1 ? c0 : 0))))];
+        } else slot = item;
+        narrow_pair_lane(B, src, dst, slot, a, b, step, miPriv, sOld[threadIdx.x], cnt, nextCount, degForce, degInc, P, O);
     }
 }
 
@@ -1364,7 +1389,7 @@ __global__ void k_tail(BodyTable B, ManifoldTable M, SolverParams P, Counters* c
 }
 
 /* start-of-step reset of the per-step counters */
-__global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount, int* cellHead, int buckets)
+__global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount, int* cellHead, int buckets, int* narrowCntNext)
 {
     /* grid scenes: the broadphase's bucket heads start empty (-1); one launch instead of a fill behind it */
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < buckets; i += gridDim.x * blockDim.x) cellHead[i] = -1;
@@ -1372,6 +1397,7 @@ __global__ void k_begin_step(Counters* cnt, DiagAccum* diag, int* nextCount, int
     cnt->numCandidates = 0; cnt->numContacts = 0; cnt->numIncidences = 0; cnt->warnings = 0; cnt->dynamicBodies = 0;
     cnt->numLevels = 0; cnt->residentBad = 0;
     *nextCount = 0;
+    if (narrowCntNext) for (int k = 0; k < kNarrowClasses; ++k) narrowCntNext[k * kNarrowCntStride] = 0;
     diag->maxPenetration = 0; diag->maxViolation = 0; diag->maxLinearSpeed = 0; diag->maxAngularSpeed = 0; diag->maxNormalImpulse = 0;
     diag->activeContacts = 0; diag->activeManifolds = 0; diag->dynamicBodies = 0;
 }

@@ -66,6 +66,20 @@ struct ManifoldTable {
     int cap;
 };
 
+/* Processing order of the narrow phase (k_narrowphase, scenes beyond the fused front end).  A wave whose 64 lanes hold edge contacts, one-point and
+ * four-point face manifolds side by side runs every path one after the other; the survivors of step s are therefore listed by CLASS — what the manifold
+ * came out as: 3-4 contact points / 2 / 1 on a face / an edge contact — and step s + 1 walks last step's manifolds class by class (most keep their class
+ * from step to step), heaviest class first.  Only the ORDER in which lanes pick manifolds changes: slots, keys and every result are what they were. */
+constexpr int kNarrowClasses = 4;
+constexpr int kNarrowCntStride = 32;                /* ints between two class counters: a 128-byte line each (atomics on one line retire one after the other) */
+struct NarrowOrder {
+    const int* permCur;   /* [kNarrowClasses][cap]: slots of last step's survivors by class; nullptr: no order (first step, after an upload) */
+    const int* cntCur;    /* [kNarrowClasses * kNarrowCntStride] */
+    int*       permNext;
+    int*       cntNext;   /* zeroed by k_begin_step */
+    int        cap;
+};
+
 /* Joint / Spring / IgnoreCollision: few, host-created, kept AoS. */
 struct GForce {
     int kind, bodyA, bodyB, pad;

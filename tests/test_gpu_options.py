@@ -99,16 +99,18 @@ def test_group_schedule_options_on_a_falling_pile():
         assert int(g.w.stats()["schedule"]) == 4 and int(g.w.stats()["numManifolds"]) > 200
 
 
-@pytest.mark.parametrize("lanes", [32, 64])
-def test_narrow_phase_lanes_on_a_grid_scene(lanes):
+@pytest.mark.parametrize("lanes,order", [(32, 1), (64, 1), (64, 0)])
+def test_narrow_phase_lanes_on_a_grid_scene(lanes, order):
     """k_narrowphase<32> / <64> (scenes beyond 4096 bodies; 64 lanes by default from 16 000 bodies on): 4 913 falling cubes into their landing, both forms
     against the oracle — manifolds, contacts and warm-started rows bit for bit (the 64-lane form keeps last step's lambda / penalty in registers and clips
-    into eight-vertex buffers)."""
+    into eight-vertex buffers).  narrow_order: the kernel walks last step's manifolds class by class (3-4 contact points / 2 / 1 on a face / edge contact)
+    so that a wave's lanes run one path — only the order in which lanes pick manifolds changes."""
     o = H.CpuWorld("orc"); o.scene("StressN:17"); o.step(128)
     g = H.HipWorld(); g.scene("StressN:17")
     g.w.set_option("narrow_lanes", lanes)
+    g.w.set_option("narrow_order", order)                  # last step's manifolds class by class (default) or slot by slot
     g.step(128)
     for s in range(4):
         o.step(6); g.step(6)
-        H.assert_same_world_fast(o, g, f"StressN:17 step {134 + 6 * s} with {lanes} lanes", check_rows=True)
+        H.assert_same_world_fast(o, g, f"StressN:17 step {134 + 6 * s} with {lanes} lanes, narrow_order={order}", check_rows=True)
     assert int(g.w.stats()["numManifolds"]) > 1500
