@@ -727,7 +727,11 @@ __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* g
 }
 
 /* Per dynamic body: order its adjacency newest-first (= the reference's body->forces walk,
- * force.cpp:21-29) and expand it into the row-incidence list consumed by k_primal. */
+ * force.cpp:21-29) and expand it into the row-incidence list consumed by k_primal.
+ * A body with at most kSortRegs forces (every cube of a pile) takes them into registers — all loads in flight at once —, ranks every entry against the
+ * others (position = how many are newer, incidence offset = how many entries those bring) and stores it where it belongs: no chain of dependent loads
+ * through an insertion sort in memory.  Longer lists (the ground slab is not swept; a body under a heap of small ones) keep the insertion sort. */
+constexpr int kSortRegs = 16;
 __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const GForce* gf, const int* adjStart, int* adjRef, int* adjOther, uint64_t* adjKey,
                               const int* incStart, int* inc, int* level, int* cursor, Counters* cnt)
 {
@@ -737,32 +741,71 @@ __global__ void k_sort_expand(BodyTable B, ManifoldTable M, const GForce* gf, co
     if (level) level[b] = 0;                                          /* (sweep by creation index: k_order_by_index is the only writer) */
     if (!B.solved[b]) return;
     const int s = adjStart[b], e = adjStart[b + 1];
-    for (int i = s + 1; i < e; ++i) {
-        uint64_t k = adjKey[i]; int r = adjRef[i], o = adjOther[i];
-        int j = i - 1;
-        while (j >= s && adjKey[j] < k) { adjKey[j + 1] = adjKey[j]; adjRef[j + 1] = adjRef[j]; adjOther[j + 1] = adjOther[j]; --j; }
-        adjKey[j + 1] = k; adjRef[j + 1] = r; adjOther[j + 1] = o;
-    }
-    int o = incStart[b];
+    const int o0 = incStart[b];
+    int o = o0;
     bool nonManifold = false;
-    for (int i = s; i < e; ++i) {
-        int r = adjRef[i];
-        int kind = inc_kind(r), idx = inc_index(r), isA = inc_isA(r);
-        if (kind == FK_MANIFOLD) {
-            int nc = M.nc[idx];
-            for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c);
-        } else if (kind == FK_JOINT) {
-            inc[o++] = make_inc(isA, FK_JOINT, idx * 2);
-            inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1);
-        } else if (kind == FK_SPRING) {
-            const int parts = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1;    /* a host force: three rows per entry */
-            for (int q = 0; q < parts; ++q) inc[o++] = make_inc(isA, FK_SPRING, idx | (q << 24));
+    if (e - s <= kSortRegs) {
+        const int d = e - s;
+        uint64_t key[kSortRegs]; int ref[kSortRegs], oth[kSortRegs], ent[kSortRegs];
+#pragma unroll
+        for (int i = 0; i < kSortRegs; ++i) {
+            key[i] = 0; ref[i] = 0; oth[i] = 0;
+            if (i < d) { key[i] = adjKey[s + i]; ref[i] = adjRef[s + i]; oth[i] = adjOther[s + i]; }
         }
-        if (kind == FK_SPRING) nonManifold = true;                     /* joints are fine for the resident schedule, springs are not */
+#pragma unroll
+        for (int i = 0; i < kSortRegs; ++i) {
+            ent[i] = 0;
+            if (i < d) {
+                const int kind = inc_kind(ref[i]), idx = inc_index(ref[i]);
+                if (kind == FK_MANIFOLD) ent[i] = M.nc[idx];
+                else if (kind == FK_JOINT) ent[i] = 2;
+                else if (kind == FK_SPRING) { ent[i] = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1; nonManifold = true; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kSortRegs; ++i) {
+            if (i < d) {
+                int rank = 0, off = 0;
+#pragma unroll
+                for (int j = 0; j < kSortRegs; ++j) {
+                    const bool newer = j < d && (key[j] > key[i] || (key[j] == key[i] && j < i));
+                    rank += newer ? 1 : 0; off += newer ? ent[j] : 0;
+                }
+                adjKey[s + rank] = key[i]; adjRef[s + rank] = ref[i]; adjOther[s + rank] = oth[i];
+                const int kind = inc_kind(ref[i]), idx = inc_index(ref[i]), isA = inc_isA(ref[i]);
+                int* out = inc + o0 + off;
+                if (kind == FK_MANIFOLD) { for (int c = 0; c < ent[i]; ++c) out[c] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
+                else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); }
+                else if (kind == FK_SPRING) { for (int q = 0; q < ent[i]; ++q) out[q] = make_inc(isA, FK_SPRING, idx | (q << 24)); }
+                o += ent[i];
+            }
+        }
+    } else {
+        for (int i = s + 1; i < e; ++i) {
+            uint64_t k = adjKey[i]; int r = adjRef[i], oo = adjOther[i];
+            int j = i - 1;
+            while (j >= s && adjKey[j] < k) { adjKey[j + 1] = adjKey[j]; adjRef[j + 1] = adjRef[j]; adjOther[j + 1] = adjOther[j]; --j; }
+            adjKey[j + 1] = k; adjRef[j + 1] = r; adjOther[j + 1] = oo;
+        }
+        for (int i = s; i < e; ++i) {
+            int r = adjRef[i];
+            int kind = inc_kind(r), idx = inc_index(r), isA = inc_isA(r);
+            if (kind == FK_MANIFOLD) {
+                int nc = M.nc[idx];
+                for (int c = 0; c < nc; ++c) inc[o++] = make_inc(isA, FK_MANIFOLD, idx * 4 + c);
+            } else if (kind == FK_JOINT) {
+                inc[o++] = make_inc(isA, FK_JOINT, idx * 2);
+                inc[o++] = make_inc(isA, FK_JOINT, idx * 2 + 1);
+            } else if (kind == FK_SPRING) {
+                const int parts = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1;    /* a host force: three rows per entry */
+                for (int q = 0; q < parts; ++q) inc[o++] = make_inc(isA, FK_SPRING, idx | (q << 24));
+            }
+            if (kind == FK_SPRING) nonManifold = true;                     /* joints are fine for the resident schedule, springs are not */
+        }
     }
     /* the resident schedule (avbd_resident.h) keeps one Manifold contact per lane of the body's wavefront */
-    if (nonManifold || o - incStart[b] > 64) atomicOr(&cnt->residentBad, 1);
-    else if (o - incStart[b] > kResLiteMaxEntriesDecl) atomicOr(&cnt->residentBad, 4);
+    if (nonManifold || o - o0 > 64) atomicOr(&cnt->residentBad, 1);
+    else if (o - o0 > kResLiteMaxEntriesDecl) atomicOr(&cnt->residentBad, 4);
 }
 
 /* Dependency levels of the Gauss-Seidel sweep: level(b) = 1 + max level of dynamic neighbours
