@@ -719,9 +719,10 @@ __global__ void k_fill_adj(ManifoldTable M, const Counters* cnt, const GForce* g
             if (item < nm) { int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; }
             else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = gforce_ref_kind(f.kind); index = item - nm; key = f.key; }
         }
+        /* (both positions first: two returning atomics in flight instead of one behind the other's stores) */
         const int pa = adj_position(a, a >= 0, solved, adjStart, cursor);
-        if (a >= 0) { adjRef[pa] = make_inc(1, kind, index); adjOther[pa] = b; adjKey[pa] = key; }
         const int pb = adj_position(b, b >= 0, solved, adjStart, cursor);
+        if (a >= 0) { adjRef[pa] = make_inc(1, kind, index); adjOther[pa] = b; adjKey[pa] = key; }
         if (b >= 0) { adjRef[pb] = make_inc(0, kind, index); adjOther[pb] = a; adjKey[pb] = key; }
     }
 }
