@@ -124,8 +124,13 @@ def test_post_stabilize_bit_exact():
             H.assert_same_world(o, g, f"postStabilize step {s + 1}")
 
 
-def test_joints_springs_ignore_bit_exact():
+@pytest.mark.parametrize("unfused", [0, 1], ids=["fused", "large-scene kernels"])
+def test_joints_springs_ignore_bit_exact(unfused):
+    """unfused: the kernels of scenes beyond 4096 bodies — k_narrowphase, k_scan / k_fill_adj / k_sort_expand (adjacency ranked in registers: two entries per
+    joint, one per spring, none for an ignore marker) — instead of the fused front end and topology of small scenes"""
     o, g = H.CpuWorld("orc"), H.HipWorld()
+    if unfused:
+        g.w.set_option("fused_front", 0); g.w.set_option("fused_topology", 0)
     for w in (o, g):
         w.add_body((30, 1, 30), 0.0, 0.5, (0, -0.5, 0))
         i1 = w.add_body((1, 1, 1), 1.0, 0.5, (0, 3.0, 0))
@@ -139,7 +144,7 @@ def test_joints_springs_ignore_bit_exact():
         w.add_spring(i3, i4, (0, 0.25, 0), (0, -0.25, 0), 500.0)
         w.add_spring(i1, i4, (0, 0, 0), (0, 0, 0), 200.0, 2.5)
         w.add_ignore(i5, i6)
-    for s in range(12):
+    for s in range(12 + 48 * unfused):
         o.step(); g.step()
         H.assert_same_world(o, g, f"joints step {s + 1}")
 
