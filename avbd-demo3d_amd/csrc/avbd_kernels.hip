@@ -177,7 +177,8 @@ __device__ __forceinline__ bool broadphase_pair_passes(const BodyTable& B, int i
     return true;
 }
 
-/* one thread per (body, one of the 27 cells around it): the centre thread also takes the body's pairs with the big bodies.
+constexpr int kGridCellsPerBody = 14;
+/* one thread per (body, one of 14 cells around it): the centre thread also takes the body's pairs with the big bodies.
  * Appending is what bounds a broadphase here (a falling 64 000-cube grid yields 250 000 candidates per step, and atomics on
  * one word retire at ~10 ns each): every thread first COUNTS its candidates — keeping the first three in registers — the workgroup
  * reserves its range with ONE atomic, then the threads write (a thread with more than three walks its list a second time).
@@ -188,10 +189,13 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
                              const int* __restrict__ adjOther, int2* cand, int candCap, Counters* cnt, int keepUnsolvedPairs)
 {
     __shared__ int sCount, sBase;
+    /* HALF the neighbourhood: the body's own cell (pairs with earlier-created bodies) and the 13 cells behind it in (z, y, x) order (pairs with every body
+     * there, whichever is the later-created one) — an unordered pair of bodies in two neighbouring cells is met exactly once, from the cell that comes first */
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = (int)(t / 27), k = (int)(t - (long long)i * 27);
+    const int i = (int)(t / kGridCellsPerBody), k = (int)(t - (long long)i * kGridCellsPerBody) + 13;
     const bool live = i < B.n;
     const bool big = live && isBig[i];
+    const bool own = k == 13;
     if (threadIdx.x == 0) sCount = 0;
     int head = -1, tx = 0, ty = 0, tz = 0;
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -203,13 +207,13 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
     __syncthreads();
     /* the pair test for a body j of the thread's bucket: in the thread's cell, earlier-created, spheres overlap, no force between them */
     auto cell_pair_passes = [&](int j) -> bool {
-        if (!(j < i)) return false;
+        if (own ? !(j < i) : j == i) return false;
         const float4 b = B.plane(BP_POSR)[j];
         const f3 dp = mk3(pi.x, pi.y, pi.z) - mk3(b.x, b.y, b.z);
         const float r = pi.w + b.w;
         if (!(dot3(dp, dp) <= r * r)) return false;
         if (grid_coord(b.x, invCell) != tx || grid_coord(b.y, invCell) != ty || grid_coord(b.z, invCell) != tz) return false;   /* another cell of this bucket */
-        return broadphase_pair_passes<true>(B, i, j, adjStart, adjOther, keepUnsolvedPairs);
+        return broadphase_pair_passes<true>(B, i > j ? i : j, i > j ? j : i, adjStart, adjOther, keepUnsolvedPairs);
     };
     int mine = 0;
     int2 h0 = make_int2(0, 0), h1 = h0, h2 = h0;
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
         }
     }
     for (int j = head; j >= 0; j = cellNext[j])
-        if (cell_pair_passes(j)) note(i, j);
+        if (cell_pair_passes(j)) note(i > j ? i : j, i > j ? j : i);
     int offset = mine ? atomicAdd(&sCount, mine) : 0;                  /* LDS: position inside the workgroup's range */
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void k_grid_pairs(BodyTable B, const unsigned 
         }
     }
     for (int j = head; j >= 0; j = cellNext[j])
-        if (cell_pair_passes(j)) put(i, j);
+        if (cell_pair_passes(j)) put(i > j ? i : j, i > j ? j : i);
 }
 
 /* ------------------------------------------------------------------------------------------
