@@ -934,7 +934,8 @@ __global__ __launch_bounds__(1024) void k_levels(BodyTable B, const int* adjStar
  * ------------------------------------------------------------------------------------------ */
 /* (warn_log, sanitize3, sanitizeq: avbd_util.h) */
 
-__device__ __forceinline__ void predict_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt)
+/* (returns whether the body is dynamic: the caller counts them — one atomic per workgroup, not one per wavefront on the Counters line) */
+__device__ __forceinline__ bool predict_body(const BodyTable& B, int i, const SolverParams& P, Counters* cnt)
 {
     float4 pr = B.plane(BP_POSR)[i];
     f3 pos = mk3(pr.x, pr.y, pr.z);
@@ -950,7 +951,6 @@ __device__ __forceinline__ void predict_body(const BodyTable& B, int i, const So
     f3 npos = pos; q4 nrot = rot;
     const float invMass = B.plane(BP_MASS)[i].y;
     if (invMass > 0.0f) {
-        atomicAdd(&cnt->dynamicBodies, 1);
         f3 v = ld3(B.plane(BP_LINV), i);
         f3 vprev = ld3(B.plane(BP_PLIN), i);
         sanitize3(v, cnt, warn_key(0, 0, i, 0), i, WK_LINVEL);
@@ -979,15 +979,29 @@ __device__ __forceinline__ void predict_body(const BodyTable& B, int i, const So
     B.plane(BP_NQUAT)[i] = packq(nrot);
     B.plane(BP_POSR)[i] = pack3(pos, pr.w);
     B.plane(BP_QUAT)[i] = packq(rot);
+    return invMass > 0.0f;
 }
 
 /* (+ the done-counters of the task schedule: primalDone[cap] | dualDone[cap], nullptr in the level mode — a fill launch less per step) */
-__global__ void k_predict(BodyTable B, SolverParams P, Counters* cnt, int* doneFlags)
+constexpr int kPredictThreads = 512;
+__global__ __launch_bounds__(kPredictThreads) void k_predict(BodyTable B, SolverParams P, Counters* cnt, int* doneFlags)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.n) return;
-    if (doneFlags) { doneFlags[i] = 0; doneFlags[B.cap + i] = 0; }
-    predict_body(B, i, P, cnt);
+    __shared__ int sDyn[kPredictThreads / 64];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool dyn = false;
+    if (i < B.n) {
+        if (doneFlags) { doneFlags[i] = 0; doneFlags[B.cap + i] = 0; }
+        dyn = predict_body(B, i, P, cnt);
+    }
+    /* the dynamic-body count of the diagnostics: 64 000 bodies are 1 000 wavefronts, and 1 000 atomics on the Counters line are 13 us of a 16 us launch */
+    const int mine = (int)__popcll(__ballot(dyn));
+    if ((threadIdx.x & 63) == 0) sDyn[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < kPredictThreads / 64; ++k) total += sDyn[k];
+        if (total) atomicAdd(&cnt->dynamicBodies, total);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1072,7 +1086,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     if (t == 0) { atomicExch(&cnt->numManifolds, nm); sBad = 0; }   /* atomics only on Counters words inside a kernel that also adds to them */
 
     /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below ---- */
-    for (int b = t; b < n; b += 1024) { predict_body(B, b, P, cnt); sSwept[b] = B.solved[b] ? 1 : 0; sLevel[b] = 0; }
+    for (int b = t; b < n; b += 1024) { if (predict_body(B, b, P, cnt)) atomicAdd(&cnt->dynamicBodies, 1); sSwept[b] = B.solved[b] ? 1 : 0; sLevel[b] = 0; }
     for (int i = t; i < nFlags; i += 1024) flags[i] = 0;
 
 #ifdef AVBD_DF_STATS
