@@ -220,6 +220,7 @@ struct AvbdContext {
     DevArr<int> dOwner, dCutOf, dCutMan, dRecIdx; DevArr<unsigned long long> dCutKeys; DevArr<CutCounters> dCutCnt;
     size_t cutOfCap = 0, recIdxCap = 0;
     hipEvent_t evLoop = nullptr, evExact = nullptr;
+    unsigned* dOverlap = nullptr; unsigned long long overlapKey = 0; bool overlapOk = false; unsigned overlapStamp = 0;   /* streams_overlap (avbd_capi_shard.inc) */
     std::vector<ExactRankArgs> hExactArgs; DevArr<ExactRankArgs> dExactArgs;
     /* chains of hand-offs share a workgroup (avbd_place.h): report of the last iteration launch, tails, this step's table */
     DevArr<int2> dCrit; DevArr<int> dTail, dPlaceSlot, dPlace; DevArr<PlaceInfo> dPlaceInfo;
@@ -253,6 +254,8 @@ struct AvbdContext {
     DevArr<unsigned> xDepCnt; DevArr<int> xRankOf;
     int groupPool = 1, groupPoolMinRounds = 3;   /* ResidentExchange::poolMode / poolMinRounds (classes with fewer bodies per sub-group take a task in hand instead) */
     int groupSpecMode = 0, groupSpecRounds = 4;   /* ResidentExchange::specMode / specRounds (AVBD_GROUP_SPEC, AVBD_GROUP_SPEC_ROUNDS) */
+    bool capDataflow = true, capLite = true, capGroups = true;   /* what the occupancy query of avbd_create found possible on this device / build: avbd_set_option cannot switch a schedule on that is not */
+    bool xwPoisoned = false;            /* a step of the exact-cut form between processes failed after its front end had run: the state is half a step ahead */
     int liveAtCreation = 1;             /* contexts of this process alive on the device when this one made its streams, itself included (hardware queues: avbd_group_step) */
     bool turnReleased = false;          /* avbd_destroy has taken this context out of its device's count (turn_begin / turn_end) */
     int exchangeFloats = 8;             /* avbd_set_exchange_floats: 8 = poses every iteration; 13 = + the velocities once per step */
@@ -775,6 +778,8 @@ int step_once(AvbdContext* c)
 {
     int rc;
     if (!c->hostForceG.empty()) return step_with_host_rows(c);
+    const bool exactProcesses = c->xwAttached && c->shardExact && c->nranks > 1 && c->mode != 0;
+    if (exactProcesses && (rc = exact_process_precheck(c))) return rc;  /* BEFORE the front end: a refused step leaves the state where it was */
     if ((rc = step_begin(c))) return rc;
     const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
     const bool needReadback = (c->mode == 0) || c->profiling;
@@ -786,7 +791,12 @@ int step_once(AvbdContext* c)
     }
     if (c->nranks > 1 || c->forceSharded) {
         if (c->mode == 0) return c->fail(AVBD_E_INVALID, "sharded runs need the data-flow mode");
-        if (c->xwAttached && c->shardExact && c->nranks > 1) return exact_process_step(c, needReadback);   /* ranks are processes, exact cuts through their windows */
+        if (exactProcesses) {                                          /* ranks are processes, exact cuts through their windows */
+            rc = exact_process_step(c, needReadback);
+            /* a failure in here comes after the front end: stepIndex, the manifold tables and the narrow-phase lists are half a step ahead */
+            if (rc) c->xwPoisoned = true;
+            return rc;
+        }
         if (!c->comm) return c->fail(AVBD_E_COMM, "context is sharded (avbd_set_ownership) but has no communicator: call avbd_comm_init or drive it through avbd_group_step");
         bool persistent = false;
         c->shardRanPersistent = false;
@@ -990,11 +1000,12 @@ int avbd_create(int device, AvbdContext** out)
             const int occX = std::min(std::min(fits((const void*)k_iterate_groups<false, 2>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 2>, kGrpLdsBytesMulti)),
                                       fits((const void*)k_iterate_groups_exact, kGrpLdsBytesMulti));
             c->exactAllowed = occX * cus >= 2 * std::min(c->iterBlocks, std::max(1, occ1) * cus);
-            if (occ1 < 1) { c->mode = 0; c->residentAllowed = false; }      /* not even one workgroup per CU: one launch per level, nothing spins */
+            c->capDataflow = occ1 >= 1;                                      /* not even one workgroup per CU: one launch per level, nothing spins */
             c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
-            if (occ2 * cus < 2 * c->iterBlocks) { c->residentLiteFrom = 0; c->residentForceLite = false; c->iterForceMode = c->iterForceMode == 2 ? 0 : c->iterForceMode; c->liteResident = false; }
-            if (occG * cus < 2 * c->iterBlocks) c->groupsMode = 0;
+            c->capLite = occ2 * cus >= 2 * c->iterBlocks;
+            c->capGroups = occG * cus >= 2 * c->iterBlocks;
             c->iterBlocksMax = std::max(1, occ1) * cus;
+            apply_capabilities(c);
         }
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
@@ -1026,7 +1037,7 @@ int avbd_destroy(AvbdContext* c)
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release(); c->dHostRows.release();
     c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release();
-    if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather);
+    if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather); if (c->dOverlap) (void)hipFree(c->dOverlap);
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
@@ -1179,10 +1190,12 @@ int avbd_set_option(AvbdContext* c, const char* key, int value)
 {
     if (!c || !key) return AVBD_E_INVALID;
     int v = value;
+    if (!std::strcmp(key, "narrow_lanes") && v != 0 && v != 32 && v != 64) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'narrow_lanes' is 0 (by the body count), 32 or 64");
     if (!std::strcmp(key, "iter_blocks")) v = std::max(1, std::min(v, c->iterBlocksMax > 0 ? c->iterBlocksMax : v));   /* every workgroup of the loop must be resident */
     if (!std::strcmp(key, "mode") && c->stepIndex != 0 && v != c->mode) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'mode' is chosen before the first step");
     const int rc = option_access(c, key, &v, true);
     if (rc) return c->fail(rc, "avbd_set_option: unknown key");
+    apply_capabilities(c);                                             /* a schedule whose workgroups cannot all be resident here stays off whatever was asked for */
     return AVBD_OK;
 }
 int avbd_get_option(AvbdContext* c, const char* key, int* value)
@@ -1194,14 +1207,18 @@ int avbd_option_count(void) { return (int)(sizeof(kOptionKeys) / sizeof(kOptionK
 const char* avbd_option_key(int i) { return (i >= 0 && i < avbd_option_count()) ? kOptionKeys[i] : nullptr; }
 
 /* ---- exact cuts between ranks that are processes ---- */
-static void exact_window_release(AvbdContext* c)
+static void exact_window_detach(AvbdContext* c)
 {
     for (int q = 0; q < kMaxExactRanks; ++q) {
         if (c->xwPeer[q] && c->xwPeer[q] != c->xwOwn) (void)hipIpcCloseMemHandle(c->xwPeer[q]);
         c->xwPeer[q] = nullptr;
     }
-    if (c->xwOwn) { (void)hipFree(c->xwOwn); c->xwOwn = nullptr; }
     c->xwAttached = false;
+}
+static void exact_window_release(AvbdContext* c)
+{
+    exact_window_detach(c);
+    if (c->xwOwn) { (void)hipFree(c->xwOwn); c->xwOwn = nullptr; }
 }
 
 int avbd_exact_window_export(AvbdContext* c, unsigned char handle[64], unsigned long long* bytes)
@@ -1235,13 +1252,15 @@ int avbd_exact_window_attach(AvbdContext* c, int nranks, const unsigned char* ha
     if (!c || !handles || ranksOnThisDevice < 1) return AVBD_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return c->fail(AVBD_E_NODEVICE, "hipSetDevice failed");
     if (!c->xwOwn || nranks != c->nranks || nranks != c->xwRanks) return c->fail(AVBD_E_INVALID, "avbd_exact_window_attach: export this rank's window first (same number of ranks)");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    exact_window_detach(c);                                            /* a second attach without a new export: the old mappings are closed, not overwritten */
     for (int q = 0; q < nranks; ++q) {
         if (q == c->rank) { c->xwPeer[q] = c->xwOwn; continue; }
         hipIpcMemHandle_t h;
         std::memcpy(&h, handles + (size_t)q * 64, 64);
         void* p = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) { (void)hipGetLastError(); return c->fail(AVBD_E_HIP, "hipIpcOpenMemHandle (a peer's window; windows of the same process cannot be opened — use avbd_group_step there)", e); }
+        if (e != hipSuccess) { (void)hipGetLastError(); exact_window_detach(c); return c->fail(AVBD_E_HIP, "hipIpcOpenMemHandle (a peer's window; windows of the same process cannot be opened — use avbd_group_step there)", e); }
         c->xwPeer[q] = (float4*)p;
     }
     /* ranks that share a device share its resident waves: every rank's loop kernel must be resident while the others' are */
@@ -1250,6 +1269,7 @@ int avbd_exact_window_attach(AvbdContext* c, int nranks, const unsigned char* ha
     c->shardExact = true; c->shardExactStrict = true;
     c->xwSharedDevice = ranksOnThisDevice > 1;
     c->xwAttached = true;
+    c->xwPoisoned = false;
     return AVBD_OK;
 }
 
@@ -1638,16 +1658,24 @@ static int rebalance_collect(AvbdContext* c, std::vector<RebalanceItem>& out)
     return AVBD_OK;
 }
 
-static int rebalance_apply(AvbdContext* c, const int* owner, int nbodies, std::vector<RebalanceItem> all)
+/* everything rebalance_apply can refuse before it touches the context (avbd_group_rebalance runs this on EVERY rank before the first one is
+ * rebuilt: a refusal on rank r > 0 used to leave ranks 0..r-1 with the new ownership and the rest with the old — ADVICE round 4) */
+static int rebalance_validate(AvbdContext* c, const int* owner, int nbodies, const std::vector<RebalanceItem>& all)
 {
-    int rc;
-    (void)hipSetDevice(c->device);
     const int n = c->nranks;
     if ((int)c->hBodies.size() != nbodies) return c->fail(AVBD_E_INVALID, "rebalance: owner[] must have one entry per body");
     if ((int)c->hOwner.size() != nbodies) return c->fail(AVBD_E_INVALID, "rebalance: the context has no ownership yet (avbd_set_ownership before the first step)");
     if (!c->hostForceG.empty()) return c->fail(AVBD_E_INVALID, "rebalance: scenes with user-defined Force subclasses cannot be sharded");
     for (int i = 0; i < nbodies; ++i) if (owner[i] >= n) return c->fail(AVBD_E_INVALID, "rebalance: owner index out of range");
     for (const RebalanceItem& it : all) if (it.rank < 0 || it.rank >= n) return c->fail(AVBD_E_INVALID, "rebalance: exporting rank out of range");
+    return AVBD_OK;
+}
+
+static int rebalance_apply(AvbdContext* c, const int* owner, int nbodies, std::vector<RebalanceItem> all)
+{
+    int rc;
+    (void)hipSetDevice(c->device);
+    if ((rc = rebalance_validate(c, owner, nbodies, all))) return rc;
     /* one copy per force: the one of the rank that swept its owner (old ownership) */
     const std::vector<int> oldOwner = c->hOwner;
     auto prefer = [&](const AvbdForce& f) -> int {
@@ -1723,6 +1751,7 @@ int avbd_group_rebalance(AvbdContext** ctxs, int n, const int* owner, int nbodie
     }
     std::vector<RebalanceItem> all;
     for (int r = 0; r < n; ++r) if ((rc = rebalance_collect(ctxs[r], all))) return rc;
+    for (int r = 0; r < n; ++r) if ((rc = rebalance_validate(ctxs[r], owner, nbodies, all))) return rc;   /* all ranks first, then apply */
     for (int r = 0; r < n; ++r) if ((rc = rebalance_apply(ctxs[r], owner, nbodies, all))) return rc;
     return AVBD_OK;
 }

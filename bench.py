@@ -216,79 +216,121 @@ def main():
 
     EXACT_FORM = "exact cuts (one process per GPU, record windows over hipIpc; bit-identical to one GPU)"
 
-    def make_world(form=None, bare=False):
+    def vote(ok):
+        """every rank takes part; True only when every rank said ok"""
+        if dist is None:
+            return bool(ok)
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def make_world():
         w = pkg.World(local_rank)
         w.scene(scene)
-        if sharded and not bare:
+        return w
+
+    def make_sharded_world(form):
+        """One world per rank in the given form, or None on EVERY rank.  The parts that can fail on one rank alone (context, scene,
+        ownership, window export / attach, communicator) run under try and are followed by a vote; the collectives in between are
+        entered by every rank or by none (a rank that raised used to jump to the all_reduce while the others sat in
+        all_gather_object or the barrier)."""
+        import torch
+        w, err, mine = None, None, None
+        try:
+            w = make_world()
             b0 = w.bodies()
             owner = pkg.partition_by_axis(b0["position"], b0["invMass"], world_size, axis=0)
             w.set_ownership(world_size, rank, owner)
             if form == EXACT_FORM:
+                mine = w.exact_window_export()
+        except Exception as e:
+            err = repr(e)
+        if vote(err is None):
+            if form == EXACT_FORM:
                 # every rank exports its record window, all ranks open all windows: nothing is exchanged during a step, every rank polls
-                # its neighbours' stamped records where they are written.  (Collective-safe: a rank that fails to
-                # export or to attach still takes part in both gathers, then every rank raises.)
-                import torch
-                handles, devs, oks = [None] * world_size, [None] * world_size, [None] * world_size
-                try:
-                    mine = w.exact_window_export()
-                except Exception as e:
-                    mine = repr(e)
+                # its neighbours' stamped records where they are written (DESIGN.md section 7)
+                handles, devs = [None] * world_size, [None] * world_size
                 dist.all_gather_object(handles, mine)
                 dist.all_gather_object(devs, (os.uname().nodename, torch.cuda.current_device()))
-                err = next((h for h in handles if not isinstance(h, bytes)), None)
-                if err is None:
-                    try:
-                        w.exact_window_attach(handles, ranks_on_this_device=sum(1 for d in devs if d == devs[rank]))
-                    except Exception as e:
-                        err = repr(e)
-                dist.all_gather_object(oks, err)
-                err = next((o for o in oks if o is not None), None)
-                if err is not None:
-                    raise RuntimeError(f"exact-cut windows could not be set up on every rank: {err}")
+                try:
+                    w.exact_window_attach(handles, ranks_on_this_device=sum(1 for d in devs if d == devs[rank]))
+                except Exception as e:
+                    err = repr(e)
             else:
                 uid = [pkg.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
-                w.comm_init(world_size, rank, uid[0])
-            dist.barrier()                                           # the ranks start stepping together (a wave gives up after 4 s without progress)
-        return w
+                try:
+                    w.comm_init(world_size, rank, uid[0])
+                except Exception as e:
+                    err = repr(e)
+            if vote(err is None):
+                dist.barrier()                                       # the ranks start stepping together (a wave gives up after 4 s without progress)
+                return w
+        if err is not None:
+            print(f"bench.py rank {rank}: the form '{form}' could not be set up ({err})", file=sys.stderr)
+        if w is not None:
+            try:
+                w.close()
+            except Exception:
+                pass
+        return None
 
     want_cpu = (rank == 0 and not sharded and not args.no_cpu)
     prof_steps = min(args.steps, 50)
 
     def measure(w):
         """untimed steps, the timed region (exactly K steps, barrier + synchronize on both sides, max over ranks), then the
-        profiled steps (HIP events around every launch on the solver's stream)"""
-        if presim:
-            w.step(presim)
-        w.step(args.warmup)
-        w.synchronize()
-        # snapshot for the CPU leg / parity (rank 0, N=1 only)
-        m = {"snap_b": None, "snap_f": None, "snap_step": w.step_index()}
-        if want_cpu:
-            m["snap_b"], m["snap_f"] = w.bodies(), w.forces()
-
-        def barrier():
-            if dist is not None:
-                dist.barrier()
+        profiled steps (HIP events around every launch on the solver's stream).  With several ranks every barrier is a vote
+        (an all-reduce every rank enters whether its own leg failed or not): None on EVERY rank when a leg failed anywhere."""
+        m, err = {}, None
+        try:
+            if presim:
+                w.step(presim)
+            w.step(args.warmup)
             w.synchronize()
-
-        barrier()
-        t0 = time.perf_counter()
-        w.step(args.steps)
-        w.synchronize()
-        m["elapsed"] = time.perf_counter() - t0
-        barrier()
-        m["end_b"] = w.bodies() if want_cpu else None
-        m["stats"] = w.stats()
-        w.profile_enable(True)
-        w.profile_reset()
-        w.step(prof_steps)
-        w.synchronize()
-        m["p"] = w.profile()
-        w.profile_enable(False)
+            # snapshot for the CPU leg / parity (rank 0, N=1 only)
+            m = {"snap_b": None, "snap_f": None, "snap_step": w.step_index()}
+            if want_cpu:
+                m["snap_b"], m["snap_f"] = w.bodies(), w.forces()
+        except Exception as e:
+            err = e
+        if not vote(err is None):                                    # barrier
+            return fail(err)
+        try:
+            w.synchronize()
+            t0 = time.perf_counter()
+            w.step(args.steps)
+            w.synchronize()
+            m["elapsed"] = time.perf_counter() - t0
+        except Exception as e:
+            err = e
+        if not vote(err is None):                                    # barrier
+            return fail(err)
+        try:
+            w.synchronize()
+            m["end_b"] = w.bodies() if want_cpu else None
+            m["stats"] = w.stats()
+            w.profile_enable(True)
+            w.profile_reset()
+            w.step(prof_steps)
+            w.synchronize()
+            m["p"] = w.profile()
+            w.profile_enable(False)
+        except Exception as e:
+            err = e
+        if not vote(err is None):
+            return fail(err)
         return m
 
-    w = make_world(bare=sharded)                                     # (sharded: every form gets a world of its own below)
+    def fail(err):
+        if err is not None:
+            if dist is None:
+                raise err
+            print(f"bench.py rank {rank}: the run failed ({err})", file=sys.stderr)
+        return None
+
+    w = make_world()                                                 # (sharded: every form gets a world of its own below)
     iterations = int(w.params()["iterations"])
     shard_form = None
     shard_other = None
@@ -314,19 +356,15 @@ def main():
             else:
                 os.environ.pop("AVBD_SHARD_GATE", None)
             try:
-                w.close()
+                if w is not None:
+                    w.close()
             except Exception:
                 pass
-            ok, mk = 1, None
-            try:
-                w = make_world(form)
-                mk = measure(w)
-            except Exception as e:
-                ok = 0
-                print(f"bench.py rank {rank}: the sharded run failed in the form '{form}' ({e})", file=sys.stderr)
-            t = torch.tensor([ok], dtype=torch.int32, device=tdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 1:
+            w = make_sharded_world(form)                             # None on every rank or a world on every rank
+            if w is None:
+                continue
+            mk = measure(w)                                          # None on every rank when any rank failed
+            if mk is not None:
                 te = torch.tensor([mk["elapsed"]], dtype=torch.float64, device=tdev)
                 dist.all_reduce(te, op=dist.ReduceOp.MAX)
                 mk["elapsed"] = float(te.item())
@@ -339,6 +377,8 @@ def main():
                        for o in forms if o != shard_form]
     else:
         m = measure(w)
+        if m is None:
+            sys.exit("bench.py: the run failed")
         if dist is not None:
             import torch
             te = torch.tensor([m["elapsed"]], dtype=torch.float64, device=tdev)
