@@ -220,7 +220,6 @@ struct AvbdContext {
     DevArr<int> dOwner, dCutOf, dCutMan, dRecIdx; DevArr<unsigned long long> dCutKeys; DevArr<CutCounters> dCutCnt;
     size_t cutOfCap = 0, recIdxCap = 0;
     hipEvent_t evLoop = nullptr, evExact = nullptr;
-    unsigned* dOverlap = nullptr; unsigned long long overlapKey = 0; bool overlapOk = false; unsigned overlapStamp = 0;   /* streams_overlap (avbd_capi_shard.inc) */
     std::vector<ExactRankArgs> hExactArgs; DevArr<ExactRankArgs> dExactArgs;
     /* chains of hand-offs share a workgroup (avbd_place.h): report of the last iteration launch, tails, this step's table */
     DevArr<int2> dCrit; DevArr<int> dTail, dPlaceSlot, dPlace; DevArr<PlaceInfo> dPlaceInfo;
@@ -242,7 +241,7 @@ struct AvbdContext {
     int maxCount = 0;                   /* rows every rank contributes to the all-gather */
     DevArr<float4> dSend, dRecv;
     /* exact cuts between processes: this rank's window, the peers' windows as this process sees them (own window at [rank]) */
-    float4* xwOwn = nullptr; float4* xwPeer[kMaxExactRanks] = {}; bool xwAttached = false; bool xwSharedDevice = false; unsigned xwSerial = 0; int xwBodyCap = 0, xwMCap = 0, xwRanks = 0;
+    float4* xwOwn = nullptr; float4* xwPeer[kMaxExactRanks] = {}; bool xwAttached = false; bool xwSharedDevice = false; unsigned xwSerial = 0; int xwBodyCap = 0, xwMCap = 0, xwGCap = 0, xwRanks = 0;
     int cutRanks = 0;
     int narrowLanes = 0;           /* narrow_lanes option: 32 / 64 lanes per workgroup of k_narrowphase, 0: by the number of pairs */
     int diagBlocksCap = 256;       /* workgroups of the contact diagnostics: each ends with five atomics on ONE line, 13 ns apiece whoever issues them (64 000 cubes: 1024 -> 50 us, 256 -> 28 us, 128 -> 34 us) */
@@ -979,7 +978,12 @@ int avbd_create(int device, AvbdContext** out)
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
-        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups_exact, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups_exact<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups_exact<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytes);
+        if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_groups<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrpLdsBytesMulti);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_iterate_groups, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         {   /* Every persistent launch spins on records that other workgroups of the same launch produce: ALL its workgroups must be
              * resident at once.  Ask the runtime how many workgroups of each kernel fit a CU with the exact dynamic LDS it is
@@ -994,11 +998,13 @@ int avbd_create(int device, AvbdContext** out)
             const int occ1 = std::min(std::min(fits((const void*)k_iterate<1, false>, c->iterLdsPad), fits((const void*)k_iterate<1, true>, c->iterLdsPad)),
                                       std::min(fits((const void*)k_iterate_single<false>, c->iterLdsPad), fits((const void*)k_iterate_single<true>, c->iterLdsPad)));
             const int occ2 = std::min(fits((const void*)k_iterate<2, false>, kIterWaves * kResProductBytesPerWaveLite), fits((const void*)k_iterate<2, true>, kIterWaves * kResProductBytesPerWaveLite));
-            const int occG = std::min(std::min(fits((const void*)k_iterate_groups<false, 0>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 0>, kGrpLdsBytesMulti)),
-                                      std::min(fits((const void*)k_iterate_groups<false, 1>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 1>, kGrpLdsBytesMulti)));
+            const int occG = std::min(std::min(std::min(fits((const void*)k_iterate_groups<false, 0>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 0>, kGrpLdsBytesMulti)),
+                                               std::min(fits((const void*)k_iterate_groups<false, 1>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 1>, kGrpLdsBytesMulti))),
+                                      std::min(fits((const void*)k_iterate_groups<false, 0, true>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 0, true>, kGrpLdsBytesMulti)));
             /* the exact-cut forms spin on records of other ranks' launches as well: the same residency prerequisite */
-            const int occX = std::min(std::min(fits((const void*)k_iterate_groups<false, 2>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 2>, kGrpLdsBytesMulti)),
-                                      fits((const void*)k_iterate_groups_exact, kGrpLdsBytesMulti));
+            const int occX = std::min(std::min(std::min(fits((const void*)k_iterate_groups<false, 2>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 2>, kGrpLdsBytesMulti)),
+                                               std::min(fits((const void*)k_iterate_groups<false, 2, true>, kGrpLdsBytes), fits((const void*)k_iterate_groups<true, 2, true>, kGrpLdsBytesMulti))),
+                                      std::min(fits((const void*)k_iterate_groups_exact<false>, kGrpLdsBytesMulti), fits((const void*)k_iterate_groups_exact<true>, kGrpLdsBytesMulti)));
             c->exactAllowed = occX * cus >= 2 * std::min(c->iterBlocks, std::max(1, occ1) * cus);
             c->capDataflow = occ1 >= 1;                                      /* not even one workgroup per CU: one launch per level, nothing spins */
             c->iterBlocks = std::min(c->iterBlocks, std::max(1, occ1) * cus);
@@ -1037,7 +1043,7 @@ int avbd_destroy(AvbdContext* c)
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release(); c->dHostRows.release();
     c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release();
-    if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather); if (c->dOverlap) (void)hipFree(c->dOverlap);
+    if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather);
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
@@ -1243,7 +1249,7 @@ int avbd_exact_window_export(AvbdContext* c, unsigned char handle[64], unsigned 
     HIPCHK(c, hipIpcGetMemHandle(&h, c->xwOwn));
     std::memcpy(handle, &h, 64);
     if (bytes) *bytes = (unsigned long long)(f4 * sizeof(float4));
-    c->xwBodyCap = c->bodyCap; c->xwMCap = c->mCap; c->xwRanks = c->nranks; c->xwSerial = 0;
+    c->xwBodyCap = c->bodyCap; c->xwMCap = c->mCap; c->xwGCap = c->gCap; c->xwRanks = c->nranks; c->xwSerial = 0;
     return AVBD_OK;
 }
 

@@ -51,13 +51,23 @@ __global__ void k_cut_rank(const unsigned long long* __restrict__ keys, const in
 
 __global__ void k_cut_fill(BodyTable B, ManifoldTable M, const int* __restrict__ order, const int* __restrict__ lvlStart, const Counters* __restrict__ cnt,
                            const int* __restrict__ incStart, const int* __restrict__ inc, const int* __restrict__ owner, int nranks, int rank,
-                           const int* __restrict__ cutOf, int localBase, int cutBase, int slotsPerCut, int* recIdx)
+                           const int* __restrict__ cutOf, int localBase, int cutBase, int slotsPerCut, int* recIdx, const GForce* __restrict__ gf, int jointBase)
 {
     const int nd = lvlStart[cnt->numLevels];
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nd; s += gridDim.x * blockDim.x) {
         const int b = order[s];
         for (int e = incStart[b]; e < incStart[b + 1]; ++e) {
             const int ent = inc[e], idx = inc_index(ent), m = idx >> 2, k = idx & 3;
+            if (inc_kind(ent) == FK_JOINT) {
+                /* a Joint half: every rank holds every GForce at the same index, so its dual record has ONE slot in the space all ranks share
+                 * (behind the contacts' slots); bit 31: the half's owner — the earlier-created dynamic endpoint — is swept by another rank */
+                const GForce& f = gf[idx >> 1];
+                const int other = inc_isA(ent) ? f.bodyB : f.bodyA;
+                int rec = jointBase + idx;
+                if (other >= 0 && other < b && owner[other] >= 0 && owner[other] != rank) rec |= 0x80000000;
+                recIdx[e] = rec;
+                continue;
+            }
             const int2 pr = M.pair[m];
             const int other = inc_isA(ent) ? pr.y : pr.x;
             const int co = cutOf[m];

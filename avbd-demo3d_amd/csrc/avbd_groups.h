@@ -303,13 +303,20 @@ __device__ __forceinline__ unsigned xldw(__amdgpu_buffer_rsrc_t r, int byteOff) 
  * (owned contacts in the Manifold tables, which only their owner writes; a first visitor's copy of normal + tangent memo
  * and the pose in arrays private to the sub-group).  The sub-groups of a wave pick independently and the wave runs their
  * picks together, so a wave that serves 4 x K bodies does several tasks per pass. */
-template <bool MULTI, int SHARDK>      /* SHARDK 0: one GPU; 1: sharded, all-gather per iteration; 2: sharded, exact cuts */
+/* JOINTS: a lane holds one Manifold contact or one half (three rows) of a Joint, as in the resident schedule (avbd_resident.h); the joint-aware code is
+ * compiled only into the kernels that scenes with Joint forces launch (it costs registers on every path).  A joint lane keeps its constants in the
+ * fields a contact lane uses for things a joint does not have — no extra registers live across the loop:
+ *   c.rA, c.rB anchors | c.normal.xyz, c.u1.x q_rel0 | c.u1.yz, c.u2.x stiffness of its three rows | c.u2.yz, c.C0n motor | pOther, (wOther, c.C0t1) the partner's
+ *   position and orientation | c.lambda, c.penalty, c.C the rows. */
+template <bool MULTI, int SHARDK, bool JOINTS = false>      /* SHARDK 0: one GPU; 1: sharded, all-gather per iteration; 2: sharded, exact cuts */
 __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
                       Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z,
                       int blockIndex /* workgroup of this rank's share of the launch */)
 {
     extern __shared__ float4 sGroups[];                              /* kGrpLdsBytes: per wave Jt | S | accs | constants */
     constexpr bool SHARD = SHARDK == 1, EXACT = SHARDK == 2;
+    static_assert(!JOINTS || SHARDK == 0 || SHARDK == 2, "joint entries: one GPU, or exact cuts (the all-gather forms keep the resident schedule)");
+    GForce* const gf = X.gf;
     /* the host queues k_iterate_groups<false>, <true> and the fallback launch one behind the other; the plan says which one runs */
     if (plan->bad || (plan->rounds[0] > 1 || plan->rounds[1] > 1 || plan->rounds[2] > 1) != MULTI) return;   /* (SHARD: the host has read the plan) */
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -354,6 +361,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     int body = -1, eBeg = 0, nRows = 0;
     bool valid = false, has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
+    bool isJoint = false, hasA = true, jFix = false;                  /* JOINTS: this lane holds a joint half (rows 3 * (idx & 1) ..); the joint has a bodyA; corrected angular sign */
     bool remote = false; int offR = 0; int ownRow = 0;                /* SHARD: the partner is swept by another rank; its row / this body's row in a gather buffer */
     bool finalD = false;                                              /* EXACT: the contact's owner is swept by another rank */
     float oinv = 0.0f, fric = 0.0f;
@@ -374,24 +382,55 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         has = valid && gl < ne;
         nRows = ne * 3;
         idx = 0; other = 0; isA = false; owned = false; moving = false;
+        if (JOINTS) { isJoint = false; hasA = true; }
         int rec = 0;
         if (MULTI) {
             const HdrT h = hdrRow ? hdrRow[gl] : hdr[round * 64 + lane];   /* filled once, before the loop */
             if (has) { idx = inc_index(h.x); isA = inc_isA(h.x) != 0; other = h.y & 0xffffff; moving = (h.y >> 24) & 1; owned = (h.y >> 25) & 1; }
-            if constexpr (EXACT) rec = has ? h.z : 0; else rec = idx;
+            if (JOINTS && has) { isJoint = inc_kind(h.x) == FK_JOINT; hasA = (h.y >> 26) & 1; }
+            if constexpr (EXACT) rec = has ? h.z : 0; else rec = (JOINTS && isJoint) ? X.jointRecBase + idx : idx;
         } else if (has) {
             const int ent = inc[e0 + gl];
             idx = inc_index(ent); isA = inc_isA(ent) != 0;
+            if (JOINTS && inc_kind(ent) == FK_JOINT) {
+                const GForce& f = gf[idx >> 1];
+                isJoint = true; hasA = f.bodyA >= 0;
+                other = isA ? f.bodyB : f.bodyA;
+                moving = other >= 0 && (EXACT ? massPlane[other].y > 0.0f : B.solved[other] != 0);
+                owned = !moving || other > b;
+                if (other < 0) other = 0;                                  /* world anchor: a fixed partner, never polled */
+                rec = EXACT ? Z.recIdx[e0 + gl] : X.jointRecBase + idx;    /* (EXACT: k_cut_fill — the same slot on every rank, bit 31 when another rank sweeps the half's owner) */
+            } else {
             const int2 pr = M.pair[idx >> 2];
             other = isA ? pr.y : pr.x;
             moving = EXACT ? massPlane[other].y > 0.0f : B.solved[other] != 0;   /* EXACT: whoever sweeps it, a dynamic partner moves */
             owned = !moving || other > b;
             rec = EXACT ? Z.recIdx[e0 + gl] : idx;
+            }
         }
         finalD = EXACT && has && (rec < 0);
         rec &= 0x7fffffff;
         if constexpr (EXACT) { peer = 0; if (Z.nPeers > 1 && has && moving) { if constexpr (MULTI) peer = hdr[round * 64 + lane].w; else peer = max(Z.owner[other], 0); } }
         offP = other * 48; offV = rec * 16; offD = rec * 32;
+    };
+    /* JOINTS: one half of a Joint (joint.cpp:68-139) — its constants and rows from the GForce record, which only the half's owner writes during the
+     * launch (and where it parks lambda / penalty between its tasks), and the partner's pose from the planes: the predicted pose of a partner that has
+     * not run yet, the constant pose of a partner nobody sweeps; a moving partner's later poses come from its records (finish_visit) */
+    auto load_joint = [&]() __attribute__((always_inline)) {
+        const GForce& f = gf[idx >> 1];
+        const int jp = (idx & 1) * 3;
+        c.rA = mk3(f.rA[0], f.rA[1], f.rA[2]); c.rB = mk3(f.rB[0], f.rB[1], f.rB[2]);
+        c.normal = mk3(f.q0[0], f.q0[1], f.q0[2]); c.u1.x = f.q0[3];
+        c.u1.y = f.stiffness[jp]; c.u1.z = f.stiffness[jp + 1]; c.u2.x = f.stiffness[jp + 2];
+        c.u2.y = f.motor[jp]; c.u2.z = f.motor[jp + 1]; c.C0n = f.motor[jp + 2];
+        c.C0t2 = (f.pad & 1) ? 1.0f : 0.0f;                            /* avbd_set_joint_angular_sign */
+        for (int k = 0; k < 3; ++k) { c.lambda[k] = f.lambda[jp + k]; c.penalty[k] = f.penalty[jp + k]; c.C[k] = f.C[jp + k]; }
+        pOther = zero3(); wOther = zero3(); c.C0t1 = 1.0f;             /* world anchor: identity */
+        if (isA || hasA) {
+            const float4 op = B.plane(BP_POSR)[other], oq = B.plane(BP_QUAT)[other];
+            pOther = mk3(op.x, op.y, op.z); wOther = mk3(oq.x, oq.y, oq.z); c.C0t1 = oq.w;
+        }
+        oinv = 0.0f; fric = 0.0f; c.penetration = 0.0f; c.stick = false;
     };
     /* everything else a task needs that does not come from another wave of this launch: the tables the earlier kernels of this step
      * wrote (first iteration), or what this sub-group parked after the body's previous task (several rounds, later iterations) */
@@ -404,7 +443,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
              * tangent memo, lambda, penalty, stick), one for what they do not (80 B: anchors, bias terms, friction, the partner's inverse
              * mass and — partners nobody sweeps — its contact point), one per body (160 B).  The planes of the Manifold tables cost a
              * cache line per field and contact: the pass was bound by those transactions, not by bytes. */
-            if (has) {
+            if (JOINTS && has && isJoint) load_joint();
+            else if (has) {
                 const size_t e = (size_t)(eBeg + gl);
                 const float4 k0 = X.parkC[e * 5], k1 = X.parkC[e * 5 + 1], k2 = X.parkC[e * 5 + 2], k3 = X.parkC[e * 5 + 3], k4 = X.parkC[e * 5 + 4];
                 const float4 s0 = X.parkS[e * 4], s1 = X.parkS[e * 4 + 1], s2 = X.parkS[e * 4 + 2], s3 = X.parkS[e * 4 + 3];
@@ -427,7 +467,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             }
             return;
         }
-        if (has) {
+        if (JOINTS && has && isJoint) load_joint();
+        else if (has) {
             oinv = massPlane[other].y;
             fric = M.fric[idx >> 2];
             load_contact<false>(M, idx, c);                           /* the tables the earlier kernels of this step wrote */
@@ -464,7 +505,9 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     /* several rounds: park the body's state until its next task (its last task has written the step's final state already) */
     auto park_body = [&]() __attribute__((always_inline)) {
         AVBD_MARK(g_park);
-        if (has) {
+        if (JOINTS && has && isJoint) {
+            if (owned) store_joint_half(gf[idx >> 1], idx & 1, c, false);      /* the other endpoint takes lambda / penalty from the dual records */
+        } else if (has) {
             int slotF = eBeg + gl;
             asm volatile("" : "+v"(slotF));
             float4* ps = X.parkS + (size_t)slotF * 4;
@@ -508,7 +551,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         if (EXACT && it >= itStop) {                                   /* the task behind the last iteration: the owner's last dual */
             if (finalD) { needD = true; sD = X.base + (unsigned)itStop; }
         } else if (has && moving) {
-            if (owned) { needV = true; sV = stampNow; needP = true; sP = stampNow; }
+            if (owned) { needV = !(JOINTS && isJoint); sV = stampNow; needP = true; sP = stampNow; }   /* (a joint's first visit mutates nothing: no visit record) */
             else if (it > 0) { needD = true; sD = X.base + (unsigned)it; needP = true; sP = sD; }
         }
         okP = !needP; okV = !needV; okD = !needD;
@@ -531,7 +574,17 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         wOwn = zero3();
         if (!MULTI) set_needs();                                      /* (several bodies per sub-group: set, and polled, when the body was examined) */
         AVBD_MARK(g_prep_replay);
-        if (has) {
+        if (JOINTS && has && isJoint) {
+            /* Jacobians of this body's three rows (joint.cpp:108-139): functions of its own orientation only */
+            JointRows jr0; jr0.rA = c.rA; jr0.rB = c.rB; jr0.q0 = mkq(c.normal.x, c.normal.y, c.normal.z, c.u1.x); jr0.fixAngular = c.C0t2 != 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                f3 Jl, Ja;
+                joint_compute_derivatives(jr0, isA, false, rot, (idx & 1) * 3 + k, Jl, Ja);
+                G[k] = zero3();
+                float* jr = J + lane * 3 + k;                          /* Jt[column][row] */
+                jr[0] = Jl.x; jr[kResRows] = Jl.y; jr[2 * kResRows] = Jl.z; jr[3 * kResRows] = Ja.x; jr[4 * kResRows] = Ja.y; jr[5 * kResRows] = Ja.z;
+            }
+        } else if (has) {
             wOwn = qrotate(rot, isA ? c.rA : c.rB);                    /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
                 if (owned) replay_normal(c, fixedN);
@@ -563,6 +616,12 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
      * owner's record, and the stored normal takes the two re-normalisations the owner's last visit and dual made (replay_normal),
      * so that both copies enter the next step's Manifold::initialize with the same bits (manifold.cpp:76-84). */
     auto final_store = [&]() __attribute__((always_inline)) {
+        if (JOINTS && finalD && isJoint) {
+            /* a Joint across a cut: every rank holds the GForce record; the half's rows on this rank's copy are the owner's last dual */
+            c.lambda[0] = bitsf(vd.x); c.lambda[1] = bitsf(vd.y); c.lambda[2] = bitsf(vd.z);
+            c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
+            store_joint_half(gf[idx >> 1], idx & 1, c, false);
+        } else
         if (finalD) {
             c.lambda[0] = bitsf(vd.x); c.lambda[1] = bitsf(vd.y); c.lambda[2] = bitsf(vd.z);
             c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
@@ -585,8 +644,11 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
 #endif
         if (needP) {
             const f3 opos = mk3(bitsf(p0.x), bitsf(p0.y), bitsf(p0.z)); const q4 orot = mkq(bitsf(p1.x), bitsf(p1.y), bitsf(p1.z), bitsf(p2.x));
+            if (JOINTS && isJoint) { pOther = opos; wOther = mk3(orot.x, orot.y, orot.z); c.C0t1 = orot.w; }
+            else {
             wOther = qrotate(orot, isA ? c.rB : c.rA);
             pOther = opos + wOther;
+            }
         }
         if (SHARD && needR) {
             /* the partner's pose after iteration it - 1, as every rank received it (Jacobi across the cut) */
@@ -603,7 +665,27 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         }
         /* ---- primal visit (solver.cpp:344-409) ---- */
         bool rowsOn = true;
-        if (has) {
+        if (JOINTS && has && isJoint) {
+            /* Joint::computeConstraint (joint.cpp:68-106) + the row forces of solver.cpp:372-385 for this half */
+            JointRows jr1; jr1.rA = c.rA; jr1.rB = c.rB; jr1.q0 = mkq(c.normal.x, c.normal.y, c.normal.z, c.u1.x);
+            const q4 orot = mkq(wOther.x, wOther.y, wOther.z, c.C0t1);
+            if (isA) joint_compute_constraint(jr1, hasA, pos, rot, pOther, orot);
+            else     joint_compute_constraint(jr1, hasA, pOther, orot, pos, rot);
+            const int jp = (idx & 1) * 3;
+            for (int k = 0; k < 3; ++k) {
+                const float stiff = k == 0 ? c.u1.y : (k == 1 ? c.u1.z : c.u2.x), motor = k == 0 ? c.u2.y : (k == 1 ? c.u2.z : c.C0n);
+                c.C[k] = jr1.C[jp + k];
+                const float lw = (stiff == FLT_MAX) ? c.lambda[k] : 0.0f;
+                const float desired = c.penalty[k] * c.C[k] + lw + motor;
+                const float f = rclamp(desired, -FLT_MAX, FLT_MAX);
+                const bool penOk = (c.penalty[k] > 0.0f) & (fabsf(c.penalty[k]) <= FLT_MAX);
+                const int r = lane * 3 + k;
+                /* not a Manifold row: no geometric-stiffness term (solver.cpp:393) — every aa entry adds -0.0f, the identity of IEEE addition, where a
+                 * Manifold row adds its gyroscopic component (diagonal) or the +0.0f of the reference's diagonal() matrix (off the diagonal) */
+                S[r] = f; S[kResRows + r] = c.penalty[k]; S[2 * kResRows + r] = -0.0f; S[3 * kResRows + r] = -0.0f; S[4 * kResRows + r] = -0.0f; S[5 * kResRows + r] = -0.0f;
+                rowsOn &= penOk;
+            }
+        } else if (has) {
             const f3 pOwn = pos + wOwn;
             contact_constraint_post(c, pre, isA ? pOwn : pOther, isA ? pOther : pOwn, fric);
             if (!owned) { v4u r = {fbits(c.lambda[1]), fbits(c.lambda[2]), c.stick ? 1u : 0u, stampNow}; xstA(rV, offV, r); }
@@ -614,6 +696,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 const bool penOk = (c.penalty[k] > 0.0f) & (fabsf(c.penalty[k]) <= FLT_MAX);   /* solver.cpp:387 */
                 const int r = lane * 3 + k;
                 S[r] = f; S[kResRows + r] = c.penalty[k]; S[2 * kResRows + r] = gyro.x; S[3 * kResRows + r] = gyro.y; S[4 * kResRows + r] = gyro.z;
+                if (JOINTS) S[5 * kResRows + r] = 0.0f;                /* (the row of the lane may have been a joint's in an earlier task) */
                 rowsOn &= penOk;
             }
         }
@@ -657,7 +740,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         }
         /* arrivals at the earlier-created partners (their task `it` reads this pose and the visit record, both on their way): as early as possible,
          * the hop from a publish to the consumer's examination is what the launch is a chain of */
-        if (SHARDK == 0 && MULTI && depSig && has && moving && !owned && (idx & 3) == 0)
+        const bool firstOfForce = (JOINTS && isJoint) ? (idx & 1) == 0 : (idx & 3) == 0;   /* one arrival per manifold / joint */
+        if (SHARDK == 0 && MULTI && depSig && has && moving && !owned && firstOfForce)
             __hip_atomic_fetch_add(X.depCnt + ctrO, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pos = mk3(grp_bcast(p.x, gBase), grp_bcast(p.y, gBase), grp_bcast(p.z, gBase));
         rot = mkq(grp_bcast(q.x, gBase), grp_bcast(q.y, gBase), grp_bcast(q.z, gBase), grp_bcast(q.w, gBase));
@@ -666,8 +750,41 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
 #endif
         AVBD_MARK(g_dual);
         GS_STAMP(9);
+        /* ---- dual update of the joint halves this body owns (solver.cpp:411-430 with Joint rows) ---- */
+        if (JOINTS && doDual && has && owned && isJoint) {
+            JointRows jr2; jr2.rA = c.rA; jr2.rB = c.rB; jr2.q0 = mkq(c.normal.x, c.normal.y, c.normal.z, c.u1.x); jr2.fixAngular = c.C0t2 != 0.0f;
+            const q4 orot = mkq(wOther.x, wOther.y, wOther.z, c.C0t1);
+            const q4 rotA = isA ? rot : orot, rotB = isA ? orot : rot;
+            if (isA) joint_compute_constraint(jr2, hasA, pos, rot, pOther, orot);
+            else     joint_compute_constraint(jr2, hasA, pOther, orot, pos, rot);
+            const int jp = (idx & 1) * 3;
+            for (int k = 0; k < 3; ++k) {
+                const int row = jp + k;
+                c.C[k] = jr2.C[row];
+                const float stiff = k == 0 ? c.u1.y : (k == 1 ? c.u1.z : c.u2.x);
+                if (stiff != FLT_MAX) continue;
+                const float lu = rclamp(c.penalty[k] * c.C[k] + c.lambda[k], -FLT_MAX, FLT_MAX);
+                const bool active = lu > -FLT_MAX && lu < FLT_MAX;
+                c.lambda[k] = lu;
+                if (active) {
+                    float lw = 0.0f, aw = 0.0f;
+                    f3 Jl, Ja;
+                    if (hasA) { joint_compute_derivatives(jr2, true, false, rotA, row, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+                    joint_compute_derivatives(jr2, false, false, rotB, row, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+                    const float betaRow = row_penalty_gain(lw, aw, P.beta);
+                    c.penalty[k] = rmin(c.penalty[k] + betaRow * fabsf(c.C[k]), kPenaltyMax);
+                }
+            }
+            if (moving) {
+                v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};
+                v4u r1 = {fbits(c.penalty[0]), fbits(c.penalty[1]), fbits(c.penalty[2]), stampNow << 1};
+                xstA(rD, offD, r0); xstA(rD, offD + 16, r1);
+                if (SHARDK == 0 && MULTI && depSig && firstOfForce && it + 1 < itStop)
+                    __hip_atomic_fetch_add(X.depCnt + ctrO, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         /* ---- dual update of the contacts this body owns (solver.cpp:411-430) ---- */
-        if (doDual && has && owned) {
+        if (doDual && has && owned && !(JOINTS && isJoint)) {
             const f3 wNew = qrotate(rot, isA ? c.rA : c.rB);
             const f3 pNew = pos + wNew;
             dual_contact_pts(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
@@ -689,7 +806,8 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             int bodyF = body, idxF = idx;
             asm volatile("" : "+v"(bodyF), "+v"(idxF));
             if (gl == 0) { B.plane(BP_POSR)[bodyF] = pack3(pos, radius); B.plane(BP_QUAT)[bodyF] = packq(rot); }
-            if (has && owned) store_contact_dual<false>(M, idxF, c, true);
+            if (JOINTS && has && owned && isJoint) store_joint_half(gf[idxF >> 1], idxF & 1, c, true);
+            else if (has && owned) store_contact_dual<false>(M, idxF, c, true);
         }
     };
 
@@ -958,17 +1076,23 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 hk[q] = bk[q] >= 0 && gl < ne;
                 ent[q] = hk[q] ? inc[e0 + gl] : 0;
             }
+            bool hA[4];                                               /* JOINTS: the joint has a bodyA */
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                oth[q] = 0;
+                oth[q] = 0; hA[q] = true;
+                if (JOINTS && hk[q] && inc_kind(ent[q]) == FK_JOINT) {
+                    const GForce& f = gf[inc_index(ent[q]) >> 1];
+                    hA[q] = f.bodyA >= 0;
+                    oth[q] = inc_isA(ent[q]) ? f.bodyB : f.bodyA;          /* -1: the world */
+                } else
                 if (hk[q]) { const int2 pr = M.pair[inc_index(ent[q]) >> 2]; oth[q] = inc_isA(ent[q]) ? pr.y : pr.x; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int w1 = 0, rc = 0;
                 if (hk[q]) {
-                    const bool mv = EXACT ? massPlane[oth[q]].y > 0.0f : B.solved[oth[q]] != 0;
-                    w1 = oth[q] | ((mv ? 1 : 0) << 24) | (((!mv || oth[q] > bk[q]) ? 1 : 0) << 25);
+                    const bool mv = (JOINTS && oth[q] < 0) ? false : (EXACT ? massPlane[oth[q]].y > 0.0f : B.solved[oth[q]] != 0);
+                    w1 = (oth[q] < 0 ? 0 : oth[q]) | ((mv ? 1 : 0) << 24) | (((!mv || oth[q] > bk[q]) ? 1 : 0) << 25) | ((hA[q] ? 1 : 0) << 26);
                     if (EXACT) rc = Z.recIdx[e0s[q] + gl];
                 }
                 if (EXACT) {
@@ -977,12 +1101,13 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     if (anyFinal && k0 + q < rounds && gl == k0 + q) itEndK = itStop + 1;
                 }
                 if (DEPC) {
-                    const bool first = hk[q] && ((w1 >> 24) & 1) && (inc_index(ent[q]) & 3) == 0;     /* one arrival per manifold with a moving partner */
+                    const bool first = hk[q] && ((w1 >> 24) & 1) &&
+                                       (inc_index(ent[q]) & ((JOINTS && inc_kind(ent[q]) == FK_JOINT) ? 1 : 3)) == 0;     /* one arrival per manifold / joint with a moving partner */
                     const unsigned nOwn = (unsigned)__popcll(__ballot(first && ((w1 >> 25) & 1)) & gMask), nOth = (unsigned)__popcll(__ballot(first && !((w1 >> 25) & 1)) & gMask);
                     if (k0 + q < rounds && gl == k0 + q) { depPerIt = nOwn + nOth; depNeed = nOwn; }
                 }
                 if (k0 + q < rounds) {
-                    if constexpr (EXACT) hdr[(k0 + q) * 64 + lane] = make_int4(ent[q], w1, rc, (Z.nPeers > 1 && hk[q]) ? max(Z.owner[oth[q]], 0) : 0);
+                    if constexpr (EXACT) hdr[(k0 + q) * 64 + lane] = make_int4(ent[q], w1, rc, (Z.nPeers > 1 && hk[q] && oth[q] >= 0) ? max(Z.owner[oth[q]], 0) : 0);
                     else hdr[(k0 + q) * 64 + lane] = make_int2(ent[q], w1);
                 }
             }
@@ -1388,12 +1513,12 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
 #endif
 }
 
-template <bool MULTI, int SHARDK>
+template <bool MULTI, int SHARDK, bool JOINTS = false>
 __global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incStart, const int* __restrict__ inc, SolverParams P, int* errWord,
                       Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z)
 {
-    iterate_groups<MULTI, SHARDK>(B, M, incStart, inc, P, errWord, cntW, X, plan, byClass, cap, sleepSel, Z, (int)blockIdx.x);
+    iterate_groups<MULTI, SHARDK, JOINTS>(B, M, incStart, inc, P, errWord, cntW, X, plan, byClass, cap, sleepSel, Z, (int)blockIdx.x);
 }
 
 /* Exact cuts with several ranks on ONE device (the emulation of avbd_group_step): all ranks in one launch, `wgPerRank` workgroups
@@ -1405,13 +1530,14 @@ struct ExactRankArgs {
     BodyTable B; ManifoldTable M; const int* incStart; const int* inc; SolverParams P; int* errWord; Counters* cntW; ResidentExchange X;
     const GroupPlan* plan; const int* byClass; int cap; int sleepSel; ShardExchange Z; int multi;
 };
+template <bool JOINTS>
 __global__ __launch_bounds__(64 * kGrpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_iterate_groups_exact(const ExactRankArgs* __restrict__ args, int wgPerRank)
 {
     const int rank = (int)blockIdx.x / wgPerRank, local = (int)blockIdx.x % wgPerRank;
     const ExactRankArgs& A = args[rank];
-    if (A.multi) iterate_groups<true, 2>(A.B, A.M, A.incStart, A.inc, A.P, A.errWord, A.cntW, A.X, A.plan, A.byClass, A.cap, A.sleepSel, A.Z, local);
-    else iterate_groups<false, 2>(A.B, A.M, A.incStart, A.inc, A.P, A.errWord, A.cntW, A.X, A.plan, A.byClass, A.cap, A.sleepSel, A.Z, local);
+    if (A.multi) iterate_groups<true, 2, JOINTS>(A.B, A.M, A.incStart, A.inc, A.P, A.errWord, A.cntW, A.X, A.plan, A.byClass, A.cap, A.sleepSel, A.Z, local);
+    else iterate_groups<false, 2, JOINTS>(A.B, A.M, A.incStart, A.inc, A.P, A.errWord, A.cntW, A.X, A.plan, A.byClass, A.cap, A.sleepSel, A.Z, local);
 }
 
 } // namespace avbd

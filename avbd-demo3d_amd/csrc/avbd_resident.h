@@ -64,6 +64,7 @@ struct ResidentExchange {
     int prStride;      /* floats per product line: kResStride, or kResStrideLite when two workgroups share a CU */
     int joints;        /* the scene has Joint forces: instantiate the joint-aware code */
     int jointRecBase;  /* record index of joint half 0 of GForce 0 in `dual` (= 4 * manifold capacity) */
+    GForce* gf;        /* group schedule with joints (k_iterate_groups<*, *, true>): the Joint records (the other kernels get them as an argument) */
     int multi;         /* more swept bodies than resident waves: every wave takes every W-th body */
     int forceMulti;    /* launches that cover part of the iteration loop (sharded runs) park state even with one body per wave */
     int planesAlways;  /* sharded runs: other kernels of the step read the pose planes after every iteration */

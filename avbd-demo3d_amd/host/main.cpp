@@ -78,7 +78,7 @@ int main(int argc, char** argv)
             s->loadSnapshot(loadPath);
             shown = loadPath;
         } else {
-            int idx = requested ? buildSceneByName(s, requested) : -1;
+            int idx = requested ? buildSceneWithSuffix(s, requested) : -1;
             if (idx < 0) scenes[0](s);
             else if (idx < sceneCount) shown = sceneNames[idx];
             else shown = requested;

@@ -9,6 +9,7 @@
 #pragma once
 
 #include "solver.h"
+#include "joint.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -133,8 +134,37 @@ static const char* sceneNames[] = {"Empty", "Ground", "Stack", "Pyramid", "Wall"
 
 static const int sceneCount = sizeof(scenes) / sizeof(scenes[0]);
 
-/* name → scene, also accepting "StressN:<n>" and "Packed:<n>"; returns the table index,
- * 100/101 for the parametrised scenes, -1 when unknown. */
+/* BASELINE configs[4]: weld Joints (joint.cpp rows) between x-adjacent cubes — Joint(cube 2k, cube 2k + 1, (0.5, 0, 0), (-0.5, 0, 0)) for the first
+ * `count` pairs in creation order (the reference has no jointed scene: build-defined, like StressN itself) */
+static void sceneAddWelds(Solver* solver, int count)
+{
+    int n = 0;
+    for (Rigid* r = solver->bodies; r; r = r->next) ++n;
+    if (n < 3 || count < 1) return;
+    Rigid** byIndex = new Rigid*[n];
+    int i = n;
+    for (Rigid* r = solver->bodies; r; r = r->next) byIndex[--i] = r;      /* the list is newest first */
+    for (int k = 0; k < count && 2 + 2 * k < n; ++k)
+        new Joint(solver, byIndex[1 + 2 * k], byIndex[2 + 2 * k], vec3(0.5f, 0.0f, 0.0f), vec3(-0.5f, 0.0f, 0.0f));
+    delete[] byIndex;
+}
+
+/* name → scene, also accepting "StressN:<n>", "Packed:<n>", "StressGrid:<x>,<y>,<z>", "PackedGrid:...", each optionally followed by "+welds:<count>";
+ * returns the table index, 100..102 for the parametrised scenes, -1 when unknown. */
+static int buildSceneByName(Solver* solver, const char* name);
+static int buildSceneWithSuffix(Solver* solver, const char* name)
+{
+    const char* plus = strstr(name, "+welds:");
+    if (!plus) return buildSceneByName(solver, name);
+    char base[96];
+    const size_t len = (size_t)(plus - name);
+    if (len == 0 || len >= sizeof(base)) return -1;
+    memcpy(base, name, len); base[len] = 0;
+    const int idx = buildSceneByName(solver, base);
+    if (idx < 0) return idx;
+    sceneAddWelds(solver, atoi(plus + 7));
+    return idx;
+}
 static int buildSceneByName(Solver* solver, const char* name)
 {
     if (!strncmp(name, "StressGrid:", 11) || !strncmp(name, "PackedGrid:", 11)) {

@@ -766,7 +766,7 @@ extern "C" int avbd_build_scene(AvbdContext* ctx, const char* name)
     avbd_get_params(ctx, &before);
     s.dt = before.dt; s.gravity = vec3(before.gravity[0], before.gravity[1], before.gravity[2]); s.iterations = before.iterations;
     s.alpha = before.alpha; s.beta = before.beta; s.gamma = before.gamma; s.postStabilize = before.postStabilize != 0;
-    int idx = buildSceneByName(&s, name);
+    int idx = buildSceneWithSuffix(&s, name);
     if (idx < 0) return AVBD_E_INVALID;
     s.flush();
     AvbdParams p;

@@ -477,7 +477,7 @@ def main():
             st3 = w3.stats()
             out = {"workload": f"{nscene} (iterations={int(w3.params()['iterations'])}) steady window: steps {npresim}..{npresim + k3}",
                    "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
-                   "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"])}
+                   "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "joints": int(st3["numJoints"]), "schedule": int(st3["schedule"])}
             # HIP events around the launches of 20 more steps
             w3.profile_enable(True); w3.profile_reset(); w3.step(20); w3.synchronize(); p3 = w3.profile(); w3.profile_enable(False)
             if p3["launches_primal"] > 0 and p3["ms_primal"] > 0:
@@ -494,10 +494,13 @@ def main():
         except Exception as e:
             return {"error": repr(e)}
 
-    strong_n1 = roofline_8k = None
+    strong_n1 = roofline_8k = joints_n1 = None
     if rank == 0 and not sharded and args.scene is None and not args.no_strong_n1:
         strong_n1 = nested_line(STRONG_SCENE, STRONG_PRESIM + 10, 50)
         roofline_8k = nested_line("StressN:20", 410, 50)
+        # BASELINE configs[4]'s scene on this one GPU: 64 000 cubes + 10 000 weld Joints between x-neighbours (host/scenes.h "+welds:<k>"); the Joint rows run in
+        # the group schedule since round 5 (a lane holds a contact or a joint half) — one Joint used to send the whole sweep to the resident schedule's parked form
+        joints_n1 = nested_line(STRONG_SCENE + "+welds:10000", STRONG_PRESIM + 10, 30)
 
     if rank == 0:
         total_steps = args.steps                                 # steps of the one scene every rank works on
@@ -515,7 +518,7 @@ def main():
                                       (f"{world_size} x-slabs of one scene, no exchange during a step (peer windows over xGMI); value = steps/s of that scene" if shard_form == EXACT_FORM else
                                        f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene"),
                        "shard_form": shard_form, "shard_other_form": shard_other,
-                       "strong_scaling_n1": strong_n1, "roofline_8k": roofline_8k,
+                       "strong_scaling_n1": strong_n1, "roofline_8k": roofline_8k, "joints_n1": joints_n1,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
                        "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
                        "whole_run_from_scratch": whole},

@@ -111,9 +111,16 @@ class CpuWorld:
             pass
 
     def scene(self, name):
-        r = self._c("scene")(self.h, name.encode())
+        base, _, welds = name.partition("+welds:")        # BASELINE configs[4]: weld joints between x-adjacent cubes (host/scenes.h: sceneAddWelds)
+        r = self._c("scene")(self.h, base.encode())
         if r < 0:
             raise ValueError("unknown scene " + name)
+        if welds:
+            n = len(self.bodies())
+            for k in range(int(welds)):
+                if 2 + 2 * k >= n:
+                    break
+                self.add_joint(1 + 2 * k, 2 + 2 * k, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
         return r
 
     def params(self):

@@ -68,6 +68,33 @@ def test_cut_pile_exact_cuts_reproduce_the_single_gpu_sweep_bit_for_bit(monkeypa
     assert int(single.diag()["activeContacts"]) > 300
 
 
+@pytest.mark.parametrize("nranks,axis,waves", [(4, 0, None), (2, 0, None), (2, 2, None), (4, 0, 8)])
+def test_joints_across_exact_cuts_reproduce_the_single_gpu_sweep(monkeypatch, nranks, axis, waves):
+    """BASELINE configs[4] in small: weld Joints between x-adjacent cubes (host/scenes.h: "+welds:<k>").  With four slabs along x every weld
+    crosses a cut: the half's owner — the earlier-created endpoint — runs the dual on its rank, the other rank reads the half's dual
+    records from the ONE slot a Joint half has in the record space all ranks share, and takes lambda / penalty from the owner's last dual
+    when the loop ends.  (The reference's body-body welds blow up — SURVEY.md section 7-5, bug-compatible — so the scene also drives the
+    non-finite sanitizers through every rank: the bits must still be the single GPU's.)"""
+    monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+    if waves:
+        monkeypatch.setenv("AVBD_GROUPS_WAVES", str(waves))          # several bodies per sub-group: joint halves parked in their GForce records
+    scene = "PackedGrid:4,4,8+welds:40"
+    pkg, worlds, owner = _ranks(scene, nranks, axis)
+    monkeypatch.delenv("AVBD_SHARD_EXACT")
+    if waves:
+        monkeypatch.delenv("AVBD_GROUPS_WAVES")
+    single = H.HipWorld(); single.scene(scene)
+    assert int((single.forces()["kind"] == 1).sum()) == 40
+    for s in range(6):
+        pkg.group_step([w.w for w in worlds], 5)
+        single.step(5)
+        bs, fs = single.bodies(), single.forces()
+        for r, w in enumerate(worlds):
+            assert int(w.w.stats()["schedule"]) == 4 and int(w.w.stats()["cutMode"]) == 3
+            assert H.same_bits(bs, w.bodies()), f"rank {r}: body state differs from the single-GPU sweep after {5 * (s + 1)} steps"
+            _same_forces(fs, w.forces(), owner, r, f"after {5 * (s + 1)} steps")
+
+
 def test_exact_cuts_with_several_bodies_per_sub_group(monkeypatch):
     """few resident waves: every sub-group serves several bodies (k_iterate_groups<true, 2>: header table with record indices,
     the task behind the last iteration examined like any other)"""
@@ -136,19 +163,19 @@ def test_cli_gpus_flag_exact_cuts_give_the_single_gpu_dump(tmp_path):
 
 def test_a_declined_exact_step_is_an_error_and_mode_2_reports_the_fall_back():
     """`avbd_set_shard_mode(ctx, 1)` promises the single-GPU bits; a step that cannot keep that promise (here: a scene
-    with a Joint — exact cuts carry contacts only) must FAIL with AVBD_E_INVALID and say why, never run the Jacobi all-gather form
+    with a Spring — exact cuts carry contacts and, since round 5, Joints; springs run in the task schedule) must FAIL with AVBD_E_INVALID and say why, never run the Jacobi all-gather form
     under the name "exact".  Mode 2 is the explicit "exact if possible": it falls back and AvbdStepStats.cutMode says which form ran."""
     def pair(mode, joint):
         pkg, worlds, owner = _ranks("PackedGrid:4,4,4", 2, 0)
         for w in worlds:
             if joint:
-                w.w.add_joint(1, 2, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+                w.w.add_spring(1, 2, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0), 800.0)
             w.w.set_shard_mode(mode)
         return pkg, worlds
     pkg, ws = pair(1, True)
     with pytest.raises(pkg.AvbdError) as e:
         pkg.group_step([w.w for w in ws], 1)
-    assert "exact cuts were requested" in str(e.value) and "joints or springs" in str(e.value)
+    assert "exact cuts were requested" in str(e.value) and "springs or user-defined forces" in str(e.value)
     pkg, ws = pair(2, True)
     pkg.group_step([w.w for w in ws], 3)
     assert all(int(w.w.stats()["cutMode"]) in (1, 2) for w in ws)

@@ -104,7 +104,8 @@ def _same_forces(single_f, rank_f, owner, rank, what):
         assert H.same_bits(s["contacts"][fld], g["contacts"][fld]), f"{what}: contact {fld} differs on rank {rank}"
 
 
-@pytest.mark.parametrize("scene,nranks,axis,steps", [("PackedGrid:4,4,8", 2, 2, (5, 10, 10)), ("PackedGrid:4,4,8", 4, 2, (10, 15)), ("Stress1000", 2, 0, (140, 30))])
+@pytest.mark.parametrize("scene,nranks,axis,steps", [("PackedGrid:4,4,8", 2, 2, (5, 10, 10)), ("PackedGrid:4,4,8", 4, 2, (10, 15)), ("Stress1000", 2, 0, (140, 30)),
+                                                     ("PackedGrid:4,4,8+welds:40", 4, 0, (10, 15)), ("Stress1000+welds:100", 2, 0, (140, 20))])
 def test_process_ranks_on_one_device_reproduce_the_single_gpu_sweep(tmp_path, scene, nranks, axis, steps):
     _run_ranks(tmp_path, scene, nranks, steps, axis)
     pkg = H.load_product()
@@ -185,6 +186,36 @@ def test_config3_in_its_stated_form_eight_process_ranks_64000_cubes(tmp_path):
             rb = np.load(os.path.join(str(tmp_path), f"bodies_{done}_{r}.npy"))
             assert H.same_bits(bs, rb), f"rank {r}: body state differs from the single-GPU sweep after {done} steps"
     assert int(single.w.stats()["numManifolds"]) > 3000
+
+
+@pytest.mark.parametrize("nranks,scene", [(4, "StressN:36+welds:10000"), (8, "StressN:40+welds:3000")])
+def test_config4_cubes_and_weld_joints_over_process_ranks(tmp_path, nranks, scene):
+    """BASELINE configs[4]: 64 000 cubes + 10 000 weld Joints, exact cuts between ranks that are processes: slabs along x are five (ten) cubes wide and the
+    welds join x-neighbours 2k | 2k + 1, so every other boundary between eight slabs cuts through welds.  The single-GPU sweep bit for bit, bodies and forces.
+    Over EIGHT processes — configs[4]'s rank count — 3 000 of the welds: one MI355X time-slices eight processes (0.16 - 0.33 s per step with 3 000 welds,
+    measured; four processes run at full speed, 5.5 ms per step), and with all 10 000 a wave's wait for a record of a process that is switched out exceeds the
+    4 s after which it gives the launch up — a limit of the emulation, not of the protocol (a node runs one process per GPU).  All 10 000 welds over FOUR
+    processes on 46 656 cubes (nine columns per slab, so that two of the three boundaries cut through welds; with 64 000 cubes four slabs are ten columns wide
+    and no weld crosses)."""
+    steps = (6, 4)
+    outs = _run_ranks(tmp_path, scene, nranks, steps, 0)
+    print(outs[0][0].strip())
+    pkg = H.load_product()
+    single = H.HipWorld(); single.scene(scene)
+    b0 = single.bodies()
+    owner = pkg.partition_by_axis(b0["pos"], b0["invMass"], nranks, axis=0)
+    f0 = single.forces()
+    crossing = int((owner[f0["bodyA"][f0["kind"] == 1]] != owner[f0["bodyB"][f0["kind"] == 1]]).sum())
+    assert crossing > 200, crossing
+    done = 0
+    for s in steps:
+        single.step(s); done += s
+        bs, fs = single.bodies(), single.forces()
+        for r in range(nranks):
+            rb = np.load(os.path.join(str(tmp_path), f"bodies_{done}_{r}.npy"))
+            rf = np.load(os.path.join(str(tmp_path), f"forces_{done}_{r}.npy"))
+            assert H.same_bits(bs, rb), f"rank {r}: body state differs from the single-GPU sweep after {done} steps"
+            _same_forces(fs, rf, owner, r, f"after {done} steps")
 
 
 def test_bench_multi_process_path_on_one_device(tmp_path):

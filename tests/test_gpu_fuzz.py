@@ -83,7 +83,8 @@ def test_random_jointed_scenes_run_the_resident_schedule_bit_exact(first):
         assert int(g.w.stats()["schedule"]) == 2 and int(g.w.stats()["numJoints"]) > 0
 
 
-def test_jointed_scene_with_several_bodies_per_wave():
+def test_jointed_scene_with_several_bodies_per_wave(monkeypatch):
+    monkeypatch.setenv("AVBD_GROUPS", "0")                    # (since round 5 the group schedule takes jointed scenes: tests/test_gpu_groups.py)
     for seed in (9001, 9003):
         o, g = H.CpuWorld("orc"), H.HipWorld()
         for w in (o, g):
@@ -100,6 +101,7 @@ def test_random_jointed_scenes_out_of_order_sweep(monkeypatch, lite):
     (AVBD_RESIDENT_OOO=1: whichever body has its inputs published, oldest iteration first), with one or two workgroups per CU.
     The order of execution changes, the data flow does not: every step bit for bit."""
     monkeypatch.setenv("AVBD_ITER_BLOCKS", "1")
+    monkeypatch.setenv("AVBD_GROUPS", "0")                    # (the parked sweep of the resident schedule is what this test is about)
     monkeypatch.setenv("AVBD_RESIDENT_OOO", "1")
     monkeypatch.setenv("AVBD_RESIDENT_FORCE_LITE", lite)
     monkeypatch.setenv("AVBD_RESIDENT_LITE_FROM", "0")

@@ -139,3 +139,55 @@ def test_wide_bodies_with_several_rounds(monkeypatch):
         o.step(); g.step()
         H.assert_same_world(o, g, f"plate with 3x3 cubes on 2 waves, step {s + 1} (groups)")
     assert _sched(g) == 4
+
+
+# ---- Joint forces in the group schedule (round 5): a lane holds one Manifold contact or one half (three rows) of a Joint -----------------
+def _jointed(seed, big=False):
+    from test_gpu_fuzz import build_jointed
+    o, g = H.CpuWorld("orc"), H.HipWorld()
+    for w in (o, g):
+        build_jointed(w, seed, big=big)
+    return o, g
+
+
+@pytest.mark.parametrize("first", [300, 320])
+def test_random_jointed_scenes_in_the_group_schedule(monkeypatch, first):
+    """Hard, soft and world-anchored joints + ignore markers beside the contacts, one body per sub-group: every step against the oracle."""
+    monkeypatch.setenv("AVBD_GROUPS", "1")
+    for seed in range(first, first + 20):
+        o, g = _jointed(seed)
+        for s in range(18):
+            o.step(); g.step()
+            H.assert_same_world(o, g, f"seed {seed} step {s + 1} (groups, joints)")
+        assert _sched(g) == 4 and int(g.w.stats()["numJoints"]) > 0
+
+
+def test_jointed_scenes_beyond_one_body_per_wave_take_the_group_schedule():
+    """1100-1900 bodies with joints: the group schedule by default (one Joint used to send the whole sweep to the resident schedule's parked form)"""
+    for seed in (9001, 9003):
+        o, g = _jointed(seed, big=True)
+        for s in range(10):
+            o.step(); g.step()
+            H.assert_same_world_fast(o, g, f"seed {seed} step {s + 1}", check_rows=True)
+        assert _sched(g) == 4
+
+
+@pytest.mark.parametrize("waves,pool,spec", [(3, 1, 0), (3, 0, 2), (3, 0, 1), (40, 1, 0), (40, 0, 0)])
+def test_jointed_scenes_with_several_bodies_per_sub_group(monkeypatch, waves, pool, spec):
+    """fewer sub-groups than bodies: joint halves are parked in their GForce records (owner) or come back with the dual records (the other endpoint);
+    pools, a task in hand and the plain loop"""
+    monkeypatch.setenv("AVBD_GROUPS", "1")
+    monkeypatch.setenv("AVBD_GROUPS_ROUNDS", "16")
+    monkeypatch.setenv("AVBD_GROUPS_WAVES", str(waves))
+    monkeypatch.setenv("AVBD_GROUP_POOL", str(pool))
+    monkeypatch.setenv("AVBD_GROUP_SPEC", str(spec))
+    big = waves >= 40
+    for seed in ((9001, 9003) if big else range(400, 410)):
+        o, g = _jointed(seed, big=big)
+        for s in range(10 if big else 14):
+            o.step(); g.step()
+            if big:
+                H.assert_same_world_fast(o, g, f"seed {seed} step {s + 1}", check_rows=True)
+            else:
+                H.assert_same_world(o, g, f"seed {seed} step {s + 1} (groups, joints, {waves} waves)")
+        assert _sched(g) == 4
