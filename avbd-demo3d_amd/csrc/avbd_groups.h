@@ -294,6 +294,33 @@ __device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* 
 }
 
 __device__ __forceinline__ float grp_bcast(float v, int srcLane) { return __shfl(v, srcLane, 64); }
+/* minimum over the 64 lanes of a wavefront (all of them active), wave-uniform: six DPP steps on the vector ALU — quads, half rows, rows, then the rows' last
+ * lanes broadcast into the rows behind them — instead of six ds_bpermute round trips through the LDS crossbar (what __shfl_xor compiles to: ~100 cycles each,
+ * and the claim loop of the pools runs this reduction up to five times per pass, one behind the other) */
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = t < v ? t : v;      /* quad_perm:[1,0,3,2] */
+    t = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = t < v ? t : v;      /* quad_perm:[2,3,0,1] */
+    t = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = t < v ? t : v;     /* row_half_mirror */
+    t = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false); v = t < v ? t : v;     /* row_mirror: every lane holds its row's minimum */
+    t = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); v = t < v ? t : v;     /* row_bcast:15 into rows 1 and 3 */
+    t = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); v = t < v ? t : v;     /* row_bcast:31 into rows 2 and 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+/* minimum over a sub-group of gw = 16 / 32 / 64 lanes (aligned; every lane of it active), in all its lanes: the four steps inside a 16-lane row on the vector ALU,
+ * the one or two across rows through the crossbar */
+__device__ __forceinline__ int group_min_i32(int v, int gw)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false); v = t < v ? t : v;
+    if (gw > 16) { t = __shfl_xor(v, 16, 64); v = t < v ? t : v; }       /* (wave-uniform: gw is the class's) */
+    if (gw > 32) { t = __shfl_xor(v, 32, 64); v = t < v ? t : v; }
+    return v;
+}
 /* the stamp word of a record alone (aux 16 = sc1, like xld) */
 __device__ __forceinline__ unsigned xldw(__amdgpu_buffer_rsrc_t r, int byteOff) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byteOff, 0, 16); }
 
@@ -1167,7 +1194,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             int kHand = 0;
             for (;;) {
                 int key = (candK && !triedK) ? ((itK << 6) | gl) : 0x7fffffff;
-                for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
+                key = group_min_i32(key, gw);
                 if (key == 0x7fffffff && !prep && !inHand && !specTried && waveIdle) {
                     /* nothing is known to be ready: the oldest task of the sub-group (not the task behind the last iteration, which prepares nothing) */
                     specTried = true;
@@ -1175,7 +1202,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     /* arrival counters: the body that misses the fewest arrivals is the likeliest to run next (the oldest one was the next
                      * to run in one case out of five at eight bodies per sub-group) */
                     if (dep && activeK && itK < itStop) key = (int)(((depNeed - min(watchVal, depNeed)) << 12) | ((unsigned)itK << 6) | (unsigned)gl);
-                    for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
+                    key = group_min_i32(key, gw);
                 }
                 const bool examine = !prep && !ready && key != 0x7fffffff;   /* uniform over the sub-group */
                 if (__ballot(examine) == 0) break;
@@ -1281,7 +1308,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             bool sel = false, triedK = false;
             for (;;) {
                 int key = (candK && !triedK) ? ((itK << 6) | gl) : 0x7fffffff;
-                for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(key, o, 64); key = other_ < key ? other_ : key; }
+                key = group_min_i32(key, gw);
                 const bool examine = !sel && key != 0x7fffffff;        /* uniform over the sub-group */
                 if (__ballot(examine) == 0) break;
                 if (examine) {
@@ -1303,7 +1330,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
 #ifdef AVBD_DF_STATS
                         {   /* was the task that runs the OLDEST task of its sub-group (what a speculative load would have fetched)? */
                             int keyO = activeK ? ((itK << 6) | gl) : 0x7fffffff;
-                            for (int o = 1; o < gw; o <<= 1) { const int other_ = __shfl_xor(keyO, o, 64); keyO = other_ < keyO ? other_ : keyO; }
+                            keyO = group_min_i32(keyO, gw);
                             if (lane == k) { dbgTasks += 1; dbgOldest += (keyO == key) ? 1 : 0; }
                         }
 #endif
@@ -1439,9 +1466,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                 int taken = 0;
                 for (int tries = 0; tries < 8 && taken < G; ++tries) {
                     int best = key[0] < key[1] ? key[0] : key[1]; best = key[2] < best ? key[2] : best;
-                    int m = best;
-                    for (int o = 1; o < 64; o <<= 1) { const int x2 = __shfl_xor(m, o, 64); m = x2 < m ? x2 : m; }
-                    m = __builtin_amdgcn_readfirstlane(m);
+                    const int m = wave_min_i32(best);
                     if (m == kInf) break;
                     bool got = false;
                     if (best == m) {                                   /* exactly one lane holds a given slot */
