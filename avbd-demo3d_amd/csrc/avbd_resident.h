@@ -237,22 +237,20 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
     const float4* p4 = reinterpret_cast<const float4*>(prLine);
     const float* ja = J + a.opA;
     const float* jb = J + (rhs ? a.opA : a.opB);
-    for (int r4 = kResRegRows; r4 < nRows; r4 += 4) {
-        float4 pv;
-        if (!SHORT || r4 - kResRegRows + 4 <= lineRows) pv = p4[(r4 - kResRegRows) >> 2];   /* wave-uniform; SHORT = false: the line holds every row */
-        else {
-            float t[4];
+    /* (round 5: EIGHT rows per trip — every trip starts with an LDS round trip in front of its dependent additions, ~130 cycles, and four bodies of the critical
+     * cycle of the steady Stress1000 pile have 20 to 36 rows past the register window; the second block of a trip is fetched only when the body has it) */
+    auto tail_products = [&](int r4) __attribute__((always_inline)) -> float4 {
+        if (!SHORT || r4 - kResRegRows + 4 <= lineRows) return p4[(r4 - kResRegRows) >> 2];   /* wave-uniform; SHORT = false: the line holds every row */
+        float t[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = r4 + k < nRows ? r4 + k : r4;
-                const float va = ja[r * 6], vb = jb[r * 6];
-                t[k] = rhs ? va : va * vb;
-            }
-            pv = make_float4(t[0], t[1], t[2], t[3]);
+        for (int k = 0; k < 4; ++k) {
+            const int r = r4 + k < nRows ? r4 + k : r4;
+            const float va = ja[r * 6], vb = jb[r * 6];
+            t[k] = rhs ? va : va * vb;
         }
-        const float4 sw = s4[r4 >> 2], gw = g4[r4 >> 2];
-        float4 ow = make_float4(1.f, 1.f, 1.f, 1.f), mw = ow;
-        if (!ALLON) { ow = o4[r4 >> 2]; if (JOINTS) mw = m4[r4 >> 2]; }
+        return make_float4(t[0], t[1], t[2], t[3]);
+    };
+    auto tail_add = [&](int r4, const float4& pv, const float4& sw, const float4& gw, const float4& ow, const float4& mw) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (r4 + k < nRows) {                                  /* wave-uniform */
@@ -265,6 +263,18 @@ __device__ __forceinline__ void accumulate_products(AccLane& a, const float (&pr
                 }
             }
         }
+    };
+    for (int r4 = kResRegRows; r4 < nRows; r4 += 8) {
+        const bool two = r4 + 4 < nRows;                               /* wave-uniform */
+        const float4 pv0 = tail_products(r4), sw0 = s4[r4 >> 2], gw0 = g4[r4 >> 2];
+        float4 ow0 = make_float4(1.f, 1.f, 1.f, 1.f), mw0 = ow0, ow1 = ow0, mw1 = ow0, pv1 = ow0, sw1 = ow0, gw1 = ow0;
+        if (!ALLON) { ow0 = o4[r4 >> 2]; if (JOINTS) mw0 = m4[r4 >> 2]; }
+        if (two) {
+            pv1 = tail_products(r4 + 4); sw1 = s4[(r4 + 4) >> 2]; gw1 = g4[(r4 + 4) >> 2];
+            if (!ALLON) { ow1 = o4[(r4 + 4) >> 2]; if (JOINTS) mw1 = m4[(r4 + 4) >> 2]; }
+        }
+        tail_add(r4, pv0, sw0, gw0, ow0, mw0);
+        if (two) tail_add(r4 + 4, pv1, sw1, gw1, ow1, mw1);
     }
 }
 
@@ -636,11 +646,14 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
                 /* the poses that come through LDS: a short loop on the flag words alone (nothing is in flight any more, a round is
                  * one LDS access), normally entered long before the flag rises — the placement puts the hand-off a task waits for
                  * LAST into its own workgroup */
+                /* (the records are read in the same round as the flag, BEHIND it: the LDS executes a wave's accesses in order and the producer writes the flag
+                 * behind the records, so the round that sees the flag holds the pose — no second round trip between the flag and the solve) */
                 bool okL = !viaLds;
                 unsigned spinsL = 0;
+                const volatile v4u AVBD_LDS* rl = CL.rec + (co >= 0 ? co : 0) * 3;
                 while (true) {
                     unsigned lf = 0;
-                    if (!okL) lf = CL.flag[co];
+                    if (!okL) { lf = CL.flag[co]; p0 = rl[0]; p1 = rl[1]; p2 = rl[2]; }
                     asm volatile("" ::: "memory");
                     if (!okL) okL = stamp_reached(lf, sP);
                     if (__all(okL)) break;
@@ -670,10 +683,6 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #endif
             if (COLO) {
                 asm volatile("" ::: "memory");
-                if (viaLds) {                                         /* behind the flag: the records it covers */
-                    const volatile v4u AVBD_LDS* r = CL.rec + co * 3;
-                    p0 = r[0]; p1 = r[1]; p2 = r[2];
-                }
                 /* whose pose did this task wait for last?  (a later-created partner: the hand-off a shared workgroup would shorten) */
                 if (lastMissing) critOther = __builtin_amdgcn_readlane(other, __ffsll((long long)lastMissing) - 1);
             }
@@ -757,7 +766,7 @@ __device__ __forceinline__ void iterate_resident(const BodyTable& B, const Manif
 #endif
             if (COLO) { volatile v4u AVBD_LDS* r = CL.rec + CL.self * 3; r[0] = r0; r[1] = r1; r[2] = r2; }
             xst(rP, o, r0); xst(rP, o + 16, r1); xst(rP, o + 32, r2);
-            if (COLO) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); CL.flag[CL.self] = stampNow; }
+            if (COLO) CL.flag[CL.self] = stampNow;                    /* (behind the three records: a wave's LDS accesses execute in order, no wait in between) */
         }
         /* lane 0's result becomes the wave's (scalar) copy of the pose */
         L.pos = mk3(bcast0(p.x), bcast0(p.y), bcast0(p.z)); L.rot = mkq(bcast0(q.x), bcast0(q.y), bcast0(q.z), bcast0(q.w));
