@@ -90,7 +90,8 @@ def dependency_chain_hops(forces, bodies, total_iterations):
     return longest
 
 
-PMC_SUMMARIES = {"Stress1000": "r4_stress1000_cli_summary.json", "StressN:20": "r4_8k_cli_summary.json", "StressN:40": "r4_64k_cli_summary.json"}
+PMC_SUMMARIES = {"Stress1000": "r5_stress1000_cli_summary.json", "StressN:20": "r5_8k_cli_summary.json", "StressN:40": "r5_64k_cli_summary.json",
+                 "StressN:40+welds:10000": "r5_64k_welds_cli_summary.json"}
 
 
 def pmc_traffic(scene, fused):

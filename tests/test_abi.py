@@ -119,12 +119,12 @@ def test_option_keys_are_enumerable_without_a_device(lib):
 
 
 def test_committed_bench_line_and_profiles_keep_the_contract():
-    """profiles/r4_bench_default.json is a line bench.py printed on an MI355X: the keys the driver reads, the two objects this tier adds (roofline with
+    """profiles/r5_bench_default.json is a line bench.py printed on an MI355X: the keys the driver reads, the two objects this tier adds (roofline with
     achieved / peak / frac / traffic, cpu_baseline with kind / cores / sample) and the nested driver-timed lines of the larger scenes; the rocprofv3 summaries
     it cites exist and name the same dominant kernels."""
     import json
     prof = os.path.join(H.ROOT, "profiles")
-    line = json.load(open(os.path.join(prof, "r4_bench_default.json")))
+    line = json.load(open(os.path.join(prof, "r5_bench_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["unit"] == "steps/s" and line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None and "workload" in line["config"]
@@ -133,11 +133,12 @@ def test_committed_bench_line_and_profiles_keep_the_contract():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["sample"] and c.get("parity") == "bit-exact"
-    for nested in ("strong_scaling_n1", "roofline_8k"):
+    for nested in ("strong_scaling_n1", "roofline_8k", "joints_n1"):       # (joints_n1: BASELINE configs[4]'s scene on one GPU, round 5)
         n = line["config"][nested]
         assert n["ms_per_step"] > 0 and abs(n["roofline"]["frac"] - n["roofline"]["achieved"] / n["roofline"]["peak"]) < 1e-4 and n["roofline"]["traffic"] > 0
-    for tag, kernel in (("stress1000", "k_iterate_single"), ("8k", "k_iterate_groups<false, 0>"), ("64k", "k_iterate_groups<true, 0>")):
-        s = json.load(open(os.path.join(prof, f"r4_{tag}_cli_summary.json")))
+    assert line["config"]["joints_n1"]["joints"] == 10000 and line["config"]["joints_n1"]["schedule"] == 4
+    for tag, kernel in (("stress1000", "k_iterate_single"), ("8k", "k_iterate_groups<false, 0, false>"), ("64k", "k_iterate_groups<true, 0, false>"), ("64k_welds", "k_iterate_groups<true, 0, true>")):
+        s = json.load(open(os.path.join(prof, f"r5_{tag}_cli_summary.json")))
         assert kernel in s["dominant_kernel"], (tag, s["dominant_kernel"])
         assert {"FETCH_SIZE", "WRITE_SIZE"} <= set(s["counters_per_dispatch_of_dominant_kernel"])
-        assert os.path.exists(os.path.join(prof, f"r4_{tag}_kernel_stats.csv"))
+        assert os.path.exists(os.path.join(prof, f"r5_{tag}_kernel_stats.csv"))
