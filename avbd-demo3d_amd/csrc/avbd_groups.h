@@ -238,13 +238,16 @@ __device__ __forceinline__ void grp_entry_ops(int entry, GAcc& a)
  * two entries of a lane at once (two independent chains).  ALLON: every row has a usable penalty (solver.cpp:387), the normal
  * case; otherwise a lhs entry skips the rows whose penalty is not positive and finite.  `rowBase`: first row of the sub-group
  * (a multiple of 48). */
-struct GAccView { const float4 *a4, *b4, *s4, *g4; bool isAA, rhs; };
+struct GAccView { const float4 *a4, *b4, *s4, *g4; bool isAA, rhs; int bMask; };
+constexpr int kGrpOnesFloat = 56;         /* accs[56..59] of a wave's first sub-group: four 1.0f — the second factor of the rhs entries (x * 1.0f == x for every x), so that the
+                                            * products of a row are two multiplications on every lane, no select in between, and pair up into packed instructions */
 __device__ __forceinline__ GAccView grp_view(const GAcc& a, const float* Jt, const float* S, int rowBase)
 {
     GAccView v;
     v.isAA = a.mode == 1; v.rhs = a.mode == 2;
     v.a4 = reinterpret_cast<const float4*>(Jt + a.opA * kResRows + rowBase);
-    v.b4 = reinterpret_cast<const float4*>(Jt + (v.rhs ? a.opA : a.opB) * kResRows + rowBase);
+    v.b4 = v.rhs ? reinterpret_cast<const float4*>(S + kGrpSSlots * kResRows + kGrpOnesFloat) : reinterpret_cast<const float4*>(Jt + a.opB * kResRows + rowBase);
+    v.bMask = v.rhs ? 0 : -1;                                        /* rhs entries: the same four 1.0f for every block */
     v.s4 = reinterpret_cast<const float4*>(S + (v.rhs ? 0 : kResRows) + rowBase);
     /* behind the row term: the gyroscopic component (diagonal aa entries), +0.0f (off-diagonal aa entries, like the reference's
      * diagonal() matrix) or -0.0f (every other entry: x + (-0.0f) == x for every x, so no lane needs a select around the addition) */
@@ -254,7 +257,7 @@ __device__ __forceinline__ GAccView grp_view(const GAcc& a, const float* Jt, con
 template <bool ALLON>
 __device__ __forceinline__ float grp_add_row(float acc, float va, float vb, float sv, float gv, const GAccView& v)
 {
-    const float pr = v.rhs ? va : va * vb;
+    const float pr = va * vb;                                        /* (rhs entries: vb = 1.0f) */
     const float nv = acc + pr * sv;
     const float nvg = nv + gv;
     if (ALLON) return nvg;
@@ -275,8 +278,8 @@ __device__ __forceinline__ void grp_accumulate(GAcc& a0, GAcc& a1, const float* 
     for (int r4 = 0; r4 < nFull; r4 += 4) {
         const float4 ca0 = ja0, cb0 = jb0, cs0 = s0, cg0 = g0, ca1 = ja1, cb1 = jb1, cs1 = s1, cg1 = g1;
         const int q = (r4 >> 2) + 1;
-        ja0 = v0.a4[q]; jb0 = v0.b4[q]; s0 = v0.s4[q]; g0 = v0.g4[q];
-        if (TWO) { ja1 = v1.a4[q]; jb1 = v1.b4[q]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
+        ja0 = v0.a4[q]; jb0 = v0.b4[q & v0.bMask]; s0 = v0.s4[q]; g0 = v0.g4[q];
+        if (TWO) { ja1 = v1.a4[q]; jb1 = v1.b4[q & v1.bMask]; s1 = v1.s4[q]; g1 = v1.g4[q]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             acc0 = grp_add_row<ALLON>(acc0, comp4(ca0, k), comp4(cb0, k), comp4(cs0, k), comp4(cg0, k), v0);
@@ -547,6 +550,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     };
 
     for (int r = lane; r < kResRows; r += 64) { S[5 * kResRows + r] = 0.0f; S[6 * kResRows + r] = -0.0f; }
+    if (lane < 4) S[kGrpSSlots * kResRows + kGrpOnesFloat + lane] = 1.0f;
 
     /* ---- what the first half of a task leaves for the second ---- */
     GAcc a0, a1;
