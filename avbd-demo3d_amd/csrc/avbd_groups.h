@@ -618,12 +618,12 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         } else if (has) {
             wOwn = qrotate(rot, isA ? c.rA : c.rB);                    /* manifold.cpp:27 and :265 use the same product */
             if (moving) {
-                if (owned) replay_normal(c, fixedN);
-                else if (it > 0) { replay_normal(c, fixedN); replay_normal(c, fixedN); }
+                if (owned) replay_normal<MULTI>(c, fixedN);          /* (<MULTI>: the unit-length test of the basis memo on the bits, see contact_basis_memo) */
+                else if (it > 0) { replay_normal<MULTI>(c, fixedN); replay_normal<MULTI>(c, fixedN); }
             }
             AVBD_MARK(g_prep_pre);
             ContactBasis db;
-            contact_constraint_pre(c, alpha, isA ? invMass : oinv, isA ? oinv : invMass, pre, db);
+            contact_constraint_pre<MULTI>(c, alpha, isA ? invMass : oinv, isA ? oinv : invMass, pre, db);
             AVBD_MARK(g_prep_deriv);
             f3 Jl[3], Ja[3];
             contact_compute_derivatives_w(db, isA, wOwn, Jl, Ja);
@@ -657,7 +657,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
             c.lambda[0] = bitsf(vd.x); c.lambda[1] = bitsf(vd.y); c.lambda[2] = bitsf(vd.z);
             c.penalty[0] = bitsf(d1.x); c.penalty[1] = bitsf(d1.y); c.penalty[2] = bitsf(d1.z);
             c.stick = (d1.w & 1u) != 0;
-            replay_normal(c, fixedN); replay_normal(c, fixedN);
+            replay_normal<MULTI>(c, fixedN); replay_normal<MULTI>(c, fixedN);
             int idxF = idx;
             asm volatile("" : "+v"(idxF));
             store_contact_dual<false>(M, idxF, c, false);
@@ -818,7 +818,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
         if (doDual && has && owned && !(JOINTS && isJoint)) {
             const f3 wNew = qrotate(rot, isA ? c.rA : c.rB);
             const f3 pNew = pos + wNew;
-            dual_contact_pts(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
+            dual_contact_pts<MULTI>(c, isA ? pNew : pOther, isA ? wNew : wOther, isA ? invMass : oinv, isA ? pOther : pNew, isA ? wOther : wNew,
                              isA ? oinv : invMass, fric, P, alpha);
             if (moving) {
                 v4u r0 = {fbits(c.lambda[0]), fbits(c.lambda[1]), fbits(c.lambda[2]), stampNow};

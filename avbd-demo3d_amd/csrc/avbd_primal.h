@@ -347,10 +347,11 @@ __device__ __forceinline__ bool eval_contact_pts(ContactRows& c, bool isA, const
 }
 
 /* dual update from rotated lever arms (wA, wB) and world points (pA, pB) */
+template <bool BITS = false>
 __device__ __forceinline__ void dual_contact_pts(ContactRows& c, f3 pA, f3 wA, float imA, f3 pB, f3 wB, float imB, float fric, const SolverParams& P, float alpha)
 {
     ContactBasis db;
-    contact_compute_constraint_pts(c, alpha, pA, pB, imA, imB, fric, db);
+    contact_compute_constraint_pts<BITS>(c, alpha, pA, pB, imA, imB, fric, db);
     bool needJ = false;
     bool active[3];
     for (int k = 0; k < 3; ++k) {

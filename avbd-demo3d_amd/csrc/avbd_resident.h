@@ -131,11 +131,12 @@ __device__ __forceinline__ void race_check_publish(const int* consumed, Counters
 /* What one computeConstraint call does to the stored normal and its tangent memo (manifold.cpp:185-186 through
  * contact_basis_memo): used to replay the calls the OTHER visitor / the dual made since this wave last touched the
  * contact.  Once the normal is a fixed point of the normalisation every later call leaves it alone. */
+template <bool BITS = false>
 __device__ __forceinline__ void replay_normal(ContactRows& c, bool& fixedN)
 {
     if (fixedN) return;
     f3 n, t1, t2; bool hit;
-    contact_basis_memo(c.normal, c.u1, c.u2, n, t1, t2, hit);
+    contact_basis_memo<BITS>(c.normal, c.u1, c.u2, n, t1, t2, hit);
     c.normal = n; c.u1 = t1; c.u2 = t2;
     fixedN = hit;
 }
