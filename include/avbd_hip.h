@@ -171,7 +171,8 @@ int  avbd_add_ignore(AvbdContext* ctx, int bodyA, int bodyB);
 int  avbd_add_force(AvbdContext* ctx, const AvbdForce* record);
 
 /* ---- scene builders of scenes.h:23-212 by exact name ("Stack", "Stress1000", ...), plus the build's
- * "StressN:<n>" / "Packed:<n>"; clears the context first like every reference scene does.  Returns
+ * "StressN:<n>" / "Packed:<n>" / "StressGrid:<x>,<y>,<z>" / "PackedGrid:...", each optionally followed by "+welds:<k>" (BASELINE configs[4]:
+ * weld Joints between the x-adjacent cubes 2j+1 | 2j+2 of the first k pairs); clears the context first like every reference scene does.  Returns
  * the scene index (>= 0) or AVBD_E_INVALID for an unknown name. ---- */
 int  avbd_build_scene(AvbdContext* ctx, const char* name);
 
@@ -300,7 +301,8 @@ int  avbd_group_step(AvbdContext** ctxs, int n, int nsteps);
  * the stamped pose / visit / dual records of the bodies and contacts across a cut exactly as it polls local ones (one address
  * space for the records of all ranks: one allocation for contexts of one process, peer-to-peer windows between GPUs); no exchange
  * during the iteration loop, one copy of the final poses per step, results bit-identical to the single-GPU sweep
- * (tests/test_gpu_exact_cuts.py).  Exact cuts carry contacts only (no joints / springs), at most 8 bodies per sub-group, and the
+ * (tests/test_gpu_exact_cuts.py).  Exact cuts carry contacts and — since round 5 — Joints (a Joint half has one record slot in the space all
+ * ranks share; no springs or user-defined forces), at most 8 bodies per sub-group, and the
  * ranks of one avbd_group_step call must share a device.  A step that cannot run them FAILS with AVBD_E_INVALID and the reason in
  * avbd_last_error — a caller that asked for single-GPU bits never gets a Jacobi coupling under that name.
  * 2: exact cuts when the step can run them, the all-gather form otherwise; AvbdStepStats.cutMode tells which one ran. */
