@@ -220,6 +220,7 @@ struct AvbdContext {
     DevArr<int> dOwner, dCutOf, dCutMan, dRecIdx; DevArr<unsigned long long> dCutKeys; DevArr<CutCounters> dCutCnt;
     size_t cutOfCap = 0, recIdxCap = 0;
     hipEvent_t evLoop = nullptr, evExact = nullptr;
+    DevArr<unsigned long long> dSpan; bool spanPending = false;   /* profiling of the persistent sharded launch: the kernel's own start / end stamps (shard_launch_persistent) */
     std::vector<ExactRankArgs> hExactArgs; DevArr<ExactRankArgs> dExactArgs;
     /* chains of hand-offs share a workgroup (avbd_place.h): report of the last iteration launch, tails, this step's table */
     DevArr<int2> dCrit; DevArr<int> dTail, dPlaceSlot, dPlace; DevArr<PlaceInfo> dPlaceInfo;
@@ -607,13 +608,14 @@ hipEvent_t next_event(AvbdContext* c)
 
 struct SpanGuard {
     AvbdContext* c; int fam; size_t e0 = 0;
-    SpanGuard(AvbdContext* ctx, int family) : c(ctx), fam(family)
+    bool on;      /* (no event is recorded on the stream while a persistent sharded launch is in flight on it: see shard_launch_persistent) */
+    SpanGuard(AvbdContext* ctx, int family) : c(ctx), fam(family), on(ctx->profiling && !ctx->spanPending)
     {
-        if (c->profiling) { e0 = c->evUsed; (void)hipEventRecord(next_event(c), c->stream); }
+        if (on) { e0 = c->evUsed; (void)hipEventRecord(next_event(c), c->stream); }
     }
     ~SpanGuard()
     {
-        if (c->profiling) { size_t e1 = c->evUsed; (void)hipEventRecord(next_event(c), c->stream); c->spans.push_back({fam, e0, e1}); }
+        if (on) { size_t e1 = c->evUsed; (void)hipEventRecord(next_event(c), c->stream); c->spans.push_back({fam, e0, e1}); }
     }
 };
 
@@ -621,6 +623,11 @@ void collect_spans(AvbdContext* c)
 {
     if (!c->profiling) return;
     (void)hipStreamSynchronize(c->stream);
+    if (c->spanPending) {                                              /* the persistent sharded launch stamps its own span (10 ns ticks) */
+        unsigned long long t[2] = {0, 0};
+        if (hipMemcpy(t, c->dSpan.p, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[0] && t[1] > t[0]) c->prof.ms_primal += (double)(t[1] - t[0]) * 1e-5;
+        c->spanPending = false;
+    }
     for (const auto& s : c->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->evPool[s.e0], c->evPool[s.e1]) != hipSuccess) continue;
@@ -1042,7 +1049,7 @@ int avbd_destroy(AvbdContext* c)
     if (c->iterDone) { (void)hipEventDestroy(c->iterDone); c->iterDone = nullptr; }
     c->dIsBig.release(); c->dBigList.release(); c->dCellHead.release(); c->dCellNext.release();
     c->dPlan.release(); c->dUnit.release(); c->dSlotOf.release(); c->dHostRows.release();
-    c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release();
+    c->dDone.release(); c->dGather[0].release(); c->dGather[1].release(); c->dRow.release(); c->dSpan.release();
     if (c->sigDone) (void)hipFree(c->sigDone); if (c->sigGather) (void)hipFree(c->sigGather);
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }

@@ -72,6 +72,7 @@ struct ShardExchange {
     float4 *peerPose[kMaxExactRanks], *peerVisit[kMaxExactRanks], *peerDual[kMaxExactRanks];
     int nPeers;
     const int* owner;         /* [bodies]: rank that sweeps a body (-1: static) — which window a partner's records are read from */
+    unsigned long long* span; /* SHARD, profiling: [0] s_memrealtime (10 ns ticks) when the launch's first wave started, [1] when the rank's last iteration was complete; nullptr: off */
     const int* recIdx;        /* [incidence entries]: record index of the entry's contact | bit 31: the contact's owner is swept by another rank
                                * (this rank's copy of the contact takes the owner's last dual from its record when the loop ends) */
 };
@@ -843,6 +844,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     };
 
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (SHARD && Z.span && w == 0 && lane == 0) Z.span[0] = t0;          /* profiling of the persistent sharded launch: its span from the device's own clock (see shard_launch_persistent) */
     unsigned long long tIdle = t0;                                   /* when this wave last made progress (bounds the spin, not the launch) */
     unsigned spins = 0;
     /* the poll of a prepared task: the records ARE the payload (avbd_resident.h); only lanes that still miss something load */
@@ -1054,7 +1056,10 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     if (lane == 0)
                         for (int k = reported; k < low; ++k) {
                             const unsigned before = __hip_atomic_fetch_add(Z.done + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (before + mine == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (before + mine == (unsigned)Z.nOwned) {
+                                __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (Z.span && k == itStop - 1) Z.span[1] = __builtin_amdgcn_s_memrealtime();   /* profiling: the rank's last iteration is complete */
+                            }
                         }
                     reported = low;
                 }
@@ -1281,7 +1286,10 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     if (lane == 0)
                         for (int k = reportedM; k < low; ++k) {
                             const unsigned before = __hip_atomic_fetch_add(Z.done + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (before + mine == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (before + mine == (unsigned)Z.nOwned) {
+                                __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (Z.span && k == itStop - 1) Z.span[1] = __builtin_amdgcn_s_memrealtime();   /* profiling: the rank's last iteration is complete */
+                            }
                         }
                     reportedM = low;
                 }
@@ -1400,7 +1408,10 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
                     if (lane == 0)
                         for (int k = reportedM; k < low; ++k) {
                             const unsigned before = __hip_atomic_fetch_add(Z.done + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (before + mine == (unsigned)Z.nOwned) __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (before + mine == (unsigned)Z.nOwned) {
+                                __hip_atomic_fetch_max(Z.doneSignal, X.base + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (Z.span && k == itStop - 1) Z.span[1] = __builtin_amdgcn_s_memrealtime();   /* profiling: the rank's last iteration is complete */
+                            }
                         }
                     reportedM = low;
                 }

@@ -297,7 +297,7 @@ def main():
         except Exception as e:
             err = e
         if not vote(err is None):                                    # barrier
-            return fail(err)
+            return fail(err, "untimed steps")
         try:
             w.synchronize()
             t0 = time.perf_counter()
@@ -307,11 +307,12 @@ def main():
         except Exception as e:
             err = e
         if not vote(err is None):                                    # barrier
-            return fail(err)
+            return fail(err, "timed steps")
         try:
             w.synchronize()
             m["end_b"] = w.bodies() if want_cpu else None
             m["stats"] = w.stats()
+            m["p"] = None
             w.profile_enable(True)
             w.profile_reset()
             w.step(prof_steps)
@@ -321,14 +322,16 @@ def main():
         except Exception as e:
             err = e
         if not vote(err is None):
-            return fail(err)
+            # the timed legs are in: a form whose PROFILED steps failed somewhere keeps its figure and loses its roofline object (sharded runs; one GPU raises)
+            fail(err, "profiled steps")
+            m["p"] = None
         return m
 
-    def fail(err):
+    def fail(err, leg):
         if err is not None:
             if dist is None:
                 raise err
-            print(f"bench.py rank {rank}: the run failed ({err})", file=sys.stderr)
+            print(f"bench.py rank {rank}: the run failed in its {leg} ({err})", file=sys.stderr)
         return None
 
     w = make_world()                                                 # (sharded: every form gets a world of its own below)
@@ -390,7 +393,7 @@ def main():
 
     # ---- roofline of the dominant kernel ----
     roof = None
-    if p["launches_primal"] > 0 and p["ms_primal"] > 0:
+    if p is not None and p["launches_primal"] > 0 and p["ms_primal"] > 0:
         per_launch_s = p["ms_primal"] * 1e-3 / p["launches_primal"]
         bytes_per_launch = p["algorithmic_bytes_primal"] / p["launches_primal"]
         achieved = bytes_per_launch / per_launch_s / 1e9

@@ -187,6 +187,33 @@ def test_rccl_single_rank_schedule_is_bit_exact(monkeypatch, shard_mode):
     expect_schedule([g], shard_mode)
 
 
+def test_profiling_the_persistent_form_of_a_rank_with_a_communicator(monkeypatch):
+    """Round 5: with profiling on, the persistent sharded launch used to carry start / stop events (and the tail's span an event behind it); in about half of all
+    runs the kernel then crawled or stopped — a dependency time-out after 4 s — while the exchange stream's waits were in flight (tools/force_dist_flake.py; it made
+    bench.py's sharded forms fail in their profiled leg).  The launch now stamps its own span with the device's clock and no event is recorded behind it: 40
+    profiled steps of a landing pile go through, the span is plausible, and the bits are the unprofiled run's."""
+    monkeypatch.setenv("AVBD_FORCE_SHARDED", "1")
+    monkeypatch.setenv("AVBD_SHARD_PERSISTENT", "1")
+    pkg = H.load_product()
+    worlds = []
+    for profiled in (True, False):
+        g = H.HipWorld(); g.scene("StressN:12")
+        b = g.bodies()
+        g.w.set_ownership(1, 0, np.where(b["invMass"] > 0, 0, -1).astype(np.int32))
+        g.w.comm_init(1, 0, pkg.comm_unique_id())
+        g.step(300)
+        if profiled:
+            g.w.profile_enable(True); g.w.profile_reset()
+        g.step(40); g.w.synchronize()
+        if profiled:
+            p = g.w.profile(); g.w.profile_enable(False)
+            assert int(p["launches_primal"]) == 40 and int(p["steps"]) == 40
+            assert 0.2 < float(p["ms_primal"]) / 40 < 5.0, float(p["ms_primal"]) / 40      # ~0.7 ms per launch; a crawl was 135 ms
+        worlds.append(g)
+    assert int(worlds[0].w.stats()["schedule"]) == 4
+    assert H.same_bits(worlds[0].bodies(), worlds[1].bodies())
+
+
 def _two_big_piles(w, n=13, gap=25.0):
     w.add_body((100, 1, 100), 0.0, 0.5, (0, -0.5, 0))
     for cx in (-gap, gap):
