@@ -844,7 +844,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     };
 
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (SHARD && Z.span && w == 0 && lane == 0) Z.span[0] = t0;          /* profiling of the persistent sharded launch: its span from the device's own clock (see shard_launch_persistent) */
+    if (SHARDK != 0 && Z.span && w == 0 && lane == 0) Z.span[0] = t0;    /* profiling of a sharded launch: its span from the device's own clock (see shard_launch_persistent) */
     unsigned long long tIdle = t0;                                   /* when this wave last made progress (bounds the spin, not the launch) */
     unsigned spins = 0;
     /* the poll of a prepared task: the records ARE the payload (avbd_resident.h); only lanes that still miss something load */
@@ -1559,6 +1559,8 @@ void k_iterate_groups(BodyTable B, ManifoldTable M, const int* __restrict__ incS
                       Counters* cntW, ResidentExchange X, const GroupPlan* __restrict__ plan, const int* __restrict__ byClass, int cap, int sleepSel, ShardExchange Z)
 {
     iterate_groups<MULTI, SHARDK, JOINTS>(B, M, incStart, inc, P, errWord, cntW, X, plan, byClass, cap, sleepSel, Z, (int)blockIdx.x);
+    /* exact cuts between processes, profiling: the end of the span is the last wave out (the all-gather form stamps "last iteration complete" itself) */
+    if (SHARDK == 2 && Z.span && (threadIdx.x & 63) == 0) atomicMax(Z.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 /* Exact cuts with several ranks on ONE device (the emulation of avbd_group_step): all ranks in one launch, `wgPerRank` workgroups
