@@ -226,6 +226,10 @@ struct AvbdContext {
     DevArr<int2> dCrit; DevArr<int> dTail, dPlaceSlot, dPlace; DevArr<PlaceInfo> dPlaceInfo;
     bool placeChains = true;       /* AVBD_PLACE=0: waves take the slots of the sweep order */
     bool placeQueued = false;      /* this step: k_place_chains has been queued on the current topology */
+    int placeEvery = 8;            /* the table is rebuilt every so many steps while the swept bodies stay the same (place_every; 1 = every step) */
+    unsigned sweptSerial = 0;      /* counts the uploads that can change which bodies are swept */
+    unsigned placeSerial = ~0u;    /* sweptSerial | waves the table in dPlace was built for */
+    int placeWaves = 0, placeAge = 0;
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
     bool rowsStale = true;         /* ownership changed: the gather rows of the bodies must be uploaded again */
     bool groupsLaunched = false;   /* the last iteration loop was offered to k_iterate_groups (the device may still decline: GroupPlan.bad) */
@@ -483,6 +487,7 @@ int upload_bodies_if_stale(AvbdContext* c)
             c->numSolved += solved[(size_t)i];
         }
         c->orderValid = false;
+        ++c->sweptSerial;
         /* the exchange layout (who sits where in the all-gather) comes from the one host function the C ABI exports */
         c->hPerm.assign((size_t)std::max(n, 1), 0);
         c->hRow.assign((size_t)std::max(n, 1), -1);
@@ -677,12 +682,21 @@ int launch_topology(AvbdContext* c, bool fromStep)
      * 0.22 ms there against 0.05 ms for the launches below — the last known manifold count decides) */
     if (fromStep && c->fusedTopology && n <= kTopoBodies && c->mode != 0 && 2ll * ((long long)c->stats.numManifolds + ng) <= kTopoEntries) {
         /* small scene: scans, scatter, per-body order, levels, predictor and flag reset as one workgroup in LDS */
+        /* (the placement of the one-body-per-wave launch follows a graph that changes slowly: while the same bodies are swept the table of an
+         * earlier step stays a valid one — every swept body has its wave — and is rebuilt every placeEvery-th step only: 5.9 of the kernel's 21 us) */
+        const int placeW = c->iterBlocks * kIterWaves;
+        const bool placing = fromStep && c->placeChains && c->orderByIndex && placeW <= 1024;
+        bool placeKeep = false;
+        if (placing) {
+            placeKeep = c->placeSerial == c->sweptSerial && c->placeWaves == placeW && ++c->placeAge < c->placeEvery;
+            if (!placeKeep) { c->placeSerial = c->sweptSerial; c->placeWaves = placeW; c->placeAge = 0; }
+        }
         hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
                            c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap /* not the error word behind them: a failure stays visible until the next synchronising call */, c->orderByIndex ? 1 : 0,
-                           (const int2*)c->dCrit.p, c->dTail.p, c->dPlaceSlot.p, c->iterBlocks * kIterWaves,
-                           (fromStep && c->placeChains && c->orderByIndex && c->iterBlocks * kIterWaves <= 1024) ? c->dPlace.p : nullptr, c->dPlaceInfo.p);
-        c->placeQueued = fromStep && c->placeChains && c->orderByIndex && c->iterBlocks * kIterWaves <= 1024;
+                           (const int2*)c->dCrit.p, c->dTail.p, c->dPlaceSlot.p, placeW, placing ? c->dPlace.p : nullptr, c->dPlaceInfo.p, placeKeep ? 1 : 0,
+                           std::max(1, std::min(c->placeEvery, 16)));
+        c->placeQueued = placing;
         c->topologyDidPredict = true;
         c->orderValid = false;
         HIPCHK(c, hipGetLastError());
@@ -2013,6 +2027,21 @@ int avbd_debug_front_times(AvbdContext* c, unsigned long long* out4)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ManifoldBuf& m = c->mbuf[c->cur];
     HIPCHK(c, hipMemcpy(out4, reinterpret_cast<unsigned long long*>(m.cC.p + (size_t)m.cap * 4 - 8), 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
+
+int avbd_debug_front_blocks(AvbdContext* c, unsigned long long* out, int blocks)
+{
+    /* -DAVBD_DF_STATS builds: sixteen words per workgroup 0 .. blocks-1 of the last k_front_small (10 ns ticks): [0] first instant, [15] last instant; of the first
+     * pair of its first group [1] after the loads, [2] after Manifold::initialize, [3] at its end, and inside initialize [4] SAT axes tested, [5] axis chosen, [6] incident face built,
+     * [7] clipped, [8] contacts chosen, [9] collide done, [10] features matched; zeros in the product build */
+    if (!c || !out || blocks < 1) return AVBD_E_INVALID;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memset(out, 0, (size_t)blocks * 16 * sizeof(unsigned long long));
+#ifdef AVBD_DF_STATS
+    HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(gFrontBlockStamps), (size_t)std::min(blocks, kFrontStampBlocks) * 16 * sizeof(unsigned long long)));
+#endif
     return AVBD_OK;
 }
 

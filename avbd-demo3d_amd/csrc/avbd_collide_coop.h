@@ -45,6 +45,15 @@ __device__ __forceinline__ float gshfl(float v, int srcLane) { return __shfl(v, 
 __device__ __forceinline__ int   gshfl(int v, int srcLane) { return __shfl(v, srcLane, 64); }
 __device__ __forceinline__ f3    gshfl(f3 v, int srcLane) { return mk3(gshfl(v.x, srcLane), gshfl(v.y, srcLane), gshfl(v.z, srcLane)); }
 __device__ __forceinline__ unsigned gballot16(bool p, int gBase) { return (unsigned)((__ballot(p) >> gBase) & 0xFFFFull); }
+#ifdef AVBD_DF_STATS
+#define COOP_STAMP(k) do { if (dbg) dbg[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define COOP_DBG_PARAM , unsigned long long* dbg = nullptr
+#define COOP_DBG_ARG , dbg
+#else
+#define COOP_STAMP(k) do { } while (0)
+#define COOP_DBG_PARAM
+#define COOP_DBG_ARG
+#endif
 __device__ __forceinline__ void gsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 /* collision.cpp:136-174 with one lane per polygon edge; returns the new vertex count (uniform over the group) */
@@ -66,24 +75,19 @@ __device__ __forceinline__ int coop_clip(const f3* in, int n, f3 pn, float po, f
         }
         if (bIn) { vB = b; emitB = 1; }
     }
-    /* exclusive prefix sum of the emitted vertices over the group's lanes = position in the reference's output */
-    const int mine = emitA + emitB;
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-        const int v = __shfl_up(incl, off, 16);
-        if (gl >= off) incl += v;
-    }
-    const int pos = incl - mine;
+    /* vertices emitted by the lanes in front of this one = position in the reference's output: two ballots instead of a prefix sum
+     * through the LDS crossbar (four dependent round trips per clip, four clips per pair) */
+    const unsigned mA = gballot16(emitA != 0, gBase), mB = gballot16(emitB != 0, gBase), below = (1u << gl) - 1u;
+    const int pos = __popc(mA & below) + __popc(mB & below);
     if (emitA && pos < kMaxPolyVerts) out[pos] = vA;                 /* (every push checks the cap on its own, like the reference) */
     if (emitB && pos + emitA < kMaxPolyVerts) out[pos + emitA] = vB;
-    const int total = gshfl(incl, gBase + 15);
+    const int total = __popc(mA) + __popc(mB);
     gsync();
     return total < kMaxPolyVerts ? total : kMaxPolyVerts;
 }
 
 /* Manifold::collide (collision.cpp:420-489, flip = false).  Contacts land in ws.raw; the count is uniform over the group. */
-__device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPose& B, CoopScratch& ws, int gl, int gBase)
+__device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPose& B, CoopScratch& ws, int gl, int gBase COOP_DBG_PARAM)
 {
     const Obb boxA = make_obb(A), boxB = make_obb(B);
     const f3 delta = boxB.center - boxA.center;
@@ -109,13 +113,15 @@ __device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPos
             separating = separation > kCollisionMargin;
         }
     }
+    COOP_STAMP(4);
     if (gballot16(separating, gBase)) return 0;                        /* (the reference returns at the first such axis: same outcome) */
 
     /* the reference's two running maxima, replayed in its order over the fifteen results */
     int faceK = -1, edgeK = -1; float faceSep = -FLT_MAX, edgeSep = -FLT_MAX;
+    const unsigned testedMask = gballot16(tested, gBase);
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
-        const bool tk = gshfl(tested ? 1 : 0, gBase + k) != 0;
+        const bool tk = (testedMask >> k) & 1u;
         const float sk = gshfl(separation, gBase + k);
         if (k < 6) { if (tk && (faceK < 0 || sk > faceSep)) { faceK = k; faceSep = sk; } }
         else       { if (tk && (edgeK < 0 || sk > edgeSep)) { edgeK = k; edgeSep = sk; } }
@@ -127,6 +133,7 @@ __device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPos
         if (relTol * edgeSep > faceSep + absTol) bestK = edgeK;
     }
     const f3 nAB = gshfl(n, gBase + bestK);
+    COOP_STAMP(5);
 
     if (bestK >= 6) {
         /* ---- edge-edge: one contact from the closest points of the two support edges (collision.cpp:396-416) ---- */
@@ -181,12 +188,14 @@ __device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPos
         clip0[gl] = gl == 0 ? c + u * xu + v * xv : (gl == 1 ? c - u * xu + v * xv : (gl == 2 ? c - u * xu - v * xv : c + u * xu - v * xv));
     }
     gsync();
+    COOP_STAMP(6);
     int count = 4;
     count = coop_clip(clip0, count, fU, dot3(fU, fC) + eU, clip1, gl, gBase);   if (!count) return 0;
     count = coop_clip(clip1, count, -fU, dot3(-fU, fC) + eU, clip0, gl, gBase); if (!count) return 0;
     count = coop_clip(clip0, count, fV, dot3(fV, fC) + eV, clip1, gl, gBase);   if (!count) return 0;
     count = coop_clip(clip1, count, -fV, dot3(-fV, fC) + eV, clip0, gl, gBase); if (!count) return 0;
 
+    COOP_STAMP(7);
     /* one lane per clipped vertex: projection onto the reference face, feature key */
     bool near_ = false; f3 xA = zero3(), xB = zero3(), mid = zero3(); int key = 0;
     if (gl < count) {
@@ -208,8 +217,10 @@ __device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPos
     /* addContact's merge-by-distance and four-contact cap, in vertex order (collision.cpp:176-206, 376-392) */
     int cc = 0, mySlot = -1;
     f3 m0 = zero3(), m1 = zero3(), m2 = zero3(), m3 = zero3();
+    /* (which candidates are near is one ballot: one round trip through the LDS crossbar per candidate instead of two) */
+    const unsigned nearMask = gballot16(near_, gBase);
     for (int i = 0; i < count && cc < kMaxContacts; ++i) {
-        if (!(gshfl(near_ ? 1 : 0, gBase + i) != 0)) continue;
+        if (!((nearMask >> i) & 1u)) continue;
         const f3 mi = gshfl(mid, gBase + i);
         bool merged = false;
         if (cc > 0 && lensq3(mi - m0) < kMergeDistSq) merged = true;
@@ -221,6 +232,7 @@ __device__ __forceinline__ int collide_boxes_coop(const BoxPose& A, const BoxPos
         ++cc;
     }
     (void)m3;
+    COOP_STAMP(8);
     if (mySlot >= 0) {
         RawContact& c = ws.raw[mySlot];
         c.feature = key;
@@ -243,25 +255,34 @@ struct CoopContact {
 
 /* Manifold::initialize (manifold.cpp:71-175).  The previous step's `oldN` contacts are in ws.old*; on return lane c < numContacts
  * holds contact c.  Returns the new contact count (0: the pair no longer touches, the reference deletes the manifold). */
-__device__ __forceinline__ int manifold_initialize_coop(int oldN, CoopScratch& ws, const BoxPose& A, const BoxPose& B, CoopContact& out, int gl, int gBase)
+/* what Manifold::initialize does with the `nNew` contacts collide_boxes_coop has left in ws.raw (nNew > 0; the two halves are separate so that
+ * the caller can request the manifold's slot in between: the round trip of that atomic then runs beside this function instead of behind it) */
+__device__ __forceinline__ void manifold_adopt_coop(int oldN, int nNew, CoopScratch& ws, const BoxPose& A, const BoxPose& B, CoopContact& out, int gl, int gBase COOP_DBG_PARAM)
 {
-    const int nNew = collide_boxes_coop(A, B, ws, gl, gBase);
-    if (nNew == 0) return 0;
-    /* feature matching: new contact i takes the first old contact with its feature key that no earlier new contact took */
+    /* feature matching: new contact i takes the first old contact with its feature key that no earlier new contact took
+     * (the eight keys are read side by side, then matched in registers) */
     int myOld = -1;
     {
+        static_assert(kMaxContacts == 4, "four new and four old feature keys");
+        int fNew[4], fOld[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fNew[i] = ws.raw[i].feature; fOld[i] = ws.oldFeature[i]; }
         unsigned used = 0;
-        for (int i = 0; i < nNew; ++i) {
-            const int fi = ws.raw[i].feature;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nNew) break;
             int best = -1;
-            for (int j = 0; j < oldN; ++j) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= oldN) break;
                 if ((used >> j) & 1u) continue;
-                if (fi == ws.oldFeature[j]) { best = j; break; }
+                if (fNew[i] == fOld[j]) { best = j; break; }
             }
             if (best >= 0) used |= 1u << best;
             if (gl == i) myOld = best;
         }
     }
+    COOP_STAMP(10);
     if (gl < nNew) {
         const RawContact& r = ws.raw[gl];
         out.feature = r.feature; out.rA = r.rA; out.rB = r.rB; out.normal = r.normal;
@@ -296,6 +317,15 @@ __device__ __forceinline__ int manifold_initialize_coop(int oldN, CoopScratch& w
         out.C0t2 = dot3(d, t2);
         out.penetration = rmax(0.0f, -dot3(d, nn));
     }
+}
+
+/* Manifold::initialize in one piece */
+__device__ __forceinline__ int manifold_initialize_coop(int oldN, CoopScratch& ws, const BoxPose& A, const BoxPose& B, CoopContact& out, int gl, int gBase COOP_DBG_PARAM)
+{
+    const int nNew = collide_boxes_coop(A, B, ws, gl, gBase COOP_DBG_ARG);
+    COOP_STAMP(9);
+    if (nNew == 0) return 0;
+    manifold_adopt_coop(oldN, nNew, ws, A, B, out, gl, gBase COOP_DBG_ARG);
     return nNew;
 }
 

@@ -392,7 +392,7 @@ __device__ __forceinline__ void iterate_groups(BodyTable B, ManifoldTable M, con
     int body = -1, eBeg = 0, nRows = 0;
     bool valid = false, has = false;
     int idx = 0, other = 0; bool isA = false, owned = false, moving = false, fixedN = false;
-    bool isJoint = false, hasA = true, jFix = false;                  /* JOINTS: this lane holds a joint half (rows 3 * (idx & 1) ..); the joint has a bodyA; corrected angular sign */
+    bool isJoint = false, hasA = true;                                /* JOINTS: this lane holds a joint half (rows 3 * (idx & 1) ..); the joint has a bodyA */
     bool remote = false; int offR = 0; int ownRow = 0;                /* SHARD: the partner is swept by another rank; its row / this body's row in a gather buffer */
     bool finalD = false;                                              /* EXACT: the contact's owner is swept by another rank */
     float oinv = 0.0f, fric = 0.0f;

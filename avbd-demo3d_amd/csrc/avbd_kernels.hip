@@ -29,6 +29,23 @@ namespace avbd {
 constexpr int kResLiteMaxEntriesDecl = 33;   /* = kResLiteMaxEntries (avbd_resident.h), needed before that header is included */
 
 
+/* Rigid::isConstrainedTo (rigid.cpp:61-69) on the CSR lists: is `other` among adjOther[s .. e)?  Eight entries per trip, loaded side by side
+ * (an entry-by-entry loop with an early exit is a chain of dependent memory round trips — six of them for a cube inside a pile — in front of
+ * every sphere-overlapping pair of the broadphase). */
+__device__ __forceinline__ bool adj_lists(const int* __restrict__ adjOther, int s, int e, int other)
+{
+    for (int k = s; k < e; k += 8) {
+        int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = adjOther[min(k + q, e - 1)];
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hit |= v[q] == other;
+        if (hit) return true;
+    }
+    return false;
+}
+
 /* ------------------------------------------------------------------------------------------
  * K1 broadphase.  Grid = T(T+1)/2 tiles of 256x256 (T = ceil(n/256)); tile (ti,tj), tj<=ti, tests
  * bodies A in tile ti against bodies B in tile tj with B < A (A is the later-created body: it
@@ -74,9 +91,7 @@ __global__ __launch_bounds__(256) void k_broadphase(BodyTable B, const int* __re
             int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
             int s, e, other;
             if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
-            bool constrained = false;
-            for (int k = s; k < e; ++k) if (adjOther[k] == other) { constrained = true; break; }
-            if (!constrained) {
+            if (!adj_lists(adjOther, s, e, other)) {
                 int slot = atomicAdd(&cnt->numCandidates, 1);
                 if (slot < candCap) cand[slot] = make_int2(i, j);
                 else atomicOr(&cnt->overflow, 1);
@@ -114,9 +129,7 @@ __global__ __launch_bounds__(256) void k_broadphase_small(BodyTable B, const int
             int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
             int s, e, other;
             if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
-            bool constrained = false;
-            for (int k = s; k < e; ++k) if (adjOther[k] == other) { constrained = true; break; }
-            if (!constrained) {
+            if (!adj_lists(adjOther, s, e, other)) {
                 int slot = atomicAdd(&cnt->numCandidates, 1);
                 if (slot < candCap) cand[slot] = make_int2(i, j);
                 else atomicOr(&cnt->overflow, 1);
@@ -173,8 +186,7 @@ __device__ __forceinline__ bool broadphase_pair_passes(const BodyTable& B, int i
     const int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
     int s, e, other;
     if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
-    for (int k = s; k < e; ++k) if (adjOther[k] == other) return false;
-    return true;
+    return !adj_lists(adjOther, s, e, other);
 }
 
 constexpr int kGridCellsPerBody = 14;
@@ -305,12 +317,28 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
 #ifdef AVBD_DF_STATS
     if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A.pos.x == 12345.0f);
 #endif
+    const bool solvedA = B.solved[a] != 0, solvedB = B.solved[b] != 0;   /* (for the degree counts at the end: requested with the boxes) */
     CoopContact cc;
-    const int nc = manifold_initialize_coop(oldN, ws, A, Bp, cc, gl, gBase);
+    const int nc = collide_boxes_coop(A, Bp, ws, gl, gBase
 #ifdef AVBD_DF_STATS
-    if (dbg) { dbg[2] = __builtin_amdgcn_s_memrealtime(); if (!nc) dbg[3] = dbg[2]; }
+                                      , dbg
+#endif
+                                      );
+#ifdef AVBD_DF_STATS
+    if (dbg) { dbg[9] = __builtin_amdgcn_s_memrealtime(); if (!nc) dbg[3] = dbg[2] = dbg[9]; }
 #endif
     if (nc == 0) return;
+    /* the manifold survives (manifold.cpp:112-117): its slot is requested now, and the round trip of that atomic runs beside the rest of initialize */
+    int slot = 0;
+    if (gl == 0) slot = atomicAdd(nextCount, 1);
+    manifold_adopt_coop(oldN, nc, ws, A, Bp, cc, gl, gBase
+#ifdef AVBD_DF_STATS
+                        , dbg
+#endif
+                        );
+#ifdef AVBD_DF_STATS
+    if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     const float combinedFriction = sqrtf(fa * fb);                     /* manifold.cpp:73 */
 
     /* warm-start decay, solver.cpp:281-293 (manifold rows have stiffness FLT_MAX: no cap) */
@@ -321,8 +349,6 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
             cc.penalty[k] = rclamp(cc.penalty[k] * P.gamma, kPenaltyMin, kPenaltyMax);
         }
     }
-    int slot = 0;
-    if (gl == 0) slot = atomicAdd(nextCount, 1);
     slot = gshfl(slot, gBase);
     if (slot >= dst.cap) { if (gl == 0) atomicOr(&cnt->overflow, 2); return; }
     if (gl == 0) {
@@ -333,8 +359,8 @@ __device__ __forceinline__ void narrow_pair(const BodyTable& B, const ManifoldTa
         atomicAdd(&degForce[a], 1);
         atomicAdd(&degForce[b], 1);
         int inc = 0;
-        if (B.solved[a]) { atomicAdd(&degInc[a], nc); inc += nc; }
-        if (B.solved[b]) { atomicAdd(&degInc[b], nc); inc += nc; }
+        if (solvedA) { atomicAdd(&degInc[a], nc); inc += nc; }
+        if (solvedB) { atomicAdd(&degInc[b], nc); inc += nc; }
         atomicAdd(reinterpret_cast<unsigned long long*>(&cnt->numContacts), ((unsigned long long)(unsigned)inc << 32) | (unsigned long long)(unsigned)nc);
     }
     if (gl < nc) {
@@ -506,6 +532,10 @@ constexpr int kFrontSlice = AVBD_FRONT_SLICE;      /* bodies one thread of the f
 constexpr int kFrontThreads = AVBD_FRONT_THREADS;   /* (2 650 one-wave workgroups took 27 us to dispatch at Stress1000: the pairs of block 0 were done after 8) */
 constexpr int kFrontPairs = kPairsPerWave * (kFrontThreads / 64);   /* pairs a workgroup collides side by side */
 constexpr int kFrontHits = kFrontThreads * kFrontSlice;   /* a workgroup can never find more */
+#ifdef AVBD_DF_STATS
+constexpr int kFrontStampBlocks = 8192;
+__device__ unsigned long long gFrontBlockStamps[16 * kFrontStampBlocks];   /* first / last instant of every workgroup of the last k_front_small (avbd_debug_front_blocks) */
+#endif
 __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
                                                     const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
                                                     int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
@@ -514,10 +544,14 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
     __shared__ int2 sHits[kFrontHits];
     __shared__ int sNumHits;
     const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;   /* gBase: first lane of the group inside its wave */
+#ifdef AVBD_DF_STATS
+    if (threadIdx.x == 0 && blockIdx.x < kFrontStampBlocks) { for (int k = 1; k < 16; ++k) gFrontBlockStamps[16 * blockIdx.x + k] = 0; gFrontBlockStamps[16 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if ((int)blockIdx.x < persistBlocks) {
 #ifdef AVBD_DF_STATS
         unsigned long long* dbg = (blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<unsigned long long*>(dst.cC + (size_t)dst.cap * 4 - 8) : nullptr;
         if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
+        if (!dbg && (threadIdx.x & 15) == 0 && blockIdx.x < kFrontStampBlocks && (threadIdx.x >> 4) < 1) dbg = gFrontBlockStamps + 16 * blockIdx.x;   /* [1..3]: after loads / initialize / end of group 0's first pair, [4..10]: inside initialize */
 #endif
         const int nOld = cnt->numManifolds;
         /* four pairs per wavefront, sixteen lanes each (avbd_collide_coop.h) */
@@ -527,6 +561,10 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
                         , dbg
 #endif
                         );
+#ifdef AVBD_DF_STATS
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x < kFrontStampBlocks) gFrontBlockStamps[16 * blockIdx.x + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
         return;
     }
     if (threadIdx.x == 0) sNumHits = 0;
@@ -541,8 +579,15 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
         const float4 a = posr[i];
         const f3 pa = mk3(a.x, a.y, a.z);
         const bool solvedI = B.solved[i] != 0;
-        for (int j = jBeg; j < jEnd; ++j) {
-            const float4 b = posr[j];
+        float4 bs[kFrontSlice];                                       /* the slice's spheres, requested side by side */
+#pragma unroll
+        for (int q = 0; q < kFrontSlice; ++q) bs[q] = posr[min(jBeg + q, jEnd - 1)];
+        const int si = adjStart[i], ei = adjStart[i + 1];
+#pragma unroll
+        for (int q = 0; q < kFrontSlice; ++q) {
+            const int j = jBeg + q;
+            if (j >= jEnd) break;
+            const float4 b = bs[q];
             f3 dp = pa - mk3(b.x, b.y, b.z);
             float r = a.w + b.w;
             if (dot3(dp, dp) <= r * r) {
@@ -550,12 +595,10 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
                     const bool bothStatic = !(B.plane(BP_MASS)[i].y > 0.0f) && !(B.plane(BP_MASS)[j].y > 0.0f);
                     if (!(keepUnsolvedPairs && bothStatic)) continue;
                 }
-                int si = adjStart[i], ei = adjStart[i + 1], sj = adjStart[j], ej = adjStart[j + 1];
+                const int sj = adjStart[j], ej = adjStart[j + 1];
                 int s, e, other;
                 if (ei - si <= ej - sj) { s = si; e = ei; other = j; } else { s = sj; e = ej; other = i; }
-                bool constrained = false;
-                for (int k = s; k < e; ++k) if (adjOther[k] == other) { constrained = true; break; }
-                if (!constrained) sHits[atomicAdd(&sNumHits, 1)] = make_int2(i, j);
+                if (!adj_lists(adjOther, s, e, other)) sHits[atomicAdd(&sNumHits, 1)] = make_int2(i, j);
             }
         }
     }
@@ -566,6 +609,10 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
         const int2 pr = sHits[h];
         narrow_pair(B, src, dst, -1, pr.x, pr.y, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase);
     }
+#ifdef AVBD_DF_STATS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < kFrontStampBlocks) gFrontBlockStamps[16 * blockIdx.x + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 /* Joint / Spring / IgnoreCollision: initialize() is a no-op returning true; apply the row decay
@@ -1062,7 +1109,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                                                           int* degForce, int* degInc, int* adjStart, int* incStart, int* adjRef, int* adjOther,
                                                           uint64_t* adjKey, int2* adjTmp, int* inc, int* level, int* lvlCount, int* lvlStart, int* order, int lvlCap,
                                                           int residentWaves, SolverParams P, int* flags, int nFlags, int byIndex,
-                                                          const int2* placeCrit, int* placeTail, int* placeSlotOf, int placeW, int* place, PlaceInfo* placeInfo)
+                                                          const int2* placeCrit, int* placeTail, int* placeSlotOf, int placeW, int* place, PlaceInfo* placeInfo, int placeKeep, int placeRounds)
 {
     extern __shared__ int sTopo[];
     __shared__ unsigned long long sWaveTotals[16];
@@ -1083,6 +1130,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     if (t == 0) tstamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int nm = *nextCount;
+    const int4 placedFor = (place && placeKeep) ? *reinterpret_cast<const int4*>(placeInfo) : make_int4(-1, 0, 0, 0);   /* {nd, groups, grouped, valid} of the table in memory */
     if (t == 0) { atomicExch(&cnt->numManifolds, nm); sBad = 0; }   /* atomics only on Counters words inside a kernel that also adds to them */
 
     /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below ---- */
@@ -1232,13 +1280,21 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             if (ndAll > residentWaves) bad |= 2;
             if (bad) atomicOr(&cnt->residentBad, bad);
         }
-        if (place) {
+#ifdef AVBD_DF_STATS
+        __syncthreads(); if (t == 0) tstamp[5] = __builtin_amdgcn_s_memrealtime();
+#endif
+        /* (kept: the host saw no upload that changes the swept bodies since the table was built, and the table is one — a step that
+         * declined the one-body-per-wave launch leaves none — for this many bodies) */
+        if (place && !(placedFor.w == 1 && placedFor.x == ndAll)) {
             /* one body per wave: which workgroup every body's wave sits in (avbd_place.h), on the sweep order just written and the
              * report of the last iteration launch; the staging area above is dead by now */
             __syncthreads();
             place_chains(order, ndAll, sBad != 0 || ndAll > residentWaves, placeCrit, placeTail, placeSlotOf, B.cap, placeW, place, placeInfo,
-                         reinterpret_cast<char*>(sTopo), sWaveTotals);
+                         reinterpret_cast<char*>(sTopo), sWaveTotals, placeRounds);
         }
+#ifdef AVBD_DF_STATS
+        __syncthreads(); if (t == 0) tstamp[6] = __builtin_amdgcn_s_memrealtime();
+#endif
         return;
     }
     /* ---- phase 4: dependency levels (level = 1 + max level of the later-created swept neighbours), relaxed in LDS ---- */

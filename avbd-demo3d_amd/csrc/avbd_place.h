@@ -30,7 +30,7 @@ constexpr int kPlaceLdsBytes = 8192 + 6 * 4096 + 3 * 1024 + 256;   /* working st
 /* the work of k_place_chains for one workgroup of 1024 threads; `lds` is kPlaceLdsBytes of 8-byte aligned LDS nobody else uses */
 __device__ __forceinline__ void place_chains(const int* __restrict__ order, int nd, bool declined, const int2* __restrict__ crit, int* __restrict__ tail,
                                              int* __restrict__ slotOf, int bodyCap, int W, int* __restrict__ place, PlaceInfo* info, char* lds,
-                                             unsigned long long* sWaveTotals /* [16] */)
+                                             unsigned long long* sWaveTotals /* [16] */, int rounds = 1)
 {
     unsigned long long* sBest = reinterpret_cast<unsigned long long*>(lds);
     int* sTail = reinterpret_cast<int*>(lds + 8192);
@@ -46,7 +46,7 @@ __device__ __forceinline__ void place_chains(const int* __restrict__ order, int 
     }
     const int body = t < nd ? order[t] : -1;
     if (body >= 0) slotOf[body] = t;
-    sBest[t] = 0ull; sTail[t] = 1; sAccepted[t] = 0; sLead[t] = t; sRank[t] = 0; sSize[t] = 1;
+    sBest[t] = 0ull; sTail[t] = 1; sFree[t] = 1; sGroupWg[t] = 1; sAccepted[t] = 0; sLead[t] = t; sRank[t] = 0; sSize[t] = 1;
     for (int s = t; s < W; s += 1024) place[s] = -1;
     __syncthreads();
 
@@ -57,13 +57,20 @@ __device__ __forceinline__ void place_chains(const int* __restrict__ order, int 
         fin = (unsigned)c.y;
         if (c.x > body && c.x < bodyCap) { const int s = slotOf[c.x]; if (s >= 0 && s < nd && order[s] == c.x) ps = s; }
     }
-    /* one round of tail[b] = 1 + max over the bodies that wait for b */
-    const int myTail = body >= 0 ? max(1, min(tail[body], 62)) : 1;
-    if (ps >= 0) atomicMax(&sTail[ps], myTail + 1);
-    __syncthreads();
-    if (body >= 0) tail[body] = sTail[t];
+    /* `rounds` rounds of tail[b] = 1 + max over the bodies that wait for b (a table that is kept for several steps relaxes that many
+     * rounds when it is rebuilt; three buffers in turn: the one after next is reset while this round's is filled) */
+    int myTail = body >= 0 ? max(1, min(tail[body], 62)) : 1;
+    for (int r = 0; r < rounds; ++r) {
+        int* const dst = r % 3 == 0 ? sTail : (r % 3 == 1 ? sFree : sGroupWg);
+        int* const afterNext = r % 3 == 0 ? sGroupWg : (r % 3 == 1 ? sTail : sFree);
+        if (ps >= 0) atomicMax(&dst[ps], myTail + 1);
+        afterNext[t] = 1;
+        __syncthreads();
+        myTail = r + 1 < rounds ? max(1, min(dst[t], 62)) : dst[t];
+    }
+    if (body >= 0) tail[body] = myTail;
     /* a body keeps the successor with the longest tail */
-    if (ps >= 0) atomicMax(&sBest[ps], ((unsigned long long)sTail[t] << 44) | ((unsigned long long)min(fin, 0xffffffu) << 12) | (unsigned long long)t);
+    if (ps >= 0) atomicMax(&sBest[ps], ((unsigned long long)myTail << 44) | ((unsigned long long)min(fin, 0xffffffu) << 12) | (unsigned long long)t);
     __syncthreads();
     const int nxt = sBest[t] ? (int)(sBest[t] & 0xfffull) : -1;
     sNext[t] = nxt;

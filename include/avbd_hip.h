@@ -370,6 +370,7 @@ int  avbd_debug_task_times(AvbdContext* ctx, unsigned* out, int iterations);
 int  avbd_debug_topology_times(AvbdContext* ctx, unsigned long long* out7);
 /* s_memrealtime at start / after loads / after Manifold::initialize / at the end of the first pair of k_front_small (stats builds) */
 int  avbd_debug_front_times(AvbdContext* ctx, unsigned long long* out4);
+int  avbd_debug_front_blocks(AvbdContext* ctx, unsigned long long* out /* 16 * blocks */, int blocks);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def test_keys_are_enumerable_and_unknown_keys_fail():
     pkg = H.load_product()
     keys = pkg.option_keys()
     assert len(keys) == len(set(keys)) >= 25
-    for k in ("place", "group_spec", "group_spec_rounds", "single_kernel", "resident_patience", "group_dep", "groups", "mode", "shard_exact"):
+    for k in ("place", "place_every", "group_spec", "group_spec_rounds", "single_kernel", "resident_patience", "group_dep", "groups", "mode", "shard_exact"):
         assert k in keys
     w = pkg.World(0)
     with pytest.raises(pkg.AvbdError):
@@ -45,11 +45,30 @@ def test_keys_are_enumerable_and_unknown_keys_fail():
     ({"resident_quiet": 0}, 2), ({"resident_quiet": 900}, 2), ({"resident": 0}, 1), ({"iter_mode": 2}, 1),
     ({"order_by_index": 0}, 2), ({"fused_topology": 0}, 2), ({"fused_front": 0}, 2), ({"fused_front": 0, "fused_topology": 0, "grid_broadphase": 0}, 2),
     ({"iter_blocks": 64, "resident_multi": 1}, None), ({"race_check": 1}, 2),
+    ({"place_every": 1}, 2), ({"place_every": 3}, 2), ({"place_every": 1000}, 2),
 ])
 def test_one_body_per_wave_options(options, schedule):
     g = _run("Pyramid", 40, options)
     if schedule is not None:
         assert int(g.w.stats()["schedule"]) == schedule, (options, int(g.w.stats()["schedule"]))
+
+
+def test_a_kept_placement_is_rebuilt_when_the_swept_bodies_change():
+    """place_every: the wave placement of the one-body-per-wave launch is kept for several steps while the same bodies are swept; a body added
+    between two steps (one more wave, another sweep order) must rebuild it at once — a stale table would leave the new body without a wave"""
+    o = H.CpuWorld("orc"); o.scene("Pyramid")
+    g = H.HipWorld(); g.scene("Pyramid"); g.w.set_option("place_every", 50)
+    o.step(12); g.step(12)
+    for w in (o, g):
+        w.add_body((1, 1, 1), 1.0, 0.5, (0.3, 9.0, 0.2))
+    o.step(9); g.step(9)
+    H.assert_same_world(o, g, "a body added at step 12 under a placement kept for 50 steps")
+    for w in (o, g):
+        w.add_body((0.5, 0.5, 0.5), 0.0, 0.5, (3.0, 0.25, 3.0))          # a static one: the swept bodies stay the same
+        w.add_body((0.7, 0.7, 0.7), 2.0, 0.5, (0.0, 11.0, 0.0))
+    o.step(14); g.step(14)
+    H.assert_same_world(o, g, "two more at step 21")
+    assert int(g.w.stats()["schedule"]) == 2
 
 
 def test_mode_levels_is_chosen_before_the_first_step():

@@ -11,6 +11,6 @@ for k in range(20):
     d = np.diff(b.astype(np.int64)) / 100.0
     d[(d < 0) | (d > 1e6)] = 0.0          # a phase the kernel skipped leaves no stamp (the default order needs no levels)
     acc += d
-names = ["predict+flags", "scan", "scatter", "rank+expand", "levels", "order"]
+names = ["predict+flags", "scan", "scatter", "rank+expand", "levels | order by index", "order | place_chains"]
 for n, v in zip(names, acc / 20): print(f"{n:16s} {v:6.2f} us")
 print("total", acc.sum() / 20)
