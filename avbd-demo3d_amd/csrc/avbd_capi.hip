@@ -230,6 +230,7 @@ struct AvbdContext {
     unsigned sweptSerial = 0;      /* counts the uploads that can change which bodies are swept */
     unsigned placeSerial = ~0u;    /* sweptSerial | waves the table in dPlace was built for */
     int placeWaves = 0, placeAge = 0;
+    unsigned smallOrderSerial = ~0u; /* sweptSerial for which k_topology_small's sweep by creation index is in c->order / level / lvlStart */
     bool groupsPlanned = false;    /* this step: k_group_plan has been queued */
     bool rowsStale = true;         /* ownership changed: the gather rows of the bodies must be uploaded again */
     bool groupsLaunched = false;   /* the last iteration loop was offered to k_iterate_groups (the device may still decline: GroupPlan.bad) */
@@ -382,6 +383,7 @@ int ensure_capacity(AvbdContext* c, int nBodies)
     HIPCHK(c, c->level.alloc(newCap));
     HIPCHK(c, c->order.alloc(newCap));
     c->orderValid = false;
+    ++c->sweptSerial;
     HIPCHK(c, c->dTileAgg.alloc((size_t)newCap / kTileBodies + 2));
     HIPCHK(c, hipMemsetAsync(c->dTileAgg.p, 0, ((size_t)newCap / kTileBodies + 2) * sizeof(tile_v4u), c->stream));
     c->tileStamp = 0;
@@ -686,16 +688,18 @@ int launch_topology(AvbdContext* c, bool fromStep)
          * earlier step stays a valid one — every swept body has its wave — and is rebuilt every placeEvery-th step only: 5.9 of the kernel's 21 us) */
         const int placeW = c->iterBlocks * kIterWaves;
         const bool placing = fromStep && c->placeChains && c->orderByIndex && placeW <= 1024;
+        const bool orderKept = c->orderByIndex && c->smallOrderSerial == c->sweptSerial;   /* (the same for the sweep order itself: 1.7 us) */
         bool placeKeep = false;
         if (placing) {
             placeKeep = c->placeSerial == c->sweptSerial && c->placeWaves == placeW && ++c->placeAge < c->placeEvery;
             if (!placeKeep) { c->placeSerial = c->sweptSerial; c->placeWaves = placeW; c->placeAge = 0; }
         }
-        hipLaunchKernelGGL(k_topology_small, dim3(1), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
+        hipLaunchKernelGGL(k_topology_small, dim3(1 + (n + 1023) / 1024), dim3(1024), kTopoLdsBytes, c->stream, B, M, c->dG.p, ng, c->dCnt.p, c->dNext.p, c->degForce.p, c->degInc.p,
                            c->adjStart.p, c->incStart.p, c->adjRef.p, c->adjOther.p, c->adjKey.p, c->adjTmp.p, c->inc.p, c->level.p, c->lvlCount.p, c->lvlStart.p,
                            c->order.p, c->lvlCap, c->iterBlocks * kIterWaves, P, c->dFlags.p, 2 * c->bodyCap /* not the error word behind them: a failure stays visible until the next synchronising call */, c->orderByIndex ? 1 : 0,
                            (const int2*)c->dCrit.p, c->dTail.p, c->dPlaceSlot.p, placeW, placing ? c->dPlace.p : nullptr, c->dPlaceInfo.p, placeKeep ? 1 : 0,
-                           std::max(1, std::min(c->placeEvery, 16)));
+                           std::max(1, std::min(c->placeEvery, 16)), orderKept ? c->numSolved : -1);
+        c->smallOrderSerial = c->orderByIndex ? c->sweptSerial : ~0u;
         c->placeQueued = placing;
         c->topologyDidPredict = true;
         c->orderValid = false;
@@ -704,6 +708,7 @@ int launch_topology(AvbdContext* c, bool fromStep)
         return AVBD_OK;
     }
     c->topologyDidPredict = false;
+    c->smallOrderSerial = ~0u;                                          /* (the kernels below write c->order / level / lvlStart their own way) */
     /* the sweep by creation index only changes with the bodies: computed once, its per-step counters then come from k_scan */
     const bool byIndex = fromStep && c->mode != 0 && c->orderByIndex;
     const bool orderCached = byIndex && c->orderValid;

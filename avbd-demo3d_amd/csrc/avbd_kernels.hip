@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
                                                           int* degForce, int* degInc, int* adjStart, int* incStart, int* adjRef, int* adjOther,
                                                           uint64_t* adjKey, int2* adjTmp, int* inc, int* level, int* lvlCount, int* lvlStart, int* order, int lvlCap,
                                                           int residentWaves, SolverParams P, int* flags, int nFlags, int byIndex,
-                                                          const int2* placeCrit, int* placeTail, int* placeSlotOf, int placeW, int* place, PlaceInfo* placeInfo, int placeKeep, int placeRounds)
+                                                          const int2* placeCrit, int* placeTail, int* placeSlotOf, int placeW, int* place, PlaceInfo* placeInfo, int placeKeep, int placeRounds, int sweptKept)
 {
     extern __shared__ int sTopo[];
     __shared__ unsigned long long sWaveTotals[16];
@@ -1127,29 +1127,49 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     unsigned char* sSwept = reinterpret_cast<unsigned char*>(sEntRows + kTopoEntries);
 #ifdef AVBD_DF_STATS
     unsigned long long* tstamp = reinterpret_cast<unsigned long long*>(flags + nFlags + 16 + 1024 * 32 + 20 * 1024 * 8);
-    if (t == 0) tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    if (t == 0 && blockIdx.x == 0) tstamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (blockIdx.x > 0) {
+        const int nb = (int)gridDim.x - 1, b = ((int)blockIdx.x - 1) * 1024 + t;
+        bool dyn = false;
+        if (b < n) dyn = predict_body(B, b, P, cnt);
+        for (int i = ((int)blockIdx.x - 1) * 1024 + t; i < nFlags; i += nb * 1024) flags[i] = 0;
+        const int mine = (int)__popcll(__ballot(dyn));                 /* the dynamic-body count of the diagnostics: one atomic per workgroup */
+        if ((t & 63) == 0) sWaveTotals[t >> 6] = (unsigned long long)mine;
+        __syncthreads();
+        if (t == 0) { int total = 0; for (int k = 0; k < 16; ++k) total += (int)sWaveTotals[k]; if (total) atomicAdd(&cnt->dynamicBodies, total); }
+        return;
+    }
     const int nm = *nextCount;
     const int4 placedFor = (place && placeKeep) ? *reinterpret_cast<const int4*>(placeInfo) : make_int4(-1, 0, 0, 0);   /* {nd, groups, grouped, valid} of the table in memory */
     if (t == 0) { atomicExch(&cnt->numManifolds, nm); sBad = 0; }   /* atomics only on Counters words inside a kernel that also adds to them */
+    /* what phases 1 and 2 read first is requested before phase 0 runs (every phase of this kernel starts with a memory round trip, and nothing
+     * overlaps them but the order of the requests): this thread's share of the degree arrays and its first force */
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = min(n, lo + chunk);
+    unsigned long long mine = 0;
+    int deg0F = 0, deg0I = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int da = degForce[i], db = degInc[i];
+        if (i == lo) { deg0F = da; deg0I = db; }
+        mine += ((unsigned long long)(unsigned)db << 32) | (unsigned)da;
+    }
+    int2 pair0 = make_int2(-1, -1); uint64_t key0 = 0; int rows0 = 0;
+    if (t < nm) { pair0 = M.pair[t]; key0 = M.key[t]; rows0 = M.nc[t]; }
 
-    /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below ---- */
-    for (int b = t; b < n; b += 1024) { if (predict_body(B, b, P, cnt)) atomicAdd(&cnt->dynamicBodies, 1); sSwept[b] = B.solved[b] ? 1 : 0; sLevel[b] = 0; }
-    for (int i = t; i < nFlags; i += 1024) flags[i] = 0;
+    /* ---- phase 0: predictor (solver.cpp:299-337) and flag reset: independent of everything below — the work of the launch's OTHER workgroups,
+     *      1024 bodies each, beside this one (3 of its 17 us when it did them itself) ---- */
+    for (int b = t; b < n; b += 1024) { sSwept[b] = B.solved[b] ? 1 : 0; sLevel[b] = 0; }
 
 #ifdef AVBD_DF_STATS
     __syncthreads(); if (t == 0) tstamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
     /* ---- phase 1: exclusive scans of the two degree arrays (one 64-bit scan: high word rows, low word forces) ---- */
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk, hi = min(n, lo + chunk);
-    unsigned long long mine = 0;
-    for (int i = lo; i < hi; ++i) mine += ((unsigned long long)(unsigned)degInc[i] << 32) | (unsigned)degForce[i];
     {
         const unsigned long long incl = block_scan_inclusive_u64(mine, sWaveTotals);
         unsigned long long base = incl - mine;
         for (int i = lo; i < hi; ++i) {
-            const int da = degForce[i], db = degInc[i];
+            const int da = i == lo ? deg0F : degForce[i], db = i == lo ? deg0I : degInc[i];
             const int a0 = (int)(unsigned)base, b0 = (int)(base >> 32);
             sAdj[i] = a0; sInc[i] = b0; adjStart[i] = a0; incStart[i] = b0; sCur[i] = 0;
             base += ((unsigned long long)(unsigned)db << 32) | (unsigned)da;
@@ -1170,7 +1190,10 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     /* ---- phase 2: scatter every force into the CSR segments of its two bodies ---- */
     for (int item = t; item < nm + ng; item += 1024) {
         int a, b, kind, index, rows; uint64_t key;
-        if (item < nm) { const int2 p = M.pair[item]; a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = M.key[item]; rows = M.nc[item]; }
+        if (item < nm) {
+            const int2 p = item == t ? pair0 : M.pair[item];
+            a = p.x; b = p.y; kind = FK_MANIFOLD; index = item; key = item == t ? key0 : M.key[item]; rows = item == t ? rows0 : M.nc[item];
+        }
         else { const GForce& f = gf[item - nm]; a = f.bodyA; b = f.bodyB; kind = f.kind; index = item - nm; key = f.key; rows = gforce_entries(f); kind = gforce_ref_kind(kind); }
         if (a >= 0) {
             const int pos = sAdj[a] + atomicAdd(&sCur[a], 1);
@@ -1190,7 +1213,30 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
 #endif
     /* ---- phase 3: newest-first order inside every swept body's segment, the row-incidence list, and the later-created
      *      swept neighbours of every swept body (what the level relaxation needs) ---- */
-    if (inLds) {
+    if (inLds && byIndex) {
+        /* one thread per ENTRY, one pass (the sweep by creation index needs no neighbour lists, so the keys stay where they are): rank of an
+         * entry = entries of the same body with a larger key, its rows start behind the rows of those entries */
+        for (int pos = t; pos < E; pos += 1024) {
+            const int2 ro = adjTmp[pos];
+            const int b = sEntBody[pos];
+            const int s0 = sAdj[b], s1 = sAdj[b + 1];
+            int rank = pos - s0, off = 0;                              /* unswept bodies keep the scatter order (never visited in order) */
+            const bool swept = sSwept[b] != 0;
+            if (swept) {
+                const unsigned long long k = sKey[pos];
+                rank = 0;
+                for (int j = s0; j < s1; ++j) { const bool newer = sKey[j] > k; rank += newer ? 1 : 0; off += newer ? (int)sEntRows[j] : 0; }
+            }
+            adjRef[s0 + rank] = ro.x; adjOther[s0 + rank] = ro.y;
+            if (swept) {
+                const int kind = inc_kind(ro.x), idx = inc_index(ro.x), isA = inc_isA(ro.x);
+                int* out = inc + sInc[b] + off;
+                if (kind == FK_MANIFOLD) { const int nc = sEntRows[pos]; for (int c = 0; c < nc; ++c) out[c] = make_inc(isA, FK_MANIFOLD, idx * 4 + c); }
+                else if (kind == FK_JOINT) { out[0] = make_inc(isA, FK_JOINT, idx * 2); out[1] = make_inc(isA, FK_JOINT, idx * 2 + 1); }
+                else if (kind == FK_SPRING) { const int parts = gf[idx].kind == FK_HOST ? gforce_entries(gf[idx]) : 1; for (int q = 0; q < parts; ++q) out[q] = make_inc(isA, FK_SPRING, idx | (q << 24)); sBad = 1; }
+            }
+        }
+    } else if (inLds) {
         /* one thread per ENTRY: rank of an entry = entries of the same body with a larger key */
         for (int pos = t; pos < E; pos += 1024) {
             const int b = sEntBody[pos];
@@ -1260,8 +1306,10 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
     if (byIndex) {
         /* data-flow schedules only need a linear extension of "later-created swept neighbours first": descending creation
          * index is one, and costs one scan instead of one relaxation sweep per level */
+        /* (sweptKept >= 0: the host has seen no upload that changes the swept bodies since this branch last wrote level / order / lvlStart — they
+         * are what they were, and that many bodies are swept) */
         int running = 0;
-        for (int base = 0; base < n; base += 1024) {
+        for (int base = 0; sweptKept < 0 && base < n; base += 1024) {
             const int b = base + t;
             const int f = (b < n && sSwept[b]) ? 1 : 0;
             const int incl = (int)block_scan_inclusive_u64((unsigned long long)f, sWaveTotals);
@@ -1271,10 +1319,10 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
             running += sTotal;
             __syncthreads();
         }
-        const int ndAll = running;
-        for (int b = t; b < n; b += 1024) if (sSwept[b]) order[ndAll - 1 - (int)sLevel[b]] = b;
+        const int ndAll = sweptKept >= 0 ? sweptKept : running;
+        if (sweptKept < 0) for (int b = t; b < n; b += 1024) if (sSwept[b]) order[ndAll - 1 - (int)sLevel[b]] = b;
         if (t == 0) {
-            lvlStart[0] = 0; lvlStart[1] = ndAll;
+            if (sweptKept < 0) { lvlStart[0] = 0; lvlStart[1] = ndAll; }
             atomicExch(&cnt->numLevels, ndAll > 0 ? 1 : 0);
             int bad = sBad ? 1 : 0;
             if (ndAll > residentWaves) bad |= 2;
