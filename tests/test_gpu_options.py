@@ -120,7 +120,7 @@ def test_group_schedule_options_on_a_falling_pile():
 
 @pytest.mark.parametrize("lanes,order", [(32, 1), (64, 1), (64, 0)])
 def test_narrow_phase_lanes_on_a_grid_scene(lanes, order):
-    """k_narrowphase<32> / <64> (scenes beyond 4096 bodies; 64 lanes by default from 16 000 bodies on): 4 913 falling cubes into their landing, both forms
+    """k_narrowphase<32> / <64> (scenes beyond 4096 bodies; 64 lanes by default from 10 000 bodies on): 4 913 falling cubes into their landing, both forms
     against the oracle — manifolds, contacts and warm-started rows bit for bit (the 64-lane form keeps last step's lambda / penalty in registers and clips
     into eight-vertex buffers).  narrow_order: the kernel walks last step's manifolds class by class (3-4 contact points / 2 / 1 on a face / edge contact)
     so that a wave's lanes run one path — only the order in which lanes pick manifolds changes."""
