@@ -713,7 +713,7 @@ int launch_topology(AvbdContext* c, bool fromStep)
     const bool byIndex = fromStep && c->mode != 0 && c->orderByIndex;
     const bool orderCached = byIndex && c->orderValid;
     hipLaunchKernelGGL(k_scan, dim3(std::max(1, (n + kTileBodies - 1) / kTileBodies)), dim3(1024), 0, c->stream, n, c->degForce.p, c->degInc.p, c->adjStart.p, c->incStart.p, c->dCnt.p, c->dNext.p,
-                       c->dTileAgg.p, ++c->tileStamp, orderCached ? c->numSolved : -1, c->iterBlocks * kIterWaves);
+                       c->dTileAgg.p, ++c->tileStamp, orderCached ? c->numSolved : -1, c->iterBlocks * kIterWaves, M.cap);
     /* (one workgroup per CU, grid-stride: the launch is bound by its scattered returning atomics — 380 000 of them at 64 000 cubes, 19 of its 37 us,
      * tools/ubench/fill_adj.hip — and fewer, longer-lived waves get them through faster: 37.6 -> 30.6 us there with 256 workgroups instead of 738) */
     hipLaunchKernelGGL(k_fill_adj, dim3(grid_for((long long)c->stats.numManifolds + c->stats.numCandidates + ng + 4096, 256, 256)), dim3(256), 0, c->stream,

@@ -700,7 +700,7 @@ __device__ __forceinline__ unsigned long long tile_exclusive_prefix(tile_v4u* ag
  * order of this scene is already on the device (it only changes with the bodies) — the step's counters that go with it are
  * set here instead of by k_order_by_index. */
 __global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc, int* adjStart, int* incStart, Counters* cnt, const int* nextCount,
-                                               tile_v4u* agg, unsigned stamp, int ndCached, int residentWaves)
+                                               tile_v4u* agg, unsigned stamp, int ndCached, int residentWaves, int manifoldCap)
 {
     __shared__ unsigned long long sWaveTotals[16];
     __shared__ unsigned long long sBcast;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(1024) void k_scan(int n, int* degForce, int* degInc
     }
     if (t == 1023 && tile == (int)gridDim.x - 1) {
         const unsigned long long total = before + incl;
-        adjStart[n] = (int)(unsigned)total; incStart[n] = (int)(total >> 32); cnt->numManifolds = *nextCount;
+        adjStart[n] = (int)(unsigned)total; incStart[n] = (int)(total >> 32); cnt->numManifolds = min(*nextCount, manifoldCap);   /* (the narrow phase counts the survivors it had no slot for as well: Counters::overflow bit 1 says so) */
         if (ndCached >= 0) {
             atomicExch(&cnt->numLevels, ndCached > 0 ? 1 : 0);
             if (ndCached > residentWaves) atomicOr(&cnt->residentBad, 2);
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(1024) void k_topology_small(BodyTable B, ManifoldTa
         if (t == 0) { int total = 0; for (int k = 0; k < 16; ++k) total += (int)sWaveTotals[k]; if (total) atomicAdd(&cnt->dynamicBodies, total); }
         return;
     }
-    const int nm = *nextCount;
+    const int nm = min(*nextCount, M.cap);                           /* (the narrow phase counts the survivors it had no slot for as well: Counters::overflow bit 1 says so) */
     const int4 placedFor = (place && placeKeep) ? *reinterpret_cast<const int4*>(placeInfo) : make_int4(-1, 0, 0, 0);   /* {nd, groups, grouped, valid} of the table in memory */
     if (t == 0) { atomicExch(&cnt->numManifolds, nm); sBad = 0; }   /* atomics only on Counters words inside a kernel that also adds to them */
     /* what phases 1 and 2 read first is requested before phase 0 runs (every phase of this kernel starts with a memory round trip, and nothing

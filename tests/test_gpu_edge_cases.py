@@ -585,3 +585,16 @@ def test_worlds_of_one_process_stepped_without_a_synchronize_in_between():
         w.w.synchronize()
         assert w.bodies().tobytes() == ref[0] and w.forces().tobytes() == ref[1], s
         w.close()
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_a_pile_too_dense_for_the_manifold_pool_is_an_error_not_a_fault(fused):
+    """548 boxes dropped into each other: 41 000 candidate pairs and more surviving manifolds than the pool of a context of this size holds.  The narrow
+    phase counts the survivors it has no slot for too (that is how the overflow is seen); everything behind it must take the pool's capacity, not that
+    count, as the number of manifolds — k_topology_small walked off the end of the table (found by tools/soak_small.py, SOAK_SCALE=4, seed 9003)."""
+    pkg = H.load_product()
+    g = H.HipWorld()
+    H.random_pile(g, np.random.default_rng(9003), 548, spread=1.2, height=5.0)
+    g.w.set_option("fused_front", fused); g.w.set_option("fused_topology", fused)
+    with pytest.raises(pkg.AvbdError, match="pool overflow"):
+        g.step(2); g.w.synchronize()
