@@ -76,19 +76,33 @@ __device__ __forceinline__ void place_chains(const int* __restrict__ order, int 
     sNext[t] = nxt;
     if (nxt >= 0) sAccepted[nxt] = 1;
     __syncthreads();
-    /* heads walk their path and cut it into groups */
-    if (body >= 0 && nxt >= 0 && !sAccepted[t]) {
+    /* heads walk their path and cut it into groups; the groups of ONE path go to workgroups of ONE XCD (workgroup g runs on XCD g % 8: a hand-off
+     * between two groups of a path then stays inside that XCD's L2, 0.88 instead of 0.98 us), paths to the XCDs in turn */
+    const bool isHead = body >= 0 && nxt >= 0 && !sAccepted[t];
+    const int pathIdx = (int)block_scan_inclusive_u64(isHead ? 1ull : 0ull, sWaveTotals) - 1;
+    if (isHead) {
         int leader = t, n = 0;
         for (int k = t; k >= 0; k = sNext[k]) {
             if (n == kPlaceWaves) { leader = k; n = 0; }
             sLead[k] = leader; sRank[k] = (unsigned char)n; sSize[leader] = (unsigned char)(n + 1);
+            if (n == 0) sMisc[leader] = pathIdx & 7;
             ++n;
         }
     }
     __syncthreads();
-    /* groups of two and more take whole workgroups, in sweep order of their leaders (at most one group per workgroup) */
+    /* groups of two and more take whole workgroups (at most one group per workgroup), on their path's XCD in sweep order of their leaders */
     const bool leads = body >= 0 && sLead[t] == t && sSize[t] >= 2;
-    const int gidx = (int)block_scan_inclusive_u64(leads ? 1ull : 0ull, sWaveTotals) - (leads ? 1 : 0);
+    int gidx;
+    if (WG % 8 == 0 && WG <= 256) {
+        const int xcd = leads ? sMisc[t] : 0;
+        const unsigned long long one = leads ? 1ull << (16 * (xcd & 3)) : 0ull;
+        const unsigned long long lo = block_scan_inclusive_u64(xcd < 4 ? one : 0ull, sWaveTotals);
+        const unsigned long long hi = block_scan_inclusive_u64(xcd >= 4 ? one : 0ull, sWaveTotals);
+        const int rank = (int)(((xcd < 4 ? lo : hi) >> (16 * (xcd & 3))) & 0xffffull) - 1;
+        gidx = (leads && rank < WG / 8) ? xcd + 8 * rank : WG;          /* (an XCD that is full: the group's bodies are placed one by one below) */
+    } else {
+        gidx = (int)block_scan_inclusive_u64(leads ? 1ull : 0ull, sWaveTotals) - (leads ? 1 : 0);
+    }
     sGroupWg[t] = (leads && gidx < WG && gidx < 256) ? gidx : -1;
     if (t < 256) sWgSize[t] = 0;
     __syncthreads();
@@ -106,7 +120,8 @@ __device__ __forceinline__ void place_chains(const int* __restrict__ order, int 
     if (isFree) sFree[freeRank] = slot;
     __syncthreads();
     if (single) place[sFree[singleRank]] = body;
-    if (t == 1023) { info->nd = nd; info->groups = min(gidx + (leads ? 1 : 0), min(WG, 256)); info->grouped = nd - (int)(incl >> 32); info->valid = 1; }
+    const int placedGroups = (int)block_scan_inclusive_u64(sGroupWg[t] >= 0 && leads ? 1ull : 0ull, sWaveTotals);
+    if (t == 1023) { info->nd = nd; info->groups = placedGroups; info->grouped = nd - (int)(incl >> 32); info->valid = 1; }
 }
 
 /* stand-alone launch (scenes whose topology is not built by the one-workgroup kernel, which otherwise runs place_chains itself) */
