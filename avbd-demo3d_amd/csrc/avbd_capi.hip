@@ -209,6 +209,8 @@ struct AvbdContext {
     bool shardMulti = false;       /* the plan of the current sharded step has several rounds */
     bool shardGateKernel = false;  /* AVBD_SHARD_GATE=kernel: the exchange stream waits and publishes with small kernels instead of hipStreamWaitValue32 / WriteValue32 */
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
+    bool poolDirty = false;        /* pool_per_body changed since the pools were allocated: the next upload of bodies re-allocates them */
+    int poolPerBody = 16;          /* pool_per_body: manifolds (and candidate pairs) the pools hold per body of the context's capacity; read when the pools are (re)allocated */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
     /* exact cuts (avbd_cuts.h): the stamped records of all ranks in one address space; the first context of a group owns it */
@@ -323,10 +325,11 @@ int grid_for(long long items, int block, int maxBlocks = 4096)
 /* (re)allocate everything that scales with the body count; preserves manifolds */
 int ensure_capacity(AvbdContext* c, int nBodies)
 {
-    if (nBodies <= c->bodyCap && c->mCap > 0) return AVBD_OK;
+    if (nBodies <= c->bodyCap && c->mCap > 0 && !c->poolDirty) return AVBD_OK;
+    c->poolDirty = false;
     int newCap = std::max(1024, c->bodyCap);
     while (newCap < nBodies) newCap *= 2;
-    const int newMCap = std::max(8192, newCap * 16);
+    const int newMCap = (int)std::min<long long>(1ll << 28, std::max<long long>(8192, (long long)newCap * c->poolPerBody));   /* (manifolds; as many candidate pairs) */
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     HIPCHK(c, c->dPlanes.alloc((size_t)BP_COUNT * newCap));
@@ -761,8 +764,8 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     if (cnt.overflow & 32) return c->fail(AVBD_E_HIP, "race checker: the schedule of this step is not race-free (two bodies of one launch share a force, or the sweep order is not a linear extension of the dependencies)");
     if (cnt.overflow & 64) return c->fail(AVBD_E_CAPACITY, "narrow phase: a clipped contact polygon had more than eight vertices (the reference's buffers hold sixteen; a quad clipped against four planes cannot have more than eight): the step's manifolds are not the reference's");
     if (cnt.overflow) {
-        char buf[160];
-        std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap);
+        char buf[320];
+        std::snprintf(buf, sizeof(buf), "device pool overflow (mask %d): candidates=%d manifolds=%d cap=%d (option pool_per_body, %d now, sizes the pools when it is set before the bodies are added)", cnt.overflow, cnt.numCandidates, cnt.numManifolds, c->mCap, c->poolPerBody);
         return c->fail(AVBD_E_CAPACITY, buf);
     }
     if (iterError == 2 || iterError == 3) {
@@ -990,6 +993,7 @@ int avbd_create(int device, AvbdContext** out)
         c->iterBlocks = std::max(1, prop.multiProcessorCount);
         c->iterLdsPad = kIterWaves * kResProductBytesPerWave;   /* 84 672 B: > half a CU's LDS, and the resident schedule's product lines */
         apply_env_options(c);                                          /* AVBD_<OPTION>: debug overrides of avbd_set_option's keys, read once here */
+        c->poolDirty = c->poolPerBody != 16;
         hipError_t fe = hipFuncSetAttribute((const void*)k_iterate<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (fe == hipSuccess) fe = hipFuncSetAttribute((const void*)k_iterate_single<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -1224,6 +1228,12 @@ int avbd_set_option(AvbdContext* c, const char* key, int value)
     int v = value;
     if (!std::strcmp(key, "narrow_lanes") && v != 0 && v != 32 && v != 64) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'narrow_lanes' is 0 (by the body count), 32 or 64");
     if (!std::strcmp(key, "iter_blocks")) v = std::max(1, std::min(v, c->iterBlocksMax > 0 ? c->iterBlocksMax : v));   /* every workgroup of the loop must be resident */
+    if (!std::strcmp(key, "pool_per_body")) {
+        /* the pools are re-allocated with the body tables at the next step: the host copy of the bodies becomes the authoritative one first (what adding a body does) */
+        (void)hipSetDevice(c->device);
+        if (int rc = download_bodies_to_host(c)) return rc;
+        c->bodiesStale = true; c->poolDirty = true;
+    }
     if (!std::strcmp(key, "mode") && c->stepIndex != 0 && v != c->mode) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'mode' is chosen before the first step");
     const int rc = option_access(c, key, &v, true);
     if (rc) return c->fail(rc, "avbd_set_option: unknown key");

@@ -598,3 +598,16 @@ def test_a_pile_too_dense_for_the_manifold_pool_is_an_error_not_a_fault(fused):
     g.w.set_option("fused_front", fused); g.w.set_option("fused_topology", fused)
     with pytest.raises(pkg.AvbdError, match="pool overflow"):
         g.step(2); g.w.synchronize()
+
+
+def test_pool_per_body_sizes_the_pools_for_a_dense_pile():
+    """the pile of the test above with pools for 64 manifolds per body: it runs, holds more manifolds than the default pools, and equals the oracle"""
+    o, g = H.CpuWorld("orc"), H.HipWorld()
+    g.w.set_option("pool_per_body", 64)
+    for w in (o, g):
+        H.random_pile(w, np.random.default_rng(9003), 548, spread=1.2, height=5.0)
+        w.set_params(iterations=5)
+    o.step(1); g.step(1)
+    assert int(g.w.stats()["numManifolds"]) > 16384              # (22 579 after the first step; the default pools of 549 bodies hold 16 384)
+    o.step(2); g.step(2)
+    H.assert_same_world(o, g, "548 boxes dropped into each other, three steps")
