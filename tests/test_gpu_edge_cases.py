@@ -611,3 +611,11 @@ def test_pool_per_body_sizes_the_pools_for_a_dense_pile():
     assert int(g.w.stats()["numManifolds"]) > 16384              # (22 579 after the first step; the default pools of 549 bodies hold 16 384)
     o.step(2); g.step(2)
     H.assert_same_world(o, g, "548 boxes dropped into each other, three steps")
+    # its snapshot restores into a context with default pools (the restore sizes them for what it is given) and goes on bit-identically
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "dense.snap")
+        g.w.save_snapshot(path)
+        h = H.HipWorld(); h.w.load_snapshot(path)
+    o.step(3); h.step(3)
+    H.assert_same_world(o, h, "three more steps behind a restore into default pools")
