@@ -210,6 +210,7 @@ struct AvbdContext {
     bool shardGateKernel = false;  /* AVBD_SHARD_GATE=kernel: the exchange stream waits and publishes with small kernels instead of hipStreamWaitValue32 / WriteValue32 */
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool poolDirty = false;        /* pool_per_body changed since the pools were allocated: the next upload of bodies re-allocates them */
+    int frontWideFrom = kFrontWideFrom;   /* front_wide_from: k_front_small with 256-thread workgroups and 16-body slices from this many bodies on */
     int poolPerBody = 16;          /* pool_per_body: manifolds (and candidate pairs) the pools hold per body of the context's capacity; read when the pools are (re)allocated */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;

@@ -522,26 +522,26 @@ __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) v
  * manifolds (they do not depend on the broadphase); every other workgroup enumerates 32 (body, 32-body slice) pair sets,
  * keeps its sphere-overlapping, unconstrained pairs in LDS and then collides them itself, one pair per lane.  Creation
  * keys make the order in which manifolds are appended irrelevant (avbd_types.h: make_manifold_key). */
-#ifndef AVBD_FRONT_SLICE
-#define AVBD_FRONT_SLICE 8
-#endif
-constexpr int kFrontSlice = AVBD_FRONT_SLICE;      /* bodies one thread of the fused broadphase tests: short slices = few candidates per workgroup, and a workgroup collides its own */
-#ifndef AVBD_FRONT_THREADS
-#define AVBD_FRONT_THREADS 128
-#endif
-constexpr int kFrontThreads = AVBD_FRONT_THREADS;   /* (2 650 one-wave workgroups took 27 us to dispatch at Stress1000: the pairs of block 0 were done after 8) */
+/* Two shapes of the launch (THREADS per workgroup, SLICE bodies per broadphase thread): 128 / 8 up to kFrontWideFrom bodies, 256 / 16 beyond (a quarter of the
+ * workgroups: the step of 1 331 / 1 728 / 2 744 / 3 375 cubes 0.708 -> 0.703 / 0.691 -> 0.687 / 0.871 -> 0.852 / 1.015 -> 0.994 ms; 1 000 and 512 cubes: the same either way, their
+ * tail is the workgroups that re-collide last step's manifolds).  Option front_wide_from. */
+constexpr int kFrontWideFrom = 1100;
+constexpr int kFrontSlice = 8;                     /* bodies one thread of the fused broadphase tests: short slices = few candidates per workgroup, and a workgroup collides its own */
+constexpr int kFrontThreads = 128;                  /* (2 650 one-wave workgroups took 27 us to dispatch at Stress1000: the pairs of block 0 were done after 8) */
 constexpr int kFrontPairs = kPairsPerWave * (kFrontThreads / 64);   /* pairs a workgroup collides side by side */
-constexpr int kFrontHits = kFrontThreads * kFrontSlice;   /* a workgroup can never find more */
+constexpr int kFrontSliceWide = 16, kFrontThreadsWide = 256, kFrontPairsWide = kPairsPerWave * (kFrontThreadsWide / 64);
 #ifdef AVBD_DF_STATS
 constexpr int kFrontStampBlocks = 8192;
 __device__ unsigned long long gFrontBlockStamps[16 * kFrontStampBlocks];   /* first / last instant of every workgroup of the last k_front_small (avbd_debug_front_blocks) */
 #endif
-__global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
+template <int THREADS, int SLICE>
+__global__ __launch_bounds__(THREADS) void k_front_small(BodyTable B, ManifoldTable src, ManifoldTable dst,
                                                     const int* __restrict__ adjStart, const int* __restrict__ adjOther, Counters* cnt, int* nextCount,
                                                     int* degForce, int* degInc, SolverParams P, int step, int persistBlocks, int keepUnsolvedPairs, int slices)
 {
-    __shared__ CoopScratch sWs[kFrontPairs];
-    __shared__ int2 sHits[kFrontHits];
+    constexpr int PAIRS = kPairsPerWave * (THREADS / 64);
+    __shared__ CoopScratch sWs[PAIRS];
+    __shared__ int2 sHits[THREADS * SLICE];                           /* a workgroup can never find more */
     __shared__ int sNumHits;
     const int gl = threadIdx.x & 15, gBase = threadIdx.x & 48, gj = threadIdx.x >> 4;   /* gBase: first lane of the group inside its wave */
 #ifdef AVBD_DF_STATS
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
 #endif
         const int nOld = cnt->numManifolds;
         /* four pairs per wavefront, sixteen lanes each (avbd_collide_coop.h) */
-        for (int item = blockIdx.x * kFrontPairs + gj; item < nOld; item += persistBlocks * kFrontPairs)
+        for (int item = blockIdx.x * PAIRS + gj; item < nOld; item += persistBlocks * PAIRS)
             narrow_pair(B, src, dst, item, 0, 0, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase
 #ifdef AVBD_DF_STATS
                         , dbg
@@ -571,20 +571,20 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
     __syncthreads();
     const float4* posr = B.plane(BP_POSR);
     const int n = B.n;
-    const int t = ((int)blockIdx.x - persistBlocks) * kFrontThreads + threadIdx.x;
+    const int t = ((int)blockIdx.x - persistBlocks) * THREADS + threadIdx.x;
     const int i = t / slices, sl = t - i * slices;
-    const int jBeg = sl * kFrontSlice;
-    int jEnd = jBeg + kFrontSlice; if (jEnd > i) jEnd = i;
+    const int jBeg = sl * SLICE;
+    int jEnd = jBeg + SLICE; if (jEnd > i) jEnd = i;
     if (i < n && jBeg < jEnd) {
         const float4 a = posr[i];
         const f3 pa = mk3(a.x, a.y, a.z);
         const bool solvedI = B.solved[i] != 0;
-        float4 bs[kFrontSlice];                                       /* the slice's spheres, requested side by side */
+        float4 bs[SLICE];                                       /* the slice's spheres, requested side by side */
 #pragma unroll
-        for (int q = 0; q < kFrontSlice; ++q) bs[q] = posr[min(jBeg + q, jEnd - 1)];
+        for (int q = 0; q < SLICE; ++q) bs[q] = posr[min(jBeg + q, jEnd - 1)];
         const int si = adjStart[i], ei = adjStart[i + 1];
 #pragma unroll
-        for (int q = 0; q < kFrontSlice; ++q) {
+        for (int q = 0; q < SLICE; ++q) {
             const int j = jBeg + q;
             if (j >= jEnd) break;
             const float4 b = bs[q];
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_small(BodyTable B, Mani
     __syncthreads();
     const int nHits = sNumHits;
     if (threadIdx.x == 0 && nHits) atomicAdd(&cnt->numCandidates, nHits);
-    for (int h = gj; h < nHits; h += kFrontPairs) {
+    for (int h = gj; h < nHits; h += PAIRS) {
         const int2 pr = sHits[h];
         narrow_pair(B, src, dst, -1, pr.x, pr.y, step, sWs[gj], cnt, nextCount, degForce, degInc, P, gl, gBase);
     }
