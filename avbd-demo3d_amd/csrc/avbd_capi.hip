@@ -211,6 +211,8 @@ struct AvbdContext {
     bool singleKernel = true;      /* AVBD_SINGLE_KERNEL=0: one-body-per-wave scenes run inside k_iterate<1> instead of k_iterate_single */
     bool poolDirty = false;        /* pool_per_body changed since the pools were allocated: the next upload of bodies re-allocates them */
     int frontWideFrom = kFrontWideFrom;   /* front_wide_from: k_front_small with 256-thread workgroups and 16-body slices from this many bodies on */
+    int gridFrom = 3200;           /* grid_from: the grid broadphase (and the narrow phase as a launch of its own) from this many bodies on: the fused front end's
+                                    * broadphase is all pairs (3 375 cubes: front end 0.079 -> 0.071 ms, the step 0.986 -> 0.977; 2 744 cubes 0.060 -> 0.070: it stays below) */
     int poolPerBody = 16;          /* pool_per_body: manifolds (and candidate pairs) the pools hold per body of the context's capacity; read when the pools are (re)allocated */
     bool raceCheck = false;        /* AVBD_RACE_CHECK=1: k_race_check after every topology rebuild (debug) */
     DevArr<int> dSlotOf;
@@ -520,7 +522,7 @@ int upload_bodies_if_stale(AvbdContext* c)
             if (c->dRecv.n < (size_t)2 * std::max(1, c->maxCount) * c->nranks) HIPCHK(c, c->dRecv.alloc((size_t)2 * std::max(1, c->maxCount) * c->nranks));
         }
     }
-    if (c->gridBroadphase && n > kTopoBodies) {
+    if (c->gridBroadphase && n >= c->gridFrom) {
         /* radius classes (radii never change after creation): cell edge = 2.002 x the largest radius that is at most 4x the
          * median; anything larger (the ground slab) is "big" and tested against every body */
         std::vector<float> rad((size_t)n);

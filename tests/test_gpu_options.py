@@ -46,7 +46,7 @@ def test_keys_are_enumerable_and_unknown_keys_fail():
     ({"order_by_index": 0}, 2), ({"fused_topology": 0}, 2), ({"fused_front": 0}, 2), ({"fused_front": 0, "fused_topology": 0, "grid_broadphase": 0}, 2),
     ({"iter_blocks": 64, "resident_multi": 1}, None), ({"race_check": 1}, 2),
     ({"place_every": 1}, 2), ({"place_every": 3}, 2), ({"place_every": 1000}, 2),
-    ({"front_wide_from": 0}, 2), ({"front_wide_from": 1 << 20}, 2),
+    ({"front_wide_from": 0}, 2), ({"front_wide_from": 1 << 20}, 2), ({"grid_from": 2}, 2), ({"grid_from": 2, "fused_topology": 0}, 2),
 ])
 def test_one_body_per_wave_options(options, schedule):
     g = _run("Pyramid", 40, options)
