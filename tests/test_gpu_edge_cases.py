@@ -526,8 +526,10 @@ def test_debug_race_checker_accepts_every_schedule(monkeypatch):
         H.assert_same_world(o, g, f"Pyramid under the race checker with {env}")
         for k in env:
             monkeypatch.delenv(k)
-    g = H.HipWorld(); g.scene("Packed:12"); g.set_params(iterations=4); g.step(6); g.w.synchronize()
+    g = H.HipWorld(); g.scene("Packed:13"); g.set_params(iterations=4); g.step(6); g.w.synchronize()
     assert int(g.w.stats()["schedule"]) == 4
+    g = H.HipWorld(); g.scene("Packed:12"); g.set_params(iterations=4); g.step(6); g.w.synchronize()
+    assert int(g.w.stats()["schedule"]) == 3                 # (1728 bodies: a wave each from the two-workgroups-per-CU launch)
 
 
 def test_corrected_joint_sign_option_welds_hold(monkeypatch):

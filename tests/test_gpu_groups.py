@@ -50,11 +50,16 @@ def test_post_stabilize_and_iteration_counts(monkeypatch, post, iters):
 
 
 def test_default_takes_scenes_beyond_one_body_per_wave():
-    """Packed:12 = 1728 cubes > 1024 waves: the group schedule by default, every body resident in a sub-group."""
+    """Packed:13 = 2197 cubes > the 2048 waves of the two-workgroups-per-CU launch: the group schedule by default, every body resident in a sub-group.
+    Packed:12 = 1728 cubes still get a wave each there (resident schedule, several-bodies form with one body per wave: 11 % faster than sixteen lanes per body)."""
+    o = H.CpuWorld("orc"); o.scene("Packed:13"); o.set_params(iterations=6); o.step(14)
+    g = H.HipWorld(); g.scene("Packed:13"); g.set_params(iterations=6); g.step(14)
+    assert _sched(g) == 4
+    H.assert_same_world_fast(o, g, "Packed:13 (groups by default)", check_rows=True)
     o = H.CpuWorld("orc"); o.scene("Packed:12"); o.set_params(iterations=6); o.step(14)
     g = H.HipWorld(); g.scene("Packed:12"); g.set_params(iterations=6); g.step(14)
-    assert _sched(g) == 4
-    H.assert_same_world_fast(o, g, "Packed:12 (groups by default)", check_rows=True)
+    assert _sched(g) == 3
+    H.assert_same_world_fast(o, g, "Packed:12 (a wave each by default)", check_rows=True)
 
 
 def _plate_scene(w, k):
@@ -162,14 +167,22 @@ def test_random_jointed_scenes_in_the_group_schedule(monkeypatch, first):
         assert _sched(g) == 4 and int(g.w.stats()["numJoints"]) > 0
 
 
-def test_jointed_scenes_beyond_one_body_per_wave_take_the_group_schedule():
-    """1100-1900 bodies with joints: the group schedule by default (one Joint used to send the whole sweep to the resident schedule's parked form)"""
+def test_jointed_scenes_beyond_one_body_per_wave_take_the_group_schedule(monkeypatch):
+    """joints beside the contacts, by default: 1100-1900 bodies get a wave each from the two-workgroups-per-CU launch (the resident schedule carries joints), and
+    beyond its 2048 waves the group schedule takes them (one Joint used to send the whole sweep to the resident schedule's parked form: 2197 cubes + 400 welds here)"""
     for seed in (9001, 9003):
         o, g = _jointed(seed, big=True)
         for s in range(10):
             o.step(); g.step()
             H.assert_same_world_fast(o, g, f"seed {seed} step {s + 1}", check_rows=True)
-        assert _sched(g) == 4
+        assert _sched(g) == 3
+    monkeypatch.setenv("AVBD_GROUPS_WAVES", "0")
+    o = H.CpuWorld("orc"); o.scene("StressN:13+welds:400"); o.set_params(iterations=6)
+    g = H.HipWorld(); g.scene("StressN:13+welds:400"); g.set_params(iterations=6)
+    for s in range(4):
+        o.step(3); g.step(3)
+        H.assert_same_world_fast(o, g, f"2197 cubes + 400 welds step {3 * (s + 1)}", check_rows=True)
+    assert _sched(g) == 4 and int(g.w.stats()["numJoints"]) == 400
 
 
 @pytest.mark.parametrize("waves,pool,spec", [(3, 1, 0), (3, 0, 2), (3, 0, 1), (40, 1, 0), (40, 0, 0)])
