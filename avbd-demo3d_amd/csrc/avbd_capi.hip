@@ -13,6 +13,7 @@
  */
 #include "../../include/avbd_hip.h"
 #include "avbd_kernels.hip"
+#include "avbd_fast_api.h"
 namespace avbd {   /* instantiated in avbd_single.hip (compiled with -O3) */
 extern template __global__ void k_iterate_single<false>(BodyTable, ManifoldTable, GForce*, const int* __restrict__, const int* __restrict__, const Counters* __restrict__,
                                                         const int* __restrict__, const int* __restrict__, SolverParams, int*, Counters*, int, int, ResidentExchange);
@@ -40,6 +41,7 @@ constexpr int kReadbackLevels = 8192;
 struct Readback {
     Counters cnt;
     GroupPlan plan;
+    int fastHdr[8];            /* first words of the FastPlan of the last fast step (numColors, numTiles, bad, rounds, numSwept), copied behind every fast sweep */
     int lvlStart[kReadbackLevels + 1];
 };
 
@@ -272,6 +274,18 @@ struct AvbdContext {
     DevArr<unsigned> dXchMismatch;      /* words of gathered velocities that differed from the re-derived ones (must stay 0) */
     void* comm = nullptr;               /* ncclComm_t (RCCL, loaded lazily) */
     bool forceSharded = false;          /* AVBD_FORCE_SHARDED=1: per-iteration exchange schedule even with one rank (tests) */
+    /* throughput sweep (avbd_fast.hip; option "sweep"): colouring + tiles rebuilt every step, one persistent launch for the loop */
+    int sweep = 0;                      /* 0: the exact schedules (default), 1: the fast sweep wherever it can run (contacts and ignore markers, one GPU or the all-gather form) */
+    int fastStamps = 1;                 /* fast_stamps: 1 stamped records between colours, 0 a grid barrier per colour (cross-check: same bits) */
+    int fastRecolor = 0;                /* fast_recolor: 1 colours every body afresh every step instead of keeping last step's colouring where it still is one */
+    int fastForm = 0;                   /* fast_form: 0 by size, 1 the latency form of k_fast_sweep (a wave per SIMD, contacts in two passes), 2 the throughput form */
+    int fastBlocks = 0;                 /* fast_blocks: workgroups of k_fast_sweep (0: by the tile count of the last plan) */
+    int fastPlanPerCU = 0, fastSweepPerCU = 0, numCU = 1;
+    bool capFast = false;
+    unsigned fastSerial = 0;
+    bool fastLaunched = false;          /* the iteration loop of the last step was offered to the fast sweep */
+    DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fPos, fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<float4> fSlotC, fBodyC, fXpose, fXL, fXP; DevArr<unsigned> fSync;
+    int fTileCap = 0, fBodyCap = 0, fMCap = 0;
     Readback* hRb = nullptr; /* pinned */
     AvbdStepStats stats{};
     int lastLevels = 0;
@@ -750,6 +764,7 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     if (withLevels)
         HIPCHK(c, hipMemcpyAsync(c->hRb->lvlStart, c->lvlStart.p, sizeof(int) * (std::min(kReadbackLevels, c->lvlCap) + 1), hipMemcpyDeviceToHost, c->stream));
     if (c->groupsLaunched) HIPCHK(c, hipMemcpyAsync(&c->hRb->plan, c->dPlan.p, sizeof(GroupPlan), hipMemcpyDeviceToHost, c->stream));
+    if (c->fastLaunched) HIPCHK(c, hipMemcpyAsync(c->hRb->fastHdr, c->fPlan.p, sizeof(c->hRb->fastHdr), hipMemcpyDeviceToHost, c->stream));
     int iterError = 0;
     if (c->dFlags.p)
         HIPCHK(c, hipMemcpyAsync(&iterError, c->dFlags.p + 2 * (size_t)c->bodyCap, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -760,6 +775,15 @@ int refresh_stats(AvbdContext* c, bool withLevels)
     c->stats.numDynamic = cnt.dynamicBodies;
     c->stats.schedule = c->mode == 0 ? 0 : ((c->residentLaunched && (cnt.residentBad & 1) == 0 && ((cnt.residentBad & 2) == 0 || c->residentMultiLaunched)) ? (((cnt.residentBad & 2) || c->residentMultiLaunched) ? 3 : 2) : 1);
     if (c->groupsLaunched && c->hRb->plan.bad == 0) c->stats.schedule = 4;   /* group schedule (avbd_groups.h) */
+    if (c->fastLaunched && c->hRb->fastHdr[2] == 0) c->stats.schedule = 5;    /* fast sweep (avbd_fast.hip) */
+    if (c->fastLaunched && (c->hRb->fastHdr[2] & 256)) {
+        int info[8] = {0};
+        (void)hipMemcpy(info, (const char*)c->fPlan.p + offsetof(FastPlan, errInfo), sizeof(info), hipMemcpyDeviceToHost);
+        char buf[320];
+        std::snprintf(buf, sizeof(buf), "k_fast_sweep: a wait timed out (grid not resident?) [tile %d body %d partner %d iteration %d: contact record %08x, visit needed %d; partner epoch %d, needed %d]",
+                      info[7], info[0], info[1], info[2], (unsigned)info[3], info[4], info[5], info[6]);
+        return c->fail(AVBD_E_HIP, buf);
+    }
     int nj = 0, ns = 0, ni = 0;
     for (const auto& g : c->hG) { nj += g.kind == FK_JOINT; ns += g.kind == FK_SPRING; ni += g.kind == FK_IGNORE; }   /* (host forces: stats.numBodies etc. only) */
     c->stats.numJoints = nj; c->stats.numSprings = ns; c->stats.numIgnores = ni;
@@ -805,11 +829,14 @@ int refresh_stats(AvbdContext* c, bool withLevels)
 
 #include "avbd_capi_exact.inc"
 
+#include "avbd_capi_fast.inc"
+
 int step_once(AvbdContext* c)
 {
     int rc;
     if (!c->hostForceG.empty()) return step_with_host_rows(c);
     const bool exactProcesses = c->xwAttached && c->shardExact && c->nranks > 1 && c->mode != 0;
+    c->fastLaunched = false;
     if (exactProcesses && (rc = exact_process_precheck(c))) return rc;  /* BEFORE the front end: a refused step leaves the state where it was */
     if ((rc = step_begin(c))) return rc;
     const int totalIt = c->params.iterations + (c->params.postStabilize ? 1 : 0);
@@ -859,6 +886,8 @@ int step_once(AvbdContext* c)
         return rccl_exchange_velocities(c);
     } else if (c->mode == 0) {
         if ((rc = step_iterate_levels(c))) return rc;
+    } else if (fast_eligible(c)) {
+        if ((rc = step_iterate_fast(c, 0, totalIt))) return rc;
     } else {
         if ((rc = step_iterate(c, 0, totalIt))) return rc;
     }
@@ -1046,6 +1075,9 @@ int avbd_create(int device, AvbdContext** out)
             c->iterBlocksMax = std::max(1, occ1) * cus;
             apply_capabilities(c);
         }
+        c->numCU = std::max(1, prop.multiProcessorCount);
+        c->capFast = fast_query(device, &c->fastPlanPerCU, &c->fastSweepPerCU) != 0;
+        (void)hipGetLastError();
         fe = hipFuncSetAttribute((const void*)k_topology_small, hipFuncAttributeMaxDynamicSharedMemorySize, kTopoLdsBytes);
         if (fe != hipSuccess) { g_createError = std::string("hipFuncSetAttribute(k_topology_small, MaxDynamicSharedMemorySize): ") + hipGetErrorString(fe); delete c; return AVBD_E_HIP; }
         fe = hipFuncSetAttribute((const void*)k_levels, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelsLdsBytes);
@@ -1080,6 +1112,8 @@ int avbd_destroy(AvbdContext* c)
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
+    c->fPlan.release(); c->fColor[0].release(); c->fColor[1].release(); c->fPos.release(); c->fCbody.release(); c->fTiles.release(); c->fSlotC.release(); c->fBodyC.release();
+    c->fXpose.release(); c->fXL.release(); c->fXP.release(); c->fSync.release();
     exact_window_release(c);
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);
@@ -2162,6 +2196,16 @@ int avbd_debug_iterate_stats(AvbdContext* c, unsigned long long* out, int waves)
     return AVBD_OK;
 }
 
+int avbd_fast_plan_info(AvbdContext* c, int out[8])
+{
+    if (!c || !out) return AVBD_E_INVALID;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!c->fPlan.p) return AVBD_OK;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->fPlan.p, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    return AVBD_OK;
+}
 int avbd_profile_enable(AvbdContext* c, int enable) { if (!c) return AVBD_E_INVALID; c->profiling = enable != 0; return AVBD_OK; }
 int avbd_profile_reset(AvbdContext* c) { if (!c) return AVBD_E_INVALID; c->prof = AvbdProfile{}; return AVBD_OK; }
 int avbd_profile_get(AvbdContext* c, AvbdProfile* out) { if (!c || !out) return AVBD_E_INVALID; *out = c->prof; return AVBD_OK; }

@@ -1,0 +1,942 @@
+/*
+ * avbd_fast.hip — the throughput sweep of the AVBD iteration loop (solver.cpp:340-431) for gfx950: "fast mode".
+ *
+ * See avbd_fast_api.h for what differs from the exact schedules (order of bodies, order of sums, who runs a dual) and
+ * DESIGN.md section 2b for the stated tolerance.  Two kernels per step:
+ *
+ *   k_fast_plan   colours the swept bodies (Jones-Plassmann rounds on the CSR adjacency the topology kernels built; the
+ *                 result is the sequential greedy colouring in priority order, whatever the timing), classes them by
+ *                 incidence count (a body gets 1 / 8 / 16 / 32 / 64 lanes), lays the (colour, class) groups out as TILES
+ *                 of 64 lanes and writes, per lane, the constants of its incidence entry (SoA planes indexed by
+ *                 tile * 64 + lane: a wave reads them with coalesced 16-byte loads) — anchors, the contact basis, bias
+ *                 terms, friction, force cap, partner, contact slot — and per body the constants of its visit.
+ *   k_fast_sweep  one persistent launch for the whole loop.  A wave owns the tiles t = w, w + W, ...; a tile visit is
+ *                 the primal solve of its 64 / G bodies: every lane evaluates its contact's three rows (computeConstraint,
+ *                 computeDerivatives, row force, gyroscopic term: the functions of avbd_rows.h), the 27 entries of the
+ *                 body's system are summed over the sub-group's lanes with DPP butterflies, the Schur solve and the pose
+ *                 update follow.  Dependencies between colours: stamped 16-byte sc1 records (pose records carry the body's
+ *                 epoch, contact records the visit count) that the consuming lane polls — or, stamps = 0, a grid barrier
+ *                 per colour (the cross-check form: both give the same bits).
+ *
+ * HBM layout and algorithmic bytes: DESIGN.md section 4b.  No MFMA: 6x6 blocks per body, three rows per contact.
+ */
+#include "avbd_fast_api.h"
+#include "avbd_rows.h"
+#include "avbd_util.h"
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace avbd {
+
+typedef unsigned fv4u __attribute__((ext_vector_type(4)));
+
+constexpr int kPlanThreads = 1024;
+constexpr int kSweepThreads = 512, kSweepThreadsLat = 256;
+constexpr unsigned long long kFastTimeoutTicks = 400000000ull;   /* 4 s of s_memrealtime (100 MHz) */
+
+enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8 };
+
+__host__ __device__ constexpr int fast_class_lanes(int cls) { return cls == 0 ? 1 : (4 << cls); }
+__device__ __forceinline__ int fast_class_of(int deg) { return deg == 0 ? 0 : (deg <= 8 ? 1 : (deg <= 16 ? 2 : (deg <= 32 ? 3 : 4))); }
+
+/* ---- memory access flavours --------------------------------------------------------------------------------------
+ * Bytes another workgroup of the SAME launch reads or writes move with sc1 accesses only (the per-XCD L2s are not
+ * coherent inside a launch, DESIGN.md "Three memory rules"): one lane, one 16-byte request. */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); }
+__device__ __forceinline__ fv4u fld(__amdgpu_buffer_rsrc_t r, int byteOff) { return __builtin_amdgcn_raw_buffer_load_b128(r, byteOff, 0, 16); }
+__device__ __forceinline__ void fst(__amdgpu_buffer_rsrc_t r, int byteOff, fv4u v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, 16); }
+__device__ __forceinline__ unsigned fu(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float uf(unsigned u) { return __uint_as_float(u); }
+
+/* ---- grid barrier ------------------------------------------------------------------------------------------------
+ * Every workgroup stores the target into its own word; wave 0 of every workgroup polls the words of all workgroups
+ * (up to 64: one load per lane) or, beyond 64 workgroups, the leader of each group of 64 polls its group and raises the
+ * group's word, and everybody polls the group words: one or two hops of ~0.7 us, no atomics on a shared word (13 ns
+ * apiece, serialised).  FENCE: plain loads / stores around it are made coherent with agent-scope fences (k_fast_plan);
+ * without it the caller moves shared bytes with sc1 accesses and only drains its stores (k_fast_sweep). */
+template <bool FENCE>
+__device__ __forceinline__ void fast_grid_barrier(unsigned* sync, int nWG, unsigned target, int* bad)
+{
+    if (FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nWG > 1 && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) __hip_atomic_store(sync + blockIdx.x, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nWG <= 64) {
+            for (;;) {
+                const unsigned v = lane < nWG ? __hip_atomic_load(sync + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                if (__all((int)(v - target) >= 0)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) { if (lane == 0) atomicOr(bad, 256); break; }
+            }
+        } else {
+            const int group = blockIdx.x >> 6, nGroups = (nWG + 63) >> 6;
+            if ((blockIdx.x & 63) == 0) {
+                const int first = group << 6;
+                for (;;) {
+                    const unsigned v = first + lane < nWG ? __hip_atomic_load(sync + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                    if (__all((int)(v - target) >= 0)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) { if (lane == 0) atomicOr(bad, 256); break; }
+                }
+                if (lane == 0) __hip_atomic_store(sync + 1024 + group, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (;;) {
+                const unsigned v = lane < nGroups ? __hip_atomic_load(sync + 1024 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                if (__all((int)(v - target) >= 0)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) { if (lane == 0) atomicOr(bad, 256); break; }
+            }
+        }
+    }
+    __syncthreads();
+    if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+/* ---- pose records --------------------------------------------------------------------------------------------------
+ * Two 16-byte records per swept body, each self-validating: (p.x p.y p.z | e16 : qw[31:16]) and (q.x q.y q.z | e16 : qw[15:0]),
+ * e16 = the body's epoch (primal updates applied this step, 0 .. 61) — seven floats and the stamp in 32 bytes. */
+__device__ __forceinline__ void pose_encode(f3 p, q4 q, unsigned epoch, fv4u& r0, fv4u& r1)
+{
+    const unsigned w = fu(q.w);
+    r0 = fv4u{fu(p.x), fu(p.y), fu(p.z), (epoch << 16) | (w >> 16)};
+    r1 = fv4u{fu(q.x), fu(q.y), fu(q.z), (epoch << 16) | (w & 0xFFFFu)};
+}
+__device__ __forceinline__ bool pose_decode(fv4u r0, fv4u r1, unsigned epoch, f3& p, q4& q)
+{
+    p = mk3(uf(r0.x), uf(r0.y), uf(r0.z));
+    q = mkq(uf(r1.x), uf(r1.y), uf(r1.z), uf((r0.w << 16) | (r1.w & 0xFFFFu)));
+    return (r0.w >> 16) == epoch && (r1.w >> 16) == epoch;
+}
+
+/* =====================================================================================================================
+ * k_fast_plan
+ * ===================================================================================================================== */
+__device__ __forceinline__ unsigned fast_hash(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+constexpr int kPlanSingleBodies = 1024;      /* up to this many bodies ONE workgroup plans the step: colours in LDS, workgroup barriers */
+constexpr int kFastRecolorAbove = 10;         /* last step's colouring is dropped (every body coloured afresh) once it has grown beyond this many colours */
+constexpr int kFastColorsFloor = 4;           /* ... and the bodies of its highest colour are coloured afresh while it has more than this many */
+constexpr int kPlanNbrRegs = 12;             /* neighbours of a body its thread keeps in registers through the rounds of the colouring */
+
+__device__ __forceinline__ unsigned fast_prio(const int* __restrict__ adjStart, int b)
+{
+    const int degAdj = adjStart[b + 1] - adjStart[b];
+    return ((unsigned)min(degAdj, 127) << 24) | (fast_hash((unsigned)b) >> 8);
+}
+
+/* k_fast_plan: colours, (colour, class) groups, tile table, body constants — one thread per body, persistent, grid barriers between the stages.
+ * SINGLE: one workgroup (launched alone, up to 1024 bodies): colours in LDS, every barrier a workgroup barrier.  Otherwise the colours move with
+ * sc1 accesses and the group counters with atomics; everything else a stage writes is read by LATER launches only (k_fast_fill, k_fast_sweep), so no
+ * fence is needed anywhere. */
+template <bool SINGLE>
+__global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
+{
+    const BodyTable& B = L.B;
+    const FastBuffers& F = L.F;
+    FastPlan* plan = F.plan;
+    const int n = B.n;
+    const int nWG = gridDim.x;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;              /* this thread's body */
+    unsigned target = L.syncBase;
+    __shared__ int sBodyBase[kFastMaxColors * kFastClasses], sTileBase[kFastMaxColors * kFastClasses], sCount[kFastMaxColors * kFastClasses];
+    __shared__ int sColorStart[kFastMaxColors + 1], sTotals[3];
+    __shared__ int sColor[SINGLE ? kPlanSingleBodies : 1];
+
+    auto barrier = [&]() {
+        if (SINGLE) __syncthreads();
+        else fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
+    };
+    auto get_color = [&](int i) -> int { return SINGLE ? sColor[i] : __hip_atomic_load(F.color + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto set_color = [&](int i, int c) { if (SINGLE) sColor[i] = c; else __hip_atomic_store(F.color + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+    /* ---- stage 0: reset, the body's neighbours, pose record, vetoes ---- */
+    for (int i = threadIdx.x; i < kFastMaxColors * kFastClasses; i += blockDim.x) sCount[i] = 0;
+    if (blockIdx.x == 0) {
+        if (!SINGLE) { for (int i = threadIdx.x; i < kFastMaxColors * kFastClasses; i += blockDim.x) atomicExch(&plan->groupCount[i], 0); }
+        if (threadIdx.x == 0) {
+            atomicExch(&plan->bad, n > (int)(gridDim.x * blockDim.x) ? 16 : 0);
+            atomicExch(&plan->remaining[0], 0); atomicExch(&plan->remaining[1], 0); atomicExch(&plan->remaining[2], 0);
+        }
+    }
+    const bool inRange = b < n;
+    const bool swept = inRange && B.solved[b] != 0;
+    int nbr[kPlanNbrRegs];                                            /* swept neighbours among the first adjacency entries, -1: none */
+    unsigned higher = 0u;                                             /* bit k: nbr[k] has the higher priority */
+    int adjS = 0, adjE = 0, deg = 0, veto = 0;
+#pragma unroll
+    for (int k = 0; k < kPlanNbrRegs; ++k) nbr[k] = -1;
+    /* Last step's colouring is kept where it is still one: a body keeps its colour unless a neighbour of higher priority held the same colour
+     * (a new contact between two bodies of one colour: the lower priority gives way) — decided on LAST step's colours alone, so the result does not
+     * depend on timing; the rounds below then colour only what is left.  A settled pile keeps every colour and the colouring costs one look at the
+     * neighbours.  (reuse = 0: the first step after an upload; or last step's colouring had grown beyond kFastRecolorAbove colours) */
+    const bool reuse = L.reuse != 0 && plan->numColors > 0 && plan->numColors <= kFastRecolorAbove;
+    int myColor = swept ? -1 : -2;
+    if (swept) {
+        adjS = L.adjStart[b]; adjE = L.adjStart[b + 1];
+        const unsigned pb = fast_prio(L.adjStart, b);
+        const int old = reuse ? F.colorPrev[b] : -1;
+        /* the bodies of last step's HIGHEST colour look for a lower one every step (they are not adjacent to each other, so they all can at once): a colouring
+         * that grew while the pile formed shrinks again, one colour per step, towards what a fresh greedy colouring finds */
+        bool keep = old >= 0 && !(plan->numColors > kFastColorsFloor && old == plan->numColors - 1);
+#pragma unroll
+        for (int k = 0; k < kPlanNbrRegs; ++k) {
+            if (adjS + k < adjE) {
+                const int p = L.adjOther[adjS + k];
+                if (p >= 0 && inc_kind(L.adjRef[adjS + k]) != FK_IGNORE && B.solved[p] != 0) {
+                    nbr[k] = p;
+                    const unsigned pp = fast_prio(L.adjStart, p);
+                    const bool hi = pp > pb || (pp == pb && p > b);
+                    if (hi) higher |= 1u << k;
+                    if (keep && hi && F.colorPrev[p] == old) keep = false;
+                }
+            }
+        }
+        if (keep && adjE - adjS > kPlanNbrRegs) {
+            for (int i = adjS + kPlanNbrRegs; i < adjE && keep; ++i) {
+                const int p = L.adjOther[i];
+                if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE || B.solved[p] == 0) continue;
+                const unsigned pp = fast_prio(L.adjStart, p);
+                if ((pp > pb || (pp == pb && p > b)) && F.colorPrev[p] == old) keep = false;
+            }
+        }
+        if (keep) myColor = old;
+        const int e0 = L.incStart[b], e1 = L.incStart[b + 1];
+        deg = e1 - e0;
+        veto = deg > 64 ? 1 : 0;
+        const float4 pr4 = B.plane(BP_POSR)[b], qr = B.plane(BP_QUAT)[b];
+        fv4u r0, r1;
+        pose_encode(mk3(pr4.x, pr4.y, pr4.z), mkq(qr.x, qr.y, qr.z, qr.w), 0u, r0, r1);
+        reinterpret_cast<fv4u*>(F.xpose)[2 * b] = r0;
+        reinterpret_cast<fv4u*>(F.xpose)[2 * b + 1] = r1;
+    }
+    if (inRange) set_color(b, myColor);
+    barrier();
+    if (veto) atomicOr(&plan->bad, veto);                             /* (behind the barrier: workgroup 0 reset the word in front of it) */
+
+    /* ---- stage 1: Jones-Plassmann colouring.  A body takes the smallest colour no coloured neighbour holds once every
+     * neighbour of HIGHER priority is coloured; lower-priority neighbours wait for it, so its colour is a function of
+     * final colours only: the sequential greedy colouring in priority order, whatever the timing of the rounds. ---- */
+    int rounds = 0;
+    for (;; ++rounds) {
+        if (myColor == -1) {
+            unsigned long long used = 0ull;
+            bool blocked = false;
+            int cn[kPlanNbrRegs];
+#pragma unroll
+            for (int k = 0; k < kPlanNbrRegs; ++k) cn[k] = nbr[k] >= 0 ? get_color(nbr[k]) : -2;
+#pragma unroll
+            for (int k = 0; k < kPlanNbrRegs; ++k) {
+                if (cn[k] >= 0) used |= 1ull << cn[k];
+                else if (cn[k] == -1 && ((higher >> k) & 1u)) blocked = true;
+            }
+            if (adjE - adjS > kPlanNbrRegs) {                         /* a long adjacency list: the rest from memory */
+                const unsigned pb = fast_prio(L.adjStart, b);
+                for (int i = adjS + kPlanNbrRegs; i < adjE && !blocked; ++i) {
+                    const int p = L.adjOther[i];
+                    if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE) continue;
+                    const int cp = get_color(p);
+                    if (cp == -2) continue;
+                    if (cp == -1) {
+                        const unsigned pp = fast_prio(L.adjStart, p);
+                        if (pp > pb || (pp == pb && p > b)) blocked = true;
+                    } else used |= 1ull << cp;
+                }
+            }
+            if (!blocked) {
+                int c = used == ~0ull ? 64 : __ffsll((long long)~used) - 1;
+                if (c >= kFastMaxColors) { atomicOr(&plan->bad, 4); c = kFastMaxColors - 1; }
+                myColor = c;
+                set_color(b, c);
+            }
+        }
+        const int wgLeft = __syncthreads_count(myColor == -1 ? 1 : 0) > 0 ? 1 : 0;
+        if (SINGLE) {
+            if (wgLeft == 0 || rounds > 4096) break;
+        } else {
+            if (threadIdx.x == 0) {
+                if (wgLeft) atomicAdd(&plan->remaining[rounds % 3], 1);
+                if (blockIdx.x == 0) atomicExch(&plan->remaining[(rounds + 1) % 3], 0);
+            }
+            barrier();
+            const int rem = __hip_atomic_load(&plan->remaining[rounds % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rem == 0 || rounds > 4096) break;
+        }
+    }
+    if (SINGLE && inRange) F.color[b] = myColor;
+
+    /* ---- stage 2: bodies per (colour, class) ---- */
+    /* (counted per workgroup in LDS first, one global atomic per group and workgroup: 64 000 bodies are 64 000 atomics on a dozen words otherwise, 13 ns apiece) */
+    int pos = 0, grp = 0;
+    if (myColor >= 0) {
+        grp = myColor * kFastClasses + fast_class_of(min(deg, 64));
+        pos = atomicAdd(&sCount[grp], 1);
+    }
+    __syncthreads();
+    if (!SINGLE) {
+        for (int i = threadIdx.x; i < kFastMaxColors * kFastClasses; i += blockDim.x) {
+            const int mine = sCount[i];
+            sBodyBase[i] = mine ? atomicAdd(&plan->groupCount[i], mine) : 0;     /* this workgroup's first position in the group */
+        }
+        __syncthreads();
+        if (myColor >= 0) pos += sBodyBase[grp];
+    }
+    barrier();
+
+    /* ---- stage 3: the tile table (colour-major, class-minor), by every workgroup for itself: lane c of the first wave takes colour c's five classes,
+     * a wave scan gives the offsets ---- */
+    if (!SINGLE) { for (int i = threadIdx.x; i < kFastMaxColors * kFastClasses; i += blockDim.x) sCount[i] = __hip_atomic_load(&plan->groupCount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        int cnt[kFastClasses], bodiesC = 0, tilesC = 0;
+#pragma unroll
+        for (int k = 0; k < kFastClasses; ++k) {
+            cnt[k] = sCount[c * kFastClasses + k];
+            const int per = 64 / fast_class_lanes(k);
+            bodiesC += cnt[k]; tilesC += (cnt[k] + per - 1) / per;
+        }
+        int bodiesIncl = bodiesC, tilesIncl = tilesC;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int bo = __shfl_up(bodiesIncl, o, 64), to = __shfl_up(tilesIncl, o, 64);
+            if (c >= o) { bodiesIncl += bo; tilesIncl += to; }
+        }
+        int bodies = bodiesIncl - bodiesC, tiles = tilesIncl - tilesC;
+        sColorStart[c] = tiles;
+#pragma unroll
+        for (int k = 0; k < kFastClasses; ++k) {
+            const int per = 64 / fast_class_lanes(k);
+            sBodyBase[c * kFastClasses + k] = bodies; sTileBase[c * kFastClasses + k] = tiles;
+            bodies += cnt[k]; tiles += (cnt[k] + per - 1) / per;
+        }
+        const unsigned long long usedColors = __ballot(bodiesC > 0);
+        if (c == 63) { sColorStart[kFastMaxColors] = tilesIncl; sTotals[0] = bodiesIncl; sTotals[1] = tilesIncl; sTotals[2] = usedColors ? 64 - __builtin_clzll(usedColors) : 0; }
+    }
+    __syncthreads();
+    const int numTiles = sTotals[1];
+    const bool overflow = numTiles > F.tileCap;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < kFastMaxColors * kFastClasses; i += blockDim.x) { plan->groupBodyBase[i] = sBodyBase[i]; plan->groupTileBase[i] = sTileBase[i]; if (SINGLE) plan->groupCount[i] = sCount[i]; }
+        for (int i = threadIdx.x; i <= kFastMaxColors; i += blockDim.x) plan->colorTileStart[i] = sColorStart[i];
+        if (threadIdx.x == 0) {
+            plan->numSwept = sTotals[0]; plan->numTiles = overflow ? 0 : numTiles; plan->numColors = sTotals[2]; plan->rounds = rounds + 1;
+            if (overflow) atomicOr(&plan->bad, 8);
+        }
+    }
+    if (overflow) return;
+
+    /* ---- stage 4: bodies into their groups, body constants, tile descriptors (read by the next launches) ---- */
+    if (myColor >= 0) {
+        const int at = sBodyBase[grp] + pos;
+        F.cbody[at] = b;
+        const float4 np = B.plane(BP_NPOS)[b], nq = B.plane(BP_NQUAT)[b], mp = B.plane(BP_MASS)[b];
+        const float4 i0 = B.plane(BP_I0)[b], i1 = B.plane(BP_I1)[b], i2 = B.plane(BP_I2)[b];
+        const float4 j0 = B.plane(BP_J0)[b], j1 = B.plane(BP_J1)[b], j2 = B.plane(BP_J2)[b];
+        F.bodyC[(size_t)0 * F.bodyCap + at] = make_float4(np.x, np.y, np.z, mp.x);
+        F.bodyC[(size_t)1 * F.bodyCap + at] = nq;
+        F.bodyC[(size_t)2 * F.bodyCap + at] = make_float4(i0.x, i1.y, i2.z, mp.y);     /* box inertia is diagonal (rigid.cpp:24-40) */
+        F.bodyC[(size_t)3 * F.bodyCap + at] = make_float4(j0.x, j1.y, j2.z, __int_as_float(b));
+    }
+    const int gtid = b, stride = gridDim.x * blockDim.x;
+    for (int g = 0; g < sTotals[2] * kFastClasses; ++g) {
+        const int cnt = sCount[g];
+        if (!cnt) continue;
+        const int k = g % kFastClasses, per = 64 / fast_class_lanes(k), nt = (cnt + per - 1) / per;
+        for (int t = gtid; t < nt; t += stride)
+            F.tiles[sTileBase[g] + t] = make_int2(sBodyBase[g] + t * per, min(per, cnt - t * per) | (k << 16) | ((g / kFastClasses) << 24));
+    }
+}
+
+/* k_fast_fill: the per-lane constants of every tile (one thread per lane), from the Manifold table of the step */
+__global__ __launch_bounds__(256) void k_fast_fill(FastLaunch L)
+{
+    const BodyTable& B = L.B;
+    const ManifoldTable& M = L.M;
+    const FastBuffers& F = L.F;
+    const FastPlan* plan = F.plan;
+    if (plan->bad != 0) return;
+    const int numTiles = plan->numTiles;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    const size_t SC = (size_t)F.slotCap;
+    for (long long idx = gtid; idx < (long long)numTiles * 64; idx += stride) {
+        const int t = (int)(idx >> 6), lane = (int)(idx & 63);
+        const int2 td = F.tiles[t];
+        const int cls = (td.y >> 16) & 0xFF, G = fast_class_lanes(cls), nb = td.y & 0xFFFF;
+        if (cls == 0) continue;                                       /* bodies without contacts: no lane constants */
+        const int j = lane / G, r = lane % G;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
+        int partner = -1, slot = 0, flags = 0;
+        if (j < nb) {
+            const int body = F.cbody[td.x + j];
+            const int e0 = L.incStart[body], deg = L.incStart[body + 1] - e0;
+            if (r < deg && r < 64) {
+                const int ent = L.inc[e0 + r];
+                if (inc_kind(ent) == FK_MANIFOLD) {
+                    const int s = inc_index(ent), m = s >> 2;
+                    const bool isA = inc_isA(ent) != 0;
+                    const int2 pr = M.pair[m];
+                    const int other = isA ? pr.y : pr.x;
+                    const float4 ra = M.cRA[s], rb = M.cRB[s], nn = M.cN[s];
+                    const float imOwn = B.plane(BP_MASS)[body].y, imOth = B.plane(BP_MASS)[other].y;
+                    /* the contact basis of this step: the fixed point of the reference's re-normalisation of the stored normal
+                     * (manifold.cpp:185-186 runs on every computeConstraint call; Manifold::initialize left it normalised once, so the
+                     * sequence is constant after one or two calls), and its tangents (manifold.cpp:43-49) */
+                    f3 nrm = mk3(nn.x, nn.y, nn.z);
+                    for (int k = 0; k < 4; ++k) {
+                        const f3 n2 = normalize_safe(nrm, mk3(0.0f, 1.0f, 0.0f));
+                        const bool same = fu(n2.x) == fu(nrm.x) && fu(n2.y) == fu(nrm.y) && fu(n2.z) == fu(nrm.z);
+                        nrm = n2;
+                        if (same) break;
+                    }
+                    f3 t1, t2;
+                    contact_tangents(nrm, t1, t2);
+                    const float invMassSum = isA ? imOwn + imOth : imOth + imOwn;      /* manifold.cpp:199-201: invMassA + invMassB */
+                    const float massScale = (invMassSum > 1.0e-6f) ? (1.0f / invMassSum) : 1.0f;
+                    const float cap = kNormalForceCap * massScale;
+                    const bool otherSwept = B.solved[other] != 0;
+                    const bool first = !otherSwept || F.color[body] < F.color[other];
+                    const f3 rOwn = isA ? mk3(ra.x, ra.y, ra.z) : mk3(rb.x, rb.y, rb.z);
+                    const f3 rOth = isA ? mk3(rb.x, rb.y, rb.z) : mk3(ra.x, ra.y, ra.z);
+                    c0 = make_float4(rOwn.x, rOwn.y, rOwn.z, ra.w);
+                    c1 = make_float4(rOth.x, rOth.y, rOth.z, rb.w);
+                    c2 = make_float4(nrm.x, nrm.y, nrm.z, nn.w);
+                    c3 = make_float4(t1.x, t1.y, t1.z, M.fric[m]);
+                    c4 = make_float4(t2.x, t2.y, t2.z, cap);
+                    partner = other; slot = s;
+                    flags = FL_VALID | (isA ? FL_ISA : 0) | (first ? FL_FIRST : 0) | (otherSwept ? 0 : FL_SOLE);
+                    if (first) {                                      /* the contact's state records start from the Manifold table */
+                        const float4 lam = M.cLam[s], pen = M.cPen[s];
+                        const int stick = M.cFS[s].y != 0 ? 1 : 0;
+                        F.xL[s] = make_float4(lam.x, lam.y, lam.z, __int_as_float(stick));
+                        F.xP[s] = make_float4(pen.x, pen.y, pen.z, __int_as_float(0));
+                    }
+                }
+            }
+        }
+        c5 = make_float4(__int_as_float(partner), __int_as_float(slot), __int_as_float(flags), 0.f);
+        const size_t at = (size_t)t * 64 + lane;
+        F.slotC[0 * SC + at] = c0; F.slotC[1 * SC + at] = c1; F.slotC[2 * SC + at] = c2;
+        F.slotC[3 * SC + at] = c3; F.slotC[4 * SC + at] = c4; F.slotC[5 * SC + at] = c5;
+    }
+}
+
+/* =====================================================================================================================
+ * k_fast_sweep
+ * ===================================================================================================================== */
+
+/* ---- sums over the lanes of a sub-group: xor butterflies on the DPP network (quad_perm, row_half_mirror, row_mirror),
+ * ds_bpermute beyond a row of 16.  Every lane of the sub-group ends with the same bits (IEEE addition is commutative). ---- */
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+    if (G >= 8) {
+        v = v + dpp_f<0xB1>(v);       /* quad_perm [1,0,3,2] */
+        v = v + dpp_f<0x4E>(v);       /* quad_perm [2,3,0,1] */
+        v = v + dpp_f<0x141>(v);      /* row_half_mirror */
+    }
+    if (G >= 16) v = v + dpp_f<0x140>(v);   /* row_mirror */
+    if (G >= 32) v = v + __shfl_xor(v, 16, 64);
+    if (G >= 64) v = v + __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ void group_sum27(float* acc)
+{
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = group_sum<G>(acc[i]);
+}
+
+/* Manifold::computeConstraint for one contact (manifold.cpp:183-243) on the step's contact basis: bias terms, force cap and
+ * basis come in as constants, the rest is contact_constraint_post of avbd_rows.h on scalars. */
+struct FastRows { float lam[3], pen[3], C[3], fmin[3], fmax[3]; bool stick; float penetration; };
+
+__device__ __forceinline__ void fast_constraint(FastRows& c, f3 n, f3 t1, f3 t2, float biasN, float biasT1, float biasT2, float cap, f3 pA, f3 pB, float fric)
+{
+    const f3 d = pA - pB;
+    const float separation = dot3(d, n) - kNormalMargin;
+    const float slip1 = dot3(d, t1);
+    const float slip2 = dot3(d, t2);
+    c.C[0] = separation + biasN;
+    c.fmin[0] = -cap;
+    c.fmax[0] = 0.0f;
+    c.C[1] = slip1 + biasT1;
+    c.C[2] = slip2 + biasT2;
+    const float warmMag = fabsf(rmin(c.lam[0], 0.0f));
+    const float trial = c.pen[0] * c.C[0] + c.lam[0];
+    const float trialMag = fabsf(rmin(trial, 0.0f));
+    float nMag = rmax(warmMag, trialMag);
+    nMag = rmin(nMag, cap);
+    float mu = fric;
+    if (!c.stick) mu *= 0.9f;
+    const float limit = mu * nMag;
+    const float lt1 = c.lam[1], lt2 = c.lam[2];
+    const float tanMag = sqrtf(lt1 * lt1 + lt2 * lt2);
+    if (tanMag > limit && tanMag > 1.0e-8f) {
+        const float s = limit / tanMag;
+        c.lam[1] *= s;
+        c.lam[2] *= s;
+    }
+    c.fmin[1] = -limit; c.fmax[1] = limit;
+    c.fmin[2] = -limit; c.fmax[2] = limit;
+    const float slipSq = c.C[1] * c.C[1] + c.C[2] * c.C[2];
+    const float tanSq = c.lam[1] * c.lam[1] + c.lam[2] * c.lam[2];
+    const float stickSq = kStickThresh * kStickThresh;
+    c.stick = (slipSq <= stickSq) && (tanSq <= limit * limit + 1.0e-8f);
+    c.penetration = rmax(0.0f, -dot3(d, n));
+}
+
+/* the dual update of one contact (solver.cpp:411-430, rowPenaltyGain :94-125) */
+__device__ __forceinline__ void fast_dual(FastRows& c, f3 n, f3 t1, f3 t2, float biasN, float biasT1, float biasT2, float cap, f3 pA, f3 wA, f3 pB, f3 wB, float fric, float beta)
+{
+    fast_constraint(c, n, t1, t2, biasN, biasT1, biasT2, cap, pA, pB, fric);
+    const f3 basis[3] = {n, t1, t2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lu = rclamp(c.pen[k] * c.C[k] + c.lam[k], c.fmin[k], c.fmax[k]);
+        const bool active = lu > c.fmin[k] && lu < c.fmax[k];
+        c.lam[k] = lu;
+        if (active) {
+            /* computeDerivatives of both endpoints (manifold.cpp:247-271): Jl = +-basis, Ja = +-(w x basis) */
+            const f3 JlA = basis[k] * 1.0f, JaA = cross3(wA, basis[k]) * 1.0f;
+            const f3 JlB = basis[k] * -1.0f, JaB = cross3(wB, basis[k]) * -1.0f;
+            float lw = 0.0f, aw = 0.0f;
+            lw += lensq3(JlA); aw += lensq3(JaA);
+            lw += lensq3(JlB); aw += lensq3(JaB);
+            const float betaRow = row_penalty_gain(lw, aw, beta);
+            c.pen[k] = rmin(c.pen[k] + betaRow * fabsf(c.C[k]), kManifoldPenaltyCap);
+        }
+    }
+}
+
+struct FastCtx {
+    __amdgpu_buffer_rsrc_t rPose, rL, rP;
+    const FastBuffers* F;
+    FastPlan* plan;
+    Counters* cnt;
+    BodyTable B; ManifoldTable M;
+    float invDt2, beta;
+    int stamps;
+};
+
+__device__ __forceinline__ float fast_alpha(const SolverParams& P, int it) { return P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha; }
+
+/* quad_perm:[c,c,c,c]: the value lane (lane & ~3) + c holds */
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), Q | (Q << 2) | (Q << 4) | (Q << 6), 0xf, 0xf, true)); }
+template <int Q>
+__device__ __forceinline__ f3 quad_bcast3(f3 v) { return mk3(quad_bcast<Q>(v.x), quad_bcast<Q>(v.y), quad_bcast<Q>(v.z)); }
+
+/* one of four values by the lane's position in its quad, as three v_cndmask (the empty asm keeps the compiler from turning the chain into a table in scratch) */
+__device__ __forceinline__ float pick4(float a, float b, float c, float d, int q)
+{
+    float r = a;
+    r = q == 1 ? b : r; asm volatile("" : "+v"(r));
+    r = q == 2 ? c : r; asm volatile("" : "+v"(r));
+    r = q == 3 ? d : r;
+    return r;
+}
+
+/* maths.h:104 with the independent divisions side by side on the lanes of a quad (c = lane & 3): L10 | L20, then L21, then z.x | z.y | z.z —
+ * the same quotients of the same bits, every lane of the quad returns x (all four hold the same A and b) */
+__device__ __forceinline__ f3 solve_ldlt3_quadlanes(m33 A, f3 b, int c)
+{
+    const f3 L0 = A.c0;
+    bool bad = fabsf(L0.x) < FLT_EPSILON;
+    const float d0 = L0.x;
+    const float q1 = (c == 0 ? L0.y : L0.z) / d0;
+    const float L10 = quad_bcast<0>(q1), L20 = quad_bcast<1>(q1);
+    const f3 L1 = A.c1 - L0 * L10;
+    bad |= fabsf(L1.y) < FLT_EPSILON;
+    const float d1 = L1.y;
+    const float L21 = L1.z / d1;
+    const f3 L2 = A.c2 - L0 * L20 - L1 * L21;
+    bad |= fabsf(L2.z) < FLT_EPSILON;
+    const float d2 = L2.z;
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    const float zq = (c == 0 ? y.x : (c == 1 ? y.y : y.z)) / (c == 0 ? d0 : (c == 1 ? d1 : d2));
+    f3 z; z.x = quad_bcast<0>(zq); z.y = quad_bcast<1>(zq); z.z = quad_bcast<2>(zq);
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    return bad ? zero3() : x;
+}
+
+/* One visit of tile `t` in iteration `it`: the primal solve (solver.cpp:344-409) of its 64 / G bodies.
+ * The lanes of a body are evaluated in two passes: first the contacts whose partner comes LATER in the colour order (and those with a partner nobody
+ * sweeps) — everything they read was published in the previous iteration, and they run the dual update of that iteration —, then the contacts whose
+ * partner has already moved in this iteration.  Only the second pass, the sums, the solve and the publish stand between the arrival of the last pose
+ * and this body's own. */
+template <int G, bool TWOPASS>
+__device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = G == 1 ? lane : lane / G, r = G == 1 ? 0 : lane % G;
+    const int nb = td.y & 0xFFFF;
+    const bool hasBody = j < nb;
+    const FastBuffers& F = *X.F;
+    const size_t SC = (size_t)F.slotCap, at = (size_t)t * 64 + lane;
+
+    /* constants of the lane's incidence entry (coalesced) and of the sub-group's body */
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
+    if (G > 1) { c5 = F.slotC[5 * SC + at]; c0 = F.slotC[0 * SC + at]; c1 = F.slotC[1 * SC + at]; c2 = F.slotC[2 * SC + at]; c3 = F.slotC[3 * SC + at]; c4 = F.slotC[4 * SC + at]; }
+    const int partner = __float_as_int(c5.x), slot = __float_as_int(c5.y), flags = __float_as_int(c5.z);
+    const bool valid = (flags & FL_VALID) != 0, isA = (flags & FL_ISA) != 0, first = (flags & FL_FIRST) != 0, sole = (flags & FL_SOLE) != 0;
+    const int bp = td.x + (hasBody ? j : 0);
+    const float4 b0 = F.bodyC[(size_t)0 * F.bodyCap + bp], b1 = F.bodyC[(size_t)1 * F.bodyCap + bp], b2 = F.bodyC[(size_t)2 * F.bodyCap + bp], b3 = F.bodyC[(size_t)3 * F.bodyCap + bp];
+    const int body = __float_as_int(b3.w);
+    const f3 npos = mk3(b0.x, b0.y, b0.z); const float mass = b0.w;
+    const q4 nrot = mkq(b1.x, b1.y, b1.z, b1.w);
+    const f3 Id = mk3(b2.x, b2.y, b2.z), Jd = mk3(b3.x, b3.y, b3.z);
+
+    /* the body's own pose: this wave published it (epoch it) */
+    f3 pos; q4 rot;
+    {
+        const fv4u o0 = fld(X.rPose, body * 32), o1 = fld(X.rPose, body * 32 + 16);
+        (void)pose_decode(o0, o1, (unsigned)it, pos, rot);
+    }
+    /* world inertia and its inverse (rigid.cpp:51-59: R * I * transpose(R), I diagonal) */
+    const m33 R = quat_to_mat(rot);
+    const m33 Rt = mtranspose(R);
+    const m33 RI = mkm(R.c0 * Id.x, R.c1 * Id.y, R.c2 * Id.z), RJ = mkm(R.c0 * Jd.x, R.c1 * Jd.y, R.c2 * Jd.z);
+    const m33 Iw = RI * Rt, invIw = RJ * Rt;
+
+    float acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+
+    if (G > 1) {
+        const f3 rOwn = mk3(c0.x, c0.y, c0.z), rOth = mk3(c1.x, c1.y, c1.z);
+        const f3 n = mk3(c2.x, c2.y, c2.z), t1 = mk3(c3.x, c3.y, c3.z), t2 = mk3(c4.x, c4.y, c4.z);
+        const float fric = c3.w, cap = c4.w;
+        const f3 wOwn = qrotate(rot, rOwn);
+        const f3 pOwn = pos + wOwn;
+        const bool moving = valid && !sole;
+        const unsigned needPartner = (unsigned)(first ? it : it + 1);
+        const unsigned needVisit = (unsigned)(first ? 2 * it : 2 * it + 1);
+#pragma unroll 1
+        for (int pass = TWOPASS ? 0 : 1; pass < 2; ++pass) {
+            const bool mine = valid && (!TWOPASS || first == (pass == 0));
+            if (!__any(mine)) continue;
+            /* ---- inputs of the pass: partner pose and the contact's records, one round trip; with stamps the lane polls until both carry this visit's stamps ---- */
+            f3 opos = zero3(); q4 orot = identq();
+            fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
+            {
+                const unsigned long long t0 = X.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                for (;;) {
+                    bool ok = true;
+                    if (mine) {
+                        sl = fld(X.rL, slot * 16); sp = fld(X.rP, slot * 16);
+                        if (moving) {
+                            const fv4u p0 = fld(X.rPose, partner * 32), p1 = fld(X.rPose, partner * 32 + 16);
+                            ok = pose_decode(p0, p1, needPartner, opos, orot);
+                            ok &= (sl.w >> 1) == needVisit;
+                            if (!first) ok &= sp.w == (unsigned)(it + 1);
+                        }
+                    }
+                    if (!X.stamps || __all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) {
+                        if (!ok) { atomicOr(&X.plan->bad, 256); X.plan->errInfo[0] = body; X.plan->errInfo[1] = partner; X.plan->errInfo[2] = it; X.plan->errInfo[3] = (int)sl.w; X.plan->errInfo[4] = (int)needVisit; X.plan->errInfo[5] = pass; X.plan->errInfo[6] = (int)needPartner; X.plan->errInfo[7] = t; }
+                        break;
+                    }
+                }
+            }
+            if (mine) {
+                if (sole) {                                           /* a partner this context does not sweep: its pose is in the body table (fixed during the launch) */
+                    const float4 pp = X.B.plane(BP_POSR)[partner], pq = X.B.plane(BP_QUAT)[partner];
+                    opos = mk3(pp.x, pp.y, pp.z); orot = mkq(pq.x, pq.y, pq.z, pq.w);
+                }
+                FastRows c;
+                c.lam[0] = uf(sl.x); c.lam[1] = uf(sl.y); c.lam[2] = uf(sl.z); c.stick = (sl.w & 1u) != 0;
+                c.pen[0] = uf(sp.x); c.pen[1] = uf(sp.y); c.pen[2] = uf(sp.z);
+                const f3 wOth = qrotate(orot, rOth);
+                const f3 pOth = opos + wOth;
+                const f3 pA = isA ? pOwn : pOth, pB = isA ? pOth : pOwn;
+                if (first && it > 0) {
+                    /* the dual update of iteration it - 1 (solver.cpp:411-430), by the force's first visitor of iteration it: no pose has
+                     * changed since the sweep of it - 1 ended */
+                    const float bs = rclamp(1.0f - fast_alpha(P, it - 1), 0.0f, 1.0f);
+                    fast_dual(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, isA ? wOwn : wOth, pB, isA ? wOth : wOwn, fric, X.beta);
+                }
+                const float bs = rclamp(1.0f - fast_alpha(P, it), 0.0f, 1.0f);
+                fast_constraint(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, pB, fric);
+                const float sign = isA ? 1.0f : -1.0f;
+                const f3 basis[3] = {n, t1, t2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f3 Jl = basis[k] * sign, Ja = cross3(wOwn, basis[k]) * sign;     /* manifold.cpp:265-270 */
+                    const float desired = c.pen[k] * c.C[k] + c.lam[k] + 0.0f;             /* solver.cpp:379-381: stiffness FLT_MAX, motor 0 */
+                    const float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+                    const float pen = c.pen[k];
+                    const bool penOk = (pen > 0.0f) && (fabsf(pen) <= FLT_MAX);
+                    const float J6[6] = {Jl.x, Jl.y, Jl.z, Ja.x, Ja.y, Ja.z};
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) acc[21 + i] += J6[i] * f;                  /* rhs += J f (solver.cpp:383-384) */
+                    if (penOk) {
+                        /* lhs += (J J^T) penalty: ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104) */
+                        acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
+                        acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                            for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
+                        acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
+                        acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
+                        const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);            /* solver.cpp:393-397 */
+                        acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
+                    }
+                }
+                /* the visit's mutations of the force (lambda cone clamp, stick; after a dual also lambda_n and the penalties); every record
+                 * validates itself, so nothing is drained before the pose is published */
+                const unsigned visit = (unsigned)(sole ? 0 : (first ? 2 * it + 1 : 2 * it + 2));
+                fst(X.rL, slot * 16, fv4u{fu(c.lam[0]), fu(c.lam[1]), fu(c.lam[2]), (visit << 1) | (c.stick ? 1u : 0u)});
+                if (first) fst(X.rP, slot * 16, fv4u{fu(c.pen[0]), fu(c.pen[1]), fu(c.pen[2]), (unsigned)(it + 1)});
+            }
+        }
+        group_sum27<G>(acc);
+    }
+
+    /* ---- the body's own terms (solver.cpp:350-369), solve6x6 (:68-83), pose update (:402-408) ---- */
+    const float invDt2 = X.invDt2;
+    const float mdt = mass * invDt2;
+    acc[0] += mdt; acc[3] += mdt; acc[5] += mdt;
+    const m33 aa0 = Iw * invDt2;
+    acc[15] += aa0.c0.x; acc[16] += aa0.c0.y; acc[17] += aa0.c0.z; acc[18] += aa0.c1.y; acc[19] += aa0.c1.z; acc[20] += aa0.c2.z;
+    const f3 rl0 = ((pos - npos) * invDt2) * mass;
+    acc[21] += rl0.x; acc[22] += rl0.y; acc[23] += rl0.z;
+    const q4 qErr = rot * qconj(nrot);
+    f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
+    rotErr = rotErr * 2.0f;
+    if (qErr.w < 0.0f) rotErr = -rotErr;
+    const f3 ra0 = Iw * (rotErr * invDt2);
+    acc[24] += ra0.x; acc[25] += ra0.y; acc[26] += ra0.z;
+
+    m33 ll, la, aa;
+    ll.c0 = mk3(acc[0], acc[1], acc[2]); ll.c1 = mk3(acc[1], acc[3], acc[4]); ll.c2 = mk3(acc[2], acc[4], acc[5]);
+    la.c0 = mk3(acc[6], acc[7], acc[8]); la.c1 = mk3(acc[9], acc[10], acc[11]); la.c2 = mk3(acc[12], acc[13], acc[14]);
+    aa.c0 = mk3(acc[15], acc[16], acc[17]); aa.c1 = mk3(acc[16], acc[18], acc[19]); aa.c2 = mk3(acc[17], acc[19], acc[20]);
+    const f3 bl = mk3(acc[21], acc[22], acc[23]), ba = mk3(acc[24], acc[25], acc[26]);
+    f3 xl, xa;
+    {
+        /* solve6x6 (solver.cpp:68-83): five 3x3 LDL^T solves, the first four on one matrix */
+        const m33 al = mtranspose(la);
+        f3 col0, col1, col2, x0, y;
+        if (G >= 8) {
+            /* every lane of the sub-group holds the whole system: lane q of a quad solves right-hand side q, the quad shares the four solutions */
+            const int q = lane & 3;
+            const f3 rhsq = mk3(pick4(la.c0.x, la.c1.x, la.c2.x, bl.x, q), pick4(la.c0.y, la.c1.y, la.c2.y, bl.y, q), pick4(la.c0.z, la.c1.z, la.c2.z, bl.z, q));
+            const f3 sol = solve_ldlt3_branchless(ll, rhsq);
+            col0 = quad_bcast3<0>(sol); col1 = quad_bcast3<1>(sol); col2 = quad_bcast3<2>(sol); x0 = quad_bcast3<3>(sol);
+            const m33 AinvB = mkm(col0, col1, col2);
+            const m33 schur = aa - al * AinvB;
+            const f3 rhs_s = ba - al * x0;
+            y = solve_ldlt3_quadlanes(schur, rhs_s, q);
+        } else {
+            col0 = solve_ldlt3_branchless(ll, la.c0); col1 = solve_ldlt3_branchless(ll, la.c1); col2 = solve_ldlt3_branchless(ll, la.c2);
+            x0 = solve_ldlt3_branchless(ll, bl);
+            const m33 AinvB = mkm(col0, col1, col2);
+            const m33 schur = aa - al * AinvB;
+            const f3 rhs_s = ba - al * x0;
+            y = solve_ldlt3_branchless(schur, rhs_s);
+        }
+        xl = x0 - mkm(col0, col1, col2) * y;
+        xa = y;
+    }
+    f3 p = pos - xl;
+    const q4 dq = mkq(xa.x, xa.y, xa.z, 0.0f);
+    q4 q = qnormalize(rot - (dq * rot) * 0.5f);
+    if (hasBody && r == 0) {
+        sanitize3(p, X.cnt, warn_key(1, it, body, 0), body, WK_POS);
+        sanitizeq(q, X.cnt, warn_key(1, it, body, 1), body, WK_ROT);
+        fv4u r0, r1;
+        pose_encode(p, q, (unsigned)(it + 1), r0, r1);
+        fst(X.rPose, body * 32, r0); fst(X.rPose, body * 32 + 16, r1);
+        if (lastOfLaunch) {                                           /* what the tail (and, sharded, the exchange) reads */
+            const float4 old = X.B.plane(BP_POSR)[body];
+            X.B.plane(BP_POSR)[body] = pack3(p, old.w);
+            X.B.plane(BP_QUAT)[body] = packq(q);
+        }
+    }
+}
+
+/* After the last iteration: the dual update of that iteration (when the reference runs one: it < iterations) by the first
+ * visitors, and the write-back of every contact's rows into the Manifold table. */
+__device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams& P, int t, int2 td, int totalIt)
+{
+    const int lane = threadIdx.x & 63;
+    const FastBuffers& F = *X.F;
+    const size_t SC = (size_t)F.slotCap, at = (size_t)t * 64 + lane;
+    const int cls = (td.y >> 16) & 0xFF;
+    if (cls == 0) return;
+    const int G = fast_class_lanes(cls), j = lane / G, nb = td.y & 0xFFFF;
+    const float4 c5 = F.slotC[5 * SC + at];
+    const int partner = __float_as_int(c5.x), slot = __float_as_int(c5.y), flags = __float_as_int(c5.z);
+    const bool valid = (flags & FL_VALID) != 0 && j < nb, isA = (flags & FL_ISA) != 0, first = (flags & FL_FIRST) != 0, sole = (flags & FL_SOLE) != 0;
+    const bool mine = valid && first;
+    const float4 c0 = F.slotC[0 * SC + at], c1 = F.slotC[1 * SC + at], c2 = F.slotC[2 * SC + at], c3 = F.slotC[3 * SC + at], c4 = F.slotC[4 * SC + at];
+    const int body = __float_as_int(F.bodyC[(size_t)3 * F.bodyCap + td.x + (j < nb ? j : 0)].w);
+    f3 pos = zero3(), opos = zero3(); q4 rot = identq(), orot = identq();
+    fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
+    {
+        const unsigned long long t0 = X.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        for (;;) {
+            bool ok = true;
+            if (mine) {
+                const fv4u o0 = fld(X.rPose, body * 32), o1 = fld(X.rPose, body * 32 + 16);
+                ok = pose_decode(o0, o1, (unsigned)totalIt, pos, rot);
+                sl = fld(X.rL, slot * 16); sp = fld(X.rP, slot * 16);
+                if (!sole) {
+                    const fv4u p0 = fld(X.rPose, partner * 32), p1 = fld(X.rPose, partner * 32 + 16);
+                    ok &= pose_decode(p0, p1, (unsigned)totalIt, opos, orot);
+                    ok &= (sl.w >> 1) == (unsigned)(2 * totalIt);
+                }
+            }
+            if (!X.stamps || __all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) { if (!ok) atomicOr(&X.plan->bad, 256); break; }
+        }
+    }
+    if (!mine) return;
+    if (sole) {
+        const float4 pp = X.B.plane(BP_POSR)[partner], pq = X.B.plane(BP_QUAT)[partner];
+        opos = mk3(pp.x, pp.y, pp.z); orot = mkq(pq.x, pq.y, pq.z, pq.w);
+    }
+    FastRows c;
+    c.lam[0] = uf(sl.x); c.lam[1] = uf(sl.y); c.lam[2] = uf(sl.z); c.stick = (sl.w & 1u) != 0;
+    c.pen[0] = uf(sp.x); c.pen[1] = uf(sp.y); c.pen[2] = uf(sp.z);
+    const f3 rOwn = mk3(c0.x, c0.y, c0.z), rOth = mk3(c1.x, c1.y, c1.z);
+    const f3 n = mk3(c2.x, c2.y, c2.z), t1 = mk3(c3.x, c3.y, c3.z), t2 = mk3(c4.x, c4.y, c4.z);
+    const f3 wOwn = qrotate(rot, rOwn), wOth = qrotate(orot, rOth);
+    const f3 pOwn = pos + wOwn, pOth = opos + wOth;
+    const f3 pA = isA ? pOwn : pOth, pB = isA ? pOth : pOwn;
+    const float bs = rclamp(1.0f - fast_alpha(P, totalIt - 1), 0.0f, 1.0f);
+    if (!P.postStabilize) {
+        fast_dual(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, c4.w, pA, isA ? wOwn : wOth, pB, isA ? wOth : wOwn, c3.w, X.beta);
+    } else {
+        /* post-stabilisation: the extra sweep has no dual (solver.cpp:411); C / fmin / fmax / penetration as a computeConstraint on the final
+         * poses leaves them (API visibility only: Manifold::initialize recomputes all four next step), lambda and stick as the last visit left them */
+        FastRows probe = c;
+        fast_constraint(probe, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, c4.w, pA, pB, c3.w);
+        for (int k = 0; k < 3; ++k) { c.C[k] = probe.C[k]; c.fmin[k] = probe.fmin[k]; c.fmax[k] = probe.fmax[k]; }
+        c.penetration = probe.penetration;
+    }
+    const ManifoldTable& M = X.M;
+    M.cN[slot] = make_float4(n.x, n.y, n.z, c2.w);
+    M.cU1[slot] = make_float4(t1.x, t1.y, t1.z, 0.f);
+    M.cU2[slot] = make_float4(t2.x, t2.y, t2.z, 0.f);
+    M.cLam[slot] = make_float4(c.lam[0], c.lam[1], c.lam[2], c.penetration);
+    M.cPen[slot] = make_float4(c.pen[0], c.pen[1], c.pen[2], 0.f);
+    M.cFS[slot].y = c.stick ? 1 : 0;
+    M.cC[slot] = make_float4(c.C[0], c.C[1], c.C[2], 0.f);
+    M.cFmin[slot] = make_float4(c.fmin[0], c.fmin[1], c.fmin[2], 0.f);
+    M.cFmax[slot] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
+}
+
+template <bool TWOPASS>
+__device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
+{
+    const int cls = __builtin_amdgcn_readfirstlane((td.y >> 16) & 0xFF);
+    switch (cls) {
+    case 0: fast_visit<1, false>(X, P, t, td, it, lastOfLaunch); break;
+    case 1: fast_visit<8, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
+    case 2: fast_visit<16, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
+    case 3: fast_visit<32, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
+    default: fast_visit<64, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
+    }
+}
+
+/* LAT: the latency form — workgroups of four waves, one wave per SIMD with the whole register file, contacts in two passes (what can be
+ * evaluated before the last pose arrives is); otherwise the throughput form — eight waves per workgroup, one pass, leaner registers. */
+template <bool LAT>
+__global__ __launch_bounds__(LAT ? kSweepThreadsLat : kSweepThreads) void k_fast_sweep(FastLaunch L)
+{
+    constexpr int kWaves = (LAT ? kSweepThreadsLat : kSweepThreads) / 64;
+    const FastBuffers& F = L.F;
+    FastPlan* plan = F.plan;
+    if (plan->bad != 0) return;                                      /* the plan declined the step: the exact schedule queued behind this launch runs it */
+    const int T = plan->numTiles, numColors = plan->numColors;
+    const int nWG = gridDim.x;
+    const int W = nWG * kWaves;
+    const int gw = (threadIdx.x >> 6) * nWG + blockIdx.x;             /* consecutive tiles go to different workgroups */
+    FastCtx X;
+    X.rPose = frsrc(F.xpose); X.rL = frsrc(F.xL); X.rP = frsrc(F.xP);
+    X.F = &F; X.plan = plan; X.cnt = L.cnt; X.B = L.B; X.M = L.M;
+    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps;
+    const SolverParams P = L.P;
+    const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
+    unsigned target = L.syncBase;
+    if (T == 0) return;
+    if (L.stamps && gw >= T) return;                                 /* nothing to do for this wave, nobody waits for it */
+
+    for (int it = L.itBegin; it < L.itEnd; ++it) {
+        for (int c = 0; c < numColors; ++c) {
+            const int t0 = plan->colorTileStart[c], t1 = plan->colorTileStart[c + 1];
+            /* this wave's tiles of the colour: t = gw (mod W) */
+            int t = t0 + ((gw - t0) % W + W) % W;
+            for (; t < t1; t += W) fast_visit_any<LAT>(X, P, t, F.tiles[t], it, it == L.itEnd - 1);
+            if (!L.stamps) fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
+        }
+    }
+    if (L.finalPass) {
+        if (L.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int t = gw; t < T; t += W) fast_final(X, P, t, F.tiles[t], totalIt);
+    }
+}
+
+/* =====================================================================================================================
+ * host side
+ * ===================================================================================================================== */
+int fast_query(int device, int* planBlocksPerCU, int* sweepBlocksPerCU)
+{
+    (void)device;
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fast_plan<false>, kPlanThreads, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_fast_sweep<false>, kSweepThreads, 0) != hipSuccess) b = 0;
+    int bl = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bl, k_fast_sweep<true>, kSweepThreadsLat, 0) != hipSuccess) bl = 0;
+    if (bl < 1) b = 0;
+    if (planBlocksPerCU) *planBlocksPerCU = a;
+    if (sweepBlocksPerCU) *sweepBlocksPerCU = b;
+    return (a > 0 && b > 0) ? 1 : 0;
+}
+
+hipError_t fast_launch_plan(hipStream_t stream, const FastLaunch& L, int planBlocksPerCU)
+{
+    const int maxWG = std::max(1, std::min(1024, L.numCU * std::max(1, planBlocksPerCU)));
+    if (L.B.n <= kPlanSingleBodies) hipLaunchKernelGGL(k_fast_plan<true>, dim3(1), dim3(kPlanThreads), 0, stream, L);
+    else {
+        const int nWG = std::max(2, std::min(maxWG, (L.B.n + kPlanThreads - 1) / kPlanThreads));
+        hipLaunchKernelGGL(k_fast_plan<false>, dim3(nWG), dim3(kPlanThreads), 0, stream, L);
+    }
+    /* (the tile count is known on the device only: a grid for the bodies' worst case would be mostly idle, so a grid-stride loop over what the plan holds) */
+    const int fillWG = std::max(1, std::min(4 * L.numCU, (int)(((long long)L.B.n * 12 + 255) / 256)));
+    hipLaunchKernelGGL(k_fast_fill, dim3(fillWG), dim3(256), 0, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& L, int sweepBlocksPerCU, int tilesHint, int forceBlocks, int form)
+{
+    /* the latency form while every tile can have a wave with a SIMD to itself (one workgroup of four waves per CU); `form`: 0 by size, 1 latency, 2 throughput */
+    const bool lat = form == 1 || (form == 0 && (tilesHint > 0 ? tilesHint <= 4 * L.numCU : L.B.n <= 16 * L.numCU));
+    const int waves = (lat ? kSweepThreadsLat : kSweepThreads) / 64;
+    const int maxWG = lat ? L.numCU : std::max(1, std::min(1024, L.numCU * std::max(1, sweepBlocksPerCU)));
+    int nWG = maxWG;
+    if (!L.stamps && tilesHint > 0) nWG = (int)(((long long)tilesHint * 5 / 4 + waves - 1) / waves) + 1;   /* (grid barrier: no more workgroups than the tiles need) */
+    if (forceBlocks > 0) nWG = forceBlocks;
+    nWG = std::max(1, std::min(maxWG, nWG));
+    if (lat) hipLaunchKernelGGL(k_fast_sweep<true>, dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L);
+    else hipLaunchKernelGGL(k_fast_sweep<false>, dim3(nWG), dim3(kSweepThreads), 0, stream, L);
+    return hipGetLastError();
+}
+
+} // namespace avbd

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AVBD_ABI_VERSION 4   /* 4: AvbdStepStats.cutMode, avbd_set_shard_mode 2, avbd_set_option / avbd_get_option; 3: avbd_set_exchange_floats, avbd_exchange_mismatches, avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
+#define AVBD_ABI_VERSION 5   /* 5: the fast sweep (option "sweep", AvbdStepStats.schedule 5, avbd_fast_plan_info); 4: AvbdStepStats.cutMode, avbd_set_shard_mode 2, avbd_set_option / avbd_get_option; 3: avbd_set_exchange_floats, avbd_exchange_mismatches, avbd_set_shard_mode, avbd_device_count, avbd_set_joint_angular_sign; 2: AvbdStepStats.schedule, snapshots, removal, set_step_index (all additions; 1 and 2 are subsets) */
 
 enum {
     AVBD_OK = 0,
@@ -113,7 +113,8 @@ typedef struct AvbdStepStats {
     int schedule;           /* how the iteration loop of that step ran: 0 one launch per level, 1 data-flow tasks (k_iterate),
                                2 resident (one wavefront per body for the whole loop, avbd_resident.h),
                                3 resident with several bodies per wavefront (more swept bodies than resident waves),
-                               4 group schedule (several bodies in flight per wavefront, avbd_groups.h) */
+                               4 group schedule (several bodies in flight per wavefront, avbd_groups.h),
+                               5 fast sweep (option "sweep" = 1: multi-colour Gauss-Seidel, avbd_fast.hip) */
     int cutMode;            /* how the ranks of a sharded step were coupled across their cuts (ABI 4): 0 not sharded, 1 all-gather, one launch
                                per iteration, 2 all-gather beside ONE persistent launch (both: Jacobi across the cut), 3 exact cuts
                                (bit-identical to one GPU).  What RAN, whatever avbd_set_shard_mode asked for */
@@ -354,6 +355,17 @@ int  avbd_device_count(void);                                            /* visi
  * SURVEY.md §7-5 —, 1 uses J_angular = dC/dtheta (-e_k for bodyA, +e_k for bodyB), with which welds hold.  Applies to the
  * joints that exist and to those added later.  There is no such switch in the reference. */
 int  avbd_set_joint_angular_sign(AvbdContext* ctx, int corrected);
+
+/* ---- the fast sweep (ABI 5): avbd_set_option(ctx, "sweep", 1) — CLI `--mode fast` -------------------------------------------------
+ * The iteration loop of solver.cpp:340-431 as a multi-colour Gauss-Seidel: the swept bodies are coloured on the device every step, the
+ * bodies of one colour are solved together (one lane per contact, the 27 entries of a body's 6x6 system summed over its lanes with
+ * DPP butterflies), a force's dual update (solver.cpp:411-430) runs at its first visit of the next iteration.  Row arithmetic is the
+ * exact mode's (same expression trees, no contraction); the ORDER of bodies and of sums is not, so results agree with the exact mode
+ * within the tolerance DESIGN.md section 2b states, not bit for bit; they are bit-identical from run to run.  Scenes with Joints,
+ * Springs or user forces, sharded contexts and bodies with more than 64 contacts take the exact schedules (AvbdStepStats.schedule says
+ * which one ran: 5 = fast sweep).  avbd_fast_plan_info: the plan of the last fast step — out[0] colours, [1] tiles of 64 lanes,
+ * [2] veto bits (0: the sweep ran), [3] rounds the colouring took, [4] swept bodies.  Synchronises.  No counterpart in the reference. */
+int  avbd_fast_plan_info(AvbdContext* ctx, int out[8]);
 
 /* ---- measurement ---- */
 int  avbd_profile_enable(AvbdContext* ctx, int enable);

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_defaults(lib):
-    assert lib.avbd_abi_version() == 4
+    assert lib.avbd_abi_version() == 5
     p = np.zeros(1, pkg.PARAMS_DT)
     assert lib.avbd_default_params(p.ctypes.data_as(C.c_void_p)) == 0
     # Solver::defaultParams, solver.cpp:240-248
