@@ -67,7 +67,7 @@ EXPORTS = [
     "avbd_force_compute_constraint", "avbd_force_compute_derivatives", "avbd_kat_collide", "avbd_kat_solve6",
     "avbd_kat_arith", "avbd_profile_enable", "avbd_profile_reset", "avbd_profile_get", "avbd_stream",
     "avbd_build_scene", "avbd_partition_by_axis", "avbd_set_ownership", "avbd_comm_unique_id", "avbd_comm_init",
-    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_debug_front_blocks", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_group_rebalance", "avbd_rebalance_export", "avbd_rebalance_import", "avbd_set_option", "avbd_get_option", "avbd_option_count", "avbd_option_key", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign", "avbd_fast_plan_info",
+    "avbd_group_step", "avbd_add_host_force", "avbd_set_host_force_callback", "avbd_debug_group_task_times", "avbd_download_force", "avbd_exchange_layout", "avbd_debug_iterate_stats", "avbd_debug_task_times", "avbd_remove_body", "avbd_remove_force", "avbd_save_snapshot", "avbd_load_snapshot", "avbd_set_step_index", "avbd_debug_topology_times", "avbd_debug_front_times", "avbd_debug_front_blocks", "avbd_pick", "avbd_get_warnings", "avbd_set_shard_mode", "avbd_group_rebalance", "avbd_rebalance_export", "avbd_rebalance_import", "avbd_set_option", "avbd_get_option", "avbd_option_count", "avbd_option_key", "avbd_exact_window_export", "avbd_exact_window_attach", "avbd_set_exchange_floats", "avbd_exchange_mismatches", "avbd_device_count", "avbd_set_joint_angular_sign", "avbd_fast_plan_info", "avbd_fast_colors",
 ]
 
 
@@ -354,6 +354,14 @@ class World:
         out = (C.c_int * 8)()
         self._chk(lib().avbd_fast_plan_info(self.h, out))
         return dict(colors=out[0], tiles=out[1], bad=out[2], rounds=out[3], swept=out[4])
+
+    def fast_colors(self):
+        """colour of every body in the last fast step's plan (-2: not swept)"""
+        out = np.zeros(max(1, self.num_bodies()), np.int32)
+        n = lib().avbd_fast_colors(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), len(out))
+        if n < 0:
+            self._chk(n)
+        return out[:n]
 
     def set_option(self, key, value):
         self._chk(self.L.avbd_set_option(self.h, key.encode(), int(value)))

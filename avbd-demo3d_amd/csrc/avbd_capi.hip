@@ -2206,6 +2206,17 @@ int avbd_fast_plan_info(AvbdContext* c, int out[8])
     HIPCHK(c, hipMemcpy(out, c->fPlan.p, 8 * sizeof(int), hipMemcpyDeviceToHost));
     return AVBD_OK;
 }
+int avbd_fast_colors(AvbdContext* c, int* out, int capacity)
+{
+    if (!c || !out) return AVBD_E_INVALID;
+    const int n = (int)c->hBodies.size();
+    if (capacity < n) return c->fail(AVBD_E_INVALID, "avbd_fast_colors: capacity below the number of bodies");
+    if (!c->fColor[c->fColorCur].p || !c->fastLaunched) return c->fail(AVBD_E_INVALID, "avbd_fast_colors: the last step was not a fast step");
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->fColor[c->fColorCur].p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return n;
+}
 int avbd_profile_enable(AvbdContext* c, int enable) { if (!c) return AVBD_E_INVALID; c->profiling = enable != 0; return AVBD_OK; }
 int avbd_profile_reset(AvbdContext* c) { if (!c) return AVBD_E_INVALID; c->prof = AvbdProfile{}; return AVBD_OK; }
 int avbd_profile_get(AvbdContext* c, AvbdProfile* out) { if (!c || !out) return AVBD_E_INVALID; *out = c->prof; return AVBD_OK; }

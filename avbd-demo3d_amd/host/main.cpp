@@ -13,7 +13,10 @@
  * creation index and body-local hit point, floats as hex so the line can be compared bit for bit),
  * --gpus N [--cuts exact|gather] (the scene sharded over N ranks of this process: N contexts on the visible devices, round robin
  * — on one GPU they share it —, slabs along x, Solver::stepGroup; `gather` = one all-gather per iteration, Jacobi across the cuts
- * (default, BASELINE configs[3..4]), `exact` = bit-identical to --gpus 1; implies --batch; state and --dump come from rank 0).
+ * (default, BASELINE configs[3..4]), `exact` = bit-identical to --gpus 1; implies --batch; state and --dump come from rank 0),
+ * --mode exact|fast (`exact`, the default, replays the reference's sweep bit for bit; `fast` is the throughput sweep of
+ * avbd_fast.hip — multi-colour Gauss-Seidel, tree-reduced sums — within the tolerance of DESIGN.md section 2b = avbd_set_option(ctx, "sweep", 1)),
+ * --option key=value (any avbd_set_option key; repeatable).
  */
 #include "solver.h"
 #include "joint.h"
@@ -25,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <utility>
 #include <vector>
 
 int main(int argc, char** argv)
@@ -38,6 +43,8 @@ int main(int argc, char** argv)
     int steps = 300; /* main.cpp:192 */
     bool quiet = false, batch = false;
     int gpus = 1; bool exactCuts = false; int rebalanceEvery = 0;
+    bool fastMode = false;
+    std::vector<std::pair<std::string, int>> options;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--nogfx") || !strcmp(argv[i], "--headless")) { /* this build is always headless */ }
         else if ((!strcmp(argv[i], "--scene") || !strcmp(argv[i], "-s")) && i + 1 < argc) requested = argv[++i];
@@ -54,6 +61,12 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = atoi(argv[++i]); if (gpus < 1) gpus = 1; }
         else if (!strcmp(argv[i], "--cuts") && i + 1 < argc) exactCuts = !strcmp(argv[++i], "exact");
         else if (!strcmp(argv[i], "--rebalance") && i + 1 < argc) rebalanceEvery = atoi(argv[++i]);   /* --gpus N: new slabs from the current positions every K steps */
+        else if (!strcmp(argv[i], "--mode") && i + 1 < argc) fastMode = !strcmp(argv[++i], "fast");
+        else if (!strcmp(argv[i], "--option") && i + 1 < argc) {
+            const char* kv = argv[++i];
+            const char* eq = strchr(kv, '=');
+            if (eq) options.emplace_back(std::string(kv, eq), atoi(eq + 1));
+        }
     }
 
     if (gpus > 1) { batch = true; quiet = true; }
@@ -83,6 +96,11 @@ int main(int argc, char** argv)
             else if (idx < sceneCount) shown = sceneNames[idx];
             else shown = requested;
         }
+    }
+    for (Solver* s : ranks) {
+        if (fastMode) avbd_set_option(s->context(), "sweep", 1);
+        for (const auto& kv : options)
+            if (avbd_set_option(s->context(), kv.first.c_str(), kv.second) != AVBD_OK) fprintf(stderr, "avbd_demo3d: --option %s: %s\n", kv.first.c_str(), avbd_last_error(s->context()));
     }
     if (gpus > 1) Solver::shardAcross(ranks.data(), gpus, 0, exactCuts);
 
@@ -126,8 +144,8 @@ int main(int argc, char** argv)
         static const char* const cutNames[4] = {"none", "all-gather per iteration (one launch per iteration)", "all-gather per iteration (persistent launch)", "exact"};
         AvbdStepStats st{};
         if (steps > 0) avbd_get_step_stats(solver->context(), &st);
-        printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\", \"ranks\": %d, \"cuts\": \"%s\"}\n", shown, steps, ms,
-               steps ? ms / steps : 0.0, gpus, cutNames[st.cutMode >= 0 && st.cutMode < 4 ? st.cutMode : 0]);
+        printf("{\"scene\": \"%s\", \"steps\": %d, \"ms_total\": %.3f, \"ms_per_step\": %.6f, \"backend\": \"hip-gfx950\", \"ranks\": %d, \"cuts\": \"%s\", \"mode\": \"%s\", \"schedule\": %d}\n", shown, steps, ms,
+               steps ? ms / steps : 0.0, gpus, cutNames[st.cutMode >= 0 && st.cutMode < 4 ? st.cutMode : 0], fastMode ? "fast" : "exact", st.schedule);
     }
     if (pickRay) {
         float r[6] = {0, 0, 0, 0, 0, 0};

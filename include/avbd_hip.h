@@ -366,6 +366,8 @@ int  avbd_set_joint_angular_sign(AvbdContext* ctx, int corrected);
  * which one ran: 5 = fast sweep).  avbd_fast_plan_info: the plan of the last fast step — out[0] colours, [1] tiles of 64 lanes,
  * [2] veto bits (0: the sweep ran), [3] rounds the colouring took, [4] swept bodies.  Synchronises.  No counterpart in the reference. */
 int  avbd_fast_plan_info(AvbdContext* ctx, int out[8]);
+/* the colour of every body in the last fast step's plan (-2: not swept); tests check that no two bodies that share a force share a colour */
+int  avbd_fast_colors(AvbdContext* ctx, int* out, int capacity_bodies);
 
 /* ---- measurement ---- */
 int  avbd_profile_enable(AvbdContext* ctx, int enable);
