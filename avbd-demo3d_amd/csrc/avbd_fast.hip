@@ -33,6 +33,7 @@ typedef unsigned fv4u __attribute__((ext_vector_type(4)));
 
 constexpr int kPlanThreads = 1024;
 constexpr int kSweepThreads = 512, kSweepThreadsLat = 256;
+constexpr int kFastLatTilesPerWave = 4;        /* the latency form up to this many tiles per wave (measured: it wins up to ~6 000 tiles = 32 000 cubes) */
 constexpr unsigned long long kFastTimeoutTicks = 400000000ull;   /* 4 s of s_memrealtime (100 MHz) */
 
 enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8 };
@@ -183,9 +184,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
         adjS = L.adjStart[b]; adjE = L.adjStart[b + 1];
         const unsigned pb = fast_prio(L.adjStart, b);
         const int old = reuse ? F.colorPrev[b] : -1;
-        /* the bodies of last step's HIGHEST colour look for a lower one every step (they are not adjacent to each other, so they all can at once): a colouring
-         * that grew while the pile formed shrinks again, one colour per step, towards what a fresh greedy colouring finds */
-        bool keep = old >= 0 && !(plan->numColors > kFastColorsFloor && old == plan->numColors - 1);
+        /* a body gives its colour up when a neighbour of higher priority held the same one (a new contact between two bodies of one colour), and also when a
+         * LOWER colour is free among its neighbours' old colours (contacts that went away): the colouring stays "greedy-stable" — as good as a fresh greedy
+         * colouring, which a colouring that is only ever repaired is not (it grew from 5 to 8 colours while the 8 000-cube pile formed) */
+        bool keep = old >= 0;
+        unsigned long long usedOld = 0ull;
 #pragma unroll
         for (int k = 0; k < kPlanNbrRegs; ++k) {
             if (adjS + k < adjE) {
@@ -195,7 +198,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
                     const unsigned pp = fast_prio(L.adjStart, p);
                     const bool hi = pp > pb || (pp == pb && p > b);
                     if (hi) higher |= 1u << k;
-                    if (keep && hi && F.colorPrev[p] == old) keep = false;
+                    if (keep) {
+                        const int po = F.colorPrev[p];
+                        if (po >= 0) usedOld |= 1ull << po;
+                        if (hi && po == old) keep = false;
+                    }
                 }
             }
         }
@@ -204,9 +211,12 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
                 const int p = L.adjOther[i];
                 if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE || B.solved[p] == 0) continue;
                 const unsigned pp = fast_prio(L.adjStart, p);
-                if ((pp > pb || (pp == pb && p > b)) && F.colorPrev[p] == old) keep = false;
+                const int po = F.colorPrev[p];
+                if (po >= 0) usedOld |= 1ull << po;
+                if ((pp > pb || (pp == pb && p > b)) && po == old) keep = false;
             }
         }
+        if (keep && (~usedOld & ((1ull << old) - 1ull)) != 0ull) keep = false;
         if (keep) myColor = old;
         const int e0 = L.incStart[b], e1 = L.incStart[b + 1];
         deg = e1 - e0;
@@ -520,6 +530,14 @@ __device__ __forceinline__ void fast_dual(FastRows& c, f3 n, f3 t1, f3 t2, float
     }
 }
 
+#ifdef AVBD_DF_STATS
+constexpr int kFastStatTiles = 2048, kFastStatIts = 64;
+__device__ unsigned gFastTimes[kFastStatTiles * kFastStatIts * 4];     /* per (tile, iteration): visit start, first pass done, inputs of the second pass in, published (10 ns ticks) */
+#define FAST_STAMP(k) do { if (t < kFastStatTiles && it < kFastStatIts && (threadIdx.x & 63) == 0) gFastTimes[((size_t)t * kFastStatIts + it) * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FAST_STAMP(k) do { } while (0)
+#endif
+
 struct FastCtx {
     __amdgpu_buffer_rsrc_t rPose, rL, rP;
     const FastBuffers* F;
@@ -576,7 +594,7 @@ __device__ __forceinline__ f3 solve_ldlt3_quadlanes(m33 A, f3 b, int c)
  * sweeps) — everything they read was published in the previous iteration, and they run the dual update of that iteration —, then the contacts whose
  * partner has already moved in this iteration.  Only the second pass, the sums, the solve and the publish stand between the arrival of the last pose
  * and this body's own. */
-template <int G, bool TWOPASS>
+template <int G, bool TWOPASS, bool HOIST>
 __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
 {
     const int lane = threadIdx.x & 63;
@@ -598,6 +616,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
     const q4 nrot = mkq(b1.x, b1.y, b1.z, b1.w);
     const f3 Id = mk3(b2.x, b2.y, b2.z), Jd = mk3(b3.x, b3.y, b3.z);
 
+    FAST_STAMP(0);
     /* the body's own pose: this wave published it (epoch it) */
     f3 pos; q4 rot;
     {
@@ -626,6 +645,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
 #pragma unroll 1
         for (int pass = TWOPASS ? 0 : 1; pass < 2; ++pass) {
             const bool mine = valid && (!TWOPASS || first == (pass == 0));
+            if (pass == 1) FAST_STAMP(1);
             if (!__any(mine)) continue;
             /* ---- inputs of the pass: partner pose and the contact's records, one round trip; with stamps the lane polls until both carry this visit's stamps ---- */
             f3 opos = zero3(); q4 orot = identq();
@@ -651,7 +671,15 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     }
                 }
             }
+            if (pass == 1) FAST_STAMP(2);
             if (mine) {
+                f3 wOwnP = wOwn;
+                float signP = isA ? 1.0f : -1.0f;
+                if (TWOPASS && !HOIST) {
+                    /* (two waves per SIMD: what depends on the body's own pose alone — Jacobians, their products, gyroscopic factors — is recomputed in each pass
+                     * instead of being kept in ninety registers across the wait; the empty asm hides the loop invariance from the compiler) */
+                    asm volatile("" : "+v"(wOwnP.x), "+v"(wOwnP.y), "+v"(wOwnP.z), "+v"(signP));
+                }
                 if (sole) {                                           /* a partner this context does not sweep: its pose is in the body table (fixed during the launch) */
                     const float4 pp = X.B.plane(BP_POSR)[partner], pq = X.B.plane(BP_QUAT)[partner];
                     opos = mk3(pp.x, pp.y, pp.z); orot = mkq(pq.x, pq.y, pq.z, pq.w);
@@ -666,15 +694,15 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     /* the dual update of iteration it - 1 (solver.cpp:411-430), by the force's first visitor of iteration it: no pose has
                      * changed since the sweep of it - 1 ended */
                     const float bs = rclamp(1.0f - fast_alpha(P, it - 1), 0.0f, 1.0f);
-                    fast_dual(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, isA ? wOwn : wOth, pB, isA ? wOth : wOwn, fric, X.beta);
+                    fast_dual(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, isA ? wOwnP : wOth, pB, isA ? wOth : wOwnP, fric, X.beta);
                 }
                 const float bs = rclamp(1.0f - fast_alpha(P, it), 0.0f, 1.0f);
                 fast_constraint(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, pB, fric);
-                const float sign = isA ? 1.0f : -1.0f;
+                const float sign = signP;
                 const f3 basis[3] = {n, t1, t2};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const f3 Jl = basis[k] * sign, Ja = cross3(wOwn, basis[k]) * sign;     /* manifold.cpp:265-270 */
+                    const f3 Jl = basis[k] * sign, Ja = cross3(wOwnP, basis[k]) * sign;     /* manifold.cpp:265-270 */
                     const float desired = c.pen[k] * c.C[k] + c.lam[k] + 0.0f;             /* solver.cpp:379-381: stiffness FLT_MAX, motor 0 */
                     const float f = rclamp(desired, c.fmin[k], c.fmax[k]);
                     const float pen = c.pen[k];
@@ -761,6 +789,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
         fv4u r0, r1;
         pose_encode(p, q, (unsigned)(it + 1), r0, r1);
         fst(X.rPose, body * 32, r0); fst(X.rPose, body * 32 + 16, r1);
+        FAST_STAMP(3);
         if (lastOfLaunch) {                                           /* what the tail (and, sharded, the exchange) reads */
             const float4 old = X.B.plane(BP_POSR)[body];
             X.B.plane(BP_POSR)[body] = pack3(p, old.w);
@@ -842,25 +871,27 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
     M.cFmax[slot] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
 }
 
-template <bool TWOPASS>
+template <int FORM>
 __device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
 {
+    constexpr bool TWOPASS = FORM != 0, HOIST = FORM == 1;
     const int cls = __builtin_amdgcn_readfirstlane((td.y >> 16) & 0xFF);
     switch (cls) {
-    case 0: fast_visit<1, false>(X, P, t, td, it, lastOfLaunch); break;
-    case 1: fast_visit<8, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
-    case 2: fast_visit<16, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
-    case 3: fast_visit<32, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
-    default: fast_visit<64, TWOPASS>(X, P, t, td, it, lastOfLaunch); break;
+    case 0: fast_visit<1, false, false>(X, P, t, td, it, lastOfLaunch); break;
+    case 1: fast_visit<8, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
+    case 2: fast_visit<16, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
+    case 3: fast_visit<32, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
+    default: fast_visit<64, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
     }
 }
 
-/* LAT: the latency form — workgroups of four waves, one wave per SIMD with the whole register file, contacts in two passes (what can be
- * evaluated before the last pose arrives is); otherwise the throughput form — eight waves per workgroup, one pass, leaner registers. */
-template <bool LAT>
-__global__ __launch_bounds__(LAT ? kSweepThreadsLat : kSweepThreads) void k_fast_sweep(FastLaunch L)
+/* FORM 1: the latency form — workgroups of four waves, one wave per SIMD with the whole register file, contacts in two passes (what can be
+ * evaluated before the last pose arrives is), everything that depends on the body's own pose alone kept across the wait; FORM 2: two passes, eight
+ * waves per workgroup (two per SIMD), nothing kept across the wait; FORM 0: one pass, eight waves per workgroup. */
+template <int FORM>
+__global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void k_fast_sweep(FastLaunch L)
 {
-    constexpr int kWaves = (LAT ? kSweepThreadsLat : kSweepThreads) / 64;
+    constexpr int kWaves = (FORM == 1 ? kSweepThreadsLat : kSweepThreads) / 64;
     const FastBuffers& F = L.F;
     FastPlan* plan = F.plan;
     if (plan->bad != 0) return;                                      /* the plan declined the step: the exact schedule queued behind this launch runs it */
@@ -883,7 +914,7 @@ __global__ __launch_bounds__(LAT ? kSweepThreadsLat : kSweepThreads) void k_fast
             const int t0 = plan->colorTileStart[c], t1 = plan->colorTileStart[c + 1];
             /* this wave's tiles of the colour: t = gw (mod W) */
             int t = t0 + ((gw - t0) % W + W) % W;
-            for (; t < t1; t += W) fast_visit_any<LAT>(X, P, t, F.tiles[t], it, it == L.itEnd - 1);
+            for (; t < t1; t += W) fast_visit_any<FORM>(X, P, t, F.tiles[t], it, it == L.itEnd - 1);
             if (!L.stamps) fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
         }
     }
@@ -893,6 +924,14 @@ __global__ __launch_bounds__(LAT ? kSweepThreadsLat : kSweepThreads) void k_fast
     }
 }
 
+#ifdef AVBD_DF_STATS
+extern "C" int avbd_debug_fast_times(unsigned* out, int words)
+{
+    const int n = std::min(words, kFastStatTiles * kFastStatIts * 4);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gFastTimes), (size_t)n * sizeof(unsigned)) == hipSuccess ? n : -1;
+}
+#endif
+
 /* =====================================================================================================================
  * host side
  * ===================================================================================================================== */
@@ -901,9 +940,11 @@ int fast_query(int device, int* planBlocksPerCU, int* sweepBlocksPerCU)
     (void)device;
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fast_plan<false>, kPlanThreads, 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_fast_sweep<false>, kSweepThreads, 0) != hipSuccess) b = 0;
-    int bl = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bl, k_fast_sweep<true>, kSweepThreadsLat, 0) != hipSuccess) bl = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_fast_sweep<0>, kSweepThreads, 0) != hipSuccess) b = 0;
+    int bl = 0, bm = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bl, k_fast_sweep<1>, kSweepThreadsLat, 0) != hipSuccess) bl = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bm, k_fast_sweep<2>, kSweepThreads, 0) != hipSuccess) bm = 0;
+    b = std::min(b, bm);
     if (bl < 1) b = 0;
     if (planBlocksPerCU) *planBlocksPerCU = a;
     if (sweepBlocksPerCU) *sweepBlocksPerCU = b;
@@ -926,16 +967,20 @@ hipError_t fast_launch_plan(hipStream_t stream, const FastLaunch& L, int planBlo
 
 hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& L, int sweepBlocksPerCU, int tilesHint, int forceBlocks, int form)
 {
-    /* the latency form while every tile can have a wave with a SIMD to itself (one workgroup of four waves per CU); `form`: 0 by size, 1 latency, 2 throughput */
-    const bool lat = form == 1 || (form == 0 && (tilesHint > 0 ? tilesHint <= 4 * L.numCU : L.B.n <= 16 * L.numCU));
+    /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
+    const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
+    /* measured (sweep us, forms 1 / 2 / 3): 13 824 cubes 585 / 671 / 915, 32 768 cubes 955 / 884 / 1056, 64 000 cubes 1534 / 1170 / 1123 */
+    const int f = form != 0 ? form : (tilesGuess <= (long long)kFastLatTilesPerWave * 4 * L.numCU ? 1 : (tilesGuess <= (long long)9 * 4 * L.numCU ? 2 : 3));
+    const bool lat = f == 1;
     const int waves = (lat ? kSweepThreadsLat : kSweepThreads) / 64;
     const int maxWG = lat ? L.numCU : std::max(1, std::min(1024, L.numCU * std::max(1, sweepBlocksPerCU)));
     int nWG = maxWG;
     if (!L.stamps && tilesHint > 0) nWG = (int)(((long long)tilesHint * 5 / 4 + waves - 1) / waves) + 1;   /* (grid barrier: no more workgroups than the tiles need) */
     if (forceBlocks > 0) nWG = forceBlocks;
     nWG = std::max(1, std::min(maxWG, nWG));
-    if (lat) hipLaunchKernelGGL(k_fast_sweep<true>, dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L);
-    else hipLaunchKernelGGL(k_fast_sweep<false>, dim3(nWG), dim3(kSweepThreads), 0, stream, L);
+    if (lat) hipLaunchKernelGGL(k_fast_sweep<1>, dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L);
+    else if (f == 2) hipLaunchKernelGGL(k_fast_sweep<2>, dim3(nWG), dim3(kSweepThreads), 0, stream, L);
+    else hipLaunchKernelGGL(k_fast_sweep<0>, dim3(nWG), dim3(kSweepThreads), 0, stream, L);
     return hipGetLastError();
 }
 

@@ -90,8 +90,20 @@ def dependency_chain_hops(forces, bodies, total_iterations):
     return longest
 
 
-PMC_SUMMARIES = {"Stress1000": "r5_stress1000_cli_summary.json", "StressN:20": "r5_8k_cli_summary.json", "StressN:40": "r5_64k_cli_summary.json",
-                 "StressN:40+welds:10000": "r5_64k_welds_cli_summary.json"}
+PMC_SUMMARIES = {"Stress1000": "r6_stress1000_cli_summary.json", "StressN:20": "r6_8k_cli_summary.json", "StressN:40": "r6_64k_cli_summary.json",
+                 "StressN:40+welds:10000": "r6_64k_welds_cli_summary.json",
+                 # the fast sweep (option "sweep" = 1, CLI --mode fast): profiles/run_all_r6.sh
+                 "fast:Stress1000": "r6_fast_1000_cli_summary.json", "fast:StressN:20": "r6_fast_8k_cli_summary.json", "fast:StressN:40": "r6_fast_64k_cli_summary.json"}
+
+
+def source_id():
+    """sha256 over the sources the library is built from (tools/source_id.py): what a committed profile must have been collected on"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import source_id as S
+        return S.source_id()
+    except Exception:
+        return None
 
 
 def pmc_traffic(scene, fused):
@@ -106,9 +118,12 @@ def pmc_traffic(scene, fused):
     if not os.path.exists(path):
         return None, None
     try:
-        d = json.load(open(path))["counters_per_dispatch_of_dominant_kernel"]     # profiles/collect_cli.sh + summarise_cli.py: KB per dispatch
+        summary = json.load(open(path))
+        d = summary["counters_per_dispatch_of_dominant_kernel"]     # profiles/collect_cli.sh + summarise_cli.py: KB per dispatch
+        same = summary.get("source_id") is not None and summary.get("source_id") == source_id()
         return round((2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0, 1), \
-            "committed profile profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the CLI on the same build and window; FETCH_SIZE x2 on gfx950; not this run)"
+            "committed profile profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the CLI on the same window; FETCH_SIZE x2 on gfx950; not this run; " + \
+            ("collected on these very sources: source_id matches)" if same else "collected on EARLIER sources: source_id differs)")
     except Exception:
         return None, None
 
@@ -498,8 +513,64 @@ def main():
         except Exception as e:
             return {"error": repr(e)}
 
+    def fast_line(nscene, npresim, k3):
+        """The same scene in the fast sweep (option "sweep" = 1: multi-colour Gauss-Seidel, tree-reduced sums), driver-timed like the
+        exact lines, with a roofline object of its own (same byte model) and the tolerance it is held to, MEASURED here: one step
+        of the fast mode against one step of the exact mode from the same state at the end of the timed window."""
+        try:
+            import harness as H
+            w3 = pkg.World(local_rank)
+            w3.scene(nscene)
+            w3.set_option("sweep", 1)
+            w3.step(npresim)
+            w3.synchronize()
+            t0 = time.perf_counter()
+            w3.step(k3)
+            w3.synchronize()
+            t3 = time.perf_counter() - t0
+            st3 = w3.stats()
+            plan = w3.fast_plan_info()
+            out = {"workload": f"{nscene} (iterations={int(w3.params()['iterations'])}) steady window: steps {npresim}..{npresim + k3}, fast sweep from step 0",
+                   "mode": "fast (option sweep = 1 / --mode fast: multi-colour Gauss-Seidel, DPP tree sums; within the stated tolerance of the exact mode, not bit-identical)",
+                   "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
+                   "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"]), "colours": plan["colors"], "tiles": plan["tiles"]}
+            w3.profile_enable(True); w3.profile_reset(); w3.step(20); w3.synchronize(); p3 = w3.profile(); w3.profile_enable(False)
+            if p3["launches_primal"] > 0 and p3["ms_primal"] > 0:
+                s3 = p3["ms_primal"] * 1e-3 / p3["launches_primal"]
+                b3 = p3["algorithmic_bytes_primal"] / p3["launches_primal"]
+                t3r, t3s = pmc_traffic("fast:" + nscene, True)
+                chain = plan["colors"] * int(w3.params()["iterations"])
+                out["roofline"] = {"bound": "hbm", "limited_by": "dependency latency: colours x iterations dependent body solves per step", "kernel": "k_fast_sweep",
+                                   "achieved": round(b3 / s3 / 1e9, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(b3 / s3 / 1e9 / 8000.0, 6),
+                                   "traffic": t3r, "traffic_source": t3s, "bytes_per_launch": round(b3, 1), "us_per_launch": round(s3 * 1e6, 3),
+                                   "dependency_chain": {"sequential_body_solves_per_step": chain, "us_per_solve_and_handoff": round(s3 * 1e6 / max(1, chain), 3)},
+                                   "kernel_ms_per_step": {k[3:]: round(float(p3[k]) / max(1, p3["steps"]), 4) for k in
+                                                          ("ms_broadphase", "ms_narrowphase", "ms_topology", "ms_predict", "ms_primal", "ms_dual", "ms_velocity")}}
+            # the tolerance, measured: fork the state, one step exact, one step fast
+            b, f, si = w3.bodies(), w3.forces(), w3.step_index()
+            we = pkg.World(local_rank); we.scene(nscene); we.set_bodies(b); we.set_forces(f); we.set_step_index(si)
+            wf = pkg.World(local_rank); wf.scene(nscene); wf.set_option("sweep", 1); wf.set_bodies(b); wf.set_forces(f); wf.set_step_index(si)
+            we.step(1); wf.step(1)
+            be, bf = we.bodies(), wf.bodies()
+            dp = float(np.linalg.norm(be["position"].astype(np.float64) - bf["position"].astype(np.float64), axis=1).max())
+            dq = np.abs(np.sum(be["orientation"].astype(np.float64) * bf["orientation"].astype(np.float64), axis=1))
+            dr = float((2.0 * np.arccos(np.clip(dq, 0.0, 1.0))).max())
+            big = int(st3["numBodies"]) > 2000
+            out["tolerance"] = {"criterion": "one step of the fast sweep against one step of the exact mode (= the reference, bit for bit) from the same state: max |dpos| over the bodies in metres, max rotation angle in radians (DESIGN.md section 2b)",
+                                "bound": {"dpos_m": 0.1 if big else 1e-3, "drot_rad": 0.3 if big else 5e-3,
+                                          "why": "a pile still in motion (violent-phase bound)" if big else "a settled pile (steady-state bound)"},
+                                "measured": {"dpos_m": dp, "drot_rad": dr}, "within_bound": bool(dp <= (0.1 if big else 1e-3) and dr <= (0.3 if big else 5e-3))}
+            we.close(); wf.close(); w3.close()
+            return out
+        except Exception as e:
+            return {"error": repr(e)}
+
     strong_n1 = roofline_8k = joints_n1 = None
+    fast_1000 = fast_8k = fast_64k = None
     if rank == 0 and not sharded and args.scene is None and not args.no_strong_n1:
+        fast_1000 = fast_line("Stress1000", 420, 200)
+        fast_8k = fast_line("StressN:20", 410, 50)
+        fast_64k = fast_line(STRONG_SCENE, STRONG_PRESIM + 10, 50)
         strong_n1 = nested_line(STRONG_SCENE, STRONG_PRESIM + 10, 50)
         roofline_8k = nested_line("StressN:20", 410, 50)
         # BASELINE configs[4]'s scene on this one GPU: 64 000 cubes + 10 000 weld Joints between x-neighbours (host/scenes.h "+welds:<k>"); the Joint rows run in
@@ -523,6 +594,7 @@ def main():
                                        f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene"),
                        "shard_form": shard_form, "shard_other_form": shard_other,
                        "strong_scaling_n1": strong_n1, "roofline_8k": roofline_8k, "joints_n1": joints_n1,
+                       "fast_1000": fast_1000, "fast_8k": fast_8k, "fast_64k": fast_64k,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
                        "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
                        "whole_run_from_scratch": whole},

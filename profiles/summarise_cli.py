@@ -21,6 +21,14 @@ def short(name):
     return head.split("::")[-1] if "::" in head else head.split(" ")[-1]
 
 S = {"tag": tag}
+try:   # what the profile was collected on: sha256 over the library's sources (tools/source_id.py) and the size of the binary that ran
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import source_id as SID
+    S["source_id"] = SID.source_id()
+    S["library_bytes"] = os.path.getsize(os.path.join(SID.ROOT, "avbd-demo3d_amd", "libavbd_hip.so"))
+    S["cli_flags"] = os.environ.get("AVBD_CLI_EXTRA", "")
+except Exception as e:
+    S["source_id"] = None
 for n in ("presim", "plain", "trace"):
     p = os.path.join(src, n + ".json")
     if os.path.exists(p):

@@ -135,7 +135,7 @@ def test_run_to_run_bit_identical():
     assert same_state(a, b)
 
 
-@pytest.mark.parametrize("recolor", [0, 1])
+@pytest.mark.parametrize("recolor", [1, 3, 1 << 20])
 def test_the_colouring_is_proper(recolor):
     """no two bodies that share a force share a colour; every swept body has one — with colours kept from step to step and with a fresh colouring every step"""
     g = fast_world("Stress1000", fast_recolor=recolor)
