@@ -283,6 +283,7 @@ struct AvbdContext {
     int fastPlanPerCU = 0, fastSweepPerCU = 0, numCU = 1;
     bool capFast = false;
     unsigned fastSerial = 0;
+    bool fastStepDeclined = false;      /* sharded: the plan of the current step declined it (read back once per step) */
     bool fastLaunched = false;          /* the iteration loop of the last step was offered to the fast sweep */
     DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fPos, fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<float4> fSlotC, fBodyC, fXpose, fXL, fXP; DevArr<unsigned> fSync;
     int fTileCap = 0, fBodyCap = 0, fMCap = 0;
@@ -858,7 +859,7 @@ int step_once(AvbdContext* c)
         if (!c->comm) return c->fail(AVBD_E_COMM, "context is sharded (avbd_set_ownership) but has no communicator: call avbd_comm_init or drive it through avbd_group_step");
         bool persistent = false;
         c->shardRanPersistent = false;
-        if ((rc = shard_plan_accepted(c, persistent))) return rc;
+        if (!fast_eligible(c) && (rc = shard_plan_accepted(c, persistent))) return rc;   /* (the fast sweep: one launch per iteration, the collective between the launches) */
         c->cutModeRan = persistent ? 2 : 1;
         if (persistent) {
             /* ONE launch for the whole loop; the exchange runs beside it on the second stream: wait until this rank has finished
@@ -877,7 +878,7 @@ int step_once(AvbdContext* c)
             return rccl_exchange_velocities(c);
         }
         for (int it = 0; it < totalIt; ++it) {
-            if ((rc = step_iterate(c, it, it + 1))) return rc;
+            if ((rc = step_iterate_any(c, it, it + 1))) return rc;
             if ((rc = step_pack(c))) return rc;
             if ((rc = rccl_allgather(c))) return rc;
             if ((rc = step_unpack(c))) return rc;

@@ -251,3 +251,71 @@ def test_fast_sweep_at_full_size(scene, at, band):
     assert abs(int(df["activeContacts"]) / int(de["activeContacts"]) - 1.0) <= band and abs(int(df["activeManifolds"]) / int(de["activeManifolds"]) - 1.0) <= band
     b = f.bodies()
     assert np.isfinite(b["pos"]).all() and np.isfinite(b["quat"]).all()
+
+
+# ---- sharded: the all-gather form on top of the fast sweep (BASELINE configs[3]) -------------------------------------------
+def _ranks(scene, n, **opts):
+    pkg = H.load_product()
+    worlds = [H.HipWorld() for _ in range(n)]
+    for w in worlds:
+        w.scene(scene); w.w.set_option("sweep", 1)
+        for k, v in opts.items():
+            w.w.set_option(k, v)
+    b = worlds[0].bodies()
+    owner = pkg.partition_by_axis(b["pos"], b["invMass"], n, axis=0)
+    for r, w in enumerate(worlds):
+        w.w.set_ownership(n, r, owner)
+    return pkg, worlds
+
+
+def test_one_rank_per_iteration_launches_equal_the_single_launch_bit_for_bit():
+    """force_sharded: one rank that owns every body runs the sharded schedule — one launch of k_fast_sweep per iteration, pack / exchange / unpack between them —
+    and must reproduce the one-launch sweep exactly: the stamps of the pose and contact records carry over from launch to launch"""
+    pkg = H.load_product()
+    a = fast_world("Stress1000"); a.step(180)
+    b = fast_world("Stress1000", force_sharded=1)
+    b.w.set_ownership(1, 0, np.where(b.bodies()["invMass"] > 0, 0, -1).astype(np.int32))
+    pkg.group_step([b.w], 180)
+    assert int(b.w.stats()["schedule"]) == 5
+    assert same_state(a, b)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_sharded_fast_sweep_stays_in_the_band_of_the_one_gpu_run(n):
+    """n x-slabs of Stress1000 on one device (avbd_group_step: device copies where one process per GPU runs the RCCL all-gather), Jacobi across the cuts:
+    every rank holds the same poses after every step (they all gather the same rows), the pile forms like the one-GPU fast run's — contacts within 8 %,
+    manifolds within 10 % over steps 250..350 — and every rank ran the fast sweep"""
+    pkg, worlds = _ranks("Stress1000", n)
+    one = fast_world("Stress1000")
+    pkg.group_step([w.w for w in worlds], 250); one.step(250)
+    for s in range(5):
+        pkg.group_step([w.w for w in worlds], 20); one.step(20)
+        b0 = worlds[0].bodies()
+        for w in worlds[1:]:
+            assert H.same_bits(b0["pos"], w.bodies()["pos"]) and H.same_bits(b0["quat"], w.bodies()["quat"])
+        assert np.isfinite(b0["pos"]).all()
+        # a contact lives on every rank that sweeps one of its bodies: count each once, by the rank that owns its first swept endpoint... the diagnostics of a rank
+        # cover the forces it holds, so compare the union through the body state instead: re-derive the contact count on one context from the gathered poses
+        d1 = one.diag()
+        tot_c = sum(int(w.diag()["activeContacts"]) for w in worlds); tot_m = sum(int(w.diag()["activeManifolds"]) for w in worlds)
+        # cut forces are held by two ranks: the sum over the ranks lies between the one-GPU count and that count plus the cut forces
+        assert 0.92 * int(d1["activeContacts"]) <= tot_c <= 1.25 * int(d1["activeContacts"]), (tot_c, int(d1["activeContacts"]))
+        assert 0.90 * int(d1["activeManifolds"]) <= tot_m <= 1.25 * int(d1["activeManifolds"]), (tot_m, int(d1["activeManifolds"]))
+    for w in worlds:
+        st = w.w.stats()
+        assert int(st["schedule"]) == 5 and int(st["cutMode"]) == 1
+
+
+def test_rccl_single_rank_fast_sweep_is_the_single_launch_bit_for_bit():
+    """the one-process-per-GPU path (RCCL communicator, ncclAllGather of 32 B per body between the per-iteration launches of k_fast_sweep) with one rank:
+    the same bits as the one-launch sweep"""
+    pkg = H.load_product()
+    g = fast_world("Pyramid", force_sharded=1)
+    b = g.bodies()
+    g.w.set_ownership(1, 0, np.where(b["invMass"] > 0, 0, -1).astype(np.int32))
+    g.w.comm_init(1, 0, pkg.comm_unique_id())
+    a = fast_world("Pyramid")
+    for s in range(3):
+        g.step(15); a.step(15)
+        assert same_state(a, g), f"after {15 * (s + 1)} steps"
+    assert int(g.w.stats()["schedule"]) == 5
