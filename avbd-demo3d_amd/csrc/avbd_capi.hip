@@ -286,7 +286,7 @@ struct AvbdContext {
     bool fastStepDeclined = false;      /* sharded: the plan of the current step declined it (read back once per step) */
     bool fastLaunched = false;          /* the iteration loop of the last step was offered to the fast sweep */
     DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fPos, fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<float4> fSlotC, fBodyC, fXpose, fXL, fXP; DevArr<unsigned> fSync;
-    int fTileCap = 0, fBodyCap = 0, fMCap = 0;
+    int fTileCap = 0, fBodyCap = 0, fMCap = 0, fGCap = 0;
     Readback* hRb = nullptr; /* pinned */
     AvbdStepStats stats{};
     int lastLevels = 0;

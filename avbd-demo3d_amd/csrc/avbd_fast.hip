@@ -36,7 +36,8 @@ constexpr int kSweepThreads = 512, kSweepThreadsLat = 256;
 constexpr int kFastLatTilesPerWave = 4;        /* the latency form up to this many tiles per wave (measured: it wins up to ~6 000 tiles = 32 000 cubes) */
 constexpr unsigned long long kFastTimeoutTicks = 400000000ull;   /* 4 s of s_memrealtime (100 MHz) */
 
-enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8 };
+enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8,
+             FL_JOINT = 16 /* the lane holds one half (three rows) of a Joint */, FL_PART1 = 32 /* ... its angular half */, FL_WORLD = 64 /* ... whose bodyA is the world */, FL_FIXANG = 128 /* avbd_set_joint_angular_sign */ };
 
 __host__ __device__ constexpr int fast_class_lanes(int cls) { return cls == 0 ? 1 : (4 << cls); }
 __device__ __forceinline__ int fast_class_of(int deg) { return deg == 0 ? 0 : (deg <= 8 ? 1 : (deg <= 16 ? 2 : (deg <= 32 ? 3 : 4))); }
@@ -428,6 +429,26 @@ __global__ __launch_bounds__(256) void k_fast_fill(FastLaunch L)
                         F.xL[s] = make_float4(lam.x, lam.y, lam.z, __int_as_float(stick));
                         F.xP[s] = make_float4(pen.x, pen.y, pen.z, __int_as_float(0));
                     }
+                } else if (inc_kind(ent) == FK_JOINT) {
+                    /* one half of a Joint (joint.cpp:68-139): rows 0-2 (anchor) or 3-5 (orientation) */
+                    const int idx = inc_index(ent), g = idx >> 1, part = idx & 1;
+                    const bool isA = inc_isA(ent) != 0;
+                    const GForce& jf = F.gf[g];
+                    const int other = isA ? jf.bodyB : jf.bodyA;
+                    const bool world = other < 0;
+                    const bool otherSwept = !world && B.solved[other] != 0;
+                    const bool first = !otherSwept || F.color[body] < F.color[other];
+                    const float* rO = isA ? jf.rA : jf.rB; const float* rT = isA ? jf.rB : jf.rA;
+                    c0 = make_float4(rO[0], rO[1], rO[2], jf.stiffness[3 * part + 0]);
+                    c1 = make_float4(rT[0], rT[1], rT[2], jf.stiffness[3 * part + 1]);
+                    c2 = make_float4(jf.q0[0], jf.q0[1], jf.q0[2], jf.stiffness[3 * part + 2]);
+                    c3 = make_float4(jf.q0[3], jf.motor[3 * part + 0], jf.motor[3 * part + 1], jf.motor[3 * part + 2]);
+                    partner = other; slot = F.jointSlotBase + idx;
+                    flags = FL_VALID | FL_JOINT | (part ? FL_PART1 : 0) | (world ? FL_WORLD : 0) | ((jf.pad & 1) ? FL_FIXANG : 0) | (isA ? FL_ISA : 0) | (first ? FL_FIRST : 0) | (otherSwept ? 0 : FL_SOLE);
+                    if (first) {
+                        F.xL[slot] = make_float4(jf.lambda[3 * part + 0], jf.lambda[3 * part + 1], jf.lambda[3 * part + 2], __int_as_float(0));
+                        F.xP[slot] = make_float4(jf.penalty[3 * part + 0], jf.penalty[3 * part + 1], jf.penalty[3 * part + 2], __int_as_float(0));
+                    }
                 }
             }
         }
@@ -538,6 +559,57 @@ __device__ unsigned gFastTimes[kFastStatTiles * kFastStatIts * 4];     /* per (t
 #define FAST_STAMP(k) do { } while (0)
 #endif
 
+/* One half of a Joint for one endpoint (joint.cpp:68-139; rows 3p .. 3p + 2): computeConstraint (no alpha, no mutation: C alone), the dual update of the
+ * previous iteration when this is the joint's first visitor (solver.cpp:411-430 with the two-endpoint rowPenaltyGain :94-125), computeDerivatives for THIS
+ * endpoint and the row forces (solver.cpp:379-381 with the rows' stiffness and motor).  Bug-compatible angular Jacobian sign unless FL_FIXANG. */
+struct FastJointOut { f3 Jl[3], Ja[3]; float f[3], C[3]; };
+__device__ __forceinline__ void fast_joint_rows(FastRows& c, FastJointOut& o, int flags, f3 wOwn, f3 pOwn, q4 rot, f3 rOth, f3 opos, q4 orot, q4 q0,
+                                                const float stiff[3], const float motor[3], bool dual, float beta)
+{
+    const bool isA = (flags & FL_ISA) != 0, part1 = (flags & FL_PART1) != 0, world = (flags & FL_WORLD) != 0, fix = (flags & FL_FIXANG) != 0;
+    const bool hasA = !world;
+    const f3 wOth = world ? zero3() : qrotate(orot, rOth);
+    const f3 pOth = world ? rOth : opos + wOth;                      /* bodyA == nullptr: rA is the world anchor (joint.cpp:78-80) */
+    const f3 wA = isA ? wOwn : wOth, wB = isA ? wOth : wOwn;
+    if (!part1) {
+        const f3 lc = isA ? pOwn - pOth : pOth - pOwn;               /* pA - pB */
+        o.C[0] = lc.x; o.C[1] = lc.y; o.C[2] = lc.z;
+    } else {
+        const q4 qA = isA ? rot : (world ? identq() : orot), qB = isA ? orot : rot;
+        const q4 cur = qconj(qA) * qB;
+        const q4 dq = cur * qconj(q0);
+        const f3 ac = mk3(dq.x, dq.y, dq.z) * 2.0f;
+        o.C[0] = ac.x; o.C[1] = ac.y; o.C[2] = ac.z;
+    }
+    const float sign = isA ? 1.0f : -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const f3 ax = mk3(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
+        if (dual && stiff[k] == FLT_MAX) {
+            const float lu = rclamp(c.pen[k] * o.C[k] + c.lam[k], -FLT_MAX, FLT_MAX);
+            const bool active = lu > -FLT_MAX && lu < FLT_MAX;
+            c.lam[k] = lu;
+            if (active) {
+                float lw = 0.0f, aw = 0.0f;
+                if (!part1) {
+                    if (hasA) { lw += lensq3(ax * 1.0f); aw += lensq3(cross3(wA, ax) * 1.0f); }
+                    lw += lensq3(ax * -1.0f); aw += lensq3(cross3(wB, ax) * -1.0f);
+                } else {
+                    if (hasA) { lw += lensq3(zero3()); aw += lensq3(ax * (fix ? -1.0f : 1.0f)); }
+                    lw += lensq3(zero3()); aw += lensq3(ax * (fix ? 1.0f : -1.0f));
+                }
+                const float betaRow = row_penalty_gain(lw, aw, beta);
+                c.pen[k] = rmin(c.pen[k] + betaRow * fabsf(o.C[k]), kPenaltyMax);
+            }
+        }
+        if (!part1) { o.Jl[k] = ax * sign; o.Ja[k] = cross3(wOwn, ax) * sign; }
+        else { o.Jl[k] = zero3(); o.Ja[k] = ax * (fix ? -sign : sign); }
+        const float lw = (stiff[k] == FLT_MAX) ? c.lam[k] : 0.0f;
+        const float desired = c.pen[k] * o.C[k] + lw + motor[k];
+        o.f[k] = rclamp(desired, -FLT_MAX, FLT_MAX);
+    }
+}
+
 struct FastCtx {
     __amdgpu_buffer_rsrc_t rPose, rL, rP;
     const FastBuffers* F;
@@ -546,6 +618,7 @@ struct FastCtx {
     BodyTable B; ManifoldTable M;
     float invDt2, beta;
     int stamps;
+    GForce* gf; int jointSlotBase;
 };
 
 __device__ __forceinline__ float fast_alpha(const SolverParams& P, int it) { return P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha; }
@@ -594,7 +667,7 @@ __device__ __forceinline__ f3 solve_ldlt3_quadlanes(m33 A, f3 b, int c)
  * sweeps) — everything they read was published in the previous iteration, and they run the dual update of that iteration —, then the contacts whose
  * partner has already moved in this iteration.  Only the second pass, the sums, the solve and the publish stand between the arrival of the last pose
  * and this body's own. */
-template <int G, bool TWOPASS, bool HOIST>
+template <int G, bool TWOPASS, bool HOIST, bool JOINTS>
 __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
 {
     const int lane = threadIdx.x & 63;
@@ -680,31 +753,46 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                      * instead of being kept in ninety registers across the wait; the empty asm hides the loop invariance from the compiler) */
                     asm volatile("" : "+v"(wOwnP.x), "+v"(wOwnP.y), "+v"(wOwnP.z), "+v"(signP));
                 }
-                if (sole) {                                           /* a partner this context does not sweep: its pose is in the body table (fixed during the launch) */
+                const bool isJoint = JOINTS && (flags & FL_JOINT) != 0;
+                if (sole && !(JOINTS && (flags & FL_WORLD) != 0)) {   /* a partner this context does not sweep: its pose is in the body table (fixed during the launch) */
                     const float4 pp = X.B.plane(BP_POSR)[partner], pq = X.B.plane(BP_QUAT)[partner];
                     opos = mk3(pp.x, pp.y, pp.z); orot = mkq(pq.x, pq.y, pq.z, pq.w);
                 }
                 FastRows c;
                 c.lam[0] = uf(sl.x); c.lam[1] = uf(sl.y); c.lam[2] = uf(sl.z); c.stick = (sl.w & 1u) != 0;
                 c.pen[0] = uf(sp.x); c.pen[1] = uf(sp.y); c.pen[2] = uf(sp.z);
-                const f3 wOth = qrotate(orot, rOth);
-                const f3 pOth = opos + wOth;
-                const f3 pA = isA ? pOwn : pOth, pB = isA ? pOth : pOwn;
-                if (first && it > 0) {
-                    /* the dual update of iteration it - 1 (solver.cpp:411-430), by the force's first visitor of iteration it: no pose has
-                     * changed since the sweep of it - 1 ended */
-                    const float bs = rclamp(1.0f - fast_alpha(P, it - 1), 0.0f, 1.0f);
-                    fast_dual(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, isA ? wOwnP : wOth, pB, isA ? wOth : wOwnP, fric, X.beta);
+                f3 rowJl[3], rowJa[3]; float rowF[3];
+                if (!isJoint) {
+                    const f3 wOth = qrotate(orot, rOth);
+                    const f3 pOth = opos + wOth;
+                    const f3 pA = isA ? pOwn : pOth, pB = isA ? pOth : pOwn;
+                    if (first && it > 0) {
+                        /* the dual update of iteration it - 1 (solver.cpp:411-430), by the force's first visitor of iteration it: no pose has
+                         * changed since the sweep of it - 1 ended */
+                        const float bs = rclamp(1.0f - fast_alpha(P, it - 1), 0.0f, 1.0f);
+                        fast_dual(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, isA ? wOwnP : wOth, pB, isA ? wOth : wOwnP, fric, X.beta);
+                    }
+                    const float bs = rclamp(1.0f - fast_alpha(P, it), 0.0f, 1.0f);
+                    fast_constraint(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, pB, fric);
+                    const float sign = signP;
+                    const f3 basis[3] = {n, t1, t2};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        rowJl[k] = basis[k] * sign; rowJa[k] = cross3(wOwnP, basis[k]) * sign;   /* manifold.cpp:265-270 */
+                        const float desired = c.pen[k] * c.C[k] + c.lam[k] + 0.0f;             /* solver.cpp:379-381: stiffness FLT_MAX, motor 0 */
+                        rowF[k] = rclamp(desired, c.fmin[k], c.fmax[k]);
+                    }
+                } else {
+                    FastJointOut jo;
+                    const float stiff[3] = {c0.w, c1.w, c2.w}, motor[3] = {c3.y, c3.z, c3.w};
+                    fast_joint_rows(c, jo, flags, wOwnP, pos + wOwnP, rot, rOth, opos, orot, mkq(c2.x, c2.y, c2.z, c3.x), stiff, motor, first && it > 0, X.beta);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { rowJl[k] = jo.Jl[k]; rowJa[k] = jo.Ja[k]; rowF[k] = jo.f[k]; }
                 }
-                const float bs = rclamp(1.0f - fast_alpha(P, it), 0.0f, 1.0f);
-                fast_constraint(c, n, t1, t2, bs * c0.w, bs * c1.w, bs * c2.w, cap, pA, pB, fric);
-                const float sign = signP;
-                const f3 basis[3] = {n, t1, t2};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const f3 Jl = basis[k] * sign, Ja = cross3(wOwnP, basis[k]) * sign;     /* manifold.cpp:265-270 */
-                    const float desired = c.pen[k] * c.C[k] + c.lam[k] + 0.0f;             /* solver.cpp:379-381: stiffness FLT_MAX, motor 0 */
-                    const float f = rclamp(desired, c.fmin[k], c.fmax[k]);
+                    const f3 Jl = rowJl[k], Ja = rowJa[k];
+                    const float f = rowF[k];
                     const float pen = c.pen[k];
                     const bool penOk = (pen > 0.0f) && (fabsf(pen) <= FLT_MAX);
                     const float J6[6] = {Jl.x, Jl.y, Jl.z, Ja.x, Ja.y, Ja.z};
@@ -720,8 +808,10 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                             for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
                         acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
                         acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
-                        const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);            /* solver.cpp:393-397 */
-                        acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
+                        if (!isJoint) {
+                            const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only */
+                            acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
+                        }
                     }
                 }
                 /* the visit's mutations of the force (lambda cone clamp, stick; after a dual also lambda_n and the penalties); every record
@@ -800,6 +890,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
 
 /* After the last iteration: the dual update of that iteration (when the reference runs one: it < iterations) by the first
  * visitors, and the write-back of every contact's rows into the Manifold table. */
+template <bool JOINTS>
 __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams& P, int t, int2 td, int totalIt)
 {
     const int lane = threadIdx.x & 63;
@@ -836,7 +927,7 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
         }
     }
     if (!mine) return;
-    if (sole) {
+    if (sole && !(JOINTS && (flags & FL_WORLD) != 0)) {
         const float4 pp = X.B.plane(BP_POSR)[partner], pq = X.B.plane(BP_QUAT)[partner];
         opos = mk3(pp.x, pp.y, pp.z); orot = mkq(pq.x, pq.y, pq.z, pq.w);
     }
@@ -844,6 +935,20 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
     c.lam[0] = uf(sl.x); c.lam[1] = uf(sl.y); c.lam[2] = uf(sl.z); c.stick = (sl.w & 1u) != 0;
     c.pen[0] = uf(sp.x); c.pen[1] = uf(sp.y); c.pen[2] = uf(sp.z);
     const f3 rOwn = mk3(c0.x, c0.y, c0.z), rOth = mk3(c1.x, c1.y, c1.z);
+    if (JOINTS && (flags & FL_JOINT) != 0) {
+        /* a Joint half: the last dual (solver.cpp:411-430) and the rows back into the GForce record (C / fmin / fmax as the last computeConstraint leaves them, joint.cpp:68-106) */
+        FastJointOut jo;
+        const float stiff[3] = {c0.w, c1.w, c2.w}, motor[3] = {c3.y, c3.z, c3.w};
+        const f3 wOwnJ = qrotate(rot, rOwn);
+        fast_joint_rows(c, jo, flags, wOwnJ, pos + wOwnJ, rot, rOth, opos, orot, mkq(c2.x, c2.y, c2.z, c3.x), stiff, motor, !P.postStabilize, X.beta);
+        const int idx = slot - X.jointSlotBase, part = idx & 1;
+        GForce& jf = X.gf[idx >> 1];
+        for (int k = 0; k < 3; ++k) {
+            jf.lambda[3 * part + k] = c.lam[k]; jf.penalty[3 * part + k] = c.pen[k];
+            jf.C[3 * part + k] = jo.C[k]; jf.fmin[3 * part + k] = -FLT_MAX; jf.fmax[3 * part + k] = FLT_MAX;
+        }
+        return;
+    }
     const f3 n = mk3(c2.x, c2.y, c2.z), t1 = mk3(c3.x, c3.y, c3.z), t2 = mk3(c4.x, c4.y, c4.z);
     const f3 wOwn = qrotate(rot, rOwn), wOth = qrotate(orot, rOth);
     const f3 pOwn = pos + wOwn, pOth = opos + wOth;
@@ -871,24 +976,24 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
     M.cFmax[slot] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
 }
 
-template <int FORM>
+template <int FORM, bool JOINTS>
 __device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
 {
     constexpr bool TWOPASS = FORM != 0, HOIST = FORM == 1;
     const int cls = __builtin_amdgcn_readfirstlane((td.y >> 16) & 0xFF);
     switch (cls) {
-    case 0: fast_visit<1, false, false>(X, P, t, td, it, lastOfLaunch); break;
-    case 1: fast_visit<8, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
-    case 2: fast_visit<16, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
-    case 3: fast_visit<32, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
-    default: fast_visit<64, TWOPASS, HOIST>(X, P, t, td, it, lastOfLaunch); break;
+    case 0: fast_visit<1, false, false, false>(X, P, t, td, it, lastOfLaunch); break;
+    case 1: fast_visit<8, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
+    case 2: fast_visit<16, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
+    case 3: fast_visit<32, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
+    default: fast_visit<64, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
     }
 }
 
 /* FORM 1: the latency form — workgroups of four waves, one wave per SIMD with the whole register file, contacts in two passes (what can be
  * evaluated before the last pose arrives is), everything that depends on the body's own pose alone kept across the wait; FORM 2: two passes, eight
  * waves per workgroup (two per SIMD), nothing kept across the wait; FORM 0: one pass, eight waves per workgroup. */
-template <int FORM>
+template <int FORM, bool JOINTS>
 __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void k_fast_sweep(FastLaunch L)
 {
     constexpr int kWaves = (FORM == 1 ? kSweepThreadsLat : kSweepThreads) / 64;
@@ -902,7 +1007,7 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     FastCtx X;
     X.rPose = frsrc(F.xpose); X.rL = frsrc(F.xL); X.rP = frsrc(F.xP);
     X.F = &F; X.plan = plan; X.cnt = L.cnt; X.B = L.B; X.M = L.M;
-    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps;
+    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps; X.gf = F.gf; X.jointSlotBase = F.jointSlotBase;
     const SolverParams P = L.P;
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     unsigned target = L.syncBase;
@@ -914,13 +1019,13 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
             const int t0 = plan->colorTileStart[c], t1 = plan->colorTileStart[c + 1];
             /* this wave's tiles of the colour: t = gw (mod W) */
             int t = t0 + ((gw - t0) % W + W) % W;
-            for (; t < t1; t += W) fast_visit_any<FORM>(X, P, t, F.tiles[t], it, it == L.itEnd - 1);
+            for (; t < t1; t += W) fast_visit_any<FORM, JOINTS>(X, P, t, F.tiles[t], it, it == L.itEnd - 1);
             if (!L.stamps) fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
         }
     }
     if (L.finalPass) {
         if (L.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int t = gw; t < T; t += W) fast_final(X, P, t, F.tiles[t], totalIt);
+        for (int t = gw; t < T; t += W) fast_final<JOINTS>(X, P, t, F.tiles[t], totalIt);
     }
 }
 
@@ -940,12 +1045,10 @@ int fast_query(int device, int* planBlocksPerCU, int* sweepBlocksPerCU)
     (void)device;
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fast_plan<false>, kPlanThreads, 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_fast_sweep<0>, kSweepThreads, 0) != hipSuccess) b = 0;
-    int bl = 0, bm = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bl, k_fast_sweep<1>, kSweepThreadsLat, 0) != hipSuccess) bl = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bm, k_fast_sweep<2>, kSweepThreads, 0) != hipSuccess) bm = 0;
-    b = std::min(b, bm);
-    if (bl < 1) b = 0;
+    auto occ = [](const void* fn, int threads) { int v = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, threads, 0) != hipSuccess) v = 0; return v; };
+    b = std::min(std::min(occ((const void*)k_fast_sweep<0, false>, kSweepThreads), occ((const void*)k_fast_sweep<2, false>, kSweepThreads)),
+                 std::min(occ((const void*)k_fast_sweep<0, true>, kSweepThreads), occ((const void*)k_fast_sweep<2, true>, kSweepThreads)));
+    if (occ((const void*)k_fast_sweep<1, false>, kSweepThreadsLat) < 1 || occ((const void*)k_fast_sweep<1, true>, kSweepThreadsLat) < 1) b = 0;
     if (planBlocksPerCU) *planBlocksPerCU = a;
     if (sweepBlocksPerCU) *sweepBlocksPerCU = b;
     return (a > 0 && b > 0) ? 1 : 0;
@@ -970,7 +1073,8 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& L, int sweepB
     /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
     const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
     /* measured (sweep us, forms 1 / 2 / 3): 13 824 cubes 585 / 671 / 915, 32 768 cubes 955 / 884 / 1056, 64 000 cubes 1534 / 1170 / 1123 */
-    const int f = form != 0 ? form : (tilesGuess <= (long long)kFastLatTilesPerWave * 4 * L.numCU ? 1 : (tilesGuess <= (long long)9 * 4 * L.numCU ? 2 : 3));
+    int f = form != 0 ? form : (tilesGuess <= (long long)kFastLatTilesPerWave * 4 * L.numCU ? 1 : (tilesGuess <= (long long)9 * 4 * L.numCU ? 2 : 3));
+    if (L.joints != 0 && f == 2) f = 3;                                /* (the joint-aware two-pass kernel at two waves per SIMD spills: 144 B per lane) */
     const bool lat = f == 1;
     const int waves = (lat ? kSweepThreadsLat : kSweepThreads) / 64;
     const int maxWG = lat ? L.numCU : std::max(1, std::min(1024, L.numCU * std::max(1, sweepBlocksPerCU)));
@@ -978,9 +1082,10 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& L, int sweepB
     if (!L.stamps && tilesHint > 0) nWG = (int)(((long long)tilesHint * 5 / 4 + waves - 1) / waves) + 1;   /* (grid barrier: no more workgroups than the tiles need) */
     if (forceBlocks > 0) nWG = forceBlocks;
     nWG = std::max(1, std::min(maxWG, nWG));
-    if (lat) hipLaunchKernelGGL(k_fast_sweep<1>, dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L);
-    else if (f == 2) hipLaunchKernelGGL(k_fast_sweep<2>, dim3(nWG), dim3(kSweepThreads), 0, stream, L);
-    else hipLaunchKernelGGL(k_fast_sweep<0>, dim3(nWG), dim3(kSweepThreads), 0, stream, L);
+    const bool joints = L.joints != 0;                                 /* (the joint-aware code is a kernel of its own: the contacts-only kernels keep their registers) */
+    if (lat) { if (joints) hipLaunchKernelGGL((k_fast_sweep<1, true>), dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<1, false>), dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L); }
+    else if (f == 2) { if (joints) hipLaunchKernelGGL((k_fast_sweep<2, true>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<2, false>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); }
+    else { if (joints) hipLaunchKernelGGL((k_fast_sweep<0, true>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<0, false>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); }
     return hipGetLastError();
 }
 

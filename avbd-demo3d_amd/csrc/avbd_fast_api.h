@@ -53,9 +53,11 @@ struct FastBuffers {
     float4* slotC;      /* [kFastSlotPlanes][slotCap] per-lane incidence constants, slot = tile * 64 + lane */
     float4* bodyC;      /* [kFastBodyPlanes][bodyCap] per-body constants by cbody position */
     float4* xpose;      /* [2 * bodyCap] stamped pose records of the swept bodies */
-    float4* xL;         /* [4 * mCap] (lambda n t1 t2, visit << 1 | stick) per contact slot */
-    float4* xP;         /* [4 * mCap] (penalty n t1 t2, stamp) */
+    float4* xL;         /* [4 * mCap + 2 * gCap] (lambda n t1 t2, visit << 1 | stick) per contact slot */
+    float4* xP;         /* [4 * mCap + 2 * gCap] (penalty n t1 t2, stamp) */
     unsigned* sync;     /* [kFastSyncWords] */
+    GForce* gf;         /* Joint records (kind FK_JOINT); a joint half's state records sit behind the contacts': slot jointSlotBase + 2 * g + part */
+    int jointSlotBase;
     int tileCap, slotCap, bodyCap, mCap;
 };
 
@@ -69,6 +71,7 @@ struct FastLaunch {
     int finalPass;          /* after the last iteration: the last dual + the write-back into the Manifold / body tables */
     int stamps;             /* 1: waves wait on the stamps of the records they read; 0: grid barrier per colour */
     int numCU;
+    int joints;             /* the scene has Joint forces: the joint-aware kernels */
     int reuse;              /* k_fast_plan: colorPrev holds last step's colouring of the same bodies */
 };
 

@@ -319,3 +319,91 @@ def test_rccl_single_rank_fast_sweep_is_the_single_launch_bit_for_bit():
         g.step(15); a.step(15)
         assert same_state(a, g), f"after {15 * (s + 1)} steps"
     assert int(g.w.stats()["schedule"]) == 5
+
+
+# ---- Joints as lane entries of the fast sweep (joint.cpp:68-139; BASELINE configs[4]) --------------------------------------------------------------------
+def test_fast_sweep_world_anchored_joints_match_the_exact_mode_to_rounding():
+    """bodies pinned to the world (hard, finite angular stiffness, finite linear stiffness; anchors violated by up to 0.5 m; both angular signs): every body is alone in
+    its colour class chain — one swept endpoint per joint — so the fast sweep runs the exact mode's sequence per body and per force (computeConstraint, dual,
+    computeConstraint) and only the order of the row sums differs: 20 steps stay within 2e-4 m / 2e-3 rad, the Joint rows within 0.5 % of their scale"""
+    def build(w):
+        w.scene("Empty")
+        ids = []
+        for k in range(6):
+            b = w.add_body((1.0, 0.6 + 0.1 * k, 0.8), 1.0 + 0.3 * k, 0.5, (2.0 * k, 3.0, 0.0), quat=(0.0, 0.1 * k, 0.0, float(np.sqrt(1.0 - 0.01 * k * k))), lin=(0.1 * k, 0.0, 0.2))
+            ids.append(b)
+        w.add_joint(-1, ids[0], (0.0, 3.5, 0.0), (0.0, 0.3, 0.0))
+        w.add_joint(-1, ids[1], (2.3, 3.2, 0.1), (0.2, 0.2, 0.0), ang_stiff=500.0)
+        w.add_joint(-1, ids[2], (4.0, 3.4, -0.2), (0.0, 0.35, 0.1), lin_stiff=3000.0)
+        w.add_joint(-1, ids[3], (6.1, 3.3, 0.0), (0.1, 0.3, 0.0), lin_stiff=5000.0, ang_stiff=50.0)
+        w.add_joint(-1, ids[4], (8.0, 3.6, 0.3), (0.0, 0.3, 0.0))
+        w.add_joint(-1, ids[4], (8.4, 3.0, 0.0), (0.4, 0.0, 0.0), ang_stiff=0.0)       # two joints on one body
+    for sign in (0, 1):
+        e = H.HipWorld(); build(e); e.w.set_joint_angular_sign(sign)
+        f = H.HipWorld(); build(f); f.w.set_option("sweep", 1); f.w.set_joint_angular_sign(sign)
+        for s in range(4):
+            e.step(5); f.step(5)
+            assert int(f.w.stats()["schedule"]) == 5, int(f.w.stats()["schedule"])
+            dp, dr = body_diff(e.bodies(), f.bodies())
+            assert dp <= 2e-4 and dr <= 2e-3, (sign, s, dp, dr)
+            fe, ff = e.forces(), f.forces()
+            assert np.array_equal(fe["kind"], ff["kind"]) and (fe["kind"] == 1).sum() == 6
+            for name in ("lambda", "penalty", "C"):
+                x, y = fe[name][:, :6].astype(np.float64), ff[name][:, :6].astype(np.float64)
+                assert np.abs(x - y).max() <= 5e-3 * max(1.0, np.abs(x).max()), (sign, s, name, np.abs(x - y).max(), np.abs(x).max())
+
+
+def test_fast_sweep_with_body_body_joints_one_step_against_the_exact_mode():
+    """a body-body weld and a chain through a soft joint, corrected angular sign (with the reference's sign a body-body weld turns by 146 degrees in ONE step,
+    SURVEY.md section 7-5, and any two orders of the sweep end metres apart), anchors satisfied at the start: the two endpoints of a joint are visited in colour
+    order instead of creation order — one step within 5e-3 m / 2e-2 rad of the exact mode's, ten steps within 5e-2 m / 0.2 rad"""
+    def build(w):
+        w.scene("Ground")
+        a = w.add_body((1, 1, 1), 1.0, 0.5, (0.0, 2.0, 0.0))
+        b = w.add_body((1, 0.5, 1), 2.0, 0.4, (1.0, 2.0, 0.0))
+        c = w.add_body((0.6, 0.6, 0.6), 1.0, 0.6, (2.0, 2.0, 0.0), lin=(0.2, 0.0, -0.1))
+        w.add_joint(a, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+        w.add_joint(b, c, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0), ang_stiff=300.0)
+    e = H.HipWorld(); build(e); e.w.set_joint_angular_sign(1)
+    f = H.HipWorld(); build(f); f.w.set_option("sweep", 1); f.w.set_joint_angular_sign(1)
+    e.step(); f.step()
+    assert int(f.w.stats()["schedule"]) == 5
+    dp, dr = body_diff(e.bodies(), f.bodies())
+    assert dp <= 5e-3 and dr <= 2e-2, (dp, dr)
+    e.step(9); f.step(9)
+    dp, dr = body_diff(e.bodies(), f.bodies())
+    assert dp <= 5e-2 and dr <= 0.2, (dp, dr)
+
+
+def test_fast_sweep_corrected_sign_welds_hold():
+    """avbd_set_joint_angular_sign(1): welded pairs fall, land and stay rigid in the fast mode like in the exact one (the relative pose of the welded bodies stays
+    within 2 cm / 0.05 rad of its initial value over 200 steps)"""
+    def build(w):
+        w.scene("Ground")
+        ids = []
+        for k in range(6):
+            a = w.add_body((1, 1, 1), 1.0, 0.5, (2.5 * k - 6.0, 2.0 + 0.3 * k, 0.0))
+            b = w.add_body((1, 1, 1), 1.0, 0.5, (2.5 * k - 5.0, 2.0 + 0.3 * k, 0.0))
+            w.add_joint(a, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+            ids.append((a, b))
+        return ids
+    f = H.HipWorld(); ids = build(f); f.w.set_option("sweep", 1); f.w.set_joint_angular_sign(1)
+    f.step(200)
+    assert int(f.w.stats()["schedule"]) == 5
+    b = f.bodies()
+    for a, c in ids:
+        d = np.linalg.norm(b["pos"][a].astype(np.float64) - b["pos"][c].astype(np.float64))
+        assert abs(d - 1.0) <= 0.02, (a, c, d)
+        assert rot_angle(b["quat"][a:a + 1], b["quat"][c:c + 1])[0] <= 0.05
+    assert np.isfinite(b["pos"]).all() and b["pos"][:, 1].min() > -1.0
+
+
+def test_fast_sweep_config5_64000_cubes_with_10k_welds_runs_the_fast_schedule():
+    """BASELINE configs[4] on one GPU in the fast mode: 64 000 cubes + 10 000 weld Joints (bug-compatible sign: the welds blow up, SURVEY.md section 7-5, in every
+    mode) — the step runs schedule 5, stamped and barrier forms agree bit for bit, the state stays finite"""
+    scene = "StressN:40+welds:10000"
+    a = fast_world(scene); b = fast_world(scene, fast_stamps=0)
+    a.step(12); b.step(12)
+    assert int(a.w.stats()["schedule"]) == 5 and int(a.w.stats()["numJoints"]) == 10000
+    assert same_state(a, b)
+    assert np.isfinite(a.bodies()["pos"]).all()
