@@ -285,7 +285,7 @@ struct AvbdContext {
     unsigned fastSerial = 0;
     bool fastStepDeclined = false;      /* sharded: the plan of the current step declined it (read back once per step) */
     bool fastLaunched = false;          /* the iteration loop of the last step was offered to the fast sweep */
-    DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fPos, fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<float4> fSlotC, fBodyC, fXpose, fXL, fXP; DevArr<unsigned> fSync;
+    DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fPos, fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<unsigned long long> fTileMask; DevArr<float4> fSlotC, fBodyC, fXpose, fXS; DevArr<unsigned> fSync;
     int fTileCap = 0, fBodyCap = 0, fMCap = 0, fGCap = 0;
     Readback* hRb = nullptr; /* pinned */
     AvbdStepStats stats{};
@@ -1113,8 +1113,8 @@ int avbd_destroy(AvbdContext* c)
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
-    c->fPlan.release(); c->fColor[0].release(); c->fColor[1].release(); c->fPos.release(); c->fCbody.release(); c->fTiles.release(); c->fSlotC.release(); c->fBodyC.release();
-    c->fXpose.release(); c->fXL.release(); c->fXP.release(); c->fSync.release();
+    c->fPlan.release(); c->fColor[0].release(); c->fColor[1].release(); c->fPos.release(); c->fCbody.release(); c->fTiles.release(); c->fTileMask.release(); c->fSlotC.release(); c->fBodyC.release();
+    c->fXpose.release(); c->fXS.release(); c->fSync.release();
     exact_window_release(c);
     if (c->comm) destroy_comm(c->comm);
     if (c->hRb) (void)hipHostFree(c->hRb);

@@ -426,8 +426,8 @@ __global__ __launch_bounds__(256) void k_fast_fill(FastLaunch L)
                     if (first) {                                      /* the contact's state records start from the Manifold table */
                         const float4 lam = M.cLam[s], pen = M.cPen[s];
                         const int stick = M.cFS[s].y != 0 ? 1 : 0;
-                        F.xL[s] = make_float4(lam.x, lam.y, lam.z, __int_as_float(stick));
-                        F.xP[s] = make_float4(pen.x, pen.y, pen.z, __int_as_float(0));
+                        F.xS[2 * (size_t)s] = make_float4(lam.x, lam.y, lam.z, __int_as_float(stick));
+                        F.xS[2 * (size_t)s + 1] = make_float4(pen.x, pen.y, pen.z, __int_as_float(0));
                     }
                 } else if (inc_kind(ent) == FK_JOINT) {
                     /* one half of a Joint (joint.cpp:68-139): rows 0-2 (anchor) or 3-5 (orientation) */
@@ -446,16 +446,22 @@ __global__ __launch_bounds__(256) void k_fast_fill(FastLaunch L)
                     partner = other; slot = F.jointSlotBase + idx;
                     flags = FL_VALID | FL_JOINT | (part ? FL_PART1 : 0) | (world ? FL_WORLD : 0) | ((jf.pad & 1) ? FL_FIXANG : 0) | (isA ? FL_ISA : 0) | (first ? FL_FIRST : 0) | (otherSwept ? 0 : FL_SOLE);
                     if (first) {
-                        F.xL[slot] = make_float4(jf.lambda[3 * part + 0], jf.lambda[3 * part + 1], jf.lambda[3 * part + 2], __int_as_float(0));
-                        F.xP[slot] = make_float4(jf.penalty[3 * part + 0], jf.penalty[3 * part + 1], jf.penalty[3 * part + 2], __int_as_float(0));
+                        F.xS[2 * (size_t)slot] = make_float4(jf.lambda[3 * part + 0], jf.lambda[3 * part + 1], jf.lambda[3 * part + 2], __int_as_float(0));
+                        F.xS[2 * (size_t)slot + 1] = make_float4(jf.penalty[3 * part + 0], jf.penalty[3 * part + 1], jf.penalty[3 * part + 2], __int_as_float(0));
                     }
                 }
             }
         }
         c5 = make_float4(__int_as_float(partner), __int_as_float(slot), __int_as_float(flags), 0.f);
         const size_t at = (size_t)t * 64 + lane;
-        F.slotC[0 * SC + at] = c0; F.slotC[1 * SC + at] = c1; F.slotC[2 * SC + at] = c2;
-        F.slotC[3 * SC + at] = c3; F.slotC[4 * SC + at] = c4; F.slotC[5 * SC + at] = c5;
+        /* (a wave of this kernel is one tile: the lanes that hold an entry, as a mask beside the tile — the sweep does not load the constants of the others: a
+         * quarter of a settled pile's lanes are padding) */
+        const unsigned long long vm = __ballot((flags & FL_VALID) != 0);
+        if (lane == 0) F.tileMask[t] = vm;
+        if (flags & FL_VALID) {
+            F.slotC[0 * SC + at] = c0; F.slotC[1 * SC + at] = c1; F.slotC[2 * SC + at] = c2;
+            F.slotC[3 * SC + at] = c3; F.slotC[4 * SC + at] = c4; F.slotC[5 * SC + at] = c5;
+        }
     }
 }
 
@@ -611,7 +617,7 @@ __device__ __forceinline__ void fast_joint_rows(FastRows& c, FastJointOut& o, in
 }
 
 struct FastCtx {
-    __amdgpu_buffer_rsrc_t rPose, rL, rP;
+    __amdgpu_buffer_rsrc_t rPose, rS;
     const FastBuffers* F;
     FastPlan* plan;
     Counters* cnt;
@@ -662,28 +668,52 @@ __device__ __forceinline__ f3 solve_ldlt3_quadlanes(m33 A, f3 b, int c)
     return bad ? zero3() : x;
 }
 
+/* what a visit reads that no other wave writes: the tile's descriptor, the lane's constants (only lanes that hold an entry load them), the sub-group's body
+ * constants.  A wave loads the NEXT tile's while it computes the current one (fast_visit's `next`); a wave with one tile loads them once for the launch. */
+struct FastTileRegs { float4 c0, c1, c2, c3, c4, c5, b0, b1, b2, b3; int2 td; int t; };
+template <int GK = 0>   /* GK: the tile's lanes per body when the caller knows them (the descriptor is in R.td already), 0: read the descriptor */
+__device__ __forceinline__ void fast_load_tile(const FastBuffers& F, int t, FastTileRegs& R)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t SC = (size_t)F.slotCap, at = (size_t)t * 64 + lane;
+    R.t = t;
+    if (GK == 0) R.td = F.tiles[t];
+    const int cls = GK == 0 ? ((R.td.y >> 16) & 0xFF) : (GK == 1 ? 0 : 1), G = GK == 0 ? fast_class_lanes(cls) : GK, nb = R.td.y & 0xFFFF;
+    const int j = lane / G;
+    R.c0 = make_float4(0.f, 0.f, 0.f, 0.f); R.c1 = R.c0; R.c2 = R.c0; R.c3 = R.c0; R.c4 = R.c0; R.c5 = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+    if (cls > 0) {
+        const unsigned long long vm = F.tileMask[t];                  /* lanes that hold an entry */
+        if ((vm >> lane) & 1ull) { R.c5 = F.slotC[5 * SC + at]; R.c0 = F.slotC[0 * SC + at]; R.c1 = F.slotC[1 * SC + at]; R.c2 = F.slotC[2 * SC + at]; R.c3 = F.slotC[3 * SC + at]; R.c4 = F.slotC[4 * SC + at]; }
+    }
+    const int bp = R.td.x + (j < nb ? j : 0);
+    R.b0 = F.bodyC[(size_t)0 * F.bodyCap + bp]; R.b1 = F.bodyC[(size_t)1 * F.bodyCap + bp]; R.b2 = F.bodyC[(size_t)2 * F.bodyCap + bp]; R.b3 = F.bodyC[(size_t)3 * F.bodyCap + bp];
+}
+
 /* One visit of tile `t` in iteration `it`: the primal solve (solver.cpp:344-409) of its 64 / G bodies.
  * The lanes of a body are evaluated in two passes: first the contacts whose partner comes LATER in the colour order (and those with a partner nobody
  * sweeps) — everything they read was published in the previous iteration, and they run the dual update of that iteration —, then the contacts whose
  * partner has already moved in this iteration.  Only the second pass, the sums, the solve and the publish stand between the arrival of the last pose
  * and this body's own. */
-template <int G, bool TWOPASS, bool HOIST, bool JOINTS>
-__device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
+template <int G, bool TWOPASS, bool HOIST, bool JOINTS, bool PRE>
+__device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams& P, const FastTileRegs& TRin, FastTileRegs& next, int nextT, int it, bool lastOfLaunch)
 {
     const int lane = threadIdx.x & 63;
     const int j = G == 1 ? lane : lane / G, r = G == 1 ? 0 : lane % G;
+    FastTileRegs TRown;
+    if (!PRE) { TRown.t = TRin.t; TRown.td = TRin.td; fast_load_tile<G>(*X.F, TRin.t, TRown); }   /* (PRE: the caller loaded them behind the previous visit's last wait) */
+    const FastTileRegs& TR = PRE ? TRin : TRown;
+    const int t = TR.t;
+    const int2 td = TR.td;
     const int nb = td.y & 0xFFFF;
     const bool hasBody = j < nb;
     const FastBuffers& F = *X.F;
-    const size_t SC = (size_t)F.slotCap, at = (size_t)t * 64 + lane;
+    bool prefetched = false;
 
     /* constants of the lane's incidence entry (coalesced) and of the sub-group's body */
-    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
-    if (G > 1) { c5 = F.slotC[5 * SC + at]; c0 = F.slotC[0 * SC + at]; c1 = F.slotC[1 * SC + at]; c2 = F.slotC[2 * SC + at]; c3 = F.slotC[3 * SC + at]; c4 = F.slotC[4 * SC + at]; }
+    const float4 c0 = TR.c0, c1 = TR.c1, c2 = TR.c2, c3 = TR.c3, c4 = TR.c4, c5 = TR.c5;
     const int partner = __float_as_int(c5.x), slot = __float_as_int(c5.y), flags = __float_as_int(c5.z);
     const bool valid = (flags & FL_VALID) != 0, isA = (flags & FL_ISA) != 0, first = (flags & FL_FIRST) != 0, sole = (flags & FL_SOLE) != 0;
-    const int bp = td.x + (hasBody ? j : 0);
-    const float4 b0 = F.bodyC[(size_t)0 * F.bodyCap + bp], b1 = F.bodyC[(size_t)1 * F.bodyCap + bp], b2 = F.bodyC[(size_t)2 * F.bodyCap + bp], b3 = F.bodyC[(size_t)3 * F.bodyCap + bp];
+    const float4 b0 = TR.b0, b1 = TR.b1, b2 = TR.b2, b3 = TR.b3;
     const int body = __float_as_int(b3.w);
     const f3 npos = mk3(b0.x, b0.y, b0.z); const float mass = b0.w;
     const q4 nrot = mkq(b1.x, b1.y, b1.z, b1.w);
@@ -728,7 +758,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 for (;;) {
                     bool ok = true;
                     if (mine) {
-                        sl = fld(X.rL, slot * 16); sp = fld(X.rP, slot * 16);
+                        sl = fld(X.rS, slot * 32); sp = fld(X.rS, slot * 32 + 16);
                         if (moving) {
                             const fv4u p0 = fld(X.rPose, partner * 32), p1 = fld(X.rPose, partner * 32 + 16);
                             ok = pose_decode(p0, p1, needPartner, opos, orot);
@@ -745,6 +775,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 }
             }
             if (pass == 1) FAST_STAMP(2);
+            if (pass == 1 && nextT >= 0 && nextT != t) { fast_load_tile(F, nextT, next); prefetched = true; }   /* (its loads return while this pass, the sums and the solve run) */
             if (mine) {
                 f3 wOwnP = wOwn;
                 float signP = isA ? 1.0f : -1.0f;
@@ -817,8 +848,8 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 /* the visit's mutations of the force (lambda cone clamp, stick; after a dual also lambda_n and the penalties); every record
                  * validates itself, so nothing is drained before the pose is published */
                 const unsigned visit = (unsigned)(sole ? 0 : (first ? 2 * it + 1 : 2 * it + 2));
-                fst(X.rL, slot * 16, fv4u{fu(c.lam[0]), fu(c.lam[1]), fu(c.lam[2]), (visit << 1) | (c.stick ? 1u : 0u)});
-                if (first) fst(X.rP, slot * 16, fv4u{fu(c.pen[0]), fu(c.pen[1]), fu(c.pen[2]), (unsigned)(it + 1)});
+                fst(X.rS, slot * 32, fv4u{fu(c.lam[0]), fu(c.lam[1]), fu(c.lam[2]), (visit << 1) | (c.stick ? 1u : 0u)});
+                if (first) fst(X.rS, slot * 32 + 16, fv4u{fu(c.pen[0]), fu(c.pen[1]), fu(c.pen[2]), (unsigned)(it + 1)});
             }
         }
         group_sum27<G>(acc);
@@ -870,6 +901,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
         xl = x0 - mkm(col0, col1, col2) * y;
         xa = y;
     }
+    if (!prefetched && nextT >= 0 && nextT != t) fast_load_tile(F, nextT, next);
     f3 p = pos - xl;
     const q4 dq = mkq(xa.x, xa.y, xa.z, 0.0f);
     q4 q = qnormalize(rot - (dq * rot) * 0.5f);
@@ -899,11 +931,12 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
     const int cls = (td.y >> 16) & 0xFF;
     if (cls == 0) return;
     const int G = fast_class_lanes(cls), j = lane / G, nb = td.y & 0xFFFF;
-    const float4 c5 = F.slotC[5 * SC + at];
+    const bool held = ((F.tileMask[t] >> lane) & 1ull) != 0;
+    float4 c5 = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f), c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0, c4 = c0;
+    if (held) { c5 = F.slotC[5 * SC + at]; c0 = F.slotC[0 * SC + at]; c1 = F.slotC[1 * SC + at]; c2 = F.slotC[2 * SC + at]; c3 = F.slotC[3 * SC + at]; c4 = F.slotC[4 * SC + at]; }
     const int partner = __float_as_int(c5.x), slot = __float_as_int(c5.y), flags = __float_as_int(c5.z);
     const bool valid = (flags & FL_VALID) != 0 && j < nb, isA = (flags & FL_ISA) != 0, first = (flags & FL_FIRST) != 0, sole = (flags & FL_SOLE) != 0;
     const bool mine = valid && first;
-    const float4 c0 = F.slotC[0 * SC + at], c1 = F.slotC[1 * SC + at], c2 = F.slotC[2 * SC + at], c3 = F.slotC[3 * SC + at], c4 = F.slotC[4 * SC + at];
     const int body = __float_as_int(F.bodyC[(size_t)3 * F.bodyCap + td.x + (j < nb ? j : 0)].w);
     f3 pos = zero3(), opos = zero3(); q4 rot = identq(), orot = identq();
     fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
@@ -914,7 +947,7 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
             if (mine) {
                 const fv4u o0 = fld(X.rPose, body * 32), o1 = fld(X.rPose, body * 32 + 16);
                 ok = pose_decode(o0, o1, (unsigned)totalIt, pos, rot);
-                sl = fld(X.rL, slot * 16); sp = fld(X.rP, slot * 16);
+                sl = fld(X.rS, slot * 32); sp = fld(X.rS, slot * 32 + 16);
                 if (!sole) {
                     const fv4u p0 = fld(X.rPose, partner * 32), p1 = fld(X.rPose, partner * 32 + 16);
                     ok &= pose_decode(p0, p1, (unsigned)totalIt, opos, orot);
@@ -976,17 +1009,17 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
     M.cFmax[slot] = make_float4(c.fmax[0], c.fmax[1], c.fmax[2], 0.f);
 }
 
-template <int FORM, bool JOINTS>
-__device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverParams& P, int t, int2 td, int it, bool lastOfLaunch)
+template <int FORM, bool JOINTS, bool PRE>
+__device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverParams& P, const FastTileRegs& R, FastTileRegs& next, int nextT, int it, bool lastOfLaunch)
 {
     constexpr bool TWOPASS = FORM != 0, HOIST = FORM == 1;
-    const int cls = __builtin_amdgcn_readfirstlane((td.y >> 16) & 0xFF);
+    const int cls = __builtin_amdgcn_readfirstlane((R.td.y >> 16) & 0xFF);
     switch (cls) {
-    case 0: fast_visit<1, false, false, false>(X, P, t, td, it, lastOfLaunch); break;
-    case 1: fast_visit<8, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
-    case 2: fast_visit<16, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
-    case 3: fast_visit<32, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
-    default: fast_visit<64, TWOPASS, HOIST, JOINTS>(X, P, t, td, it, lastOfLaunch); break;
+    case 0: fast_visit<1, false, false, false, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 1: fast_visit<8, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 2: fast_visit<16, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 3: fast_visit<32, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    default: fast_visit<64, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
     }
 }
 
@@ -1005,7 +1038,7 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     const int W = nWG * kWaves;
     const int gw = (threadIdx.x >> 6) * nWG + blockIdx.x;             /* consecutive tiles go to different workgroups */
     FastCtx X;
-    X.rPose = frsrc(F.xpose); X.rL = frsrc(F.xL); X.rP = frsrc(F.xP);
+    X.rPose = frsrc(F.xpose); X.rS = frsrc(F.xS);
     X.F = &F; X.plan = plan; X.cnt = L.cnt; X.B = L.B; X.M = L.M;
     X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps; X.gf = F.gf; X.jointSlotBase = F.jointSlotBase;
     const SolverParams P = L.P;
@@ -1014,13 +1047,42 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     if (T == 0) return;
     if (L.stamps && gw >= T) return;                                 /* nothing to do for this wave, nobody waits for it */
 
-    for (int it = L.itBegin; it < L.itEnd; ++it) {
-        for (int c = 0; c < numColors; ++c) {
-            const int t0 = plan->colorTileStart[c], t1 = plan->colorTileStart[c + 1];
-            /* this wave's tiles of the colour: t = gw (mod W) */
-            int t = t0 + ((gw - t0) % W + W) % W;
-            for (; t < t1; t += W) fast_visit_any<FORM, JOINTS>(X, P, t, F.tiles[t], it, it == L.itEnd - 1);
-            if (!L.stamps) fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
+    if (L.stamps && FORM == 1) {
+        /* stamped records: a wave's tiles in ascending order are in colour order (tiles are laid out colour by colour) — no phases, every visit waits for
+         * its own inputs.  Latency form (one wave per SIMD, registers to spare): the constants of the next visit's tile are loaded behind the current visit's
+         * last wait; a wave with one tile keeps them for the whole launch */
+        FastTileRegs cur, nxt;
+        fast_load_tile(F, gw, cur);
+        for (int it = L.itBegin; it < L.itEnd; ++it) {
+            for (int t = gw; t < T; t += W) {
+                const bool more = t + W < T;
+                const int nextT = more ? t + W : (it + 1 < L.itEnd ? gw : -1);
+                nxt = cur;
+                fast_visit_any<FORM, JOINTS, true>(X, P, cur, nxt, nextT, it, it == L.itEnd - 1);
+                cur = nxt;
+            }
+        }
+    } else if (L.stamps) {
+        for (int it = L.itBegin; it < L.itEnd; ++it) {
+            for (int t = gw; t < T; t += W) {
+                FastTileRegs cur, nxt;
+                cur.t = t; cur.td = F.tiles[t];
+                fast_visit_any<FORM, JOINTS, false>(X, P, cur, nxt, -1, it, it == L.itEnd - 1);
+            }
+        }
+    } else {
+        for (int it = L.itBegin; it < L.itEnd; ++it) {
+            for (int c = 0; c < numColors; ++c) {
+                const int t0 = plan->colorTileStart[c], t1 = plan->colorTileStart[c + 1];
+                /* this wave's tiles of the colour: t = gw (mod W) */
+                int t = t0 + ((gw - t0) % W + W) % W;
+                for (; t < t1; t += W) {
+                    FastTileRegs cur, nxt;
+                    cur.t = t; cur.td = F.tiles[t];
+                    fast_visit_any<FORM, JOINTS, false>(X, P, cur, nxt, -1, it, it == L.itEnd - 1);
+                }
+                fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
+            }
         }
     }
     if (L.finalPass) {

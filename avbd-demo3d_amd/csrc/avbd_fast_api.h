@@ -50,11 +50,12 @@ struct FastBuffers {
     int*    posInGroup; /* [bodyCap] */
     int*    cbody;      /* [bodyCap] bodies by (colour, class) */
     int2*   tiles;      /* [tileCap] {first index into cbody, bodies | class << 16} */
+    unsigned long long* tileMask; /* [tileCap] lanes of the tile that hold an entry */
     float4* slotC;      /* [kFastSlotPlanes][slotCap] per-lane incidence constants, slot = tile * 64 + lane */
     float4* bodyC;      /* [kFastBodyPlanes][bodyCap] per-body constants by cbody position */
     float4* xpose;      /* [2 * bodyCap] stamped pose records of the swept bodies */
-    float4* xL;         /* [4 * mCap + 2 * gCap] (lambda n t1 t2, visit << 1 | stick) per contact slot */
-    float4* xP;         /* [4 * mCap + 2 * gCap] (penalty n t1 t2, stamp) */
+    float4* xS;         /* [2 * (4 * mCap + 2 * gCap)] per contact slot (a Joint half behind the contacts'): (lambda n t1 t2, visit << 1 | stick), (penalty n t1 t2, stamp) —
+                         * neighbours in memory: one 64-byte sector per lane and visit */
     unsigned* sync;     /* [kFastSyncWords] */
     GForce* gf;         /* Joint records (kind FK_JOINT); a joint half's state records sit behind the contacts': slot jointSlotBase + 2 * g + part */
     int jointSlotBase;
