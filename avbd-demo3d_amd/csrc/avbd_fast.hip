@@ -128,10 +128,10 @@ constexpr int kFastRecolorAbove = 10;         /* last step's colouring is droppe
 constexpr int kFastColorsFloor = 4;           /* ... and the bodies of its highest colour are coloured afresh while it has more than this many */
 constexpr int kPlanNbrRegs = 12;             /* neighbours of a body its thread keeps in registers through the rounds of the colouring */
 
-__device__ __forceinline__ unsigned fast_prio(const int* __restrict__ adjStart, int b)
+__device__ __forceinline__ unsigned fast_prio(const int* __restrict__ adjStart, int b, unsigned seed)
 {
     const int degAdj = adjStart[b + 1] - adjStart[b];
-    return ((unsigned)min(degAdj, 127) << 24) | (fast_hash((unsigned)b) >> 8);
+    return ((unsigned)min(degAdj, 127) << 24) | (fast_hash((unsigned)b + seed * 0x9e3779b9u) >> 8);
 }
 
 /* k_fast_plan: colours, (colour, class) groups, tile table, body constants — one thread per body, persistent, grid barriers between the stages.
@@ -180,10 +180,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
      * depend on timing; the rounds below then colour only what is left.  A settled pile keeps every colour and the colouring costs one look at the
      * neighbours.  (reuse = 0: the first step after an upload; or last step's colouring had grown beyond kFastRecolorAbove colours) */
     const bool reuse = L.reuse != 0 && plan->numColors > 0 && plan->numColors <= kFastRecolorAbove;
+    /* the hash that breaks the ties of the priorities has a seed: greedy colourings of one pile differ by a colour from seed to seed (Stress1000: 4 for three
+     * seeds in four, 5 for the fourth; a colour is 20 dependent solves per step), so a fresh colouring that needed MORE colours than the best of the fresh colourings
+     * before it moves on to the next seed for the colourings to come — decided on the device from the plan's own history, the same in every run */
+    const unsigned seed = (unsigned)plan->seed + (unsigned)L.seedBase;
     int myColor = swept ? -1 : -2;
     if (swept) {
         adjS = L.adjStart[b]; adjE = L.adjStart[b + 1];
-        const unsigned pb = fast_prio(L.adjStart, b);
+        const unsigned pb = fast_prio(L.adjStart, b, seed);
         const int old = reuse ? F.colorPrev[b] : -1;
         /* a body gives its colour up when a neighbour of higher priority held the same one (a new contact between two bodies of one colour), and also when a
          * LOWER colour is free among its neighbours' old colours (contacts that went away): the colouring stays "greedy-stable" — as good as a fresh greedy
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
                 const int p = L.adjOther[adjS + k];
                 if (p >= 0 && inc_kind(L.adjRef[adjS + k]) != FK_IGNORE && B.solved[p] != 0) {
                     nbr[k] = p;
-                    const unsigned pp = fast_prio(L.adjStart, p);
+                    const unsigned pp = fast_prio(L.adjStart, p, seed);
                     const bool hi = pp > pb || (pp == pb && p > b);
                     if (hi) higher |= 1u << k;
                     if (keep) {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
             for (int i = adjS + kPlanNbrRegs; i < adjE && keep; ++i) {
                 const int p = L.adjOther[i];
                 if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE || B.solved[p] == 0) continue;
-                const unsigned pp = fast_prio(L.adjStart, p);
+                const unsigned pp = fast_prio(L.adjStart, p, seed);
                 const int po = F.colorPrev[p];
                 if (po >= 0) usedOld |= 1ull << po;
                 if ((pp > pb || (pp == pb && p > b)) && po == old) keep = false;
@@ -249,14 +253,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
                 else if (cn[k] == -1 && ((higher >> k) & 1u)) blocked = true;
             }
             if (adjE - adjS > kPlanNbrRegs) {                         /* a long adjacency list: the rest from memory */
-                const unsigned pb = fast_prio(L.adjStart, b);
+                const unsigned pb = fast_prio(L.adjStart, b, seed);
                 for (int i = adjS + kPlanNbrRegs; i < adjE && !blocked; ++i) {
                     const int p = L.adjOther[i];
                     if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE) continue;
                     const int cp = get_color(p);
                     if (cp == -2) continue;
                     if (cp == -1) {
-                        const unsigned pp = fast_prio(L.adjStart, p);
+                        const unsigned pp = fast_prio(L.adjStart, p, seed);
                         if (pp > pb || (pp == pb && p > b)) blocked = true;
                     } else used |= 1ull << cp;
                 }
@@ -339,6 +343,13 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
         for (int i = threadIdx.x; i <= kFastMaxColors; i += blockDim.x) plan->colorTileStart[i] = sColorStart[i];
         if (threadIdx.x == 0) {
             plan->numSwept = sTotals[0]; plan->numTiles = overflow ? 0 : numTiles; plan->numColors = sTotals[2]; plan->rounds = rounds + 1;
+            if (!reuse) {
+                /* (the fewest colours a fresh colouring needed lately — forgotten after 64 of them, the pile changes —: a colouring that needs more tries the next seed) */
+                int best = plan->lastFreshColors, age = plan->pad[0] + 1;
+                if (best <= 0 || sTotals[2] < best || age > 64) { best = sTotals[2]; age = 0; }
+                else if (sTotals[2] > best) plan->seed = plan->seed + 1;
+                plan->lastFreshColors = best; plan->pad[0] = age;
+            }
             if (overflow) atomicOr(&plan->bad, 8);
         }
     }

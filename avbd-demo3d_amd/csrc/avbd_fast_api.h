@@ -34,7 +34,9 @@ struct FastPlan {
                          * 4: more than kFastMaxColors colours, 8: tile table overflow, 256: a grid barrier / stamp wait timed out */
     int rounds;         /* rounds the colouring took */
     int numSwept;
-    int pad[3];
+    int seed;           /* seed of the priorities' tie-breaking hash (moves on when a fresh colouring needed more colours than the one before) */
+    int lastFreshColors;
+    int pad[1];
     int colorTileStart[kFastMaxColors + 1];
     int groupCount[kFastMaxColors * kFastClasses];
     int groupBodyBase[kFastMaxColors * kFastClasses];
@@ -73,6 +75,7 @@ struct FastLaunch {
     int stamps;             /* 1: waves wait on the stamps of the records they read; 0: grid barrier per colour */
     int numCU;
     int joints;             /* the scene has Joint forces: the joint-aware kernels */
+    int seedBase;           /* option fast_seed: added to the plan's own seed */
     int reuse;              /* k_fast_plan: colorPrev holds last step's colouring of the same bodies */
 };
 
