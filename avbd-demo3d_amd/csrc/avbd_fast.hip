@@ -835,25 +835,25 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 for (int k = 0; k < 3; ++k) {
                     const f3 Jl = rowJl[k], Ja = rowJa[k];
                     const float f = rowF[k];
-                    const float pen = c.pen[k];
-                    const bool penOk = (pen > 0.0f) && (fabsf(pen) <= FLT_MAX);
+                    /* lhs += (J J^T) penalty only for a positive, finite penalty (solver.cpp:387): a row that fails the test adds +0.0f products instead of
+                     * branching (every product is finite, so x * 0 is an exact zero and the sums do not change) */
+                    const bool penOk = (c.pen[k] > 0.0f) && (fabsf(c.pen[k]) <= FLT_MAX);
+                    const float pen = penOk ? c.pen[k] : 0.0f;
                     const float J6[6] = {Jl.x, Jl.y, Jl.z, Ja.x, Ja.y, Ja.z};
 #pragma unroll
                     for (int i = 0; i < 6; ++i) acc[21 + i] += J6[i] * f;                  /* rhs += J f (solver.cpp:383-384) */
-                    if (penOk) {
-                        /* lhs += (J J^T) penalty: ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104) */
-                        acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
-                        acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
+                    /* ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104) */
+                    acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
+                    acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
 #pragma unroll
-                        for (int jj = 0; jj < 3; ++jj)
+                    for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
-                            for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
-                        acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
-                        acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
-                        if (!isJoint) {
-                            const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only */
-                            acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
-                        }
+                        for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
+                    acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
+                    acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
+                    if (!isJoint) {
+                        const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * (penOk ? fabsf(f) : 0.0f);   /* solver.cpp:393-397: Manifold rows only */
+                        acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
                     }
                 }
                 /* the visit's mutations of the force (lambda cone clamp, stick; after a dual also lambda_n and the penalties); every record
@@ -898,7 +898,9 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
             const f3 sol = solve_ldlt3_branchless(ll, rhsq);
             col0 = quad_bcast3<0>(sol); col1 = quad_bcast3<1>(sol); col2 = quad_bcast3<2>(sol); x0 = quad_bcast3<3>(sol);
             const m33 AinvB = mkm(col0, col1, col2);
-            const m33 schur = aa - al * AinvB;
+            m33 schur;                                                /* (maths.h:104 reads the lower triangle only: c0, c1.y, c1.z, c2.z) */
+            schur.c0 = aa.c0 - al * col0;
+            { const f3 p1 = al * col1, p2 = al * col2; schur.c1 = mk3(0.0f, aa.c1.y - p1.y, aa.c1.z - p1.z); schur.c2 = mk3(0.0f, 0.0f, aa.c2.z - p2.z); }
             const f3 rhs_s = ba - al * x0;
             y = solve_ldlt3_quadlanes(schur, rhs_s, q);
         } else {

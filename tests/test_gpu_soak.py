@@ -1,0 +1,111 @@
+"""A bounded slice of the builder's soaks (tools/soak_small.py, soak_mixed.py; VERDICT round 5: "soaks are outside the suite") inside `pytest -m gpu`: random piles
+through the small scenes' fused kernels with bodies added while the wave placement is kept, heaps on a platform (long force lists), pools that overflow — an error,
+never a fault — all against the CPU oracle bit for bit; and the same random scenes in the FAST sweep (option "sweep" = 1): finite, bit-identical from run to run and
+between the stamped / barrier forms, one step from the exact mode's state within the violent-phase bound, joints / ignore markers / bodies added mid-run."""
+import numpy as np
+import pytest
+
+import harness as H
+from test_gpu_fuzz import build as build_random
+
+pytestmark = pytest.mark.gpu
+
+
+def _pile(w, seed):
+    r2 = np.random.default_rng(seed)
+    n = int(np.random.default_rng(seed).integers(40, 140))
+    if seed % 3 == 1:                                      # a platform under a heap of small boxes: long lists
+        w.add_body((40, 1, 40), 0.0, 0.6, (0, -0.5, 0))
+        w.add_body((3.0, 0.4, 3.0), 1.0, 0.5, (0.0, 0.25, 0.0))
+        H.random_pile(w, r2, 2 * n, spread=1.2, height=4.0, ground=False, size_range=(0.25, 0.5))
+    else:
+        H.random_pile(w, r2, n, spread=float(1.2 + 1.5 * (seed % 3)), height=5.0)
+    w.set_params(iterations=5 + seed % 4)
+
+
+@pytest.mark.parametrize("first", [7000, 7010, 7020, 7030])
+def test_soak_small_scenes_exact(first):
+    """tools/soak_small.py, 10 seeds per case: 60 steps, bodies added at steps 17 / 41 under a kept placement, every fourth step compared with the oracle"""
+    for seed in range(first, first + 10):
+        o, g = H.CpuWorld("orc"), H.HipWorld()
+        for w in (o, g):
+            _pile(w, seed)
+        g.w.set_option("place_every", (1, 3, 8, 50)[seed % 4])
+        try:
+            for s in range(60):
+                o.step(); g.step()
+                if s in (17, 41) and seed % 2 == 0:
+                    for w in (o, g):
+                        w.add_body((0.8, 0.8, 0.8), 0.0 if s == 41 and seed % 4 == 0 else 1.5, 0.5, (0.1 * (seed % 7), 7.0 + 0.01 * s, -0.2))
+                if s % 4 == 3:
+                    H.assert_same_world(o, g, f"seed {seed} step {s + 1}")
+        except H.load_product().AvbdError as e:
+            assert "pool overflow" in str(e), (seed, str(e))      # AVBD_E_CAPACITY: a pile denser than the pools is an error, never a fault
+        g.close()
+
+
+def test_pool_overflow_is_an_error_not_a_fault():
+    pkg = H.load_product()
+    g = H.HipWorld()
+    g.w.set_option("pool_per_body", 4)
+    H.random_pile(g, np.random.default_rng(5), 900, spread=1.0, height=3.0, size_range=(0.3, 0.5))
+    with pytest.raises(pkg.AvbdError) as e:
+        for _ in range(80):
+            g.step(5); g.w.stats()
+    assert "pool overflow" in str(e.value)
+
+
+@pytest.mark.parametrize("first", [300, 320])
+def test_soak_random_scenes_fast_sweep(first):
+    """the fuzz scenes of test_gpu_fuzz.py (random boxes, sizes, frictions, velocities, gravity, iterations, post-stabilisation; sometimes joints / ignore markers —
+    scenes with a spring take the exact schedules and must then equal the oracle) in the fast sweep: same bits in the stamped and the barrier form, finite state,
+    and every step that ran the fast sweep did so with a proper plan"""
+    pkg = H.load_product()
+    for seed in range(first, first + 20):
+        a, b = H.HipWorld(), H.HipWorld()
+        for w, stamps in ((a, 1), (b, 0)):
+            build_random(w, seed)
+            w.w.set_option("sweep", 1); w.w.set_option("fast_stamps", stamps)
+        o = None
+        has_spring = any(int(k) == 2 for k in a.forces()["kind"]) if len(a.forces()) else False
+        if has_spring:
+            o = H.CpuWorld("orc"); build_random(o, seed)
+        for s in range(12):
+            a.step(); b.step()
+            if o is not None:
+                o.step()
+                H.assert_same_world(o, a, f"seed {seed} step {s + 1}: a scene with a spring runs the exact schedules")
+            else:
+                ba, bb = a.bodies(), b.bodies()
+                assert H.same_bits(ba, bb), (seed, s)
+                assert np.isfinite(ba["pos"]).all() and np.isfinite(ba["quat"]).all() and np.isfinite(ba["linVel"]).all(), (seed, s)
+        sched = int(a.w.stats()["schedule"])
+        assert (sched != 5) if has_spring else (sched == 5 or (a.w.fast_plan_info()["bad"] & 1)), (seed, sched, a.w.fast_plan_info())
+        a.close(); b.close()
+
+
+def test_soak_fast_sweep_bodies_added_mid_run_and_one_step_bound():
+    """random piles in the fast sweep with bodies added between steps (new bodies: fresh colouring, larger tables); then one step from the exact mode's state stays within
+    the violent-phase bound of DESIGN.md section 2b (0.1 m / 0.3 rad) — the piles are still tumbling"""
+    for seed in (7001, 7002, 7004, 7006):
+        e, f = H.HipWorld(), H.HipWorld()
+        for w in (e, f):
+            _pile(w, seed)
+        f.w.set_option("sweep", 1)
+        for s in range(50):
+            e.step(); f.step()
+            if s in (17, 41):
+                for w in (e, f):
+                    w.add_body((0.8, 0.8, 0.8), 1.5, 0.5, (0.1 * (seed % 7), 7.0 + 0.01 * s, -0.2))
+        assert int(f.w.stats()["schedule"]) == 5 or (f.w.fast_plan_info()["bad"] & 1)
+        assert np.isfinite(f.bodies()["pos"]).all()
+        # fork the exact world's state: one step each
+        b, fr = e.bodies(), e.forces()
+        f2 = H.HipWorld(); _pile(f2, seed)
+        for _ in range(2):
+            f2.add_body((0.8, 0.8, 0.8), 1.5, 0.5, (0.0, 7.0, -0.2))
+        f2.w.set_option("sweep", 1); f2.set_bodies(b); f2.set_forces(fr); f2.set_step_index(e.step_index())
+        e.step(); f2.step()
+        be, bf = e.bodies(), f2.bodies()
+        dp = np.linalg.norm(be["pos"].astype(np.float64) - bf["pos"].astype(np.float64), axis=1).max()
+        assert dp <= 0.1, (seed, dp)

@@ -1,4 +1,2 @@
-for seed in 0 1 2; do timeout 300 python tools/fast_prof.py Stress1000 400 200 sweep=1 fast_seed=$seed 2>&1 | head -2 | tr '\n' ' '; echo; done
-timeout 300 python tools/fast_prof.py StressN:14 300 50 sweep=1 2>&1 | head -2 | tr '\n' ' '; echo
-timeout 300 python tools/fast_prof.py StressN:20 410 50 sweep=1 2>&1 | head -2 | tr '\n' ' '; echo
-timeout 300 python tools/fast_prof.py StressN:40 470 20 sweep=1 2>&1 | head -2 | tr '\n' ' '; echo
+for f in 1 2; do timeout 300 python tools/fast_prof.py StressN:20 410 50 sweep=1 fast_form=$f 2>&1 | head -2 | tr '\n' ' '; echo; done
+for f in 1 2; do timeout 300 python tools/fast_prof.py StressN:16 400 50 sweep=1 fast_form=$f 2>&1 | head -2 | tr '\n' ' '; echo; done
