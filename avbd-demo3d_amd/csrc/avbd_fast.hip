@@ -37,7 +37,8 @@ constexpr int kFastLatTilesPerWave = 4;        /* the latency form up to this ma
 constexpr unsigned long long kFastTimeoutTicks = 400000000ull;   /* 4 s of s_memrealtime (100 MHz) */
 
 enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8,
-             FL_JOINT = 16 /* the lane holds one half (three rows) of a Joint */, FL_PART1 = 32 /* ... its angular half */, FL_WORLD = 64 /* ... whose bodyA is the world */, FL_FIXANG = 128 /* avbd_set_joint_angular_sign */ };
+             FL_JOINT = 16 /* the lane holds one half (three rows) of a Joint */, FL_PART1 = 32 /* ... its angular half */, FL_WORLD = 64 /* ... whose bodyA is the world */, FL_FIXANG = 128 /* avbd_set_joint_angular_sign */,
+             FL_SPRING = 256 /* the lane holds a Spring (one row; FL_JOINT is set too: the lane takes the generic-force path) */ };
 
 __host__ __device__ constexpr int fast_class_lanes(int cls) { return cls == 0 ? 1 : (4 << cls); }
 __device__ __forceinline__ int fast_class_of(int deg) { return deg == 0 ? 0 : (deg <= 8 ? 1 : (deg <= 16 ? 2 : (deg <= 32 ? 3 : 4))); }
@@ -460,6 +461,25 @@ __global__ __launch_bounds__(256) void k_fast_fill(FastLaunch L)
                         F.xS[2 * (size_t)slot] = make_float4(jf.lambda[3 * part + 0], jf.lambda[3 * part + 1], jf.lambda[3 * part + 2], __int_as_float(0));
                         F.xS[2 * (size_t)slot + 1] = make_float4(jf.penalty[3 * part + 0], jf.penalty[3 * part + 1], jf.penalty[3 * part + 2], __int_as_float(0));
                     }
+                } else if (inc_kind(ent) == FK_SPRING && F.gf[inc_index(ent) & 0xFFFFFF].kind == FK_SPRING) {
+                    /* a Spring (spring.cpp:33-90): one row */
+                    const int g = inc_index(ent) & 0xFFFFFF;
+                    const bool isA = inc_isA(ent) != 0;
+                    const GForce& sf = F.gf[g];
+                    const int other = isA ? sf.bodyB : sf.bodyA;
+                    const bool world = other < 0;
+                    const bool otherSwept = !world && B.solved[other] != 0;
+                    const bool first = !otherSwept || F.color[body] < F.color[other];
+                    const float* rO = isA ? sf.rA : sf.rB; const float* rT = isA ? sf.rB : sf.rA;
+                    c0 = make_float4(rO[0], rO[1], rO[2], sf.stiffness[0]);
+                    c1 = make_float4(rT[0], rT[1], rT[2], sf.restLength);
+                    c2 = make_float4(sf.fmin[0], sf.fmax[0], sf.motor[0], 0.f);
+                    partner = other; slot = F.jointSlotBase + 2 * g;
+                    flags = FL_VALID | FL_JOINT | FL_SPRING | (world ? FL_WORLD : 0) | (isA ? FL_ISA : 0) | (first ? FL_FIRST : 0) | (otherSwept ? 0 : FL_SOLE);
+                    if (first) {
+                        F.xS[2 * (size_t)slot] = make_float4(sf.lambda[0], 0.f, 0.f, __int_as_float(0));
+                        F.xS[2 * (size_t)slot + 1] = make_float4(sf.penalty[0], 0.f, 0.f, __int_as_float(0));
+                    }
                 }
             }
         }
@@ -625,6 +645,38 @@ __device__ __forceinline__ void fast_joint_rows(FastRows& c, FastJointOut& o, in
         const float desired = c.pen[k] * o.C[k] + lw + motor[k];
         o.f[k] = rclamp(desired, -FLT_MAX, FLT_MAX);
     }
+}
+
+/* A Spring for one endpoint (spring.cpp:33-90; one row): computeConstraint (C = |pA - pB| - rest), the dual update of the previous iteration when the row is a hard
+ * one (stiffness FLT_MAX; a spring's usual finite stiffness has no lambda and no dual, solver.cpp:416-418), computeDerivatives for THIS endpoint, the row force. */
+__device__ __forceinline__ void fast_spring_rows(FastRows& c, FastJointOut& o, int flags, f3 pos, q4 rot, f3 rOwn, f3 opos, q4 orot, f3 rOth,
+                                                 float rest, float stiff, float motor, float fmin, float fmax, bool dual, float beta)
+{
+    const bool isA = (flags & FL_ISA) != 0, hasA = (flags & FL_WORLD) == 0;
+    const f3 posA = isA ? pos : opos, posB = isA ? opos : pos;
+    const q4 rotA = isA ? rot : orot, rotB = isA ? orot : rot;
+    SpringRows sr;
+    sr.rA = isA ? rOwn : rOth; sr.rB = isA ? rOth : rOwn; sr.restLength = rest; sr.C = 0.0f;
+    spring_compute_constraint(sr, hasA, posA, rotA, posB, rotB);
+    o.C[0] = sr.C; o.C[1] = 0.0f; o.C[2] = 0.0f;
+    if (dual && stiff == FLT_MAX) {
+        const float lu = rclamp(c.pen[0] * sr.C + c.lam[0], fmin, fmax);
+        const bool active = lu > fmin && lu < fmax;
+        c.lam[0] = lu;
+        if (active) {
+            float lw = 0.0f, aw = 0.0f;
+            f3 Jl, Ja;
+            if (hasA) { spring_compute_derivatives(sr, true, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja); }
+            spring_compute_derivatives(sr, false, hasA, posA, rotA, posB, rotB, Jl, Ja); lw += lensq3(Jl); aw += lensq3(Ja);
+            const float betaRow = row_penalty_gain(lw, aw, beta);
+            c.pen[0] = rmin(c.pen[0] + betaRow * fabsf(sr.C), kPenaltyMax);
+        }
+    }
+    spring_compute_derivatives(sr, isA, hasA, posA, rotA, posB, rotB, o.Jl[0], o.Ja[0]);
+    const float lw = (stiff == FLT_MAX) ? c.lam[0] : 0.0f;
+    o.f[0] = rclamp(c.pen[0] * sr.C + lw + motor, fmin, fmax);
+    o.Jl[1] = zero3(); o.Ja[1] = zero3(); o.f[1] = 0.0f; o.Jl[2] = zero3(); o.Ja[2] = zero3(); o.f[2] = 0.0f;
+    c.pen[1] = 0.0f; c.pen[2] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
 }
 
 struct FastCtx {
@@ -826,8 +878,11 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     }
                 } else {
                     FastJointOut jo;
-                    const float stiff[3] = {c0.w, c1.w, c2.w}, motor[3] = {c3.y, c3.z, c3.w};
-                    fast_joint_rows(c, jo, flags, wOwnP, pos + wOwnP, rot, rOth, opos, orot, mkq(c2.x, c2.y, c2.z, c3.x), stiff, motor, first && it > 0, X.beta);
+                    if (flags & FL_SPRING) fast_spring_rows(c, jo, flags, pos, rot, rOwn, opos, orot, rOth, c1.w, c0.w, c2.z, c2.x, c2.y, first && it > 0, X.beta);
+                    else {
+                        const float stiff[3] = {c0.w, c1.w, c2.w}, motor[3] = {c3.y, c3.z, c3.w};
+                        fast_joint_rows(c, jo, flags, wOwnP, pos + wOwnP, rot, rOth, opos, orot, mkq(c2.x, c2.y, c2.z, c3.x), stiff, motor, first && it > 0, X.beta);
+                    }
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { rowJl[k] = jo.Jl[k]; rowJa[k] = jo.Ja[k]; rowF[k] = jo.f[k]; }
                 }
@@ -984,6 +1039,12 @@ __device__ __forceinline__ void fast_final(const FastCtx& X, const SolverParams&
     if (JOINTS && (flags & FL_JOINT) != 0) {
         /* a Joint half: the last dual (solver.cpp:411-430) and the rows back into the GForce record (C / fmin / fmax as the last computeConstraint leaves them, joint.cpp:68-106) */
         FastJointOut jo;
+        if (flags & FL_SPRING) {
+            fast_spring_rows(c, jo, flags, pos, rot, rOwn, opos, orot, rOth, c1.w, c0.w, c2.z, c2.x, c2.y, !P.postStabilize, X.beta);
+            GForce& sf = X.gf[(slot - X.jointSlotBase) >> 1];
+            sf.lambda[0] = c.lam[0]; sf.penalty[0] = c.pen[0]; sf.C[0] = jo.C[0];
+            return;
+        }
         const float stiff[3] = {c0.w, c1.w, c2.w}, motor[3] = {c3.y, c3.z, c3.w};
         const f3 wOwnJ = qrotate(rot, rOwn);
         fast_joint_rows(c, jo, flags, wOwnJ, pos + wOwnJ, rot, rOth, opos, orot, mkq(c2.x, c2.y, c2.z, c3.x), stiff, motor, !P.postStabilize, X.beta);

@@ -361,8 +361,8 @@ int  avbd_set_joint_angular_sign(AvbdContext* ctx, int corrected);
  * bodies of one colour are solved together (one lane per contact, the 27 entries of a body's 6x6 system summed over its lanes with
  * DPP butterflies), a force's dual update (solver.cpp:411-430) runs at its first visit of the next iteration.  Row arithmetic is the
  * exact mode's (same expression trees, no contraction); the ORDER of bodies and of sums is not, so results agree with the exact mode
- * within the tolerance DESIGN.md section 2b states, not bit for bit; they are bit-identical from run to run.  Scenes with Joints,
- * Springs or user forces, sharded contexts and bodies with more than 64 contacts take the exact schedules (AvbdStepStats.schedule says
+ * within the tolerance DESIGN.md section 2b states, not bit for bit; they are bit-identical from run to run.  Contacts, Joints and Springs are
+ * lane entries of the sweep; scenes with user forces, exact cuts and bodies with more than 64 contacts take the exact schedules (AvbdStepStats.schedule says
  * which one ran: 5 = fast sweep).  avbd_fast_plan_info: the plan of the last fast step — out[0] colours, [1] tiles of 64 lanes,
  * [2] veto bits (0: the sweep ran), [3] rounds the colouring took, [4] swept bodies.  Synchronises.  No counterpart in the reference. */
 int  avbd_fast_plan_info(AvbdContext* ctx, int out[8]);

@@ -6,7 +6,7 @@ each with the value tools/fast_tolerance.py measured on an MI355X next to it:
  (i)   one teacher-forced step from the reference's snapshots / from the exact mode's own state: max |dpos| in metres, max rotation angle in radians;
  (ii)  invariants of whole runs against the reference's diagnostics (contact / manifold counts in a band, first contact on the same step, Stack standing);
  (iii) bit-identical results from run to run and between the forms of the kernel (stamped records / grid barrier, latency / throughput form, any grid size).
-Scenes the fast sweep does not take (Joints, Springs, a body with more than 64 contacts) must run the exact schedules: bit-exact against the oracle."""
+What the fast sweep does not take (the level mode, a body with more than 64 contacts) must run the exact schedules: bit-exact against the oracle."""
 import json
 import os
 import subprocess
@@ -193,15 +193,43 @@ def test_stack_stands_and_pyramid_settles():
 
 
 # ---- what the fast sweep declines ----------------------------------------------------------------------------------------------------
-def test_scenes_with_joints_or_springs_take_the_exact_schedules_bit_for_bit():
+def test_the_level_mode_ignores_the_sweep_option_and_stays_bit_exact():
+    """mode 0 (one launch per Gauss-Seidel level, the first correct path) is not a data-flow schedule: with sweep = 1 it still runs the exact sweep, bit for bit"""
     o = H.CpuWorld("orc"); g = H.HipWorld()
     for w in (o, g):
         H.build_row_api_scene(w, "@jointed")
-    g.w.set_option("sweep", 1)
-    for s in range(4):
+    g.w.set_option("mode", 0); g.w.set_option("sweep", 1)
+    for s in range(3):
         o.step(5); g.step(5)
-        H.assert_same_world(o, g, f"@jointed with sweep = 1, step {5 * s + 5}")
-    assert int(g.w.stats()["schedule"]) != 5
+        H.assert_same_world(o, g, f"@jointed, level mode with sweep = 1, step {5 * s + 5}")
+    assert int(g.w.stats()["schedule"]) == 0
+
+
+def test_fast_sweep_springs_match_the_exact_mode_to_rounding():
+    """bodies hung from a static beam by springs (soft: finite stiffness, no lambda; hard: stiffness FLT_MAX, lambda and a dual update) and a spring between a body and a
+    static post: one swept endpoint per spring, so the fast sweep runs the exact mode's sequence per body — 30 steps within 2e-4 m / 2e-3 rad, rows within 0.5 %"""
+    def build(w):
+        w.scene("Empty")
+        post = w.add_body((0.5, 4.0, 0.5), 0.0, 0.5, (-3.0, 2.0, 0.0))
+        beam = w.add_body((12.0, 0.4, 0.5), 0.0, 0.5, (3.0, 6.0, 0.0))                          # a static beam the bodies hang from
+        ids = [w.add_body((0.8, 0.6 + 0.1 * k, 0.7), 1.0 + 0.5 * k, 0.5, (2.0 * k, 3.0, 0.0), quat=(0.0, 0.1 * k, 0.0, float(np.sqrt(1.0 - 0.01 * k * k))), lin=(0.1, 0.0, 0.1 * k)) for k in range(4)]
+        w.add_spring(beam, ids[0], (-3.0, -0.2, 0.0), (0.0, 0.3, 0.0), 800.0, 1.5)
+        w.add_spring(beam, ids[1], (-0.8, -0.2, 0.1), (0.2, 0.3, 0.0), 3000.0)
+        w.add_spring(beam, ids[2], (1.0, -0.2, 0.0), (0.0, 0.35, 0.0), H.FLT_MAX, 1.8)          # a hard row: lambda + penalty ramp
+        w.add_spring(post, ids[3], (0.0, 1.5, 0.0), (0.0, 0.3, 0.0), 500.0, 8.5)
+        w.add_spring(beam, ids[3], (3.0, -0.2, 0.0), (0.0, 0.3, 0.2), 1500.0)                   # two springs on one body
+    e = H.HipWorld(); build(e)
+    f = H.HipWorld(); build(f); f.w.set_option("sweep", 1)
+    for s in range(6):
+        e.step(5); f.step(5)
+        assert int(f.w.stats()["schedule"]) == 5, int(f.w.stats()["schedule"])
+        dp, dr = body_diff(e.bodies(), f.bodies())
+        assert dp <= 2e-4 and dr <= 2e-3, (s, dp, dr)
+        fe, ff = e.forces(), f.forces()
+        assert np.array_equal(fe["kind"], ff["kind"]) and (fe["kind"] == 2).sum() == 5
+        for name in ("lambda", "penalty", "C"):
+            x, y = fe[name][:, :1].astype(np.float64), ff[name][:, :1].astype(np.float64)
+            assert np.abs(x - y).max() <= 5e-3 * max(1.0, np.abs(x).max()), (s, name, np.abs(x - y).max(), np.abs(x).max())
 
 
 def test_a_body_with_more_than_64_contacts_is_declined_on_the_device_and_runs_exactly():

@@ -57,8 +57,7 @@ def test_pool_overflow_is_an_error_not_a_fault():
 
 @pytest.mark.parametrize("first", [300, 320])
 def test_soak_random_scenes_fast_sweep(first):
-    """the fuzz scenes of test_gpu_fuzz.py (random boxes, sizes, frictions, velocities, gravity, iterations, post-stabilisation; sometimes joints / ignore markers —
-    scenes with a spring take the exact schedules and must then equal the oracle) in the fast sweep: same bits in the stamped and the barrier form, finite state,
+    """the fuzz scenes of test_gpu_fuzz.py (random boxes, sizes, frictions, velocities, gravity, iterations, post-stabilisation; sometimes joints / springs / ignore markers) in the fast sweep: same bits in the stamped and the barrier form, finite state,
     and every step that ran the fast sweep did so with a proper plan"""
     pkg = H.load_product()
     for seed in range(first, first + 20):
@@ -66,21 +65,13 @@ def test_soak_random_scenes_fast_sweep(first):
         for w, stamps in ((a, 1), (b, 0)):
             build_random(w, seed)
             w.w.set_option("sweep", 1); w.w.set_option("fast_stamps", stamps)
-        o = None
-        has_spring = any(int(k) == 2 for k in a.forces()["kind"]) if len(a.forces()) else False
-        if has_spring:
-            o = H.CpuWorld("orc"); build_random(o, seed)
         for s in range(12):
             a.step(); b.step()
-            if o is not None:
-                o.step()
-                H.assert_same_world(o, a, f"seed {seed} step {s + 1}: a scene with a spring runs the exact schedules")
-            else:
-                ba, bb = a.bodies(), b.bodies()
-                assert H.same_bits(ba, bb), (seed, s)
-                assert np.isfinite(ba["pos"]).all() and np.isfinite(ba["quat"]).all() and np.isfinite(ba["linVel"]).all(), (seed, s)
+            ba, bb = a.bodies(), b.bodies()
+            assert H.same_bits(ba, bb), (seed, s)
+            assert np.isfinite(ba["pos"]).all() and np.isfinite(ba["quat"]).all() and np.isfinite(ba["linVel"]).all(), (seed, s)
         sched = int(a.w.stats()["schedule"])
-        assert (sched != 5) if has_spring else (sched == 5 or (a.w.fast_plan_info()["bad"] & 1)), (seed, sched, a.w.fast_plan_info())
+        assert sched == 5 or (a.w.fast_plan_info()["bad"] & 1), (seed, sched, a.w.fast_plan_info())
         a.close(); b.close()
 
 
