@@ -353,6 +353,7 @@ def main():
     iterations = int(w.params()["iterations"])
     shard_form = None
     shard_other = None
+    fast_sharded = None
     if sharded:                                                      # (--force-dist with one rank takes the same path)
         # Both forms of the sharded step are measured — one persistent launch per step with the collective on a second stream BESIDE
         # it, and one launch per iteration with the collective between the launches — and the line reports the faster
@@ -390,6 +391,32 @@ def main():
                 results[form] = mk
         if not results:
             sys.exit("bench.py: the sharded run failed in every form")
+        # the same sharded scene in the FAST sweep (option "sweep" = 1): one launch of k_fast_sweep per iteration, the all-gather between the
+        # launches — north_star's own multi-GPU form; reported beside the exact forms (config.fast_sharded), never as `value`
+        fast_sharded = None
+        if os.environ.get("AVBD_BENCH_FAST_SHARDED", "1") != "0" and os.environ.get("AVBD_BENCH_ONE_DEVICE") != "1":
+            os.environ["AVBD_SHARD_PERSISTENT"] = "0"
+            os.environ.pop("AVBD_SHARD_GATE", None)
+            try:
+                if w is not None:
+                    w.close()
+            except Exception:
+                pass
+            w = make_sharded_world("one launch per iteration")
+            if w is not None:
+                ok = True
+                try:
+                    w.set_option("sweep", 1)
+                except Exception:
+                    ok = False
+                if vote(ok):
+                    mk = measure(w)
+                    if mk is not None:
+                        te = torch.tensor([mk["elapsed"]], dtype=torch.float64, device=tdev)
+                        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                        fast_sharded = {"form": "fast sweep (multi-colour Gauss-Seidel inside every slab), one launch per iteration, RCCL all-gather of 32 B/body between the launches; Jacobi across the cuts",
+                                        "ms_per_step": round(float(te.item()) / args.steps * 1e3, 5), "value": round(args.steps / float(te.item()), 3), "unit": "steps/s",
+                                        "schedule": int(mk["stats"]["schedule"]), "tolerance": "DESIGN.md section 2b (fast mode) + Jacobi across the cuts (section 7)"}
         shard_form = min(results, key=lambda f: results[f]["elapsed"])
         m = results[shard_form]
         shard_other = [{"form": o, "ms_per_step": round(results[o]["elapsed"] / args.steps * 1e3, 5)} if o in results else {"form": o, "failed": True}
@@ -566,11 +593,12 @@ def main():
             return {"error": repr(e)}
 
     strong_n1 = roofline_8k = joints_n1 = None
-    fast_1000 = fast_8k = fast_64k = None
+    fast_1000 = fast_8k = fast_64k = fast_64k_welds = None
     if rank == 0 and not sharded and args.scene is None and not args.no_strong_n1:
         fast_1000 = fast_line("Stress1000", 420, 200)
         fast_8k = fast_line("StressN:20", 410, 50)
         fast_64k = fast_line(STRONG_SCENE, STRONG_PRESIM + 10, 50)
+        fast_64k_welds = fast_line(STRONG_SCENE + "+welds:10000", STRONG_PRESIM + 10, 30)      # BASELINE configs[4] in the fast sweep (Joint halves as lane entries)
         strong_n1 = nested_line(STRONG_SCENE, STRONG_PRESIM + 10, 50)
         roofline_8k = nested_line("StressN:20", 410, 50)
         # BASELINE configs[4]'s scene on this one GPU: 64 000 cubes + 10 000 weld Joints between x-neighbours (host/scenes.h "+welds:<k>"); the Joint rows run in
@@ -592,9 +620,9 @@ def main():
                        "parallelism": "1 GPU" if not sharded else
                                       (f"{world_size} x-slabs of one scene, no exchange during a step (peer windows over xGMI); value = steps/s of that scene" if shard_form == EXACT_FORM else
                                        f"{world_size} x-slabs of one scene, RCCL all-gather of 32 B/body after every iteration; value = steps/s of that scene"),
-                       "shard_form": shard_form, "shard_other_form": shard_other,
+                       "shard_form": shard_form, "shard_other_form": shard_other, "fast_sharded": fast_sharded,
                        "strong_scaling_n1": strong_n1, "roofline_8k": roofline_8k, "joints_n1": joints_n1,
-                       "fast_1000": fast_1000, "fast_8k": fast_8k, "fast_64k": fast_64k,
+                       "fast_1000": fast_1000, "fast_8k": fast_8k, "fast_64k": fast_64k, "fast_64k_welds": fast_64k_welds,
                        "bodies": int(stats["numBodies"]), "manifolds": int(stats["numManifolds"]), "contacts": int(stats["numContacts"]),
                        "incidences": int(stats["numIncidences"]), "levels": int(stats["numLevels"]), "B_step_bytes": ab["B_step"],
                        "whole_run_from_scratch": whole},
