@@ -278,6 +278,8 @@ struct AvbdContext {
     int sweep = 0;                      /* 0: the exact schedules (default), 1: the fast sweep wherever it can run (contacts and ignore markers, one GPU or the all-gather form) */
     int fastStamps = 1;                 /* fast_stamps: 1 stamped records between colours, 0 a grid barrier per colour (cross-check: same bits) */
     int fastRecolor = 0;                /* fast_recolor: every how many steps every body is coloured afresh (1: every step; 0: by size); in between last step's colouring is kept where it still is one */
+    int fastSleep = -1;                 /* fast_sleep: back-off between two looks of a waiting lane, s_sleep 1 / 4 / 16 / 64 (-1: by the kernel's form) */
+    int fastXcd = 0;                    /* fast_xcd: latency form, consecutive tiles fill one XCD before the next */
     int fastSeed = 0;                   /* fast_seed: added to the seed of the colouring's tie-breaking hash */
     int fastForm = 0;                   /* fast_form: 0 by size, 1 the latency form of k_fast_sweep (a wave per SIMD, contacts in two passes), 2 the throughput form */
     int fastBlocks = 0;                 /* fast_blocks: workgroups of k_fast_sweep (0: by the tile count of the last plan) */

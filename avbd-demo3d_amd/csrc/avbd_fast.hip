@@ -688,6 +688,7 @@ struct FastCtx {
     float invDt2, beta;
     int stamps;
     GForce* gf; int jointSlotBase;
+    int sleepSel;
 };
 
 __device__ __forceinline__ float fast_alpha(const SolverParams& P, int it) { return P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha; }
@@ -817,6 +818,8 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
             f3 opos = zero3(); q4 orot = identq();
             fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
             {
+                /* (measured and not kept, latency form: TWO looks in flight — the second issued before the first is examined — so that a record landing just behind a
+                 * look is seen half a round trip earlier: Stress1000 272 -> 299 us per launch, 8 000 cubes 476 -> 531: the second look's traffic costs more) */
                 const unsigned long long t0 = X.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 for (;;) {
                     bool ok = true;
@@ -830,7 +833,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                         }
                     }
                     if (!X.stamps || __all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    if (X.sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (X.sleepSel == 1) __builtin_amdgcn_s_sleep(4); else if (X.sleepSel == 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) {
                         if (!ok) { atomicOr(&X.plan->bad, 256); X.plan->errInfo[0] = body; X.plan->errInfo[1] = partner; X.plan->errInfo[2] = it; X.plan->errInfo[3] = (int)sl.w; X.plan->errInfo[4] = (int)needVisit; X.plan->errInfo[5] = pass; X.plan->errInfo[6] = (int)needPartner; X.plan->errInfo[7] = t; }
                         break;
@@ -890,25 +893,26 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 for (int k = 0; k < 3; ++k) {
                     const f3 Jl = rowJl[k], Ja = rowJa[k];
                     const float f = rowF[k];
-                    /* lhs += (J J^T) penalty only for a positive, finite penalty (solver.cpp:387): a row that fails the test adds +0.0f products instead of
-                     * branching (every product is finite, so x * 0 is an exact zero and the sums do not change) */
-                    const bool penOk = (c.pen[k] > 0.0f) && (fabsf(c.pen[k]) <= FLT_MAX);
-                    const float pen = penOk ? c.pen[k] : 0.0f;
+                    const float pen = c.pen[k];
+                    const bool penOk = (pen > 0.0f) && (fabsf(pen) <= FLT_MAX);
                     const float J6[6] = {Jl.x, Jl.y, Jl.z, Ja.x, Ja.y, Ja.z};
 #pragma unroll
                     for (int i = 0; i < 6; ++i) acc[21 + i] += J6[i] * f;                  /* rhs += J f (solver.cpp:383-384) */
-                    /* ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104) */
-                    acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
-                    acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
+                    if (penOk) {
+                        /* lhs += (J J^T) penalty: ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104).  (Measured: a
+                         * branch-free form — a failing row adds zero products — takes 9 more registers and spills in the two-waves-per-SIMD form; no time gained) */
+                        acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
+                        acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
 #pragma unroll
-                    for (int jj = 0; jj < 3; ++jj)
+                        for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
-                        for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
-                    acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
-                    acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
-                    if (!isJoint) {
-                        const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * (penOk ? fabsf(f) : 0.0f);   /* solver.cpp:393-397: Manifold rows only */
-                        acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
+                            for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
+                        acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
+                        acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
+                        if (!isJoint) {
+                            const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only */
+                            acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
+                        }
                     }
                 }
                 /* the visit's mutations of the force (lambda cone clamp, stick; after a dual also lambda_n and the penalties); every record
@@ -1110,11 +1114,17 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     const int T = plan->numTiles, numColors = plan->numColors;
     const int nWG = gridDim.x;
     const int W = nWG * kWaves;
-    const int gw = (threadIdx.x >> 6) * nWG + blockIdx.x;             /* consecutive tiles go to different workgroups */
+    int gw = (threadIdx.x >> 6) * nWG + blockIdx.x;                   /* consecutive tiles go to different workgroups */
+    if (FORM == 1 && L.xcdLocal && (nWG & 7) == 0) {
+        /* latency form: workgroup b sits on XCD b % 8 (round robin, tools/ubench/xcd_pingpong.hip), and a hand-off inside one XCD costs 0.5 us where one across
+         * XCDs costs 0.7: consecutive tiles fill the SIMDs of ONE XCD before the next (a small scene lives on one or two of them) */
+        const int x = blockIdx.x & 7, cu = blockIdx.x >> 3, perX = nWG >> 3;
+        gw = x * (perX * kWaves) + (threadIdx.x >> 6) * perX + cu;
+    }
     FastCtx X;
     X.rPose = frsrc(F.xpose); X.rS = frsrc(F.xS);
     X.F = &F; X.plan = plan; X.cnt = L.cnt; X.B = L.B; X.M = L.M;
-    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps; X.gf = F.gf; X.jointSlotBase = F.jointSlotBase;
+    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps; X.gf = F.gf; X.jointSlotBase = F.jointSlotBase; X.sleepSel = L.sleepSel;
     const SolverParams P = L.P;
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     unsigned target = L.syncBase;
@@ -1204,14 +1214,16 @@ hipError_t fast_launch_plan(hipStream_t stream, const FastLaunch& L, int planBlo
     return hipGetLastError();
 }
 
-hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& L, int sweepBlocksPerCU, int tilesHint, int forceBlocks, int form)
+hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& Lin, int sweepBlocksPerCU, int tilesHint, int forceBlocks, int form)
 {
+    FastLaunch L = Lin;
     /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
     const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
     /* measured (sweep us, forms 1 / 2 / 3): 13 824 cubes 585 / 671 / 915, 32 768 cubes 955 / 884 / 1056, 64 000 cubes 1534 / 1170 / 1123 */
     int f = form != 0 ? form : (tilesGuess <= (long long)kFastLatTilesPerWave * 4 * L.numCU ? 1 : (tilesGuess <= (long long)9 * 4 * L.numCU ? 2 : 3));
     if (L.joints != 0 && f == 2) f = 3;                                /* (the joint-aware two-pass kernel at two waves per SIMD spills: 144 B per lane) */
     const bool lat = f == 1;
+    if (L.sleepSel < 0) L.sleepSel = f == 3 ? 2 : 0;                   /* (64 000 cubes, one pass: s_sleep 16 between two looks 1 201 -> 1 160 us; small scenes: s_sleep 1, 272 against 298) */
     const int waves = (lat ? kSweepThreadsLat : kSweepThreads) / 64;
     const int maxWG = lat ? L.numCU : std::max(1, std::min(1024, L.numCU * std::max(1, sweepBlocksPerCU)));
     int nWG = maxWG;

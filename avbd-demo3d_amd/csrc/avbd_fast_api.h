@@ -75,6 +75,8 @@ struct FastLaunch {
     int stamps;             /* 1: waves wait on the stamps of the records they read; 0: grid barrier per colour */
     int numCU;
     int joints;             /* the scene has Joint forces: the joint-aware kernels */
+    int sleepSel;           /* back-off between two looks at the records: s_sleep 1 / 4 / 16 / 64 */
+    int xcdLocal;           /* latency form: consecutive tiles on one XCD */
     int seedBase;           /* option fast_seed: added to the plan's own seed */
     int reuse;              /* k_fast_plan: colorPrev holds last step's colouring of the same bodies */
 };
