@@ -821,10 +821,11 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 /* (measured and not kept, latency form: TWO looks in flight — the second issued before the first is examined — so that a record landing just behind a
                  * look is seen half a round trip earlier: Stress1000 272 -> 299 us per launch, 8 000 cubes 476 -> 531: the second look's traffic costs more) */
                 const unsigned long long t0 = X.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                bool ok = !mine;                                       /* a lane that has its records stops looking: a waiting wave re-reads only what it still misses */
                 for (;;) {
-                    bool ok = true;
-                    if (mine) {
+                    if (!ok) {
                         sl = fld(X.rS, slot * 32); sp = fld(X.rS, slot * 32 + 16);
+                        ok = true;
                         if (moving) {
                             const fv4u p0 = fld(X.rPose, partner * 32), p1 = fld(X.rPose, partner * 32 + 16);
                             ok = pose_decode(p0, p1, needPartner, opos, orot);
