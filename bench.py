@@ -560,7 +560,7 @@ def main():
             out = {"workload": f"{nscene} (iterations={int(w3.params()['iterations'])}) steady window: steps {npresim}..{npresim + k3}, fast sweep from step 0",
                    "mode": "fast (option sweep = 1 / --mode fast: multi-colour Gauss-Seidel, DPP tree sums; within the stated tolerance of the exact mode, not bit-identical)",
                    "value": round(k3 / t3, 3), "unit": "steps/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "n_gpus": 1,
-                   "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "schedule": int(st3["schedule"]), "colours": plan["colors"], "tiles": plan["tiles"]}
+                   "bodies": int(st3["numBodies"]), "contacts": int(st3["numContacts"]), "joints": int(st3["numJoints"]), "schedule": int(st3["schedule"]), "colours": plan["colors"], "tiles": plan["tiles"]}
             w3.profile_enable(True); w3.profile_reset(); w3.step(20); w3.synchronize(); p3 = w3.profile(); w3.profile_enable(False)
             if p3["launches_primal"] > 0 and p3["ms_primal"] > 0:
                 s3 = p3["ms_primal"] * 1e-3 / p3["launches_primal"]
@@ -583,6 +583,14 @@ def main():
             dq = np.abs(np.sum(be["orientation"].astype(np.float64) * bf["orientation"].astype(np.float64), axis=1))
             dr = float((2.0 * np.arccos(np.clip(dq, 0.0, 1.0))).max())
             big = int(st3["numBodies"]) > 2000
+            if int(st3["numJoints"]) > 0:
+                # BASELINE configs[4]: body-body welds with the reference's angular Jacobian sign turn by 146 degrees in ONE step in every mode;
+                # any two orders of the sweep end metres apart — a throughput workload, held to schedule / determinism / finiteness (tests/test_gpu_fast.py), not to a distance
+                out["tolerance"] = {"criterion": "none for this scene: the reference's own weld Joints blow up (SURVEY.md section 7-5: bug-compatible angular sign), one step of ANY two sweep orders differs by metres; "
+                                                 "Joint rows are held to the exact mode on stable joints (tests/test_gpu_fast.py: world-anchored joints to rounding, corrected-sign welds within 5e-3 m per step)",
+                                    "bound": None, "measured": {"dpos_m": dp, "drot_rad": dr}, "within_bound": None}
+                we.close(); wf.close(); w3.close()
+                return out
             out["tolerance"] = {"criterion": "one step of the fast sweep against one step of the exact mode (= the reference, bit for bit) from the same state: max |dpos| over the bodies in metres, max rotation angle in radians (DESIGN.md section 2b)",
                                 "bound": {"dpos_m": 0.1 if big else 1e-3, "drot_rad": 0.3 if big else 5e-3,
                                           "why": "a pile still in motion (violent-phase bound)" if big else "a settled pile (steady-state bound)"},
