@@ -119,12 +119,15 @@ def test_option_keys_are_enumerable_without_a_device(lib):
 
 
 def test_committed_bench_line_and_profiles_keep_the_contract():
-    """profiles/r5_bench_default.json is a line bench.py printed on an MI355X: the keys the driver reads, the two objects this tier adds (roofline with
-    achieved / peak / frac / traffic, cpu_baseline with kind / cores / sample) and the nested driver-timed lines of the larger scenes; the rocprofv3 summaries
-    it cites exist and name the same dominant kernels."""
+    """profiles/r6_bench_default.json is a line bench.py printed on an MI355X: the keys the driver reads, the two objects this tier adds (roofline with
+    achieved / peak / frac / traffic, cpu_baseline with kind / cores / sample), the nested driver-timed lines of the larger scenes and of the fast sweep
+    (each with value, roofline and a measured tolerance); the rocprofv3 summaries it cites exist, name the same dominant kernels and record the id of
+    the library sources they were collected on — the id of the sources in this tree (tools/source_id.py)."""
     import json
+    import subprocess
+    import sys
     prof = os.path.join(H.ROOT, "profiles")
-    line = json.load(open(os.path.join(prof, "r5_bench_default.json")))
+    line = json.load(open(os.path.join(prof, "r6_bench_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["unit"] == "steps/s" and line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None and "workload" in line["config"]
@@ -137,8 +140,22 @@ def test_committed_bench_line_and_profiles_keep_the_contract():
         n = line["config"][nested]
         assert n["ms_per_step"] > 0 and abs(n["roofline"]["frac"] - n["roofline"]["achieved"] / n["roofline"]["peak"]) < 1e-4 and n["roofline"]["traffic"] > 0
     assert line["config"]["joints_n1"]["joints"] == 10000 and line["config"]["joints_n1"]["schedule"] == 4
-    for tag, kernel in (("stress1000", "k_iterate_single"), ("8k", "k_iterate_groups<false, 0, false>"), ("64k", "k_iterate_groups<true, 0, false>"), ("64k_welds", "k_iterate_groups<true, 0, true>")):
-        s = json.load(open(os.path.join(prof, f"r5_{tag}_cli_summary.json")))
+    # round 6: the fast sweep beside the exact mode — never the headline value, each with its own roofline and the tolerance measured in that run
+    assert line["config"]["mode"].startswith("exact")
+    for nested in ("fast_1000", "fast_8k", "fast_64k"):
+        n = line["config"][nested]
+        assert n["schedule"] == 5 and n["mode"].startswith("fast") and abs(n["value"] * n["ms_per_step"] - 1000.0) < 1.0 and 1 <= n["colours"] <= 64
+        assert n["roofline"]["kernel"] == "k_fast_sweep" and abs(n["roofline"]["frac"] - n["roofline"]["achieved"] / n["roofline"]["peak"]) < 1e-4 and n["roofline"]["traffic"] > 0
+        t = n["tolerance"]
+        assert t["within_bound"] is True and t["measured"]["dpos_m"] <= t["bound"]["dpos_m"] and t["measured"]["drot_rad"] <= t["bound"]["drot_rad"]
+    assert line["config"]["fast_1000"]["value"] > line["value"] and line["config"]["fast_64k"]["ms_per_step"] < line["config"]["strong_scaling_n1"]["ms_per_step"]
+    w = line["config"]["fast_64k_welds"]
+    assert w["joints"] == 10000 and w["schedule"] == 5 and w["tolerance"]["bound"] is None
+    sid = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "source_id.py")], capture_output=True, text=True, check=True).stdout.strip()
+    for tag, kernel in (("stress1000", "k_iterate_single"), ("8k", "k_iterate_groups<false, 0, false>"), ("64k", "k_iterate_groups<true, 0, false>"), ("64k_welds", "k_iterate_groups<true, 0, true>"),
+                        ("fast_1000", "k_fast_sweep<1, false>"), ("fast_8k", "k_fast_sweep<1, false>"), ("fast_64k", "k_fast_sweep<0, false>")):
+        s = json.load(open(os.path.join(prof, f"r6_{tag}_cli_summary.json")))
         assert kernel in s["dominant_kernel"], (tag, s["dominant_kernel"])
         assert {"FETCH_SIZE", "WRITE_SIZE"} <= set(s["counters_per_dispatch_of_dominant_kernel"])
-        assert os.path.exists(os.path.join(prof, f"r5_{tag}_kernel_stats.csv"))
+        assert os.path.exists(os.path.join(prof, f"r6_{tag}_kernel_stats.csv"))
+        assert s["source_id"] == sid, f"profiles/r6_{tag}_cli_summary.json was collected on other sources ({s['source_id']} != {sid}): re-run profiles/run_all_r6.sh"
