@@ -107,6 +107,7 @@ struct AvbdContext {
     std::string err;
     AvbdParams params;
     int stepIndex = 0;
+    int stepsSinceLoad = 0;                  /* steps this context has run on its present content (avbd_clear / a restore start it again): ownership may be set while it is 0 */
 
     /* host mirror of bodies (authoritative only while !deviceAhead) */
     std::vector<AvbdBody> hBodies;
@@ -280,6 +281,7 @@ struct AvbdContext {
     int fastRecolor = 0;                /* fast_recolor: every how many steps every body is coloured afresh (1: every step; 0: by size); in between last step's colouring is kept where it still is one */
     int fastSleep = -1;                 /* fast_sleep: back-off between two looks of a waiting lane, s_sleep 1 / 4 / 16 / 64 (-1: by the kernel's form) */
     int fastXcd = 0;                    /* fast_xcd: latency form, consecutive tiles fill one XCD before the next */
+    int fastOneXcd = 4096;              /* fast_one_xcd: latency form, a step of at most this many tiles — and at most one per wave of an XCD — runs on one XCD and hands records over through its L2 (0: never) */
     int fastSeed = 0;                   /* fast_seed: added to the seed of the colouring's tie-breaking hash */
     int fastForm = 0;                   /* fast_form: 0 by size, 1 the latency form of k_fast_sweep (a wave per SIMD, contacts in two passes), 2 the throughput form */
     int fastBlocks = 0;                 /* fast_blocks: workgroups of k_fast_sweep (0: by the tile count of the last plan) */
@@ -1149,7 +1151,7 @@ int avbd_clear(AvbdContext* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->hBodies.clear(); c->hI.clear(); c->hJ.clear(); c->hG.clear(); c->hostForceG.clear(); c->hHostRows.clear();
     c->bodiesStale = true; c->deviceAhead = false; c->gStale = true; c->gDeviceAhead = false; c->adjDirty = true;
-    c->stepIndex = 0; c->hostKeyCounter = 1; c->numStatic = 0;
+    c->stepIndex = 0; c->stepsSinceLoad = 0; c->hostKeyCounter = 1; c->numStatic = 0;
     c->stats = AvbdStepStats{};
     HIPCHK(c, hipMemsetAsync(c->dCnt.p, 0, sizeof(Counters), c->stream));
     HIPCHK(c, hipMemsetAsync(c->dDiag.p, 0, sizeof(DiagAccum), c->stream));
@@ -2028,10 +2030,35 @@ int avbd_set_ownership(AvbdContext* c, int nranks, int rank, const int* owner, i
     (void)hipSetDevice(c->device);
     int rc = download_bodies_to_host(c);
     if (rc) return rc;
-    if (c->stepIndex != 0) return c->fail(AVBD_E_INVALID, "ownership is static: set it before the first step");
+    /* before this context has stepped on its present content: a fresh scene, or one restored from a snapshot (avbd_load_snapshot: stepIndex is the snapshot's,
+     * the whole force list is here and every rank keeps what touches its slab from the first sharded step on).  Later: avbd_group_rebalance / avbd_rebalance_import */
+    if (c->stepsSinceLoad != 0) return c->fail(AVBD_E_INVALID, "ownership is static: set it before the first step of a scene or right after avbd_load_snapshot (later: avbd_group_rebalance)");
     c->nranks = nranks; c->rank = rank;
     c->hOwner.assign(owner, owner + n);
     c->bodiesStale = true; c->adjDirty = true;
+    /* A context that already holds manifolds (a snapshot was loaded, or state uploaded): keep what a rank of a run started from scratch would hold — the manifolds that touch a
+     * body it sweeps, every other force — with keys from the position in the ONE list every rank was handed (what avbd_group_rebalance leaves; a manifold between two bodies of
+     * other ranks stalled the all-gather form's sweep). */
+    const int nf = nranks > 1 ? avbd_num_forces(c) : 0;
+    if (nf > 0) {
+        std::vector<AvbdForce> all((size_t)nf), mine; std::vector<uint64_t> mineKeys;
+        std::vector<AvbdBody> bodies((size_t)std::max(n, 1));
+        if ((rc = avbd_download_forces(c, all.data(), nf)) < 0) return rc;
+        for (int i = 0; i < nf; ++i) {
+            const AvbdForce& f = all[(size_t)i];
+            const bool ta = f.bodyA >= 0 && f.bodyA < n && owner[f.bodyA] == rank, tb = f.bodyB >= 0 && f.bodyB < n && owner[f.bodyB] == rank;
+            if (f.kind != AVBD_FORCE_MANIFOLD || ta || tb) { mine.push_back(f); mineKeys.push_back(make_host_key(0, (uint64_t)(nf - i))); }
+        }
+        if ((int)mine.size() != nf) {
+            if (n && (rc = avbd_download_bodies(c, bodies.data(), n)) < 0) return rc;
+            const AvbdParams params = c->params;
+            const int stepIndex = c->stepIndex;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if ((rc = restore_state(c, params, stepIndex, bodies.data(), n, mine.data(), (int)mine.size(), mineKeys.data()))) return rc;
+            c->hOwner.assign(owner, owner + n);
+            c->bodiesStale = true; c->adjDirty = true;
+        }
+    }
     return AVBD_OK;
 }
 

@@ -6,7 +6,7 @@
  *
  *   k_fast_plan   colours the swept bodies (Jones-Plassmann rounds on the CSR adjacency the topology kernels built; the
  *                 result is the sequential greedy colouring in priority order, whatever the timing), classes them by
- *                 incidence count (a body gets 1 / 8 / 16 / 32 / 64 lanes), lays the (colour, class) groups out as TILES
+ *                 incidence count (a body gets 1 / 4 / 8 / 16 / 32 / 64 lanes), lays the (colour, class) groups out as TILES
  *                 of 64 lanes and writes, per lane, the constants of its incidence entry (SoA planes indexed by
  *                 tile * 64 + lane: a wave reads them with coalesced 16-byte loads) — anchors, the contact basis, bias
  *                 terms, friction, force cap, partner, contact slot — and per body the constants of its visit.
@@ -40,8 +40,8 @@ enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8,
              FL_JOINT = 16 /* the lane holds one half (three rows) of a Joint */, FL_PART1 = 32 /* ... its angular half */, FL_WORLD = 64 /* ... whose bodyA is the world */, FL_FIXANG = 128 /* avbd_set_joint_angular_sign */,
              FL_SPRING = 256 /* the lane holds a Spring (one row; FL_JOINT is set too: the lane takes the generic-force path) */ };
 
-__host__ __device__ constexpr int fast_class_lanes(int cls) { return cls == 0 ? 1 : (4 << cls); }
-__device__ __forceinline__ int fast_class_of(int deg) { return deg == 0 ? 0 : (deg <= 8 ? 1 : (deg <= 16 ? 2 : (deg <= 32 ? 3 : 4))); }
+__host__ __device__ constexpr int fast_class_lanes(int cls) { return cls == 0 ? 1 : (2 << cls); }
+__device__ __forceinline__ int fast_class_of(int deg) { return deg == 0 ? 0 : (deg <= 4 ? 1 : (deg <= 8 ? 2 : (deg <= 16 ? 3 : (deg <= 32 ? 4 : 5)))); }
 
 /* ---- memory access flavours --------------------------------------------------------------------------------------
  * Bytes another workgroup of the SAME launch reads or writes move with sc1 accesses only (the per-XCD L2s are not
@@ -49,6 +49,10 @@ __device__ __forceinline__ int fast_class_of(int deg) { return deg == 0 ? 0 : (d
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); }
 __device__ __forceinline__ fv4u fld(__amdgpu_buffer_rsrc_t r, int byteOff) { return __builtin_amdgcn_raw_buffer_load_b128(r, byteOff, 0, 16); }
 __device__ __forceinline__ void fst(__amdgpu_buffer_rsrc_t r, int byteOff, fv4u v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, 16); }
+/* ... or, when every wave of the launch sits on ONE XCD (k_fast_sweep's one-XCD form): a plain store — the line stays in that XCD's L2, where the sc1 loads of the
+ * other CUs find it (a hand-off of 0.3 us instead of 0.5 - 0.7, tools/ubench/xcd_pingpong.hip) */
+__device__ __forceinline__ void fst_local(__amdgpu_buffer_rsrc_t r, int byteOff, fv4u v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, 0); }
+__device__ __forceinline__ unsigned fast_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15u; }
 __device__ __forceinline__ unsigned fu(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float uf(unsigned u) { return __uint_as_float(u); }
 
@@ -124,7 +128,6 @@ __device__ __forceinline__ unsigned fast_hash(unsigned x)
     return x;
 }
 
-constexpr int kPlanSingleBodies = 1024;      /* up to this many bodies ONE workgroup plans the step: colours in LDS, workgroup barriers */
 constexpr int kFastRecolorAbove = 10;         /* last step's colouring is dropped (every body coloured afresh) once it has grown beyond this many colours */
 constexpr int kFastColorsFloor = 4;           /* ... and the bodies of its highest colour are coloured afresh while it has more than this many */
 constexpr int kPlanNbrRegs = 12;             /* neighbours of a body its thread keeps in registers through the rounds of the colouring */
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;              /* this thread's body */
     unsigned target = L.syncBase;
     __shared__ int sBodyBase[kFastMaxColors * kFastClasses], sTileBase[kFastMaxColors * kFastClasses], sCount[kFastMaxColors * kFastClasses];
+    __shared__ int sNative[kFastMaxColors * kFastClasses], sIn[kFastMaxColors * kFastClasses], sOut[kFastMaxColors * kFastClasses];   /* (the leftovers of a class that move up one: stage 3) */
     __shared__ int sColorStart[kFastMaxColors + 1], sTotals[3];
     __shared__ int sColor[SINGLE ? kPlanSingleBodies : 1];
 
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
     int nbr[kPlanNbrRegs];                                            /* swept neighbours among the first adjacency entries, -1: none */
     unsigned higher = 0u;                                             /* bit k: nbr[k] has the higher priority */
     int adjS = 0, adjE = 0, deg = 0, veto = 0;
+    bool isolated = false;                                            /* a swept body none of whose forces leads to another swept body: nobody waits for it, it waits for nobody */
 #pragma unroll
     for (int k = 0; k < kPlanNbrRegs; ++k) nbr[k] = -1;
     /* Last step's colouring is kept where it is still one: a body keeps its colour unless a neighbour of higher priority held the same colour
@@ -224,6 +229,16 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
         }
         if (keep && (~usedOld & ((1ull << old) - 1ull)) != 0ull) keep = false;
         if (keep) myColor = old;
+        {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < kPlanNbrRegs; ++k) any |= nbr[k] >= 0;
+            for (int i = adjS + kPlanNbrRegs; i < adjE && !any; ++i) {
+                const int p = L.adjOther[i];
+                any = p >= 0 && inc_kind(L.adjRef[i]) != FK_IGNORE && B.solved[p] != 0;
+            }
+            isolated = !any;
+        }
         const int e0 = L.incStart[b], e1 = L.incStart[b + 1];
         deg = e1 - e0;
         veto = deg > 64 ? 1 : 0;
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
             }
             if (!blocked) {
                 int c = used == ~0ull ? 64 : __ffsll((long long)~used) - 1;
-                if (c >= kFastMaxColors) { atomicOr(&plan->bad, 4); c = kFastMaxColors - 1; }
+                if (c >= kFastIsolatedRow) { atomicOr(&plan->bad, 4); c = kFastIsolatedRow - 1; }   /* (the last row of the group table is the isolated bodies') */
                 myColor = c;
                 set_color(b, c);
             }
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
     /* (counted per workgroup in LDS first, one global atomic per group and workgroup: 64 000 bodies are 64 000 atomics on a dozen words otherwise, 13 ns apiece) */
     int pos = 0, grp = 0;
     if (myColor >= 0) {
-        grp = myColor * kFastClasses + fast_class_of(min(deg, 64));
+        grp = (isolated ? kFastIsolatedRow : myColor) * kFastClasses + fast_class_of(min(deg, 64));
         pos = atomicAdd(&sCount[grp], 1);
     }
     __syncthreads();
@@ -312,11 +327,25 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
     __syncthreads();
     if (threadIdx.x < 64) {
         const int c = threadIdx.x;
-        int cnt[kFastClasses], bodiesC = 0, tilesC = 0;
+        /* The bodies of a (colour, class) group that do not fill its last tile move up one class when the next class's last tile has the room (a body with 3 contacts
+         * sits in 8 lanes as well as in 4): one tile less per group that does — Stress1000: 131 tiles instead of 137, and below the 128 waves of one XCD most steps.
+         * In a group the bodies that came up stand first, its own behind them, so the ones that move on are always its own. */
+        int cnt[kFastClasses], bodiesC = 0, tilesC = 0, in = 0;
 #pragma unroll
         for (int k = 0; k < kFastClasses; ++k) {
-            cnt[k] = sCount[c * kFastClasses + k];
+            const int native = sCount[c * kFastClasses + k];
             const int per = 64 / fast_class_lanes(k);
+            const int tot = native + in;
+            const int r = tot % per;
+            int out = 0;
+            if (k >= 1 && k + 1 < kFastClasses && r > 0 && r <= native) {
+                const int perUp = 64 / fast_class_lanes(k + 1), nativeUp = sCount[c * kFastClasses + k + 1];
+                const int slack = (perUp - nativeUp % perUp) % perUp;
+                if (r <= slack) out = r;
+            }
+            sNative[c * kFastClasses + k] = native; sIn[c * kFastClasses + k] = in; sOut[c * kFastClasses + k] = out;
+            cnt[k] = tot - out;
+            in = out;
             bodiesC += cnt[k]; tilesC += (cnt[k] + per - 1) / per;
         }
         int bodiesIncl = bodiesC, tilesIncl = tilesC;
@@ -331,9 +360,10 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
         for (int k = 0; k < kFastClasses; ++k) {
             const int per = 64 / fast_class_lanes(k);
             sBodyBase[c * kFastClasses + k] = bodies; sTileBase[c * kFastClasses + k] = tiles;
+            sCount[c * kFastClasses + k] = cnt[k];                     /* (what stage 4 and the plan hold: the groups as they are laid out) */
             bodies += cnt[k]; tiles += (cnt[k] + per - 1) / per;
         }
-        const unsigned long long usedColors = __ballot(bodiesC > 0);
+        const unsigned long long usedColors = __ballot(bodiesC > 0) & ~(1ull << kFastIsolatedRow);
         if (c == 63) { sColorStart[kFastMaxColors] = tilesIncl; sTotals[0] = bodiesIncl; sTotals[1] = tilesIncl; sTotals[2] = usedColors ? 64 - __builtin_clzll(usedColors) : 0; }
     }
     __syncthreads();
@@ -358,7 +388,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
 
     /* ---- stage 4: bodies into their groups, body constants, tile descriptors (read by the next launches) ---- */
     if (myColor >= 0) {
-        const int at = sBodyBase[grp] + pos;
+        const int stay = sNative[grp] - sOut[grp];
+        const int at = pos >= stay ? sBodyBase[grp + 1] + (pos - stay) : sBodyBase[grp] + sIn[grp] + pos;
         F.cbody[at] = b;
         const float4 np = B.plane(BP_NPOS)[b], nq = B.plane(BP_NQUAT)[b], mp = B.plane(BP_MASS)[b];
         const float4 i0 = B.plane(BP_I0)[b], i1 = B.plane(BP_I1)[b], i2 = B.plane(BP_I2)[b];
@@ -369,7 +400,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
         F.bodyC[(size_t)3 * F.bodyCap + at] = make_float4(j0.x, j1.y, j2.z, __int_as_float(b));
     }
     const int gtid = b, stride = gridDim.x * blockDim.x;
-    for (int g = 0; g < sTotals[2] * kFastClasses; ++g) {
+    for (int gi = 0; gi < (sTotals[2] + 1) * kFastClasses; ++gi) {
+        const int g = gi < sTotals[2] * kFastClasses ? gi : kFastIsolatedRow * kFastClasses + (gi - sTotals[2] * kFastClasses);   /* the colours' rows, then the isolated bodies' */
         const int cnt = sCount[g];
         if (!cnt) continue;
         const int k = g % kFastClasses, per = 64 / fast_class_lanes(k), nt = (cnt + per - 1) / per;
@@ -508,11 +540,11 @@ __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builti
 template <int G>
 __device__ __forceinline__ float group_sum(float v)
 {
-    if (G >= 8) {
+    if (G >= 4) {
         v = v + dpp_f<0xB1>(v);       /* quad_perm [1,0,3,2] */
         v = v + dpp_f<0x4E>(v);       /* quad_perm [2,3,0,1] */
-        v = v + dpp_f<0x141>(v);      /* row_half_mirror */
     }
+    if (G >= 8) v = v + dpp_f<0x141>(v);    /* row_half_mirror */
     if (G >= 16) v = v + dpp_f<0x140>(v);   /* row_mirror */
     if (G >= 32) v = v + __shfl_xor(v, 16, 64);
     if (G >= 64) v = v + __shfl_xor(v, 32, 64);
@@ -588,12 +620,29 @@ __device__ __forceinline__ void fast_dual(FastRows& c, f3 n, f3 t1, f3 t2, float
     }
 }
 
+/* -DAVBD_ASM_MARKS: comments in the generated assembly (one set per lanes-per-body instantiation) that tools/kernel_resources.py splits the instruction mix at */
+#ifdef AVBD_ASM_MARKS
+#define FAST_MARK(name) asm volatile("; AVBD_MARK " #name "_g%0" :: "n"(G) : "memory")
+#else
+#define FAST_MARK(name) do { } while (0)
+#endif
+
 #ifdef AVBD_DF_STATS
 constexpr int kFastStatTiles = 2048, kFastStatIts = 64;
 __device__ unsigned gFastTimes[kFastStatTiles * kFastStatIts * 4];     /* per (tile, iteration): visit start, first pass done, inputs of the second pass in, published (10 ns ticks) */
-#define FAST_STAMP(k) do { if (t < kFastStatTiles && it < kFastStatIts && (threadIdx.x & 63) == 0) gFastTimes[((size_t)t * kFastStatIts + it) * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define FAST_STAMP_(k) do { if (t < kFastStatTiles && it < kFastStatIts - 1 && (threadIdx.x & 63) == 0) gFastTimes[((size_t)t * kFastStatIts + it) * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#if AVBD_DF_STATS == 2      /* the path behind the last arrival: inputs in (0), rows done (1), solved (2), published (3) */
+#define FAST_STAMP(k) do { if ((k) == 3) FAST_STAMP_(3); } while (0)
+#define FAST_STAMPB(k) FAST_STAMP_(k)
+#else
+#define FAST_STAMP(k) FAST_STAMP_(k)
+#define FAST_STAMPB(k) do { } while (0)
+#endif
+#define FAST_STAT_COLOUR(colour) do { if (t < kFastStatTiles && it == 0 && (threadIdx.x & 63) == 0) gFastTimes[((size_t)t * kFastStatIts + kFastStatIts - 1) * 4] = (unsigned)(colour); } while (0)   /* (the last iteration slot holds the tile's colour) */
 #else
 #define FAST_STAMP(k) do { } while (0)
+#define FAST_STAMPB(k) do { } while (0)
+#define FAST_STAT_COLOUR(colour) do { } while (0)
 #endif
 
 /* One half of a Joint for one endpoint (joint.cpp:68-139; rows 3p .. 3p + 2): computeConstraint (no alpha, no mutation: C alone), the dual update of the
@@ -689,6 +738,7 @@ struct FastCtx {
     int stamps;
     GForce* gf; int jointSlotBase;
     int sleepSel;
+    bool local;          /* every wave of this launch runs on one XCD: records are handed over with plain stores */
 };
 
 __device__ __forceinline__ float fast_alpha(const SolverParams& P, int it) { return P.postStabilize ? (it < P.iterations ? 1.0f : 0.0f) : P.alpha; }
@@ -725,6 +775,40 @@ __device__ __forceinline__ f3 solve_ldlt3_quadlanes(m33 A, f3 b, int c)
     const f3 L2 = A.c2 - L0 * L20 - L1 * L21;
     bad |= fabsf(L2.z) < FLT_EPSILON;
     const float d2 = L2.z;
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    const float zq = (c == 0 ? y.x : (c == 1 ? y.y : y.z)) / (c == 0 ? d0 : (c == 1 ? d1 : d2));
+    f3 z; z.x = quad_bcast<0>(zq); z.y = quad_bcast<1>(zq); z.z = quad_bcast<2>(zq);
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    return bad ? zero3() : x;
+}
+
+/* maths.h:104 in two halves for the latency form: the factorisation (what solve_ldlt3_branchless computes before it touches b; L10 | L20 side by side on the lanes
+ * of a quad) and the substitution — per lane for its own right-hand side, or with its three divisions side by side on the lanes of a quad that share b.  The same
+ * quotients, products and differences as the one-piece solve. */
+__device__ __forceinline__ void fast_ldlt3_factor(m33 A, int c, float& L10, float& L20, float& L21, float& d0, float& d1, float& d2, bool& bad)
+{
+    const f3 L0 = A.c0;
+    bad = fabsf(L0.x) < FLT_EPSILON;
+    d0 = L0.x;
+    const float q1 = (c == 0 ? L0.y : L0.z) / d0;
+    L10 = quad_bcast<0>(q1); L20 = quad_bcast<1>(q1);
+    const f3 L1 = A.c1 - L0 * L10;
+    bad |= fabsf(L1.y) < FLT_EPSILON;
+    d1 = L1.y;
+    L21 = L1.z / d1;
+    const f3 L2 = A.c2 - L0 * L20 - L1 * L21;
+    bad |= fabsf(L2.z) < FLT_EPSILON;
+    d2 = L2.z;
+}
+__device__ __forceinline__ f3 fast_ldlt3_subst_lane(float L10, float L20, float L21, float d0, float d1, float d2, bool bad, f3 b)
+{
+    f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
+    f3 z; z.x = y.x / d0; z.y = y.y / d1; z.z = y.z / d2;
+    f3 x; x.z = z.z; x.y = z.y - L21 * x.z; x.x = z.x - L10 * x.y - L20 * x.z;
+    return bad ? zero3() : x;
+}
+__device__ __forceinline__ f3 fast_ldlt3_subst_quad(float L10, float L20, float L21, float d0, float d1, float d2, bool bad, f3 b, int c)
+{
     f3 y; y.x = b.x; y.y = b.y - L10 * y.x; y.z = b.z - L20 * y.x - L21 * y.y;
     const float zq = (c == 0 ? y.x : (c == 1 ? y.y : y.z)) / (c == 0 ? d0 : (c == 1 ? d1 : d2));
     f3 z; z.x = quad_bcast<0>(zq); z.y = quad_bcast<1>(zq); z.z = quad_bcast<2>(zq);
@@ -783,7 +867,8 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
     const q4 nrot = mkq(b1.x, b1.y, b1.z, b1.w);
     const f3 Id = mk3(b2.x, b2.y, b2.z), Jd = mk3(b3.x, b3.y, b3.z);
 
-    FAST_STAMP(0);
+    FAST_MARK(fv_start);
+    FAST_STAMP(0); FAST_STAT_COLOUR((td.y >> 24) & 0xFF);
     /* the body's own pose: this wave published it (epoch it) */
     f3 pos; q4 rot;
     {
@@ -796,9 +881,36 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
     const m33 RI = mkm(R.c0 * Id.x, R.c1 * Id.y, R.c2 * Id.z), RJ = mkm(R.c0 * Jd.x, R.c1 * Jd.y, R.c2 * Jd.z);
     const m33 Iw = RI * Rt, invIw = RJ * Rt;
 
-    float acc[27];
+    /* the body's system, summed per lane and then over the sub-group: acc[0..20] the J J^T penalty part of lhs (ll lower, la, aa lower), gy[] the gyroscopic
+     * diagonal, rh[] the right-hand side.  Every form of the kernel adds them up in this one order: (sum of acc) + the body's own terms, then + (sum of gy). */
+    float acc[21], gy[3], rh[6];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+    for (int i = 0; i < 21; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gy[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rh[i] = 0.0f;
+
+    /* the body's own terms (solver.cpp:350-369).  (Computed here, ahead of the waits, in every form: behind them the one-pass form takes 230 registers instead of
+     * 193 and the two-waves-per-SIMD form spills 80 B instead of 32) */
+    const float invDt2 = X.invDt2;
+    const float mdt = mass * invDt2;
+    const m33 aa0 = Iw * invDt2;
+    const f3 rl0 = ((pos - npos) * invDt2) * mass;
+    const q4 qErr = rot * qconj(nrot);
+    f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
+    rotErr = rotErr * 2.0f;
+    if (qErr.w < 0.0f) rotErr = -rotErr;
+    const f3 ra0 = Iw * (rotErr * invDt2);
+
+    /* SPLIT (latency form, contacts): what the second pass's lanes need arrives in two parts — the contact's records (lambda, penalty: written by the partner
+     * BEFORE its sums and its solve) and the partner's new pose (after them).  Everything that needs only the first — the J J^T penalty part of lhs, its 21
+     * sums, the factorisation of ll, ll^-1 la and the Schur complement up to the gyroscopic diagonal — runs while the pose is still on its way; behind the pose
+     * come the rows' forces, nine sums, one substitution, the 3x3 Schur solve and the pose update.  Same operations on the same values as the other forms. */
+    constexpr bool SPLIT = TWOPASS && HOIST && !JOINTS && G >= 4;
+    float fL10 = 0.0f, fL20 = 0.0f, fL21 = 0.0f, fd0 = 1.0f, fd1 = 1.0f, fd2 = 1.0f; bool fbad = false;
+    f3 col0 = zero3(), col1 = zero3(), col2 = zero3(), schurOff = zero3(), pDiag = zero3(), aaDiag = zero3();
+    m33 al = mkm(zero3(), zero3(), zero3());
 
     if (G > 1) {
         const f3 rOwn = mk3(c0.x, c0.y, c0.z), rOth = mk3(c1.x, c1.y, c1.z);
@@ -809,14 +921,83 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
         const bool moving = valid && !sole;
         const unsigned needPartner = (unsigned)(first ? it : it + 1);
         const unsigned needVisit = (unsigned)(first ? 2 * it : 2 * it + 1);
+        /* lhs += (J J^T) penalty: ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104).  (Measured: a
+         * branch-free form — a failing row adds zero products — takes 9 more registers and spills in the two-waves-per-SIMD form; no time gained) */
+        auto lhs_add = [&](f3 Jl, f3 Ja, float pen) {
+            const float J6[6] = {Jl.x, Jl.y, Jl.z, Ja.x, Ja.y, Ja.z};
+            acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
+            acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
+            acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
+            acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
+        };
+        fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
 #pragma unroll 1
         for (int pass = TWOPASS ? 0 : 1; pass < 2; ++pass) {
             const bool mine = valid && (!TWOPASS || first == (pass == 0));
             if (pass == 1) FAST_STAMP(1);
-            if (!__any(mine)) continue;
+            FAST_MARK(fv_pass_top);
+            const bool early = SPLIT && pass == 1;
+            if (early) {
+                if (__any(mine)) {
+                    /* the records of the second pass's contacts (their first visitor wrote them in this iteration) ... */
+                    const unsigned long long t0 = X.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                    bool ok = !mine;
+                    for (;;) {
+                        if (!ok) {
+                            sl = fld(X.rS, slot * 32); sp = fld(X.rS, slot * 32 + 16);
+                            ok = (sl.w >> 1) == needVisit && sp.w == (unsigned)(it + 1);
+                        }
+                        if (!X.stamps || __all(ok)) break;
+                        if (X.sleepSel == 0) __builtin_amdgcn_s_sleep(1); else if (X.sleepSel == 1) __builtin_amdgcn_s_sleep(4); else if (X.sleepSel == 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) {
+                            if (!ok) { atomicOr(&X.plan->bad, 256); X.plan->errInfo[0] = body; X.plan->errInfo[1] = partner; X.plan->errInfo[2] = it; X.plan->errInfo[3] = (int)sl.w; X.plan->errInfo[4] = (int)needVisit; X.plan->errInfo[5] = 2; X.plan->errInfo[6] = (int)needPartner; X.plan->errInfo[7] = t; }
+                            break;
+                        }
+                    }
+                    /* ... and their part of lhs */
+                    if (mine) {
+                        const float sign = isA ? 1.0f : -1.0f;
+                        const f3 basis[3] = {n, t1, t2};
+                        const float pen3[3] = {uf(sp.x), uf(sp.y), uf(sp.z)};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const bool penOk = (pen3[k] > 0.0f) && (fabsf(pen3[k]) <= FLT_MAX);
+                            if (penOk) lhs_add(basis[k] * sign, cross3(wOwn, basis[k]) * sign, pen3[k]);
+                        }
+                    }
+                }
+                FAST_MARK(fv_presolve);
+                /* lhs without the gyroscopic diagonal, the factorisation of ll, ll^-1 la, the Schur complement's pose-independent part */
+#pragma unroll
+                for (int i = 0; i < 21; ++i) acc[i] = group_sum<G>(acc[i]);
+                acc[0] += mdt; acc[3] += mdt; acc[5] += mdt;
+                acc[15] += aa0.c0.x; acc[16] += aa0.c0.y; acc[17] += aa0.c0.z; acc[18] += aa0.c1.y; acc[19] += aa0.c1.z; acc[20] += aa0.c2.z;
+                m33 ll, la;
+                ll.c0 = mk3(acc[0], acc[1], acc[2]); ll.c1 = mk3(acc[1], acc[3], acc[4]); ll.c2 = mk3(acc[2], acc[4], acc[5]);
+                la.c0 = mk3(acc[6], acc[7], acc[8]); la.c1 = mk3(acc[9], acc[10], acc[11]); la.c2 = mk3(acc[12], acc[13], acc[14]);
+                al = mtranspose(la);
+                fast_ldlt3_factor(ll, lane & 3, fL10, fL20, fL21, fd0, fd1, fd2, fbad);
+                {
+                    const int q = lane & 3;
+                    const f3 rhsq = mk3(pick4(la.c0.x, la.c1.x, la.c2.x, la.c2.x, q), pick4(la.c0.y, la.c1.y, la.c2.y, la.c2.y, q), pick4(la.c0.z, la.c1.z, la.c2.z, la.c2.z, q));
+                    const f3 sol = fast_ldlt3_subst_lane(fL10, fL20, fL21, fd0, fd1, fd2, fbad, rhsq);
+                    col0 = quad_bcast3<0>(sol); col1 = quad_bcast3<1>(sol); col2 = quad_bcast3<2>(sol);
+                }
+                {
+                    const f3 p0 = al * col0, p1 = al * col1, p2 = al * col2;
+                    schurOff = mk3(acc[16] - p0.y, acc[17] - p0.z, acc[19] - p1.z);       /* schur c0.y, c0.z, c1.z */
+                    pDiag = mk3(p0.x, p1.y, p2.z);
+                    aaDiag = mk3(acc[15], acc[18], acc[20]);
+                }
+            }
+            if (!__any(mine)) { if (pass == 1) FAST_STAMP(2); continue; }
+            FAST_MARK(fv_poll);
             /* ---- inputs of the pass: partner pose and the contact's records, one round trip; with stamps the lane polls until both carry this visit's stamps ---- */
             f3 opos = zero3(); q4 orot = identq();
-            fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
             {
                 /* (measured and not kept, latency form: TWO looks in flight — the second issued before the first is examined — so that a record landing just behind a
                  * look is seen half a round trip earlier: Stress1000 272 -> 299 us per launch, 8 000 cubes 476 -> 531: the second look's traffic costs more) */
@@ -824,13 +1005,15 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                 bool ok = !mine;                                       /* a lane that has its records stops looking: a waiting wave re-reads only what it still misses */
                 for (;;) {
                     if (!ok) {
-                        sl = fld(X.rS, slot * 32); sp = fld(X.rS, slot * 32 + 16);
+                        if (!early) { sl = fld(X.rS, slot * 32); sp = fld(X.rS, slot * 32 + 16); }
                         ok = true;
                         if (moving) {
                             const fv4u p0 = fld(X.rPose, partner * 32), p1 = fld(X.rPose, partner * 32 + 16);
                             ok = pose_decode(p0, p1, needPartner, opos, orot);
-                            ok &= (sl.w >> 1) == needVisit;
-                            if (!first) ok &= sp.w == (unsigned)(it + 1);
+                            if (!early) {
+                                ok &= (sl.w >> 1) == needVisit;
+                                if (!first) ok &= sp.w == (unsigned)(it + 1);
+                            }
                         }
                     }
                     if (!X.stamps || __all(ok)) break;
@@ -841,7 +1024,9 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     }
                 }
             }
+            FAST_MARK(fv_rows);
             if (pass == 1) FAST_STAMP(2);
+            FAST_STAMPB(0);
             if (pass == 1 && nextT >= 0 && nextT != t) { fast_load_tile(F, nextT, next); prefetched = true; }   /* (its loads return while this pass, the sums and the solve run) */
             if (mine) {
                 f3 wOwnP = wOwn;
@@ -898,82 +1083,86 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     const bool penOk = (pen > 0.0f) && (fabsf(pen) <= FLT_MAX);
                     const float J6[6] = {Jl.x, Jl.y, Jl.z, Ja.x, Ja.y, Ja.z};
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) acc[21 + i] += J6[i] * f;                  /* rhs += J f (solver.cpp:383-384) */
+                    for (int i = 0; i < 6; ++i) rh[i] += J6[i] * f;                        /* rhs += J f (solver.cpp:383-384) */
                     if (penOk) {
-                        /* lhs += (J J^T) penalty: ll lower, la, aa lower (solver.cpp:387-391; al = la^T, the upper triangles are never read, maths.h:104).  (Measured: a
-                         * branch-free form — a failing row adds zero products — takes 9 more registers and spills in the two-waves-per-SIMD form; no time gained) */
-                        acc[0] += (Jl.x * Jl.x) * pen; acc[1] += (Jl.y * Jl.x) * pen; acc[2] += (Jl.z * Jl.x) * pen;
-                        acc[3] += (Jl.y * Jl.y) * pen; acc[4] += (Jl.z * Jl.y) * pen; acc[5] += (Jl.z * Jl.z) * pen;
-#pragma unroll
-                        for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-                            for (int ii = 0; ii < 3; ++ii) acc[6 + 3 * jj + ii] += (J6[ii] * J6[3 + jj]) * pen;
-                        acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
-                        acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
+                        if (!early) lhs_add(Jl, Ja, pen);
                         if (!isJoint) {
                             const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only */
-                            acc[15] += gyro.x; acc[18] += gyro.y; acc[20] += gyro.z;
+                            gy[0] += gyro.x; gy[1] += gyro.y; gy[2] += gyro.z;
                         }
                     }
                 }
                 /* the visit's mutations of the force (lambda cone clamp, stick; after a dual also lambda_n and the penalties); every record
                  * validates itself, so nothing is drained before the pose is published */
                 const unsigned visit = (unsigned)(sole ? 0 : (first ? 2 * it + 1 : 2 * it + 2));
-                fst(X.rS, slot * 32, fv4u{fu(c.lam[0]), fu(c.lam[1]), fu(c.lam[2]), (visit << 1) | (c.stick ? 1u : 0u)});
-                if (first) fst(X.rS, slot * 32 + 16, fv4u{fu(c.pen[0]), fu(c.pen[1]), fu(c.pen[2]), (unsigned)(it + 1)});
+                const fv4u recL = fv4u{fu(c.lam[0]), fu(c.lam[1]), fu(c.lam[2]), (visit << 1) | (c.stick ? 1u : 0u)}, recP = fv4u{fu(c.pen[0]), fu(c.pen[1]), fu(c.pen[2]), (unsigned)(it + 1)};
+                if (HOIST && X.local) { fst_local(X.rS, slot * 32, recL); if (first) fst_local(X.rS, slot * 32 + 16, recP); }
+                else { fst(X.rS, slot * 32, recL); if (first) fst(X.rS, slot * 32 + 16, recP); }
             }
         }
-        group_sum27<G>(acc);
+        FAST_STAMPB(1);
+        FAST_MARK(fv_sums);
+        if (!SPLIT) {
+#pragma unroll
+            for (int i = 0; i < 21; ++i) acc[i] = group_sum<G>(acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gy[i] = group_sum<G>(gy[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rh[i] = group_sum<G>(rh[i]);
     }
 
-    /* ---- the body's own terms (solver.cpp:350-369), solve6x6 (:68-83), pose update (:402-408) ---- */
-    const float invDt2 = X.invDt2;
-    const float mdt = mass * invDt2;
-    acc[0] += mdt; acc[3] += mdt; acc[5] += mdt;
-    const m33 aa0 = Iw * invDt2;
-    acc[15] += aa0.c0.x; acc[16] += aa0.c0.y; acc[17] += aa0.c0.z; acc[18] += aa0.c1.y; acc[19] += aa0.c1.z; acc[20] += aa0.c2.z;
-    const f3 rl0 = ((pos - npos) * invDt2) * mass;
-    acc[21] += rl0.x; acc[22] += rl0.y; acc[23] += rl0.z;
-    const q4 qErr = rot * qconj(nrot);
-    f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
-    rotErr = rotErr * 2.0f;
-    if (qErr.w < 0.0f) rotErr = -rotErr;
-    const f3 ra0 = Iw * (rotErr * invDt2);
-    acc[24] += ra0.x; acc[25] += ra0.y; acc[26] += ra0.z;
-
-    m33 ll, la, aa;
-    ll.c0 = mk3(acc[0], acc[1], acc[2]); ll.c1 = mk3(acc[1], acc[3], acc[4]); ll.c2 = mk3(acc[2], acc[4], acc[5]);
-    la.c0 = mk3(acc[6], acc[7], acc[8]); la.c1 = mk3(acc[9], acc[10], acc[11]); la.c2 = mk3(acc[12], acc[13], acc[14]);
-    aa.c0 = mk3(acc[15], acc[16], acc[17]); aa.c1 = mk3(acc[16], acc[18], acc[19]); aa.c2 = mk3(acc[17], acc[19], acc[20]);
-    const f3 bl = mk3(acc[21], acc[22], acc[23]), ba = mk3(acc[24], acc[25], acc[26]);
+    FAST_MARK(fv_solve);
+    /* ---- solve6x6 (solver.cpp:68-83: five 3x3 LDL^T solves, the first four on one matrix), pose update (:402-408) ---- */
+    rh[0] += rl0.x; rh[1] += rl0.y; rh[2] += rl0.z;
+    rh[3] += ra0.x; rh[4] += ra0.y; rh[5] += ra0.z;
+    const f3 bl = mk3(rh[0], rh[1], rh[2]), ba = mk3(rh[3], rh[4], rh[5]);
     f3 xl, xa;
-    {
-        /* solve6x6 (solver.cpp:68-83): five 3x3 LDL^T solves, the first four on one matrix */
-        const m33 al = mtranspose(la);
-        f3 col0, col1, col2, x0, y;
-        if (G >= 8) {
+    if (SPLIT) {
+        const int q = lane & 3;
+        const f3 x0 = fast_ldlt3_subst_quad(fL10, fL20, fL21, fd0, fd1, fd2, fbad, bl, q);
+        m33 schur;                                                    /* (maths.h:104 reads the lower triangle only: c0, c1.y, c1.z, c2.z) */
+        schur.c0 = mk3((aaDiag.x + gy[0]) - pDiag.x, schurOff.x, schurOff.y);
+        schur.c1 = mk3(0.0f, (aaDiag.y + gy[1]) - pDiag.y, schurOff.z);
+        schur.c2 = mk3(0.0f, 0.0f, (aaDiag.z + gy[2]) - pDiag.z);
+        const f3 rhs_s = ba - al * x0;
+        const f3 y = solve_ldlt3_quadlanes(schur, rhs_s, q);
+        xl = x0 - mkm(col0, col1, col2) * y;
+        xa = y;
+    } else {
+        acc[0] += mdt; acc[3] += mdt; acc[5] += mdt;
+        acc[15] += aa0.c0.x; acc[16] += aa0.c0.y; acc[17] += aa0.c0.z; acc[18] += aa0.c1.y; acc[19] += aa0.c1.z; acc[20] += aa0.c2.z;
+        acc[15] += gy[0]; acc[18] += gy[1]; acc[20] += gy[2];
+        m33 ll, la, aa;
+        ll.c0 = mk3(acc[0], acc[1], acc[2]); ll.c1 = mk3(acc[1], acc[3], acc[4]); ll.c2 = mk3(acc[2], acc[4], acc[5]);
+        la.c0 = mk3(acc[6], acc[7], acc[8]); la.c1 = mk3(acc[9], acc[10], acc[11]); la.c2 = mk3(acc[12], acc[13], acc[14]);
+        aa.c0 = mk3(acc[15], acc[16], acc[17]); aa.c1 = mk3(acc[16], acc[18], acc[19]); aa.c2 = mk3(acc[17], acc[19], acc[20]);
+        const m33 alT = mtranspose(la);
+        f3 c0s, c1s, c2s, x0, y;
+        if (G >= 4) {
             /* every lane of the sub-group holds the whole system: lane q of a quad solves right-hand side q, the quad shares the four solutions */
             const int q = lane & 3;
             const f3 rhsq = mk3(pick4(la.c0.x, la.c1.x, la.c2.x, bl.x, q), pick4(la.c0.y, la.c1.y, la.c2.y, bl.y, q), pick4(la.c0.z, la.c1.z, la.c2.z, bl.z, q));
             const f3 sol = solve_ldlt3_branchless(ll, rhsq);
-            col0 = quad_bcast3<0>(sol); col1 = quad_bcast3<1>(sol); col2 = quad_bcast3<2>(sol); x0 = quad_bcast3<3>(sol);
-            const m33 AinvB = mkm(col0, col1, col2);
+            c0s = quad_bcast3<0>(sol); c1s = quad_bcast3<1>(sol); c2s = quad_bcast3<2>(sol); x0 = quad_bcast3<3>(sol);
             m33 schur;                                                /* (maths.h:104 reads the lower triangle only: c0, c1.y, c1.z, c2.z) */
-            schur.c0 = aa.c0 - al * col0;
-            { const f3 p1 = al * col1, p2 = al * col2; schur.c1 = mk3(0.0f, aa.c1.y - p1.y, aa.c1.z - p1.z); schur.c2 = mk3(0.0f, 0.0f, aa.c2.z - p2.z); }
-            const f3 rhs_s = ba - al * x0;
+            schur.c0 = aa.c0 - alT * c0s;
+            { const f3 p1 = alT * c1s, p2 = alT * c2s; schur.c1 = mk3(0.0f, aa.c1.y - p1.y, aa.c1.z - p1.z); schur.c2 = mk3(0.0f, 0.0f, aa.c2.z - p2.z); }
+            const f3 rhs_s = ba - alT * x0;
             y = solve_ldlt3_quadlanes(schur, rhs_s, q);
         } else {
-            col0 = solve_ldlt3_branchless(ll, la.c0); col1 = solve_ldlt3_branchless(ll, la.c1); col2 = solve_ldlt3_branchless(ll, la.c2);
+            c0s = solve_ldlt3_branchless(ll, la.c0); c1s = solve_ldlt3_branchless(ll, la.c1); c2s = solve_ldlt3_branchless(ll, la.c2);
             x0 = solve_ldlt3_branchless(ll, bl);
-            const m33 AinvB = mkm(col0, col1, col2);
-            const m33 schur = aa - al * AinvB;
-            const f3 rhs_s = ba - al * x0;
+            const m33 AinvB = mkm(c0s, c1s, c2s);
+            const m33 schur = aa - alT * AinvB;
+            const f3 rhs_s = ba - alT * x0;
             y = solve_ldlt3_branchless(schur, rhs_s);
         }
-        xl = x0 - mkm(col0, col1, col2) * y;
+        xl = x0 - mkm(c0s, c1s, c2s) * y;
         xa = y;
     }
+    FAST_STAMPB(2);
+    FAST_MARK(fv_pose);
     if (!prefetched && nextT >= 0 && nextT != t) fast_load_tile(F, nextT, next);
     f3 p = pos - xl;
     const q4 dq = mkq(xa.x, xa.y, xa.z, 0.0f);
@@ -983,8 +1172,10 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
         sanitizeq(q, X.cnt, warn_key(1, it, body, 1), body, WK_ROT);
         fv4u r0, r1;
         pose_encode(p, q, (unsigned)(it + 1), r0, r1);
-        fst(X.rPose, body * 32, r0); fst(X.rPose, body * 32 + 16, r1);
+        if (HOIST && X.local) { fst_local(X.rPose, body * 32, r0); fst_local(X.rPose, body * 32 + 16, r1); }
+        else { fst(X.rPose, body * 32, r0); fst(X.rPose, body * 32 + 16, r1); }
         FAST_STAMP(3);
+        FAST_MARK(fv_published);
         if (lastOfLaunch) {                                           /* what the tail (and, sharded, the exchange) reads */
             const float4 old = X.B.plane(BP_POSR)[body];
             X.B.plane(BP_POSR)[body] = pack3(p, old.w);
@@ -1095,9 +1286,10 @@ __device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverPar
     const int cls = __builtin_amdgcn_readfirstlane((R.td.y >> 16) & 0xFF);
     switch (cls) {
     case 0: fast_visit<1, false, false, false, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
-    case 1: fast_visit<8, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
-    case 2: fast_visit<16, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
-    case 3: fast_visit<32, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 1: fast_visit<4, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 2: fast_visit<8, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 3: fast_visit<16, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
+    case 4: fast_visit<32, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
     default: fast_visit<64, TWOPASS, HOIST, JOINTS, PRE>(X, P, R, next, nextT, it, lastOfLaunch); break;
     }
 }
@@ -1113,35 +1305,77 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     FastPlan* plan = F.plan;
     if (plan->bad != 0) return;                                      /* the plan declined the step: the exact schedule queued behind this launch runs it */
     const int T = plan->numTiles, numColors = plan->numColors;
-    const int nWG = gridDim.x;
+    int nWG = gridDim.x;
+    int wg = blockIdx.x;
+    bool local = false;
+    const int Treal = plan->colorTileStart[kFastIsolatedRow];        /* tiles [Treal, T): the bodies without a swept neighbour */
+    int isoFirst = -1, isoStep = 0;                                  /* one-XCD form, a wave outside that XCD: its tiles among those */
+    if (FORM == 1 && L.stamps && L.oneXcdTiles > 0 && Treal <= L.oneXcdTiles && Treal <= (nWG >> 3) * kWaves && (nWG & 7) == 0 && (nWG >> 3) <= 64) {
+        /* a small step — one tile per wave of an XCD at most — on ONE XCD: the workgroups with blockIdx % 8 == 0 (dealt to one XCD, round robin) call the roll — every one
+         * leaves its HW_REG_XCC_ID, stamped with this launch, and reads everybody's — and hand records over with plain stores when all of them answer from the same XCD
+         * (otherwise: sc1 stores as everywhere else).  The other seven eighths of the grid take the tiles of the bodies without a swept neighbour (a third of Stress1000's
+         * cubes lie alone on the ground): nothing they write is read by anybody before the launch ends. */
+        if ((wg & 7) != 0) {
+            const int ow = ((wg >> 3) * 7 + (wg & 7) - 1) * kWaves + (threadIdx.x >> 6);
+            isoFirst = Treal + ow; isoStep = (nWG - (nWG >> 3)) * kWaves;
+        } else {
+            wg >>= 3; nWG >>= 3;
+            __shared__ int sLocal;
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                const unsigned tag = L.syncBase | ((unsigned)(L.itBegin + 1) << 4), mine = fast_xcc_id();
+                unsigned* roll = F.sync + kFastXcdSlots;
+                if (lane == 0) __hip_atomic_store(roll + wg, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned v = tag | mine;
+                for (;;) {
+                    if (lane < nWG) v = __hip_atomic_load(roll + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((v & ~15u) == tag)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) { if (lane == 0) atomicOr(&plan->bad, 256); v = tag | 15u; break; }
+                }
+                const bool same = __all((v & 15u) == mine);
+                if (lane == 0) sLocal = same ? 1 : 0;
+            }
+            __syncthreads();
+            local = sLocal != 0;
+        }
+    }
     const int W = nWG * kWaves;
-    int gw = (threadIdx.x >> 6) * nWG + blockIdx.x;                   /* consecutive tiles go to different workgroups */
-    if (FORM == 1 && L.xcdLocal && (nWG & 7) == 0) {
+    int gw = (threadIdx.x >> 6) * nWG + wg;                           /* consecutive tiles go to different workgroups */
+    if (FORM == 1 && L.xcdLocal && !local && (nWG & 7) == 0) {
         /* latency form: workgroup b sits on XCD b % 8 (round robin, tools/ubench/xcd_pingpong.hip), and a hand-off inside one XCD costs 0.5 us where one across
          * XCDs costs 0.7: consecutive tiles fill the SIMDs of ONE XCD before the next (a small scene lives on one or two of them) */
-        const int x = blockIdx.x & 7, cu = blockIdx.x >> 3, perX = nWG >> 3;
+        const int x = wg & 7, cu = wg >> 3, perX = nWG >> 3;
         gw = x * (perX * kWaves) + (threadIdx.x >> 6) * perX + cu;
     }
     FastCtx X;
     X.rPose = frsrc(F.xpose); X.rS = frsrc(F.xS);
     X.F = &F; X.plan = plan; X.cnt = L.cnt; X.B = L.B; X.M = L.M;
-    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps; X.gf = F.gf; X.jointSlotBase = F.jointSlotBase; X.sleepSel = L.sleepSel;
+    X.invDt2 = 1.0f / (L.P.dt * L.P.dt); X.beta = L.P.beta; X.stamps = L.stamps; X.gf = F.gf; X.jointSlotBase = F.jointSlotBase; X.sleepSel = L.sleepSel; X.local = local;
     const SolverParams P = L.P;
     const int totalIt = P.iterations + (P.postStabilize ? 1 : 0);
     unsigned target = L.syncBase;
     if (T == 0) return;
-    if (L.stamps && gw >= T) return;                                 /* nothing to do for this wave, nobody waits for it */
+    /* this wave's tiles: t = tFirst, tFirst + tStep, ... below tEnd */
+    int tFirst = gw, tStep = W, tEnd = T;
+    if (isoFirst >= 0) { tFirst = isoFirst; tStep = isoStep; }
+    else if (local || (FORM == 1 && nWG != (int)gridDim.x)) tEnd = Treal;     /* (the XCD's own waves: the tiles with neighbours) */
+    if (L.stamps && tFirst >= tEnd) return;                            /* nothing to do for this wave, nobody waits for it */
 
     if (L.stamps && FORM == 1) {
         /* stamped records: a wave's tiles in ascending order are in colour order (tiles are laid out colour by colour) — no phases, every visit waits for
          * its own inputs.  Latency form (one wave per SIMD, registers to spare): the constants of the next visit's tile are loaded behind the current visit's
          * last wait; a wave with one tile keeps them for the whole launch */
+        /* (measured and not kept: the one-XCD form with TWO tiles per wave — Stress1000's 155 tiles on the 128 waves of an XCD — also with a wave's second tile chosen half
+         * the colours away from its first: 274 / 294 us against 250 on all XCDs.  A wave starts the later tile's visit — own pose, first pass, pre-solve: 3.3 us of work —
+         * only when the earlier one has published, and two colours further on is less than that away) */
         FastTileRegs cur, nxt;
-        fast_load_tile(F, gw, cur);
+        fast_load_tile(F, tFirst, cur);
         for (int it = L.itBegin; it < L.itEnd; ++it) {
-            for (int t = gw; t < T; t += W) {
-                const bool more = t + W < T;
-                const int nextT = more ? t + W : (it + 1 < L.itEnd ? gw : -1);
+            for (int t = tFirst; t < tEnd; t += tStep) {
+                const bool more = t + tStep < tEnd;
+                const int nextT = more ? t + tStep : (it + 1 < L.itEnd ? tFirst : -1);
                 nxt = cur;
                 fast_visit_any<FORM, JOINTS, true>(X, P, cur, nxt, nextT, it, it == L.itEnd - 1);
                 cur = nxt;
@@ -1157,14 +1391,17 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
         }
     } else {
         for (int it = L.itBegin; it < L.itEnd; ++it) {
-            for (int c = 0; c < numColors; ++c) {
-                const int t0 = plan->colorTileStart[c], t1 = plan->colorTileStart[c + 1];
-                /* this wave's tiles of the colour: t = gw (mod W) */
-                int t = t0 + ((gw - t0) % W + W) % W;
-                for (; t < t1; t += W) {
-                    FastTileRegs cur, nxt;
-                    cur.t = t; cur.td = F.tiles[t];
-                    fast_visit_any<FORM, JOINTS, false>(X, P, cur, nxt, -1, it, it == L.itEnd - 1);
+            for (int c = 0; c < max(1, numColors); ++c) {              /* (no colour at all: only bodies without a swept neighbour) */
+                const int t0 = plan->colorTileStart[c], t1 = c < numColors ? plan->colorTileStart[c + 1] : t0;
+                /* this wave's tiles of the colour: t = gw (mod W); the bodies without a swept neighbour go with the first colour */
+                for (int part = 0; part < (c == 0 ? 2 : 1); ++part) {
+                    const int p0 = part == 0 ? t0 : Treal, p1 = part == 0 ? t1 : T;
+                    int t = p0 + ((gw - p0) % W + W) % W;
+                    for (; t < p1; t += W) {
+                        FastTileRegs cur, nxt;
+                        cur.t = t; cur.td = F.tiles[t];
+                        fast_visit_any<FORM, JOINTS, false>(X, P, cur, nxt, -1, it, it == L.itEnd - 1);
+                    }
                 }
                 fast_grid_barrier<false>(F.sync, nWG, ++target, &plan->bad);
             }
@@ -1172,7 +1409,7 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     }
     if (L.finalPass) {
         if (L.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int t = gw; t < T; t += W) fast_final<JOINTS>(X, P, t, F.tiles[t], totalIt);
+        for (int t = tFirst; t < tEnd; t += tStep) fast_final<JOINTS>(X, P, t, F.tiles[t], totalIt);
     }
 }
 

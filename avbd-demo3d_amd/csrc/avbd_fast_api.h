@@ -21,8 +21,12 @@
 namespace avbd {
 
 constexpr int kFastMaxColors = 64;
-constexpr int kFastClasses = 5;                 /* lanes per body: 1 (no incidence), 8, 16, 32, 64 */
-constexpr int kFastSyncWords = 2048;            /* grid barrier: [0, 1024) one word per workgroup, [1024, 1088) one per group of 64 workgroups */
+constexpr int kFastClasses = 6;                 /* lanes per body: 1 (no incidence), 4, 8, 16, 32, 64 */
+constexpr int kFastSyncWords = 2048;            /* grid barrier: [0, 1024) one word per workgroup, [1024, 1088) one per group of 64 workgroups; [1536, 1600) the XCD roll call of the one-XCD form */
+constexpr int kFastXcdSlots = 1536;
+constexpr int kFastIsolatedRow = 63;            /* the last row of the (colour, class) group table holds the swept bodies without a swept neighbour (their colour is 0): their tiles come last,
+                                                 * FastPlan.colorTileStart[kFastIsolatedRow] is where — no visit of theirs ever waits, and nobody waits for them */
+constexpr int kPlanSingleBodies = 1024;         /* up to this many bodies ONE workgroup plans the step: colours in LDS, workgroup barriers */
 constexpr int kFastSlotPlanes = 6;
 constexpr int kFastBodyPlanes = 4;
 
@@ -77,6 +81,8 @@ struct FastLaunch {
     int joints;             /* the scene has Joint forces: the joint-aware kernels */
     int sleepSel;           /* back-off between two looks at the records: s_sleep 1 / 4 / 16 / 64 */
     int xcdLocal;           /* latency form: consecutive tiles on one XCD */
+    int oneXcdTiles;        /* latency form: a step of at most this many tiles runs on the workgroups of ONE XCD (those with blockIdx % 8 == 0, checked against HW_REG_XCC_ID) and hands
+                             * its records over with plain stores that stay in that XCD's L2 (0: never) */
     int seedBase;           /* option fast_seed: added to the plan's own seed */
     int reuse;              /* k_fast_plan: colorPrev holds last step's colouring of the same bodies */
 };

@@ -283,7 +283,10 @@ int  avbd_kat_arith(AvbdContext* ctx, int n, const float* a, const float* b, flo
  * touch one of its bodies, sweeps its own bodies exactly (later-created first) against the last gathered poses of
  * the others, and after EVERY solver iteration all ranks all-gather {position, orientation} (RCCL over xGMI, 32 B
  * per body).  Across the cut this is a Jacobi coupling, so sharded results are close to, not bit-identical with,
- * the single-GPU sweep.  There is no such mode in the reference. */
+ * the single-GPU sweep.  There is no such mode in the reference.
+ * avbd_set_ownership is accepted while the context has not stepped on its present content: on a freshly built scene, or right after
+ * avbd_load_snapshot / the upload calls (every rank loads the same snapshot, cuts the slabs from the restored positions, steps on);
+ * once steps have run, ownership moves with avbd_group_rebalance / avbd_rebalance_import. */
 int  avbd_partition_by_axis(int n, const float* position /* 3n */, const float* invMass /* n */, int nranks, int axis, int* owner /* n out */);
 int  avbd_set_ownership(AvbdContext* ctx, int nranks, int rank, const int* owner, int n);
 /* Layout of the per-iteration exchange for an ownership vector; host-only, needs no device (the contract of the

@@ -254,3 +254,64 @@ def test_rebalance_on_a_falling_pile_and_in_the_all_gather_form(monkeypatch):
             for w in first_half + worlds:
                 w.close()
     assert H.same_bits(states[0], states[1]), "one launch per iteration and the persistent form are the same iteration"
+
+
+@pytest.mark.parametrize("form", ["exact", "allgather", "fast"])
+def test_a_snapshot_restored_into_sharded_contexts_continues_the_run(monkeypatch, tmp_path, form):
+    """a snapshot written by ONE context (avbd_save_snapshot: all bodies, the whole force list, stepIndex, parameters) is loaded
+    into every rank of a sharded group, the slabs are cut from the restored positions, and the group steps on.  With exact cuts the continuation is the
+    single-GPU run's, bit for bit; in the all-gather forms (exact rows or the fast sweep; Jacobi across the cuts) every rank ends with the same gathered
+    state, the restored ranks equal ranks that were handed the same state through the upload calls, and the pile stays where the one-GPU run has it."""
+    scene, nranks, before, after = "StressN:8", 2, 170, 12
+    single = H.HipWorld(); single.scene(scene); single.step(before)
+    assert int(single.w.stats()["numManifolds"]) > 100
+    snap = str(tmp_path / "pile.snap")
+    single.w.save_snapshot(snap)
+    pkg = H.load_product()
+    if form == "exact":
+        monkeypatch.setenv("AVBD_SHARD_EXACT", "1")
+
+    def ranks(load):
+        ws = [H.HipWorld() for _ in range(nranks)]
+        for w in ws:
+            if load:
+                w.w.load_snapshot(snap)
+            else:
+                w.scene(scene); w.set_bodies(single_b); w.set_forces(single_f)
+            if form == "fast":
+                w.w.set_option("sweep", 1)
+        b = ws[0].bodies()
+        owner = pkg.partition_by_axis(b["pos"], b["invMass"], nranks, axis=0)
+        for r, w in enumerate(ws):
+            w.w.set_ownership(nranks, r, owner)
+            if not load:
+                w.set_step_index(before)
+        return ws, owner
+
+    single_b, single_f = single.bodies().copy(), single.forces().copy()
+    restored, owner = ranks(True)
+    assert all(w.w.step_index() == before for w in restored)
+    assert all(H.same_bits(single_b, w.bodies()) for w in restored)
+    pkg.group_step([w.w for w in restored], after)
+    single.step(after)
+    if form == "exact":
+        monkeypatch.delenv("AVBD_SHARD_EXACT")
+        for r, w in enumerate(restored):
+            assert int(w.w.stats()["cutMode"]) == 3
+            assert H.same_bits(single.bodies(), w.bodies()), f"rank {r}: the restored sharded run left the single-GPU run"
+            _same_forces(single.forces(), w.forces(), owner, r, "restored")
+        return
+    got = [(w.bodies().copy(), int(w.w.stats()["schedule"])) for w in restored]
+    for w in restored:
+        w.close()                                                    # (no more contexts alive on the device than it has hardware queues: avbd_group_step's persistent form)
+    uploaded, _ = ranks(False)
+    pkg.group_step([w.w for w in uploaded], after)
+    for r in range(nranks):
+        assert got[r][1] == (5 if form == "fast" else int(uploaded[r].w.stats()["schedule"]))
+        assert H.same_bits(got[0][0], got[r][0]), f"rank {r}: gathered state differs between the ranks"
+        assert H.same_bits(uploaded[r].bodies(), got[r][0]), f"rank {r}: snapshot restore and upload calls give different runs"
+    bs, bg = single.bodies(), got[0][0]
+    dyn = bs["invMass"] > 0
+    d = np.abs(bs["pos"][dyn].astype(np.float64) - bg["pos"][dyn])          # a pile that is still landing (cubes arrive at 16 m/s): measured 0.52 m worst cube, 0.03 m mean
+    assert np.all(np.isfinite(bg["pos"])) and float(d.max()) < 1.5 and float(d.mean()) < 0.15, (float(d.max()), float(d.mean()))
+    assert int(uploaded[0].diag()["dynamicBodies"]) == int(single.diag()["dynamicBodies"])
