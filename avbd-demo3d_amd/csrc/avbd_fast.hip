@@ -33,7 +33,6 @@ typedef unsigned fv4u __attribute__((ext_vector_type(4)));
 
 constexpr int kPlanThreads = 1024;
 constexpr int kSweepThreads = 512, kSweepThreadsLat = 256;
-constexpr int kFastLatTilesPerWave = 4;        /* the latency form up to this many tiles per wave (measured: it wins up to ~6 000 tiles = 32 000 cubes) */
 constexpr unsigned long long kFastTimeoutTicks = 400000000ull;   /* 4 s of s_memrealtime (100 MHz) */
 
 enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8,
@@ -1457,8 +1456,9 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& Lin, int swee
     FastLaunch L = Lin;
     /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
     const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
-    /* measured (sweep us, forms 1 / 2 / 3): 13 824 cubes 585 / 671 / 915, 32 768 cubes 955 / 884 / 1056, 64 000 cubes 1534 / 1170 / 1123 */
-    int f = form != 0 ? form : (tilesGuess <= (long long)kFastLatTilesPerWave * 4 * L.numCU ? 1 : (tilesGuess <= (long long)9 * 4 * L.numCU ? 2 : 3));
+    /* measured (sweep us, forms 1 / 2 / 3; tiles): 4 096 cubes 315 / 425 / 502 (750), 8 000 cubes 426 / 524 / 591 (1 377), 13 824 cubes 561 / 575 / 630 (2 333), 21 952 cubes
+     * 761 / 632 / 675 (3 700), 32 768 cubes 1 024 / 754 / 743 (5 596), 46 656 cubes 1 433 / 956 / 904 (8 000): the latency form up to 2.5 tiles per wave, one pass from 5 on */
+    int f = form != 0 ? form : (tilesGuess * 2 <= (long long)5 * 4 * L.numCU ? 1 : (tilesGuess <= (long long)5 * 4 * L.numCU ? 2 : 3));
     if (L.joints != 0 && f == 2) f = 3;                                /* (the joint-aware two-pass kernel at two waves per SIMD spills: 144 B per lane) */
     const bool lat = f == 1;
     if (L.sleepSel < 0) L.sleepSel = f == 3 ? 2 : 0;                   /* (64 000 cubes, one pass: s_sleep 16 between two looks 1 201 -> 1 160 us; small scenes: s_sleep 1, 272 against 298) */

@@ -113,10 +113,11 @@ def test_fast_post_stabilize_step():
 # ---- (iii) forms of the kernel: the same bits ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("scene,steps,params", [("Stress1000", 170, None), ("Packed:6", 25, dict(iterations=8)), ("Pyramid", 40, None)])
 def test_every_form_of_the_fast_sweep_gives_the_same_bits(scene, steps, params):
-    """stamped records vs a grid barrier per colour, latency vs throughput form of k_fast_sweep, few workgroups (several tiles per wave): only WHEN a body is
-    visited changes, never what it reads — through first contact and the landing (colours kept, lost and re-picked every step)"""
+    """stamped records vs a grid barrier per colour, latency vs throughput forms of k_fast_sweep, the latency form on one XCD (plain-store hand-offs through its L2; the default
+    where the tiles with neighbours fit) vs on all of them, few workgroups (several tiles per wave): only WHEN a body is visited changes, never what it reads — through first
+    contact and the landing (colours kept, lost and re-picked every step; the first steps have no colour at all: every body is in the isolated row)"""
     ref = None
-    for opts in ({}, {"fast_stamps": 0}, {"fast_form": 2}, {"fast_form": 1, "fast_blocks": 3}, {"fast_form": 2, "fast_blocks": 2, "fast_stamps": 0}):
+    for opts in ({}, {"fast_one_xcd": 0}, {"fast_stamps": 0}, {"fast_form": 2}, {"fast_form": 3}, {"fast_form": 1, "fast_blocks": 3}, {"fast_form": 2, "fast_blocks": 2, "fast_stamps": 0}):
         g = fast_world(scene, **opts)
         if params:
             g.set_params(**params)
