@@ -281,6 +281,7 @@ struct AvbdContext {
     int fastRecolor = 0;                /* fast_recolor: every how many steps every body is coloured afresh (1: every step; 0: by size); in between last step's colouring is kept where it still is one */
     int fastSleep = -1;                 /* fast_sleep: back-off between two looks of a waiting lane, s_sleep 1 / 4 / 16 / 64 (-1: by the kernel's form) */
     int fastXcd = 0;                    /* fast_xcd: latency form, consecutive tiles fill one XCD before the next */
+    int debugFastXcdMismatch = 0;       /* debug_fast_xcd_mismatch: the one-XCD form's roll call answers "several XCDs": its workgroups hand over with sc1 stores (the path a dispatcher that deals workgroups otherwise would take) */
     int fastOneXcd = 4096;              /* fast_one_xcd: latency form, a step of at most this many tiles — and at most one per wave of an XCD — runs on one XCD and hands records over through its L2 (0: never) */
     int fastSeed = 0;                   /* fast_seed: added to the seed of the colouring's tie-breaking hash */
     int fastForm = 0;                   /* fast_form: 0 by size, 1 the latency form of k_fast_sweep (a wave per SIMD, contacts in two passes), 2 the throughput form */

@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     if (penOk) {
                         if (!early) lhs_add(Jl, Ja, pen);
                         if (!isJoint) {
-                            const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only */
+                            const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only (latency form: the factor is hoisted out of the pass loop by the compiler; written out by hand it changes nothing) */
                             gy[0] += gyro.x; gy[1] += gyro.y; gy[2] += gyro.z;
                         }
                     }
@@ -1309,7 +1309,8 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
     bool local = false;
     const int Treal = plan->colorTileStart[kFastIsolatedRow];        /* tiles [Treal, T): the bodies without a swept neighbour */
     int isoFirst = -1, isoStep = 0;                                  /* one-XCD form, a wave outside that XCD: its tiles among those */
-    if (FORM == 1 && L.stamps && L.oneXcdTiles > 0 && Treal <= L.oneXcdTiles && Treal <= (nWG >> 3) * kWaves && (nWG & 7) == 0 && (nWG >> 3) <= 64) {
+    const int oneXcdTiles = L.oneXcdTiles & 0xFFFFF;                  /* (bit 30: debug, the roll call answers "several XCDs" whatever it finds) */
+    if (FORM == 1 && L.stamps && oneXcdTiles > 0 && Treal <= oneXcdTiles && Treal <= (nWG >> 3) * kWaves && (nWG & 7) == 0 && (nWG >> 3) <= 64) {
         /* a small step — one tile per wave of an XCD at most — on ONE XCD: the workgroups with blockIdx % 8 == 0 (dealt to one XCD, round robin) call the roll — every one
          * leaves its HW_REG_XCC_ID, stamped with this launch, and reads everybody's — and hand records over with plain stores when all of them answer from the same XCD
          * (otherwise: sc1 stores as everywhere else).  The other seven eighths of the grid take the tiles of the bodies without a swept neighbour (a third of Stress1000's
@@ -1333,7 +1334,7 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > kFastTimeoutTicks) { if (lane == 0) atomicOr(&plan->bad, 256); v = tag | 15u; break; }
                 }
-                const bool same = __all((v & 15u) == mine);
+                const bool same = __all((v & 15u) == mine) && ((L.oneXcdTiles >> 30) & 1) == 0;
                 if (lane == 0) sLocal = same ? 1 : 0;
             }
             __syncthreads();
@@ -1369,6 +1370,8 @@ __global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void 
         /* (measured and not kept: the one-XCD form with TWO tiles per wave — Stress1000's 155 tiles on the 128 waves of an XCD — also with a wave's second tile chosen half
          * the colours away from its first: 274 / 294 us against 250 on all XCDs.  A wave starts the later tile's visit — own pose, first pass, pre-solve: 3.3 us of work —
          * only when the earlier one has published, and two colours further on is less than that away) */
+        /* (also measured and not kept, one or two tiles per wave on all XCDs, 6 000 - 12 000 cubes: a wave's second tile chosen by the plan at least two colours away from its
+         * first — the last colours' tiles off the waves of the first colour's — instead of tile + W: 8 000 cubes 431 -> 422 us, 10 648 cubes 489 -> 560) */
         FastTileRegs cur, nxt;
         fast_load_tile(F, tFirst, cur);
         for (int it = L.itBegin; it < L.itEnd; ++it) {

@@ -117,7 +117,7 @@ def test_every_form_of_the_fast_sweep_gives_the_same_bits(scene, steps, params):
     where the tiles with neighbours fit) vs on all of them, few workgroups (several tiles per wave): only WHEN a body is visited changes, never what it reads — through first
     contact and the landing (colours kept, lost and re-picked every step; the first steps have no colour at all: every body is in the isolated row)"""
     ref = None
-    for opts in ({}, {"fast_one_xcd": 0}, {"fast_stamps": 0}, {"fast_form": 2}, {"fast_form": 3}, {"fast_form": 1, "fast_blocks": 3}, {"fast_form": 2, "fast_blocks": 2, "fast_stamps": 0}):
+    for opts in ({}, {"fast_one_xcd": 0}, {"debug_fast_xcd_mismatch": 1}, {"fast_stamps": 0}, {"fast_form": 2}, {"fast_form": 3}, {"fast_form": 1, "fast_blocks": 3}, {"fast_form": 2, "fast_blocks": 2, "fast_stamps": 0}):
         g = fast_world(scene, **opts)
         if params:
             g.set_params(**params)
