@@ -291,7 +291,7 @@ struct AvbdContext {
     unsigned fastSerial = 0;
     bool fastStepDeclined = false;      /* sharded: the plan of the current step declined it (read back once per step) */
     bool fastLaunched = false;          /* the iteration loop of the last step was offered to the fast sweep */
-    DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fPos, fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<unsigned long long> fTileMask; DevArr<float4> fSlotC, fBodyC, fXpose, fXS; DevArr<unsigned> fSync;
+    DevArr<FastPlan> fPlan; DevArr<int> fColor[2], fCbody; int fColorCur = 0; unsigned fastColorSerial = ~0u;   /* fColor: this step's / last step's colours; fastColorSerial: sweptSerial the colours in fColor[fColorCur] belong to */ DevArr<int2> fTiles; DevArr<unsigned long long> fTileMask; DevArr<float4> fSlotC, fBodyC, fXpose, fXS; DevArr<unsigned> fSync;
     int fTileCap = 0, fBodyCap = 0, fMCap = 0, fGCap = 0;
     Readback* hRb = nullptr; /* pinned */
     AvbdStepStats stats{};
@@ -1119,7 +1119,7 @@ int avbd_destroy(AvbdContext* c)
     if (c->evBegin) (void)hipEventDestroy(c->evBegin); if (c->evGathered) (void)hipEventDestroy(c->evGathered);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     c->xPose.release(); c->xVisit.release(); c->xDual.release(); c->xPrivN.release(); c->xPrivPose.release(); c->xProbe.release(); c->adjTmp.release();
-    c->fPlan.release(); c->fColor[0].release(); c->fColor[1].release(); c->fPos.release(); c->fCbody.release(); c->fTiles.release(); c->fTileMask.release(); c->fSlotC.release(); c->fBodyC.release();
+    c->fPlan.release(); c->fColor[0].release(); c->fColor[1].release(); c->fCbody.release(); c->fTiles.release(); c->fTileMask.release(); c->fSlotC.release(); c->fBodyC.release();
     c->fXpose.release(); c->fXS.release(); c->fSync.release();
     exact_window_release(c);
     if (c->comm) destroy_comm(c->comm);
@@ -1273,10 +1273,14 @@ int avbd_set_option(AvbdContext* c, const char* key, int value)
     if (!std::strcmp(key, "narrow_lanes") && v != 0 && v != 32 && v != 64) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'narrow_lanes' is 0 (by the body count), 32 or 64");
     if (!std::strcmp(key, "iter_blocks")) v = std::max(1, std::min(v, c->iterBlocksMax > 0 ? c->iterBlocksMax : v));   /* every workgroup of the loop must be resident */
     if (!std::strcmp(key, "pool_per_body")) {
-        /* the pools are re-allocated with the body tables at the next step: the host copy of the bodies becomes the authoritative one first (what adding a body does) */
-        (void)hipSetDevice(c->device);
-        if (int rc = download_bodies_to_host(c)) return rc;
-        c->bodiesStale = true; c->poolDirty = true;
+        /* (validated BEFORE anything is touched, and a value the pools already cover changes nothing — they never shrink: ADVICE round 5) */
+        if (v < 4 || v > 4096) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'pool_per_body' is 4 .. 4096");
+        if (v > c->poolPerBody) {
+            /* the pools are re-allocated with the body tables at the next step: the host copy of the bodies becomes the authoritative one first (what adding a body does) */
+            (void)hipSetDevice(c->device);
+            if (int rc = download_bodies_to_host(c)) return rc;
+            c->bodiesStale = true; c->poolDirty = true;
+        }
     }
     if (!std::strcmp(key, "mode") && c->stepIndex != 0 && v != c->mode) return c->fail(AVBD_E_INVALID, "avbd_set_option: 'mode' is chosen before the first step");
     const int rc = option_access(c, key, &v, true);

@@ -128,7 +128,6 @@ __device__ __forceinline__ unsigned fast_hash(unsigned x)
 }
 
 constexpr int kFastRecolorAbove = 10;         /* last step's colouring is dropped (every body coloured afresh) once it has grown beyond this many colours */
-constexpr int kFastColorsFloor = 4;           /* ... and the bodies of its highest colour are coloured afresh while it has more than this many */
 constexpr int kPlanNbrRegs = 12;             /* neighbours of a body its thread keeps in registers through the rounds of the colouring */
 
 __device__ __forceinline__ unsigned fast_prio(const int* __restrict__ adjStart, int b, unsigned seed)

@@ -53,7 +53,6 @@ struct FastBuffers {
     FastPlan* plan;
     int*    color;      /* [bodyCap] colour of a swept body, -2: not swept */
     const int* colorPrev; /* [bodyCap] last step's colours (the two arrays alternate) */
-    int*    posInGroup; /* [bodyCap] */
     int*    cbody;      /* [bodyCap] bodies by (colour, class) */
     int2*   tiles;      /* [tileCap] {first index into cbody, bodies | class << 16} */
     unsigned long long* tileMask; /* [tileCap] lanes of the tile that hold an entry */

@@ -274,12 +274,21 @@ def main():
                 except Exception as e:
                     err = repr(e)
             else:
-                uid = [pkg.comm_unique_id() if rank == 0 else None]
+                # (rank 0's uid under try, broadcast unconditionally — None on failure —, then a vote: no rank is left alone in a collective)
+                uid = [None]
+                if rank == 0:
+                    try:
+                        uid = [pkg.comm_unique_id()]
+                    except Exception as e:
+                        err = repr(e)
                 dist.broadcast_object_list(uid, src=0)
-                try:
-                    w.comm_init(world_size, rank, uid[0])
-                except Exception as e:
-                    err = repr(e)
+                if vote(uid[0] is not None and err is None):
+                    try:
+                        w.comm_init(world_size, rank, uid[0])
+                    except Exception as e:
+                        err = repr(e)
+                elif err is None:
+                    err = "rank 0 could not make the communicator's unique id"
             if vote(err is None):
                 dist.barrier()                                       # the ranks start stepping together (a wave gives up after 4 s without progress)
                 return w
