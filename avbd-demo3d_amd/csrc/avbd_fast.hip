@@ -906,6 +906,9 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
      * sums, the factorisation of ll, ll^-1 la and the Schur complement up to the gyroscopic diagonal — runs while the pose is still on its way; behind the pose
      * come the rows' forces, nine sums, one substitution, the 3x3 Schur solve and the pose update.  Same operations on the same values as the other forms. */
     constexpr bool SPLIT = TWOPASS && HOIST && !JOINTS && G >= 4;
+    /* (measured and not kept: the split taken at run time only where a tile HAS a second pass — the first colour's and the isolated row's tiles have everything behind their one
+     * wait anyway, and the one-piece sums and solve are shorter than the two halves back to back —: both paths in one kernel, 172 -> 206 KB of code and 146 -> 179 spill
+     * registers, Stress1000 208 -> 224 us, 8 000 cubes 430 -> 455) */
     float fL10 = 0.0f, fL20 = 0.0f, fL21 = 0.0f, fd0 = 1.0f, fd1 = 1.0f, fd2 = 1.0f; bool fbad = false;
     f3 col0 = zero3(), col1 = zero3(), col2 = zero3(), schurOff = zero3(), pDiag = zero3(), aaDiag = zero3();
     m33 al = mkm(zero3(), zero3(), zero3());
