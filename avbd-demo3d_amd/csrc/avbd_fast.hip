@@ -188,10 +188,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
      * seeds in four, 5 for the fourth; a colour is 20 dependent solves per step), so a fresh colouring that needed MORE colours than the best of the fresh colourings
      * before it moves on to the next seed for the colourings to come — decided on the device from the plan's own history, the same in every run */
     const unsigned seed = (unsigned)plan->seed + (unsigned)L.seedBase;
+    /* (one workgroup: every body's priority once, through LDS — a thread read the degrees of its twelve neighbours from memory otherwise) */
+    __shared__ unsigned sPrio[SINGLE ? kPlanSingleBodies : 1];
+    if (SINGLE) { if (inRange) sPrio[b] = fast_prio(L.adjStart, b, seed); __syncthreads(); }
+    auto prio_of = [&](int i) -> unsigned { return SINGLE ? sPrio[i] : fast_prio(L.adjStart, i, seed); };
     int myColor = swept ? -1 : -2;
     if (swept) {
         adjS = L.adjStart[b]; adjE = L.adjStart[b + 1];
-        const unsigned pb = fast_prio(L.adjStart, b, seed);
+        const unsigned pb = prio_of(b);
         const int old = reuse ? F.colorPrev[b] : -1;
         /* a body gives its colour up when a neighbour of higher priority held the same one (a new contact between two bodies of one colour), and also when a
          * LOWER colour is free among its neighbours' old colours (contacts that went away): the colouring stays "greedy-stable" — as good as a fresh greedy
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
                 const int p = L.adjOther[adjS + k];
                 if (p >= 0 && inc_kind(L.adjRef[adjS + k]) != FK_IGNORE && B.solved[p] != 0) {
                     nbr[k] = p;
-                    const unsigned pp = fast_prio(L.adjStart, p, seed);
+                    const unsigned pp = prio_of(p);
                     const bool hi = pp > pb || (pp == pb && p > b);
                     if (hi) higher |= 1u << k;
                     if (keep) {
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
             for (int i = adjS + kPlanNbrRegs; i < adjE && keep; ++i) {
                 const int p = L.adjOther[i];
                 if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE || B.solved[p] == 0) continue;
-                const unsigned pp = fast_prio(L.adjStart, p, seed);
+                const unsigned pp = prio_of(p);
                 const int po = F.colorPrev[p];
                 if (po >= 0) usedOld |= 1ull << po;
                 if ((pp > pb || (pp == pb && p > b)) && po == old) keep = false;
@@ -267,14 +271,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
                 else if (cn[k] == -1 && ((higher >> k) & 1u)) blocked = true;
             }
             if (adjE - adjS > kPlanNbrRegs) {                         /* a long adjacency list: the rest from memory */
-                const unsigned pb = fast_prio(L.adjStart, b, seed);
+                const unsigned pb = prio_of(b);
                 for (int i = adjS + kPlanNbrRegs; i < adjE && !blocked; ++i) {
                     const int p = L.adjOther[i];
                     if (p < 0 || inc_kind(L.adjRef[i]) == FK_IGNORE) continue;
                     const int cp = get_color(p);
                     if (cp == -2) continue;
                     if (cp == -1) {
-                        const unsigned pp = fast_prio(L.adjStart, p, seed);
+                        const unsigned pp = prio_of(p);
                         if (pp > pb || (pp == pb && p > b)) blocked = true;
                     } else used |= 1ull << cp;
                 }
@@ -894,12 +898,15 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
     const float invDt2 = X.invDt2;
     const float mdt = mass * invDt2;
     const m33 aa0 = Iw * invDt2;
-    const f3 rl0 = ((pos - npos) * invDt2) * mass;
+    f3 rl0 = ((pos - npos) * invDt2) * mass;
     const q4 qErr = rot * qconj(nrot);
     f3 rotErr = mk3(qErr.x, qErr.y, qErr.z);
     rotErr = rotErr * 2.0f;
     if (qErr.w < 0.0f) rotErr = -rotErr;
-    const f3 ra0 = Iw * (rotErr * invDt2);
+    f3 ra0 = Iw * (rotErr * invDt2);
+    /* latency form: evaluated HERE — the compiler sinks what is first used behind the waits (these sixty instructions sat between the nine sums and the substitution,
+     * on the path behind the last arrival); the empty asm pins the six values in front of the pass loop */
+    if (HOIST) asm volatile("" : "+v"(rl0.x), "+v"(rl0.y), "+v"(rl0.z), "+v"(ra0.x), "+v"(ra0.y), "+v"(ra0.z));
 
     /* SPLIT (latency form, contacts): what the second pass's lanes need arrives in two parts — the contact's records (lambda, penalty: written by the partner
      * BEFORE its sums and its solve) and the partner's new pose (after them).  Everything that needs only the first — the J J^T penalty part of lhs, its 21
