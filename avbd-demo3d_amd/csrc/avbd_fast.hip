@@ -32,7 +32,7 @@ namespace avbd {
 typedef unsigned fv4u __attribute__((ext_vector_type(4)));
 
 constexpr int kPlanThreads = 1024;
-constexpr int kSweepThreads = 512, kSweepThreadsLat = 256;
+constexpr int kSweepThreads = 512, kSweepThreadsLat = 256, kSweepThreadsOne = 768;   /* two-pass form: two waves per SIMD; latency form: one; one-pass form: three (146 registers) */
 constexpr unsigned long long kFastTimeoutTicks = 400000000ull;   /* 4 s of s_memrealtime (100 MHz) */
 
 enum : int { FL_VALID = 1, FL_ISA = 2, FL_FIRST = 4, FL_SOLE = 8,
@@ -1306,9 +1306,9 @@ __device__ __forceinline__ void fast_visit_any(const FastCtx& X, const SolverPar
  * evaluated before the last pose arrives is), everything that depends on the body's own pose alone kept across the wait; FORM 2: two passes, eight
  * waves per workgroup (two per SIMD), nothing kept across the wait; FORM 0: one pass, eight waves per workgroup. */
 template <int FORM, bool JOINTS>
-__global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : kSweepThreads) void k_fast_sweep(FastLaunch L)
+__global__ __launch_bounds__(FORM == 1 ? kSweepThreadsLat : (FORM == 0 && !JOINTS ? kSweepThreadsOne : kSweepThreads)) void k_fast_sweep(FastLaunch L)
 {
-    constexpr int kWaves = (FORM == 1 ? kSweepThreadsLat : kSweepThreads) / 64;
+    constexpr int kWaves = (FORM == 1 ? kSweepThreadsLat : (FORM == 0 && !JOINTS ? kSweepThreadsOne : kSweepThreads)) / 64;
     const FastBuffers& F = L.F;
     FastPlan* plan = F.plan;
     if (plan->bad != 0) return;                                      /* the plan declined the step: the exact schedule queued behind this launch runs it */
@@ -1441,7 +1441,7 @@ int fast_query(int device, int* planBlocksPerCU, int* sweepBlocksPerCU)
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fast_plan<false>, kPlanThreads, 0) != hipSuccess) a = 0;
     auto occ = [](const void* fn, int threads) { int v = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, threads, 0) != hipSuccess) v = 0; return v; };
-    b = std::min(std::min(occ((const void*)k_fast_sweep<0, false>, kSweepThreads), occ((const void*)k_fast_sweep<2, false>, kSweepThreads)),
+    b = std::min(std::min(occ((const void*)k_fast_sweep<0, false>, kSweepThreadsOne), occ((const void*)k_fast_sweep<2, false>, kSweepThreads)),
                  std::min(occ((const void*)k_fast_sweep<0, true>, kSweepThreads), occ((const void*)k_fast_sweep<2, true>, kSweepThreads)));
     if (occ((const void*)k_fast_sweep<1, false>, kSweepThreadsLat) < 1 || occ((const void*)k_fast_sweep<1, true>, kSweepThreadsLat) < 1) b = 0;
     if (planBlocksPerCU) *planBlocksPerCU = a;
@@ -1468,13 +1468,14 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& Lin, int swee
     FastLaunch L = Lin;
     /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
     const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
-    /* measured (sweep us, forms 1 / 2 / 3; tiles): 4 096 cubes 315 / 425 / 502 (750), 8 000 cubes 426 / 524 / 591 (1 377), 13 824 cubes 561 / 575 / 630 (2 333), 21 952 cubes
-     * 761 / 632 / 675 (3 700), 32 768 cubes 1 024 / 754 / 743 (5 596), 46 656 cubes 1 433 / 956 / 904 (8 000): the latency form up to 2.5 tiles per wave, one pass from 5 on */
-    int f = form != 0 ? form : (tilesGuess * 2 <= (long long)5 * 4 * L.numCU ? 1 : (tilesGuess <= (long long)5 * 4 * L.numCU ? 2 : 3));
+    /* measured (sweep us, forms 1 / 2 / 3; tiles; final build, no SLP vectoriser): 8 000 cubes 422 / 493 / 543 (1 377), 10 648 cubes 467 / 513 / 542 (1 800), 13 824 cubes
+     * 560 / 550 / 657 (2 333), 21 952 cubes 745 / 589 / 701 (3 700), 32 768 cubes 1 007 / 687 / 738 (5 596), 46 656 cubes - / 891 / 814 (8 000), 64 000 cubes - / 1 010 / 868
+     * (11 174): the latency form up to 2.25 tiles per wave, one pass from 6.5 on */
+    int f = form != 0 ? form : (tilesGuess * 4 <= (long long)9 * 4 * L.numCU ? 1 : (tilesGuess * 2 <= (long long)13 * 4 * L.numCU ? 2 : 3));
     if (L.joints != 0 && f == 2) f = 3;                                /* (the joint-aware two-pass kernel at two waves per SIMD spills: 144 B per lane) */
     const bool lat = f == 1;
     if (L.sleepSel < 0) L.sleepSel = f == 3 ? 2 : 0;                   /* (64 000 cubes, one pass: s_sleep 16 between two looks 1 201 -> 1 160 us; small scenes: s_sleep 1, 272 against 298) */
-    const int waves = (lat ? kSweepThreadsLat : kSweepThreads) / 64;
+    const int waves = (lat ? kSweepThreadsLat : (f == 3 && L.joints == 0 ? kSweepThreadsOne : kSweepThreads)) / 64;
     const int maxWG = lat ? L.numCU : std::max(1, std::min(1024, L.numCU * std::max(1, sweepBlocksPerCU)));
     int nWG = maxWG;
     if (!L.stamps && tilesHint > 0) nWG = (int)(((long long)tilesHint * 5 / 4 + waves - 1) / waves) + 1;   /* (grid barrier: no more workgroups than the tiles need) */
@@ -1483,7 +1484,7 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& Lin, int swee
     const bool joints = L.joints != 0;                                 /* (the joint-aware code is a kernel of its own: the contacts-only kernels keep their registers) */
     if (lat) { if (joints) hipLaunchKernelGGL((k_fast_sweep<1, true>), dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<1, false>), dim3(nWG), dim3(kSweepThreadsLat), 0, stream, L); }
     else if (f == 2) { if (joints) hipLaunchKernelGGL((k_fast_sweep<2, true>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<2, false>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); }
-    else { if (joints) hipLaunchKernelGGL((k_fast_sweep<0, true>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<0, false>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); }
+    else { if (joints) hipLaunchKernelGGL((k_fast_sweep<0, true>), dim3(nWG), dim3(kSweepThreads), 0, stream, L); else hipLaunchKernelGGL((k_fast_sweep<0, false>), dim3(nWG), dim3(kSweepThreadsOne), 0, stream, L); }
     return hipGetLastError();
 }
 
