@@ -942,6 +942,16 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
             acc[15] += (Ja.x * Ja.x) * pen; acc[16] += (Ja.y * Ja.x) * pen; acc[17] += (Ja.z * Ja.x) * pen;
             acc[18] += (Ja.y * Ja.y) * pen; acc[19] += (Ja.z * Ja.y) * pen; acc[20] += (Ja.z * Ja.z) * pen;
         };
+        /* two-waves-per-SIMD form: the angular Jacobians and the gyroscopic factors of the lane's three rows (functions of the body's own pose) are kept across the wait — 18
+         * registers; their 63 products per row still are recomputed in each pass (ninety more would spill) */
+        constexpr bool KEEPJ = TWOPASS && !HOIST && !JOINTS;
+        f3 keepJa[3] = {zero3(), zero3(), zero3()}, keepG[3] = {zero3(), zero3(), zero3()};
+        if (KEEPJ) {
+            const float sign = isA ? 1.0f : -1.0f;
+            const f3 basis[3] = {n, t1, t2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { keepJa[k] = cross3(wOwn, basis[k]) * sign; keepG[k] = abs3(cross3(keepJa[k], invIw * keepJa[k])); }
+        }
         fv4u sl = fv4u{0u, 0u, 0u, 0u}, sp = sl;
 #pragma unroll 1
         for (int pass = TWOPASS ? 0 : 1; pass < 2; ++pass) {
@@ -1069,7 +1079,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     const f3 basis[3] = {n, t1, t2};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        rowJl[k] = basis[k] * sign; rowJa[k] = cross3(wOwnP, basis[k]) * sign;   /* manifold.cpp:265-270 */
+                        rowJl[k] = basis[k] * sign; rowJa[k] = KEEPJ ? keepJa[k] : cross3(wOwnP, basis[k]) * sign;   /* manifold.cpp:265-270 */
                         const float desired = c.pen[k] * c.C[k] + c.lam[k] + 0.0f;             /* solver.cpp:379-381: stiffness FLT_MAX, motor 0 */
                         rowF[k] = rclamp(desired, c.fmin[k], c.fmax[k]);
                     }
@@ -1095,7 +1105,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
                     if (penOk) {
                         if (!early) lhs_add(Jl, Ja, pen);
                         if (!isJoint) {
-                            const f3 gyro = abs3(cross3(Ja, invIw * Ja)) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only (latency form: the factor is hoisted out of the pass loop by the compiler; written out by hand it changes nothing) */
+                            const f3 gyro = (KEEPJ ? keepG[k] : abs3(cross3(Ja, invIw * Ja))) * fabsf(f);        /* solver.cpp:393-397: Manifold rows only (latency form: the factor is hoisted out of the pass loop by the compiler; written out by hand it changes nothing) */
                             gy[0] += gyro.x; gy[1] += gyro.y; gy[2] += gyro.z;
                         }
                     }
@@ -1468,10 +1478,10 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& Lin, int swee
     FastLaunch L = Lin;
     /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
     const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
-    /* measured (sweep us, forms 1 / 2 / 3; tiles; final build, no SLP vectoriser): 8 000 cubes 422 / 493 / 543 (1 377), 10 648 cubes 467 / 513 / 542 (1 800), 13 824 cubes
-     * 560 / 550 / 657 (2 333), 21 952 cubes 745 / 589 / 701 (3 700), 32 768 cubes 1 007 / 687 / 738 (5 596), 46 656 cubes - / 891 / 814 (8 000), 64 000 cubes - / 1 010 / 868
-     * (11 174): the latency form up to 2.25 tiles per wave, one pass from 6.5 on */
-    int f = form != 0 ? form : (tilesGuess * 4 <= (long long)9 * 4 * L.numCU ? 1 : (tilesGuess * 2 <= (long long)13 * 4 * L.numCU ? 2 : 3));
+    /* measured (ms per step, forms 1 / 2 / 3; tiles; final build): 8 000 cubes 0.598 / 0.667 / 0.724 (1 377), 10 648 cubes 0.661 / 0.681 / 0.742 (1 800), 13 824 cubes
+     * 0.748 / 0.733 / 0.840 (2 333), 21 952 cubes 0.921 / 0.777 / 0.923 (3 700), 32 768 cubes 1.274 / 0.952 / 1.026 (5 596), 39 304 cubes - / 0.997 / 1.069 (6 700), 46 656 cubes
+     * - / 1.140 / 1.126 (8 000), 64 000 cubes - / 1.454 / 1.295 (11 174): the latency form up to 2.25 tiles per wave, one pass from 7.25 on */
+    int f = form != 0 ? form : (tilesGuess * 4 <= (long long)9 * 4 * L.numCU ? 1 : (tilesGuess * 4 <= (long long)29 * 4 * L.numCU ? 2 : 3));
     if (L.joints != 0 && f == 2) f = 3;                                /* (the joint-aware two-pass kernel at two waves per SIMD spills: 144 B per lane) */
     const bool lat = f == 1;
     if (L.sleepSel < 0) L.sleepSel = f == 3 ? 2 : 0;                   /* (64 000 cubes, one pass: s_sleep 16 between two looks 1 201 -> 1 160 us; small scenes: s_sleep 1, 272 against 298) */
