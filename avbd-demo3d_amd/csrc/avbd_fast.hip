@@ -183,7 +183,10 @@ __global__ __launch_bounds__(kPlanThreads) void k_fast_plan(FastLaunch L)
      * (a new contact between two bodies of one colour: the lower priority gives way) — decided on LAST step's colours alone, so the result does not
      * depend on timing; the rounds below then colour only what is left.  A settled pile keeps every colour and the colouring costs one look at the
      * neighbours.  (reuse = 0: the first step after an upload; or last step's colouring had grown beyond kFastRecolorAbove colours) */
-    const bool reuse = L.reuse != 0 && plan->numColors > 0 && plan->numColors <= kFastRecolorAbove;
+    /* (a scheduled slot for a fresh colouring is passed over while the kept colouring needs no more colours than the best fresh one of late did: a fresh colouring is 11 us at
+     * Stress1000, 40 - 60 beyond one workgroup) */
+    const bool reuse = L.reuse != 0 && plan->numColors > 0 && plan->numColors <= kFastRecolorAbove &&
+                       (L.freshDue == 0 || (L.freshDue == 1 && plan->lastFreshColors > 0 && plan->numColors <= plan->lastFreshColors));
     /* the hash that breaks the ties of the priorities has a seed: greedy colourings of one pile differ by a colour from seed to seed (Stress1000: 4 for three
      * seeds in four, 5 for the fourth; a colour is 20 dependent solves per step), so a fresh colouring that needed MORE colours than the best of the fresh colourings
      * before it moves on to the next seed for the colourings to come — decided on the device from the plan's own history, the same in every run */

@@ -84,6 +84,8 @@ struct FastLaunch {
                              * its records over with plain stores that stay in that XCD's L2 (0: never) */
     int seedBase;           /* option fast_seed: added to the plan's own seed */
     int reuse;              /* k_fast_plan: colorPrev holds last step's colouring of the same bodies */
+    int freshDue;           /* ... and this step is one of the scheduled slots for a fresh colouring (every fast_recolor-th step): taken when the kept colouring has more colours than the best
+                             * fresh one lately; 2: taken in any case (every 32nd slot: a pile that changed may colour with fewer) */
 };
 
 /* occupancy of the kernels on `device` (workgroups per CU), 0 when one does not fit */
