@@ -159,3 +159,7 @@ def test_committed_bench_line_and_profiles_keep_the_contract():
         assert {"FETCH_SIZE", "WRITE_SIZE"} <= set(s["counters_per_dispatch_of_dominant_kernel"])
         assert os.path.exists(os.path.join(prof, f"r6_{tag}_kernel_stats.csv"))
         assert s["source_id"] == sid, f"profiles/r6_{tag}_cli_summary.json was collected on other sources ({s['source_id']} != {sid}): re-run profiles/run_all_r6.sh"
+    # the resource table and the instruction budget of the round are those of the same sources
+    for name in ("r6_kernel_resources.txt", "r6_instruction_budget.txt"):
+        head = open(os.path.join(prof, name)).readline()
+        assert f"source_id {sid}" in head, f"profiles/{name} was made from other sources: {head.strip()[-40:]}"
