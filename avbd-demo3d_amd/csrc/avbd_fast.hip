@@ -909,7 +909,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
     f3 ra0 = Iw * (rotErr * invDt2);
     /* latency form: evaluated HERE — the compiler sinks what is first used behind the waits (these sixty instructions sat between the nine sums and the substitution,
      * on the path behind the last arrival); the empty asm pins the six values in front of the pass loop */
-    if (HOIST) asm volatile("" : "+v"(rl0.x), "+v"(rl0.y), "+v"(rl0.z), "+v"(ra0.x), "+v"(ra0.y), "+v"(ra0.z));
+    if (HOIST || !JOINTS) asm volatile("" : "+v"(rl0.x), "+v"(rl0.y), "+v"(rl0.z), "+v"(ra0.x), "+v"(ra0.y), "+v"(ra0.z));
 
     /* SPLIT (latency form, contacts): what the second pass's lanes need arrives in two parts — the contact's records (lambda, penalty: written by the partner
      * BEFORE its sums and its solve) and the partner's new pose (after them).  Everything that needs only the first — the J J^T penalty part of lhs, its 21
