@@ -1052,7 +1052,7 @@ __device__ __forceinline__ void fast_visit(const FastCtx& X, const SolverParams&
             if (mine) {
                 f3 wOwnP = wOwn;
                 float signP = isA ? 1.0f : -1.0f;
-                if (TWOPASS && !HOIST) {
+                if (TWOPASS && !HOIST && JOINTS) {   /* (the contacts-only two-pass form: since the unit is built without the SLP vectoriser the compiler may hoist there too — 256 registers, 16 B of scratch, 2 % faster) */
                     /* (two waves per SIMD: what depends on the body's own pose alone — Jacobians, their products, gyroscopic factors — is recomputed in each pass
                      * instead of being kept in ninety registers across the wait; the empty asm hides the loop invariance from the compiler) */
                     asm volatile("" : "+v"(wOwnP.x), "+v"(wOwnP.y), "+v"(wOwnP.z), "+v"(signP));
@@ -1481,10 +1481,10 @@ hipError_t fast_launch_sweep(hipStream_t stream, const FastLaunch& Lin, int swee
     FastLaunch L = Lin;
     /* `form`: 0 by size, 1 latency (one wave per SIMD), 2 two waves per SIMD in two passes, 3 one pass */
     const long long tilesGuess = tilesHint > 0 ? tilesHint : ((long long)L.B.n * 3) / 16;   /* (a settled pile of cubes: 0.17 tiles per body) */
-    /* measured (ms per step, forms 1 / 2 / 3; tiles; final build): 8 000 cubes 0.598 / 0.667 / 0.724 (1 377), 10 648 cubes 0.661 / 0.681 / 0.742 (1 800), 13 824 cubes
-     * 0.748 / 0.733 / 0.840 (2 333), 21 952 cubes 0.921 / 0.777 / 0.923 (3 700), 32 768 cubes 1.274 / 0.952 / 1.026 (5 596), 39 304 cubes - / 0.997 / 1.069 (6 700), 46 656 cubes
-     * - / 1.140 / 1.126 (8 000), 64 000 cubes - / 1.454 / 1.295 (11 174): the latency form up to 2.25 tiles per wave, one pass from 7.25 on */
-    int f = form != 0 ? form : (tilesGuess * 4 <= (long long)9 * 4 * L.numCU ? 1 : (tilesGuess * 4 <= (long long)29 * 4 * L.numCU ? 2 : 3));
+    /* measured (ms per step, forms 1 / 2 / 3; tiles; final build): 8 000 cubes 0.596 / 0.615 / 0.724 (1 377), 10 648 cubes 0.652 / 0.649 / 0.742 (1 800), 13 824 cubes
+     * 0.748 / 0.712 / 0.840 (2 333), 21 952 cubes 0.921 / 0.745 / 0.923 (3 700), 32 768 cubes 1.274 / 0.922 / 1.026 (5 596), 39 304 cubes - / 0.971 / 1.051 (6 700), 46 656 cubes
+     * - / 1.117 / 1.114 (8 000), 64 000 cubes - / 1.454 / 1.289 (11 174): the latency form up to 1.75 tiles per wave, one pass from 7.75 on */
+    int f = form != 0 ? form : (tilesGuess * 4 <= (long long)7 * 4 * L.numCU ? 1 : (tilesGuess * 4 <= (long long)31 * 4 * L.numCU ? 2 : 3));
     if (L.joints != 0 && f == 2) f = 3;                                /* (the joint-aware two-pass kernel at two waves per SIMD spills: 144 B per lane) */
     const bool lat = f == 1;
     if (L.sleepSel < 0) L.sleepSel = f == 3 ? 2 : 0;                   /* (64 000 cubes, one pass: s_sleep 16 between two looks 1 201 -> 1 160 us; small scenes: s_sleep 1, 272 against 298) */
